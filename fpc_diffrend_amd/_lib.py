@@ -1,0 +1,129 @@
+"""
+ctypes binding of libfpcdr.so (C ABI: include/fpcdr.h).  No CPU fallback exists: if the library is
+missing or fails to load, every op raises -- the HIP path is the only product path.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfpcdr.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MAX_ATTR = 32
+MAX_MIP = 16
+ABI_VERSION = 1
+
+FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
+BOUNDARY = {'wrap': 0, 'clamp': 1}
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int32
+
+
+class RasterizeFwd(ctypes.Structure):
+    _fields_ = [("pos", _p), ("tri", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i), ("scratch", _p),
+                ("rast", _p), ("rast_db", _p)]
+
+
+class RasterizeBwd(ctypes.Structure):
+    _fields_ = [("pos", _p), ("tri", _p), ("rast", _p), ("dy", _p), ("ddb", _p), ("B", _i), ("V", _i), ("T", _i),
+                ("H", _i), ("W", _i), ("grad_pos", _p)]
+
+
+class InterpolateFwd(ctypes.Structure):
+    _fields_ = [("attr", _p), ("rast", _p), ("tri", _p), ("rast_db", _p), ("B", _i), ("H", _i), ("W", _i), ("Ba", _i),
+                ("Vt", _i), ("A", _i), ("T", _i), ("n_diff", _i), ("diff_idx", _i * MAX_ATTR), ("out", _p),
+                ("out_da", _p)]
+
+
+class InterpolateBwd(ctypes.Structure):
+    _fields_ = [("attr", _p), ("rast", _p), ("tri", _p), ("rast_db", _p), ("dy", _p), ("dda", _p), ("B", _i),
+                ("H", _i), ("W", _i), ("Ba", _i), ("Vt", _i), ("A", _i), ("T", _i), ("n_diff", _i),
+                ("diff_idx", _i * MAX_ATTR), ("grad_attr", _p), ("grad_rast", _p), ("grad_rast_db", _p)]
+
+
+class TextureFwd(ctypes.Structure):
+    _fields_ = [("tex", _p * (MAX_MIP + 1)), ("n_levels", _i), ("uv", _p), ("uv_da", _p), ("mip_level_bias", _p),
+                ("B", _i), ("H", _i), ("W", _i), ("Bt", _i), ("Ht", _i), ("Wt", _i), ("C", _i), ("filter_mode", _i),
+                ("boundary_mode", _i), ("out", _p)]
+
+
+class TextureBwd(ctypes.Structure):
+    _fields_ = [("tex", _p * (MAX_MIP + 1)), ("n_levels", _i), ("uv", _p), ("uv_da", _p), ("mip_level_bias", _p),
+                ("dy", _p), ("B", _i), ("H", _i), ("W", _i), ("Bt", _i), ("Ht", _i), ("Wt", _i), ("C", _i),
+                ("filter_mode", _i), ("boundary_mode", _i), ("grad_tex", _p * (MAX_MIP + 1)), ("grad_uv", _p),
+                ("grad_uv_da", _p), ("grad_mip_level_bias", _p)]
+
+
+class AntialiasFwd(ctypes.Structure):
+    _fields_ = [("color", _p), ("rast", _p), ("pos", _p), ("tri", _p), ("adj", _p), ("B", _i), ("H", _i), ("W", _i),
+                ("C", _i), ("V", _i), ("T", _i), ("sil", _p), ("flags", _p), ("out", _p)]
+
+
+class AntialiasBwd(ctypes.Structure):
+    _fields_ = [("color", _p), ("rast", _p), ("pos", _p), ("tri", _p), ("adj", _p), ("dy", _p), ("B", _i), ("H", _i),
+                ("W", _i), ("C", _i), ("V", _i), ("T", _i), ("sil", _p), ("flags", _p),
+                ("pos_gradient_boost", ctypes.c_float), ("grad_color", _p), ("grad_pos", _p)]
+
+
+# every symbol include/fpcdr.h declares: name -> (restype, argtypes)
+_sz = ctypes.c_size_t
+_int = ctypes.c_int
+SYMBOLS = {
+    "fpcdr_abi_version": (_int, []),
+    "fpcdr_last_error": (ctypes.c_char_p, []),
+    "fpcdr_rasterize_scratch_bytes": (_sz, [_i, _i]),
+    "fpcdr_rasterize_fwd": (_int, [ctypes.POINTER(RasterizeFwd), _p]),
+    "fpcdr_rasterize_bwd": (_int, [ctypes.POINTER(RasterizeBwd), _p]),
+    "fpcdr_interpolate_fwd": (_int, [ctypes.POINTER(InterpolateFwd), _p]),
+    "fpcdr_interpolate_bwd": (_int, [ctypes.POINTER(InterpolateBwd), _p]),
+    "fpcdr_mip_downsample": (_int, [_p, _p, _i, _i, _i, _i, _p]),
+    "fpcdr_mip_downsample_bwd": (_int, [_p, _p, _i, _i, _i, _i, _p]),
+    "fpcdr_texture_fwd": (_int, [ctypes.POINTER(TextureFwd), _p]),
+    "fpcdr_texture_bwd": (_int, [ctypes.POINTER(TextureBwd), _p]),
+    "fpcdr_topology_scratch_bytes": (_sz, [_i]),
+    "fpcdr_topology_build": (_int, [_p, _i, _p, _p, _p]),
+    "fpcdr_antialias_flags_bytes": (_sz, [_i, _i, _i]),
+    "fpcdr_antialias_fwd": (_int, [ctypes.POINTER(AntialiasFwd), _p]),
+    "fpcdr_antialias_bwd": (_int, [ctypes.POINTER(AntialiasBwd), _p]),
+    "fpcdr_blend_fwd": (_int, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "fpcdr_blend_bwd_w": (_int, [_p, _p, _p, _i, _i, _i, _p]),
+    "fpcdr_blend_bwd_basis": (_int, [_p, _p, _p, _i, _i, _i, _p]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of libfpcdr.so (recipe: csrc/Makefile); cross-compiles without a GPU."""
+    cmd = ["make", "-s", "-C", CSRC, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    """Load libfpcdr.so and bind every symbol of include/fpcdr.h.  Raises if it is missing -- no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C {CSRC}`). There is no CPU fallback for the raster ops.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.fpcdr_abi_version()
+    if ver != ABI_VERSION:
+        raise RuntimeError(f"libfpcdr.so ABI version {ver} != binding {ABI_VERSION}; rebuild the extension")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().fpcdr_last_error()
+        raise RuntimeError(f"fpcdr error {rc}: {msg.decode() if msg else '?'}")

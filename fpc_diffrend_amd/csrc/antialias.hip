@@ -1,0 +1,450 @@
+// antialias forward / backward + topology for gfx950 (MI355X).
+//
+// Performs the work of `dr.antialias(colour, rast_out, pos_clip, pos_idx)` at reference
+// src/torch/fit.py:160 (nvdiffrast op, absent from the reference tree): at horizontally / vertically
+// adjacent pixel pairs showing different triangles, if a silhouette edge of the nearer triangle crosses
+// the segment between the two pixel centres, the two colours are blended by the crossing position.
+// This is the only source of visibility (silhouette) gradients in the fit loop.
+//
+// MI355X-first structure -- no global work list, no colour atomics:
+//   k_topo_*   once per index buffer: open-addressed edge table (atomicCAS on 64-bit keys; commutative
+//              count / sum updates so the result does not depend on insertion order) resolved into
+//              adj[T][3] = opposite vertex of the one neighbouring triangle (or -1 boundary, -2 non-manifold).
+//   k_sil      per (image, triangle): 3 bits "edge e is a silhouette edge in this image".  Interior
+//              pixel pairs (the vast majority of id discontinuities on a 30k-triangle mesh) are then
+//              rejected by one byte load.
+//   k_aa_fwd   one pixel per lane, GATHER form: every pixel evaluates its four pairs and adds only
+//              the blends it receives, so the colour is written once with plain stores, the result is
+//              deterministic, and HBM traffic is the algorithmic 16 + 8C bytes per pixel.  The wave
+//              (64 consecutive pixels of a row) publishes two 64-bit ballot words: pair (p,p+x) /
+//              (p,p+y) blended.
+//   k_aa_bwd   reads those two bit planes (2 bits per pixel): waves without a flagged pair copy dy to
+//              grad_colour -- the HBM-bound bulk, 8C bytes per pixel; flagged pixels re-evaluate their
+//              pairs, gather their colour-gradient corrections and scatter d(alpha)/d(pos) sparsely.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// topology
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned long long EMPTY_KEY = ~0ull;
+
+__host__ __device__ inline unsigned int topo_capacity(int T) {
+    unsigned int need = (unsigned int)T * 6u, cap = 64;
+    while (cap < need) cap <<= 1;
+    return cap;
+}
+
+__device__ __forceinline__ unsigned int hash_key(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (unsigned int)k;
+}
+
+__global__ void k_topo_init(unsigned long long *keys, unsigned int *cnt, unsigned int *sum, unsigned int cap) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) { keys[i] = EMPTY_KEY; cnt[i] = 0; sum[i] = 0; }
+}
+
+__device__ __forceinline__ unsigned long long edge_key(int a, int b) {
+    unsigned int lo = (unsigned int)min(a, b), hi = (unsigned int)max(a, b);
+    return ((unsigned long long)lo << 32) | hi;
+}
+
+__global__ void k_topo_insert(const int32_t *__restrict__ tri, int T, unsigned long long *keys, unsigned int *cnt,
+                              unsigned int *sum, unsigned int cap) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * T) return;
+    const int t = i / 3, e = i - 3 * t;
+    const int a = tri[3 * t + (e + 1) % 3], b = tri[3 * t + (e + 2) % 3], o = tri[3 * t + e];
+    const unsigned long long key = edge_key(a, b);
+    unsigned int slot = hash_key(key) & (cap - 1);
+    for (unsigned int probe = 0; probe < cap; ++probe) {
+        const unsigned long long prev = atomicCAS(&keys[slot], EMPTY_KEY, key);
+        if (prev == EMPTY_KEY || prev == key) {
+            atomicAdd(&cnt[slot], 1u);
+            atomicAdd(&sum[slot], (unsigned int)o);
+            return;
+        }
+        slot = (slot + 1) & (cap - 1);
+    }
+}
+
+__global__ void k_topo_resolve(const int32_t *__restrict__ tri, int T, const unsigned long long *keys, const unsigned int *cnt,
+                               const unsigned int *sum, unsigned int cap, int32_t *__restrict__ adj) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * T) return;
+    const int t = i / 3, e = i - 3 * t;
+    const int a = tri[3 * t + (e + 1) % 3], b = tri[3 * t + (e + 2) % 3], o = tri[3 * t + e];
+    const unsigned long long key = edge_key(a, b);
+    unsigned int slot = hash_key(key) & (cap - 1);
+    int res = -2;
+    for (unsigned int probe = 0; probe < cap; ++probe) {
+        const unsigned long long k = keys[slot];
+        if (k == key) {
+            const unsigned int c = cnt[slot];
+            res = (c == 1) ? -1 : (c == 2 ? (int)(sum[slot] - (unsigned int)o) : -2);
+            break;
+        }
+        if (k == EMPTY_KEY) break;
+        slot = (slot + 1) & (cap - 1);
+    }
+    adj[i] = res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-image silhouette classification (uncentred pixel-scaled homogeneous coordinates)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sil(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                             const int32_t *__restrict__ adj, int B, int V, int T, float hw, float hh,
+                                             uint8_t *__restrict__ sil) {
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * T) return;
+    const int b = (int)(gid / T), t = (int)(gid - (long long)b * T);
+    const float4 *p = pos + (size_t)b * V;
+    int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    unsigned int bits = 0;
+    bool ok = true;
+    for (int k = 0; k < 3; ++k) ok &= (vi[k] >= 0 && vi[k] < V);
+    if (ok) {
+        float qx[3], qy[3], qw[3];
+        for (int k = 0; k < 3; ++k) {
+            const float4 c = p[vi[k]];
+            qx[k] = c.x * hw; qy[k] = c.y * hh; qw[k] = c.w;
+        }
+        for (int e = 0; e < 3; ++e) {
+            const int ad = adj[3 * t + e];
+            if (ad == -1) { bits |= 1u << e; continue; }
+            if (ad < 0 || ad >= V) continue;
+            const int a = (e + 1) % 3, bb = (e + 2) % 3;
+            const float Lx = qy[a] * qw[bb] - qw[a] * qy[bb];
+            const float Ly = qw[a] * qx[bb] - qx[a] * qw[bb];
+            const float Lz = qx[a] * qy[bb] - qy[a] * qx[bb];
+            const float so = Lx * qx[e] + Ly * qy[e] + Lz * qw[e];
+            const float4 c = p[ad];
+            const float sp = Lx * (c.x * hw) + Ly * (c.y * hh) + Lz * c.w;
+            if ((so > 0.0f && sp > 0.0f) || (so < 0.0f && sp < 0.0f)) bits |= 1u << e;
+        }
+    }
+    sil[gid] = (uint8_t)bits;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair analysis shared by forward and backward
+// ------------------------------------------------------------------------------------------------
+struct PairSel {
+    int tau;      // chosen triangle, -1 = nothing to do
+    int use1;     // 1: the triangle belongs to the second pixel of the pair
+};
+
+// ids are 1-based (0 = empty); z = rast.z
+__device__ __forceinline__ PairSel pair_select(int id0, float z0, int id1, float z1, int T) {
+    PairSel s;
+    s.use1 = (id0 == 0) ? 1 : ((id1 == 0) ? 0 : (z1 < z0 ? 1 : 0));
+    s.tau = (s.use1 ? id1 : id0) - 1;
+    if (s.tau < 0 || s.tau >= T) s.tau = -1;
+    return s;
+}
+
+struct EdgeEval {
+    bool active;
+    float t, Lx, Ly, Lz, qax, qay, wa, qbx, qby, wb;
+};
+
+// d: 0 = x pair, 1 = y pair; s = +1 if the partner pixel lies in +d direction from P, else -1
+__device__ __forceinline__ EdgeEval edge_eval(float4 ca, float4 cb, float hw, float hh, float fxp, float fyp, int d, float s) {
+    EdgeEval r;
+    r.qax = ca.x * hw - fxp * ca.w; r.qay = ca.y * hh - fyp * ca.w; r.wa = ca.w;
+    r.qbx = cb.x * hw - fxp * cb.w; r.qby = cb.y * hh - fyp * cb.w; r.wb = cb.w;
+    r.Lx = r.qay * r.wb - r.wa * r.qby;
+    r.Ly = r.wa * r.qbx - r.qax * r.wb;
+    r.Lz = r.qax * r.qby - r.qay * r.qbx;
+    float Ld, Lo, ya, yb;
+    bool orient;
+    if (d == 0) { Ld = r.Lx; Lo = r.Ly; ya = r.qay; yb = r.qby; orient = fabsf(Ld) >= fabsf(Lo); }
+    else        { Ld = r.Ly; Lo = r.Lx; ya = r.qax; yb = r.qbx; orient = fabsf(Ld) > fabsf(Lo); }
+    const bool extent = (ya < 0.0f) != (yb < 0.0f);
+    const bool nz = Ld != 0.0f;
+    const float den = nz ? s * Ld : 1.0f;
+    r.t = -r.Lz / den;
+    r.active = orient && extent && nz && (r.t >= 0.0f) && (r.t <= 1.0f);
+    return r;
+}
+
+struct AAGeom {
+    const float4 *pos;   // image's vertex buffer
+    const int32_t *tri;
+    const uint8_t *sil;  // image's silhouette bits
+    int T, W, H;
+    float hw, hh;
+};
+
+// Evaluate pair (x0,y0)-(x0+dx,y0+dy) (d = 0/1).  For every active silhouette edge calls
+// f(t, Px, Py, Qx, Qy, va, vb, ev, s).
+template <typename F>
+__device__ __forceinline__ bool for_active_edges(const AAGeom &g, int x0, int y0, int d, int id0, float z0, int id1, float z1, F &&f) {
+    const PairSel ps = pair_select(id0, z0, id1, z1, g.T);
+    if (ps.tau < 0) return false;
+    const unsigned int bits = g.sil[ps.tau];
+    if (bits == 0) return false;
+    const int x1 = x0 + (d == 0), y1 = y0 + (d == 1);
+    const int Px = ps.use1 ? x1 : x0, Py = ps.use1 ? y1 : y0;
+    const int Qx = ps.use1 ? x0 : x1, Qy = ps.use1 ? y0 : y1;
+    const float s = ps.use1 ? -1.0f : 1.0f;
+    const float fxp = (float)Px + 0.5f - g.hw, fyp = (float)Py + 0.5f - g.hh;
+    const int vi[3] = {g.tri[3 * ps.tau], g.tri[3 * ps.tau + 1], g.tri[3 * ps.tau + 2]};
+    const float4 c[3] = {g.pos[vi[0]], g.pos[vi[1]], g.pos[vi[2]]};
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        if (!((bits >> e) & 1u)) continue;
+        const int a = (e + 1) % 3, b = (e + 2) % 3;
+        const EdgeEval ev = edge_eval(c[a], c[b], g.hw, g.hh, fxp, fyp, d, s);
+        if (ev.active) {
+            any = true;
+            f(ev.t, Px, Py, Qx, Qy, vi[a], vi[b], ev, s);
+        }
+    }
+    return any;
+}
+
+__device__ __forceinline__ float2 load_zid(const float4 *rast, size_t off) {
+    const float4 r = rast[off];
+    return make_float2(r.z, r.w);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int CS>
+__global__ void __launch_bounds__(256) k_aa_fwd(const float *__restrict__ color, const float4 *__restrict__ rast,
+                                                const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                const uint8_t *__restrict__ sil, int B, int H, int W, int C_dyn, int V, int T,
+                                                unsigned long long *__restrict__ flags, float *__restrict__ out) {
+    const int C = CS > 0 ? CS : C_dyn;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wave, b = blockIdx.z;
+    const int Wq = FPCDR_AA_ROW_WORDS(W);
+    bool fx_flag = false, fy_flag = false;
+    if (y < H) {
+        if (x < W) {
+            const size_t img = (size_t)b * H * W;
+            const size_t off = img + (size_t)y * W + x;
+            const float2 me = load_zid(rast, off);
+            const int id = (int)me.y;
+            const bool hasR = x + 1 < W, hasL = x > 0, hasU = y + 1 < H, hasD = y > 0;
+            const float2 nR = hasR ? load_zid(rast, off + 1) : me;
+            const float2 nL = hasL ? load_zid(rast, off - 1) : me;
+            const float2 nU = hasU ? load_zid(rast, off + W) : me;
+            const float2 nD = hasD ? load_zid(rast, off - W) : me;
+            float acc[CS > 0 ? CS : 1];
+            const float *cme = color + off * C;
+            if (CS > 0) {
+#pragma unroll
+                for (int c = 0; c < CS; ++c) acc[c] = cme[c];
+            }
+            const bool disc = ((int)nR.y != id) | ((int)nL.y != id) | ((int)nU.y != id) | ((int)nD.y != id);
+            if (!disc) {
+                if (CS > 0) {
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) out[off * C + c] = acc[c];
+                } else {
+                    for (int c = 0; c < C; ++c) out[off * C + c] = cme[c];
+                }
+            } else {
+                AAGeom g = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
+                // gather: add what THIS pixel receives from each of its four pairs
+                auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own, bool &flag) {
+                    if ((int)p0.y == (int)p1.y) return;
+                    bool hit = for_active_edges(g, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
+                        [&](float t, int Px, int Py, int Qx, int Qy, int, int, const EdgeEval &, float) {
+                            const bool far = t >= 0.5f;
+                            const int rx = far ? Qx : Px, ry = far ? Qy : Py;
+                            if (rx != x || ry != y) return;
+                            const int ox = far ? Px : Qx, oy = far ? Py : Qy;
+                            const float amt = far ? t - 0.5f : 0.5f - t;
+                            const float *co = color + (img + (size_t)oy * W + ox) * C;
+                            if (CS > 0) {
+#pragma unroll
+                                for (int c = 0; c < CS; ++c) acc[c] += amt * (co[c] - cme[c]);
+                            } else {
+                                for (int c = 0; c < C; ++c) out[off * C + c] += amt * (co[c] - cme[c]);
+                            }
+                        });
+                    if (own && hit) flag = true;
+                };
+                if (CS == 0) for (int c = 0; c < C; ++c) out[off * C + c] = cme[c];
+                bool dummy = false;
+                if (hasR) visit(x, y, 0, me, nR, true, fx_flag);
+                if (hasU) visit(x, y, 1, me, nU, true, fy_flag);
+                if (hasL) visit(x - 1, y, 0, nL, me, false, dummy);
+                if (hasD) visit(x, y - 1, 1, nD, me, false, dummy);
+                if (CS > 0) {
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) out[off * C + c] = acc[c];
+                }
+            }
+        }
+        const unsigned long long bx = __ballot(fx_flag), by = __ballot(fy_flag);
+        if (lane == 0) {
+            const size_t plane = (size_t)B * H * Wq;
+            const size_t wi = ((size_t)b * H + y) * Wq + blockIdx.x;
+            flags[wi] = bx;
+            flags[plane + wi] = by;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int CS>
+__global__ void __launch_bounds__(256) k_aa_bwd(const float *__restrict__ color, const float4 *__restrict__ rast,
+                                                const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                const uint8_t *__restrict__ sil, const float *__restrict__ dy, int B, int H,
+                                                int W, int C_dyn, int V, int T, const unsigned long long *__restrict__ flags,
+                                                float boost, float *__restrict__ grad_color, float *__restrict__ grad_pos) {
+    const int C = CS > 0 ? CS : C_dyn;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wave, b = blockIdx.z;
+    if (y >= H) return;
+    const int Wq = FPCDR_AA_ROW_WORDS(W);
+    const size_t plane = (size_t)B * H * Wq;
+    const size_t wi = ((size_t)b * H + y) * Wq + blockIdx.x;
+    // wave-uniform flag words: own row (x pairs, y pairs), word to the left, row below (y pairs)
+    const unsigned long long fx = flags[wi], fy = flags[plane + wi];
+    const unsigned long long fxl = blockIdx.x > 0 ? flags[wi - 1] : 0ull;
+    const unsigned long long fyd = y > 0 ? flags[plane + wi - Wq] : 0ull;
+    const bool wave_any = (fx | fy | fyd | (fxl >> 63)) != 0ull;
+    if (x >= W) return;
+    const size_t img = (size_t)b * H * W;
+    const size_t off = img + (size_t)y * W + x;
+    const float *g = dy + off * C;
+    float *go = grad_color + off * C;
+    if (!wave_any) {
+        if (CS > 0) {
+#pragma unroll
+            for (int c = 0; c < CS; ++c) go[c] = g[c];
+        } else {
+            for (int c = 0; c < C; ++c) go[c] = g[c];
+        }
+        return;
+    }
+    const bool own_x = (fx >> lane) & 1ull, own_y = (fy >> lane) & 1ull;
+    const bool left_x = lane > 0 ? ((fx >> (lane - 1)) & 1ull) : ((fxl >> 63) & 1ull);
+    const bool down_y = (fyd >> lane) & 1ull;
+    for (int c = 0; c < C; ++c) go[c] = g[c];
+    if (!(own_x | own_y | left_x | down_y)) return;
+    AAGeom geo = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
+    float *gp = grad_pos + (size_t)b * V * 4;
+    const float2 me = load_zid(rast, off);
+    auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own) {
+        for_active_edges(geo, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
+            [&](float t, int Px, int Py, int Qx, int Qy, int va, int vb, const EdgeEval &ev, float s) {
+                const bool far = t >= 0.5f;
+                const int rx = far ? Qx : Px, ry = far ? Qy : Py;
+                const int ox = far ? Px : Qx, oy = far ? Py : Qy;
+                const float amt = far ? t - 0.5f : 0.5f - t;
+                const size_t roff = img + (size_t)ry * W + rx;
+                const float *gr = dy + roff * C;
+                // colour gradient: out[r] = c[r] + amt (c[o] - c[r])
+                if (rx == x && ry == y) {
+                    for (int c = 0; c < C; ++c) go[c] -= amt * gr[c];
+                } else {  // this pixel is the "other" one
+                    for (int c = 0; c < C; ++c) go[c] += amt * gr[c];
+                }
+                if (!own) return;
+                // position gradient (once per pair, by the pair's owner)
+                const float *cP = color + (img + (size_t)Py * W + Px) * C;
+                const float *cQ = color + (img + (size_t)Qy * W + Qx) * C;
+                float G = 0.f;
+                for (int c = 0; c < C; ++c) G += gr[c] * (cP[c] - cQ[c]);
+                G *= boost;
+                if (G == 0.0f) return;
+                const float Ld = d == 0 ? ev.Lx : ev.Ly;
+                const float gLz = -G / (s * Ld);
+                const float gLd = -G * t / Ld;
+                const float gLx = d == 0 ? gLd : 0.0f, gLy = d == 0 ? 0.0f : gLd;
+                float g_qax = 0.f, g_qay = 0.f, g_wa = 0.f, g_qbx = 0.f, g_qby = 0.f, g_wb = 0.f;
+                g_qay += gLx * ev.wb; g_wb += gLx * ev.qay; g_wa -= gLx * ev.qby; g_qby -= gLx * ev.wa;
+                g_wa += gLy * ev.qbx; g_qbx += gLy * ev.wa; g_qax -= gLy * ev.wb; g_wb -= gLy * ev.qax;
+                g_qax += gLz * ev.qby; g_qby += gLz * ev.qax; g_qay -= gLz * ev.qbx; g_qbx -= gLz * ev.qay;
+                const float fxp = (float)Px + 0.5f - geo.hw, fyp = (float)Py + 0.5f - geo.hh;
+                atomicAdd(gp + 4 * (size_t)va + 0, g_qax * geo.hw);
+                atomicAdd(gp + 4 * (size_t)va + 1, g_qay * geo.hh);
+                atomicAdd(gp + 4 * (size_t)va + 3, g_wa - fxp * g_qax - fyp * g_qay);
+                atomicAdd(gp + 4 * (size_t)vb + 0, g_qbx * geo.hw);
+                atomicAdd(gp + 4 * (size_t)vb + 1, g_qby * geo.hh);
+                atomicAdd(gp + 4 * (size_t)vb + 3, g_wb - fxp * g_qbx - fyp * g_qby);
+            });
+    };
+    if (own_x) visit(x, y, 0, me, load_zid(rast, off + 1), true);
+    if (own_y) visit(x, y, 1, me, load_zid(rast, off + W), true);
+    if (left_x) visit(x - 1, y, 0, load_zid(rast, off - 1), me, false);
+    if (down_y) visit(x, y - 1, 1, load_zid(rast, off - W), me, false);
+}
+
+}  // namespace
+
+extern "C" size_t fpcdr_topology_scratch_bytes(int32_t T) {
+    if (T <= 0) return 0;
+    return (size_t)topo_capacity(T) * 16;
+}
+
+extern "C" int fpcdr_topology_build(const int32_t *tri, int32_t T, void *scratch, int32_t *adj, void *stream) {
+    FPCDR_REQUIRE(tri && scratch && adj, "null pointer");
+    FPCDR_REQUIRE(T > 0 && T < (1 << 28), "T out of range");
+    const unsigned int cap = topo_capacity(T);
+    unsigned long long *keys = (unsigned long long *)scratch;
+    unsigned int *cnt = (unsigned int *)(keys + cap);
+    unsigned int *sum = cnt + cap;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_topo_init, dim3(fpcdr_cdiv(cap, 256)), dim3(256), 0, st, keys, cnt, sum, cap);
+    hipLaunchKernelGGL(k_topo_insert, dim3(fpcdr_cdiv(3ll * T, 256)), dim3(256), 0, st, tri, T, keys, cnt, sum, cap);
+    hipLaunchKernelGGL(k_topo_resolve, dim3(fpcdr_cdiv(3ll * T, 256)), dim3(256), 0, st, tri, T, keys, cnt, sum, cap, adj);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" size_t fpcdr_antialias_flags_bytes(int32_t B, int32_t H, int32_t W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)2 * B * H * FPCDR_AA_ROW_WORDS(W) * sizeof(uint64_t);
+}
+
+extern "C" int fpcdr_antialias_fwd(const fpcdr_antialias_fwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->color && p->rast && p->pos && p->tri && p->adj && p->sil && p->flags && p->out, "null pointer");
+    FPCDR_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->C > 0 && p->V > 0 && p->T > 0, "sizes must be positive");
+    FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 4) <= 65535, "image batch / height too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sil, dim3(fpcdr_cdiv((long long)p->B * p->T, 256)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                       p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil);
+    dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 4), p->B);
+#define LAUNCH_FWD(CS)                                                                                                   \
+    hipLaunchKernelGGL(k_aa_fwd<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, \
+                       p->tri, p->sil, p->B, p->H, p->W, p->C, p->V, p->T, (unsigned long long *)p->flags, p->out)
+    if (p->C == 1) LAUNCH_FWD(1);
+    else if (p->C == 3) LAUNCH_FWD(3);
+    else if (p->C == 4) LAUNCH_FWD(4);
+    else LAUNCH_FWD(0);
+#undef LAUNCH_FWD
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_antialias_bwd(const fpcdr_antialias_bwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->color && p->rast && p->pos && p->tri && p->adj && p->dy && p->sil && p->flags && p->grad_color && p->grad_pos,
+                  "null pointer");
+    FPCDR_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->C > 0 && p->V > 0 && p->T > 0, "sizes must be positive");
+    FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 4) <= 65535, "image batch / height too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 4), p->B);
+#define LAUNCH_BWD(CS)                                                                                                   \
+    hipLaunchKernelGGL(k_aa_bwd<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, \
+                       p->tri, p->sil, p->dy, p->B, p->H, p->W, p->C, p->V, p->T, (const unsigned long long *)p->flags,  \
+                       p->pos_gradient_boost, p->grad_color, p->grad_pos)
+    if (p->C == 1) LAUNCH_BWD(1);
+    else if (p->C == 3) LAUNCH_BWD(3);
+    else if (p->C == 4) LAUNCH_BWD(4);
+    else LAUNCH_BWD(0);
+#undef LAUNCH_BWD
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}

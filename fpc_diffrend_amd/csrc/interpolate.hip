@@ -1,0 +1,223 @@
+// interpolate forward / backward for gfx950 (MI355X).
+//
+// Performs the work of `dr.interpolate(uv[None], rast_out, uv_idx[, rast_db, diff_attrs='all'])` at
+// reference src/torch/fit.py:154 and :157 (nvdiffrast op, absent from the reference tree).
+//
+// Pure streaming kernels, one pixel per lane, bounded by HBM:
+//   fwd  reads rast (16 B/px, one float4 per lane, fully coalesced), gathers 3 x A attribute floats
+//        from an L2-resident vertex table and writes A floats (+ 2*n_diff differentials);
+//   bwd  reads dy + rast, writes grad_rast as one float4 per lane; the attribute gradient (only when
+//        the caller asks for it -- the reference's uv carries no gradient, fit.py:431) is scattered
+//        with wave-level pre-reduction by vertex before the f32 atomics.
+#include "common.h"
+
+namespace {
+
+struct DiffIdx { int32_t v[FPCDR_MAX_ATTR]; };
+
+template <int A_STATIC>
+__global__ void __launch_bounds__(256) k_interp_fwd(const float *__restrict__ attr, const float4 *__restrict__ rast,
+                                                    const int32_t *__restrict__ tri, const float4 *__restrict__ rast_db,
+                                                    long long npix_img, int B, int Ba, int Vt, int A_dyn, int T, int n_diff,
+                                                    DiffIdx didx, float *__restrict__ out, float *__restrict__ out_da) {
+    const int A = A_STATIC > 0 ? A_STATIC : A_dyn;
+    const long long total = npix_img * B;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float4 r = rast[i];
+        const int t = (int)r.w - 1;
+        float *o = out + i * A;
+        if (t < 0 || t >= T) {
+            if (A_STATIC == 2) {
+                *reinterpret_cast<float2 *>(o) = make_float2(0.f, 0.f);
+            } else {
+                for (int k = 0; k < A; ++k) o[k] = 0.f;
+            }
+            if (n_diff > 0) {
+                float *od = out_da + i * 2 * n_diff;
+                if (A_STATIC == 2 && n_diff == 2) {
+                    *reinterpret_cast<float4 *>(od) = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    for (int k = 0; k < 2 * n_diff; ++k) od[k] = 0.f;
+                }
+            }
+            continue;
+        }
+        const int b = (int)(i / npix_img);
+        const float *ab = attr + (Ba > 1 ? (size_t)b * Vt * A : 0);
+        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        const float *a0 = ab + (size_t)i0 * A, *a1 = ab + (size_t)i1 * A, *a2 = ab + (size_t)i2 * A;
+        const float u = r.x, v = r.y, w = 1.0f - u - v;
+        if (A_STATIC == 2) {
+            const float2 q0 = *reinterpret_cast<const float2 *>(a0);
+            const float2 q1 = *reinterpret_cast<const float2 *>(a1);
+            const float2 q2 = *reinterpret_cast<const float2 *>(a2);
+            *reinterpret_cast<float2 *>(o) = make_float2(u * q0.x + v * q1.x + w * q2.x, u * q0.y + v * q1.y + w * q2.y);
+            if (n_diff == 2) {
+                const float4 d = rast_db[i];
+                float e0[2] = {q0.x - q2.x, q0.y - q2.y}, e1[2] = {q1.x - q2.x, q1.y - q2.y};
+                float r_[4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = didx.v[j];
+                    const float f0 = k == 0 ? e0[0] : e0[1], f1 = k == 0 ? e1[0] : e1[1];
+                    r_[2 * j] = d.x * f0 + d.z * f1;
+                    r_[2 * j + 1] = d.y * f0 + d.w * f1;
+                }
+                *reinterpret_cast<float4 *>(out_da + i * 4) = make_float4(r_[0], r_[1], r_[2], r_[3]);
+                continue;
+            }
+        } else {
+            for (int k = 0; k < A; ++k) o[k] = u * a0[k] + v * a1[k] + w * a2[k];
+        }
+        if (n_diff > 0) {
+            const float4 d = rast_db[i];
+            float *od = out_da + i * 2 * n_diff;
+            for (int j = 0; j < n_diff; ++j) {
+                const int k = didx.v[j];
+                const float e0 = a0[k] - a2[k], e1 = a1[k] - a2[k];
+                od[2 * j] = d.x * e0 + d.z * e1;
+                od[2 * j + 1] = d.y * e0 + d.w * e1;
+            }
+        }
+    }
+}
+
+// Backward.  2-D launch (8x8 pixel tile per wave) so lanes of a wave tend to share triangles when
+// the attribute gradient is scattered.
+template <bool GRAD_ATTR>
+__global__ void __launch_bounds__(256) k_interp_bwd(const float *__restrict__ attr, const float4 *__restrict__ rast,
+                                                    const int32_t *__restrict__ tri, const float4 *__restrict__ rast_db,
+                                                    const float *__restrict__ dy, const float *__restrict__ dda, int B,
+                                                    int H, int W, int Ba, int Vt, int A, int T, int n_diff, DiffIdx didx,
+                                                    float *__restrict__ grad_attr, float4 *__restrict__ grad_rast,
+                                                    float4 *__restrict__ grad_rast_db) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // with an attribute gradient: 8x8 pixel tile per wave; without: 256 consecutive pixels of a row per block
+    const int px = GRAD_ATTR ? blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7) : blockIdx.x * 256 + threadIdx.x;
+    const int py = GRAD_ATTR ? blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3) : blockIdx.y;
+    const int b = blockIdx.z;
+    const bool inside = px < W && py < H;
+    const size_t i = ((size_t)b * H + (inside ? py : 0)) * W + (inside ? px : 0);
+    int t = -1;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inside) {
+        r = rast[i];
+        t = (int)r.w - 1;
+        if (t >= T) t = -1;
+    }
+    float4 gr = make_float4(0.f, 0.f, 0.f, 0.f), gdb = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i0 = -1, i1 = -1, i2 = -1;
+    const float *ab = attr + (Ba > 1 ? (size_t)b * Vt * A : 0);
+    float *gab = GRAD_ATTR ? grad_attr + (Ba > 1 ? (size_t)b * Vt * A : 0) : nullptr;
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0) {
+        i0 = tri[3 * t]; i1 = tri[3 * t + 1]; i2 = tri[3 * t + 2];
+        const float *a0 = ab + (size_t)i0 * A, *a1 = ab + (size_t)i1 * A, *a2 = ab + (size_t)i2 * A;
+        const float *g = dy + i * A;
+        float gu = 0.f, gv = 0.f;
+        for (int k = 0; k < A; ++k) {
+            const float gk = g[k], c2 = a2[k];
+            gu += gk * (a0[k] - c2);
+            gv += gk * (a1[k] - c2);
+        }
+        gr.x = gu; gr.y = gv;
+        if (n_diff > 0) {
+            d = rast_db[i];
+            const float *gd = dda + i * 2 * n_diff;
+            for (int j = 0; j < n_diff; ++j) {
+                const int k = didx.v[j];
+                const float e0 = a0[k] - a2[k], e1 = a1[k] - a2[k];
+                const float gx = gd[2 * j], gy = gd[2 * j + 1];
+                gdb.x += gx * e0; gdb.y += gy * e0; gdb.z += gx * e1; gdb.w += gy * e1;
+            }
+        }
+    }
+    if (inside) {
+        grad_rast[i] = gr;
+        if (n_diff > 0) grad_rast_db[i] = gdb;
+    }
+    if (GRAD_ATTR) {
+        if (__ballot(t >= 0) == 0ull) return;
+        const float u = r.x, v = r.y, w = 1.0f - u - v;
+        // one attribute channel at a time: three group-reduced atomics per channel
+        for (int k = 0; k < A; ++k) {
+            float gk = (t >= 0) ? dy[i * A + k] : 0.f;
+            float ge0 = 0.f, ge1 = 0.f;
+            if (t >= 0 && n_diff > 0) {
+                for (int j = 0; j < n_diff; ++j)
+                    if (didx.v[j] == k) {
+                        const float gx = dda[i * 2 * n_diff + 2 * j], gy = dda[i * 2 * n_diff + 2 * j + 1];
+                        ge0 += gx * d.x + gy * d.y;
+                        ge1 += gx * d.z + gy * d.w;
+                    }
+            }
+            {
+                float *const dst[1] = {gab + (size_t)max(i0, 0) * A + k};
+                const float val[1] = {u * gk + ge0};
+                wave_group_atomic_add<1>(i0, dst, val);
+            }
+            {
+                float *const dst[1] = {gab + (size_t)max(i1, 0) * A + k};
+                const float val[1] = {v * gk + ge1};
+                wave_group_atomic_add<1>(i1, dst, val);
+            }
+            {
+                float *const dst[1] = {gab + (size_t)max(i2, 0) * A + k};
+                const float val[1] = {w * gk - ge0 - ge1};
+                wave_group_atomic_add<1>(i2, dst, val);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int fpcdr_interpolate_fwd(const fpcdr_interpolate_fwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->attr && p->rast && p->tri && p->out, "null pointer");
+    FPCDR_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->Vt > 0 && p->A > 0 && p->T > 0, "sizes must be positive");
+    FPCDR_REQUIRE(p->Ba == 1 || p->Ba == p->B, "attr batch must be 1 or B");
+    FPCDR_REQUIRE(p->n_diff >= 0 && p->n_diff <= FPCDR_MAX_ATTR, "n_diff out of range");
+    FPCDR_REQUIRE(p->n_diff == 0 || (p->rast_db && p->out_da), "differentials need rast_db and out_da");
+    DiffIdx di;
+    for (int j = 0; j < FPCDR_MAX_ATTR; ++j) di.v[j] = j < p->n_diff ? p->diff_idx[j] : 0;
+    for (int j = 0; j < p->n_diff; ++j) FPCDR_REQUIRE(di.v[j] >= 0 && di.v[j] < p->A, "diff_idx out of range");
+    const long long npix = (long long)p->H * p->W;
+    const long long total = npix * p->B;
+    const int grid = (int)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
+    hipStream_t st = (hipStream_t)stream;
+    if (p->A == 2)
+        hipLaunchKernelGGL(k_interp_fwd<2>, dim3(grid), dim3(256), 0, st, p->attr, (const float4 *)p->rast, p->tri,
+                           (const float4 *)p->rast_db, npix, p->B, p->Ba, p->Vt, p->A, p->T, p->n_diff, di, p->out, p->out_da);
+    else
+        hipLaunchKernelGGL(k_interp_fwd<0>, dim3(grid), dim3(256), 0, st, p->attr, (const float4 *)p->rast, p->tri,
+                           (const float4 *)p->rast_db, npix, p->B, p->Ba, p->Vt, p->A, p->T, p->n_diff, di, p->out, p->out_da);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_interpolate_bwd(const fpcdr_interpolate_bwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->attr && p->rast && p->tri && p->dy && p->grad_rast, "null pointer");
+    FPCDR_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->Vt > 0 && p->A > 0 && p->T > 0, "sizes must be positive");
+    FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
+    FPCDR_REQUIRE(p->Ba == 1 || p->Ba == p->B, "attr batch must be 1 or B");
+    FPCDR_REQUIRE(p->n_diff >= 0 && p->n_diff <= FPCDR_MAX_ATTR, "n_diff out of range");
+    FPCDR_REQUIRE(p->n_diff == 0 || (p->rast_db && p->dda && p->grad_rast_db), "differentials need rast_db, dda, grad_rast_db");
+    DiffIdx di;
+    for (int j = 0; j < FPCDR_MAX_ATTR; ++j) di.v[j] = j < p->n_diff ? p->diff_idx[j] : 0;
+    for (int j = 0; j < p->n_diff; ++j) FPCDR_REQUIRE(di.v[j] >= 0 && di.v[j] < p->A, "diff_idx out of range");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
+    dim3 grid_rows(fpcdr_cdiv(p->W, 256), p->H, p->B);
+    if (p->grad_attr)
+        hipLaunchKernelGGL(k_interp_bwd<true>, grid, dim3(256), 0, st, p->attr, (const float4 *)p->rast, p->tri,
+                           (const float4 *)p->rast_db, p->dy, p->dda, p->B, p->H, p->W, p->Ba, p->Vt, p->A, p->T, p->n_diff, di,
+                           p->grad_attr, (float4 *)p->grad_rast, (float4 *)p->grad_rast_db);
+    else
+        hipLaunchKernelGGL(k_interp_bwd<false>, grid_rows, dim3(256), 0, st, p->attr, (const float4 *)p->rast, p->tri,
+                           (const float4 *)p->rast_db, p->dy, p->dda, p->B, p->H, p->W, p->Ba, p->Vt, p->A, p->T, p->n_diff, di,
+                           p->grad_attr, (float4 *)p->grad_rast, (float4 *)p->grad_rast_db);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}

@@ -1,0 +1,475 @@
+// rasterize forward / backward for gfx950 (MI355X).
+//
+// Performs the work of `dr.rasterize(glctx, pos_clip, pos_idx, resolution)` at reference
+// src/torch/fit.py:151, which the reference delegates to nvdiffrast + the OpenGL hardware
+// rasteriser (context at fit.py:484).  MI355X exposes no graphics pipeline, so this is a complete
+// software pipeline designed for CDNA4:
+//
+//   k_setup   one thread per (image, triangle): clip -> 24.8 fixed point (double arithmetic, rules
+//             R1-R3 of DESIGN.md), writes a 48-byte record + an 8-byte pixel bounding box, and folds
+//             the image-wide bounding box with integer atomics.
+//   k_bins    one 256-thread workgroup per 64x64-pixel bin.  The bin scans the image's bounding
+//             boxes (8 B per triangle, L2 resident), keeps the overlapping triangles IN ORDER in
+//             LDS, 256 at a time, expands them to edge equations in LDS and marks which of the bin's
+//             64 8x8 tiles each one touches (bit masks in LDS).  Each wave owns 16 tiles, one pixel
+//             per lane: coverage by exact int64 edge functions, depth in double, winner kept in
+//             registers -- no global atomics, no per-pixel depth buffer in HBM, and the result does
+//             not depend on scheduling (ascending triangle order + strict "<").  The same wave then
+//             shades its pixels (perspective-correct barycentrics and their screen-space derivatives
+//             in f32) and writes rast / rast_db exactly once, 128-byte row segments per tile row.
+//   k_grad    one thread per pixel: recomputes the shading terms, chains (dL/du, dL/dv, dL/d db) to
+//             the three clip-space vertices and scatters with wave-level pre-reduction by vertex.
+//
+// Arithmetic that decides integer outputs uses only + - * / floor on IEEE doubles / int64 and is
+// compiled with -ffp-contract=off, so it agrees bit for bit with oracle/raster_ref.c.
+#include "common.h"
+
+namespace {
+
+constexpr int SUBPIX = 256;
+constexpr int HALFPIX = 128;
+constexpr double GUARD = 16777216.0;  // 2^24
+
+constexpr int BIN = 64;          // pixels per bin side
+constexpr int TILE = 8;          // pixels per tile side (one wave = one tile = 64 lanes)
+constexpr int TILES_X = BIN / TILE;
+constexpr int NTILES = TILES_X * TILES_X;   // 64 tiles per bin
+constexpr int BATCH = 256;       // triangles expanded in LDS at a time (= block size)
+constexpr int TILES_PER_WAVE = NTILES / 4;  // 16
+
+struct __attribute__((aligned(16))) TriRec {  // 48 bytes
+    int32_t X0, Y0, X1, Y1, X2, Y2;
+    double q0, q1, q2;
+};
+struct __attribute__((aligned(8))) TriBox {  // inclusive pixel bbox; x0 > x1 = dropped
+    int16_t x0, y0, x1, y1;
+};
+struct ImgBox { int32_t x0, y0, x1, y1; };  // folded with atomicMin/atomicMax
+
+struct __attribute__((aligned(16))) EdgeRec {  // LDS, 80 bytes
+    int32_t A0, B0, A1, B1, A2, B2;
+    int32_t nb;       // bit e set: edge e does NOT own ties (E == 0 is outside)
+    int32_t id;       // triangle index
+    long long C0, C1, C2;   // biased: C - nb_e
+    double q0, q1, q2;
+};
+
+__device__ __forceinline__ long long floordiv256(long long a) { return a >> 8; }  // arithmetic shift = floor
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                int B, int V, int T, int H, int W, TriRec *__restrict__ recs,
+                                                TriBox *__restrict__ boxes, ImgBox *__restrict__ ibox) {
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * T) return;
+    int b = (int)(gid / T), t = (int)(gid - (long long)b * T);
+    TriBox box = {1, 1, 0, 0};
+    int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+    bool ok = !(i0 < 0 || i0 >= V || i1 < 0 || i1 >= V || i2 < 0 || i2 >= V);
+    long long X[3], Y[3];
+    double zw[3];
+    if (ok) {
+        const float4 *p = pos + (size_t)b * V;
+        float4 v[3] = {p[i0], p[i1], p[i2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float w = v[i].w;
+            if (!(w > 0.0f)) { ok = false; }
+            double dw = (double)(ok ? w : 1.0f);
+            double xs = (double)v[i].x / dw;
+            double ys = (double)v[i].y / dw;
+            double fx = floor((xs * 0.5 + 0.5) * (double)(W * SUBPIX) + 0.5);
+            double fy = floor((ys * 0.5 + 0.5) * (double)(H * SUBPIX) + 0.5);
+            if (!(fabs(fx) <= GUARD) || !(fabs(fy) <= GUARD)) { ok = false; fx = 0.0; fy = 0.0; }
+            X[i] = (long long)fx;
+            Y[i] = (long long)fy;
+            zw[i] = (double)v[i].z / dw;
+        }
+    }
+    if (ok) {
+        long long D = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
+        if (D == 0) ok = false;
+        if (ok) {
+            double Dd = (double)(D > 0 ? D : -D);
+            long long xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
+            long long ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
+            long long px0 = floordiv256(xmin - HALFPIX + SUBPIX - 1), px1 = floordiv256(xmax - HALFPIX);
+            long long py0 = floordiv256(ymin - HALFPIX + SUBPIX - 1), py1 = floordiv256(ymax - HALFPIX);
+            px0 = max(px0, 0ll); py0 = max(py0, 0ll);
+            px1 = min(px1, (long long)W - 1); py1 = min(py1, (long long)H - 1);
+            if (px0 > px1 || py0 > py1) ok = false;
+            if (ok) {
+                box = {(int16_t)px0, (int16_t)py0, (int16_t)px1, (int16_t)py1};
+                TriRec r;
+                r.X0 = (int32_t)X[0]; r.Y0 = (int32_t)Y[0];
+                r.X1 = (int32_t)X[1]; r.Y1 = (int32_t)Y[1];
+                r.X2 = (int32_t)X[2]; r.Y2 = (int32_t)Y[2];
+                r.q0 = zw[0] / Dd; r.q1 = zw[1] / Dd; r.q2 = zw[2] / Dd;
+                recs[gid] = r;
+                atomicMin(&ibox[b].x0, (int)px0); atomicMin(&ibox[b].y0, (int)py0);
+                atomicMax(&ibox[b].x1, (int)px1); atomicMax(&ibox[b].y1, (int)py1);
+            }
+        }
+    }
+    boxes[gid] = box;
+}
+
+__global__ void k_init_ibox(ImgBox *ibox, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) ibox[i] = {0x7fffffff, 0x7fffffff, -1, -1};
+}
+
+// ---------------------------------------------------------------------------------------------
+// f32 shading of one pixel: perspective-correct barycentrics of vertices 0,1, z/w and (optionally)
+// the screen-space derivatives.  fx,fy = pixel centre in NDC.
+struct Shade { float u, v, zw, dudx, dudy, dvdx, dvdy; };
+
+__device__ __forceinline__ Shade shade_pixel(float4 v0, float4 v1, float4 v2, float fx, float fy, float sx, float sy) {
+    float p0x = v0.x - fx * v0.w, p0y = v0.y - fy * v0.w;
+    float p1x = v1.x - fx * v1.w, p1y = v1.y - fy * v1.w;
+    float p2x = v2.x - fx * v2.w, p2y = v2.y - fy * v2.w;
+    float a0 = p1x * p2y - p1y * p2x;
+    float a1 = p2x * p0y - p2y * p0x;
+    float a2 = p0x * p1y - p0y * p1x;
+    float at = a0 + a1 + a2;
+    float iw = 1.0f / at;
+    float b0 = a0 * iw, b1 = a1 * iw;
+    Shade s;
+    float zw = (a0 * v0.z + a1 * v1.z + a2 * v2.z) / (a0 * v0.w + a1 * v1.w + a2 * v2.w);
+    s.zw = fminf(fmaxf(zw, -1.0f), 1.0f);
+    float da0x = v2.w * p1y - v1.w * p2y, da0y = v1.w * p2x - v2.w * p1x;
+    float da1x = v0.w * p2y - v2.w * p0y, da1y = v2.w * p0x - v0.w * p2x;
+    float da2x = v1.w * p0y - v0.w * p1y, da2y = v0.w * p1x - v1.w * p0x;
+    float datx = da0x + da1x + da2x, daty = da0y + da1y + da2y;
+    s.dudx = (da0x - b0 * datx) * iw * sx;
+    s.dudy = (da0y - b0 * daty) * iw * sy;
+    s.dvdx = (da1x - b1 * datx) * iw * sx;
+    s.dvdy = (da1y - b1 * daty) * iw * sy;
+    float uc = fminf(fmaxf(b0, 0.0f), 1.0f), vc = fminf(fmaxf(b1, 0.0f), 1.0f);
+    float sc = 1.0f / fmaxf(uc + vc, 1.0f);
+    s.u = uc * sc;
+    s.v = vc * sc;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <bool WRITE_DB>
+__global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                              int V, int T, int H, int W, const TriRec *__restrict__ recs,
+                                              const TriBox *__restrict__ boxes, const ImgBox *__restrict__ ibox,
+                                              float4 *__restrict__ rast, float4 *__restrict__ rast_db) {
+    __shared__ EdgeRec s_tri[BATCH];
+    __shared__ unsigned long long s_mask[NTILES][BATCH / 64];
+    __shared__ int s_list[2 * BATCH];   // pending triangle indices (ascending); first BATCH = current batch
+    __shared__ int s_wave_cnt[2][4];
+
+    const int b = blockIdx.z;
+    const int bin_x0 = blockIdx.x * BIN, bin_y0 = blockIdx.y * BIN;
+    const int bin_x1 = min(bin_x0 + BIN, W) - 1, bin_y1 = min(bin_y0 + BIN, H) - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lx = lane & 7, ly = lane >> 3;
+
+    double best_d[TILES_PER_WAVE];
+    int best_id[TILES_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < TILES_PER_WAVE; ++k) { best_d[k] = 2.0; best_id[k] = -1; }
+
+    const ImgBox ib = ibox[b];
+    const bool bin_live = !(ib.x1 < bin_x0 || ib.x0 > bin_x1 || ib.y1 < bin_y0 || ib.y0 > bin_y1);
+
+    if (bin_live) {
+        for (int k = tid; k < NTILES * (BATCH / 64); k += 256) (&s_mask[0][0])[k] = 0ull;
+        const TriBox *bx = boxes + (size_t)b * T;
+        const TriRec *rc = recs + (size_t)b * T;
+        const int n_chunks = (T + 255) / 256;
+        int pending = 0;  // block-uniform: entries waiting in s_list
+        for (int chunk = 0; chunk <= n_chunks; ++chunk) {
+            const bool last = (chunk == n_chunks);
+            // ---- scan 256 bounding boxes, append hits in ascending order ----
+            if (!last) {
+                const int t = chunk * 256 + tid;
+                bool hit = false;
+                if (t < T) {
+                    const TriBox q = bx[t];
+                    hit = (q.x0 <= q.x1) && !(q.x1 < bin_x0 || q.x0 > bin_x1 || q.y1 < bin_y0 || q.y0 > bin_y1);
+                }
+                const unsigned long long bal = __ballot(hit);
+                int *cnt = s_wave_cnt[chunk & 1];
+                if (lane == 0) cnt[wave] = __popcll(bal);
+                __syncthreads();
+                const int c0 = cnt[0], c1 = cnt[1], c2 = cnt[2], c3 = cnt[3];
+                const int base = pending + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+                if (hit) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = t;
+                pending += c0 + c1 + c2 + c3;
+            }
+            // ---- process a batch when full (or flush at the end) ----
+            while (pending >= BATCH || (last && pending > 0)) {
+                const int n = min(pending, BATCH);
+                __syncthreads();  // s_list entries and cleared masks are visible
+                // expand triangle `tid` of the batch into edge equations and mark its tiles
+                if (tid < n) {
+                    const int t = s_list[tid];
+                    const TriRec r = rc[t];
+                    long long X0 = r.X0, Y0 = r.Y0, X1 = r.X1, Y1 = r.Y1, X2 = r.X2, Y2 = r.Y2;
+                    long long D = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
+                    long long s = D > 0 ? 1 : -1;
+                    EdgeRec e;
+                    long long A, Bc;
+                    int nb = 0;
+                    // edge 0: (1,2)  edge 1: (2,0)  edge 2: (0,1)
+                    A = -(Y2 - Y1) * s; Bc = (X2 - X1) * s;
+                    e.A0 = (int32_t)A; e.B0 = (int32_t)Bc;
+                    { bool own = (-A > 0) || (A == 0 && Bc < 0); nb |= own ? 0 : 1; e.C0 = -(A * X1 + Bc * Y1) - (own ? 0 : 1); }
+                    A = -(Y0 - Y2) * s; Bc = (X0 - X2) * s;
+                    e.A1 = (int32_t)A; e.B1 = (int32_t)Bc;
+                    { bool own = (-A > 0) || (A == 0 && Bc < 0); nb |= own ? 0 : 2; e.C1 = -(A * X2 + Bc * Y2) - (own ? 0 : 1); }
+                    A = -(Y1 - Y0) * s; Bc = (X1 - X0) * s;
+                    e.A2 = (int32_t)A; e.B2 = (int32_t)Bc;
+                    { bool own = (-A > 0) || (A == 0 && Bc < 0); nb |= own ? 0 : 4; e.C2 = -(A * X0 + Bc * Y0) - (own ? 0 : 1); }
+                    e.nb = nb; e.id = t;
+                    e.q0 = r.q0; e.q1 = r.q1; e.q2 = r.q2;
+                    s_tri[tid] = e;
+                    const TriBox q = bx[t];
+                    int tx0 = (max((int)q.x0, bin_x0) - bin_x0) >> 3, tx1 = (min((int)q.x1, bin_x1) - bin_x0) >> 3;
+                    int ty0 = (max((int)q.y0, bin_y0) - bin_y0) >> 3, ty1 = (min((int)q.y1, bin_y1) - bin_y0) >> 3;
+                    unsigned long long bit = 1ull << (tid & 63);
+                    for (int ty = ty0; ty <= ty1; ++ty)
+                        for (int tx = tx0; tx <= tx1; ++tx) atomicOr(&s_mask[ty * TILES_X + tx][tid >> 6], bit);
+                }
+                __syncthreads();
+                // ---- fine raster: this wave's 16 tiles, one pixel per lane ----
+#pragma unroll
+                for (int k = 0; k < TILES_PER_WAVE; ++k) {
+                    const int tile = wave * TILES_PER_WAVE + k;
+                    const int px = bin_x0 + (tile & 7) * TILE + lx, py = bin_y0 + (tile >> 3) * TILE + ly;
+                    const int Px = px * SUBPIX + HALFPIX, Py = py * SUBPIX + HALFPIX;
+                    double bd = best_d[k];
+                    int bi = best_id[k];
+                    for (int wd = 0; wd < BATCH / 64; ++wd) {
+                        unsigned long long m = s_mask[tile][wd];
+                        unsigned int mlo = __builtin_amdgcn_readfirstlane((unsigned int)m);
+                        unsigned int mhi = __builtin_amdgcn_readfirstlane((unsigned int)(m >> 32));
+                        m = ((unsigned long long)mhi << 32) | mlo;
+                        while (m) {
+                            const int j = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const EdgeRec &e = s_tri[wd * 64 + j];
+                            long long E0 = (long long)e.A0 * Px + ((long long)e.B0 * Py + e.C0);
+                            long long E1 = (long long)e.A1 * Px + ((long long)e.B1 * Py + e.C1);
+                            long long E2 = (long long)e.A2 * Px + ((long long)e.B2 * Py + e.C2);
+                            if ((E0 | E1 | E2) >= 0) {
+                                const int nb = e.nb;
+                                E0 += (nb & 1); E1 += ((nb >> 1) & 1); E2 += ((nb >> 2) & 1);
+                                double d = ((double)E0 * e.q0 + (double)E1 * e.q1) + (double)E2 * e.q2;
+                                if (d >= -1.0 && d <= 1.0 && d < bd) { bd = d; bi = e.id; }
+                            }
+                        }
+                    }
+                    best_d[k] = bd;
+                    best_id[k] = bi;
+                }
+                __syncthreads();
+                // ---- retire the batch: shift the remaining pending entries down, clear masks ----
+                const int rest = pending - n;
+                int moved = (tid < rest) ? s_list[n + tid] : 0;
+                for (int k = tid; k < NTILES * (BATCH / 64); k += 256) (&s_mask[0][0])[k] = 0ull;
+                __syncthreads();
+                if (tid < rest) s_list[tid] = moved;
+                pending = rest;
+            }
+        }
+    }
+
+    // ---- shade + write (every pixel of the bin is written exactly once) ----
+    const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
+    const float4 *p = pos + (size_t)b * V;
+#pragma unroll
+    for (int k = 0; k < TILES_PER_WAVE; ++k) {
+        const int tile = wave * TILES_PER_WAVE + k;
+        const int px = bin_x0 + (tile & 7) * TILE + lx, py = bin_y0 + (tile >> 3) * TILE + ly;
+        if (px >= W || py >= H) continue;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int t = best_id[k];
+        if (t >= 0) {
+            const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+            const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
+            const float fy = (2.0f * (float)py + 1.0f) / (float)H - 1.0f;
+            Shade s = shade_pixel(p[i0], p[i1], p[i2], fx, fy, sx, sy);
+            o = make_float4(s.u, s.v, s.zw, (float)(t + 1));
+            d = make_float4(s.dudx, s.dudy, s.dvdx, s.dvdy);
+        }
+        const size_t off = ((size_t)b * H + py) * W + px;
+        rast[off] = o;
+        if (WRITE_DB) rast_db[off] = d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_DDB>
+__global__ void __launch_bounds__(256) k_grad(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                              const float4 *__restrict__ rast, const float4 *__restrict__ dy,
+                                              const float4 *__restrict__ ddb, int B, int V, int T, int H, int W,
+                                              float *__restrict__ grad_pos) {
+    // block = 8 x 8 pixel tile per wave (4 waves = 16 x 16) so that lanes of a wave share triangles
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int b = blockIdx.z;
+    int key0 = -1, key1 = -1, key2 = -1;
+    float g0[3] = {0, 0, 0}, g1[3] = {0, 0, 0}, g2[3] = {0, 0, 0};  // (x, y, w) per vertex
+    if (px < W && py < H) {
+        const size_t off = ((size_t)b * H + py) * W + px;
+        const float4 r = rast[off];
+        const int t = (int)r.w - 1;
+        if (t >= 0 && t < T) {
+            const float4 g = dy[off];
+            float4 gd = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (HAS_DDB) gd = ddb[off];
+            if (g.x != 0.f || g.y != 0.f || gd.x != 0.f || gd.y != 0.f || gd.z != 0.f || gd.w != 0.f) {
+                const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+                const float4 *p = pos + (size_t)b * V;
+                const float4 v0 = p[i0], v1 = p[i1], v2 = p[i2];
+                const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
+                const float fy = (2.0f * (float)py + 1.0f) / (float)H - 1.0f;
+                const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
+                // ---- forward recompute ----
+                const float w0 = v0.w, w1 = v1.w, w2 = v2.w;
+                const float p0x = v0.x - fx * w0, p0y = v0.y - fy * w0;
+                const float p1x = v1.x - fx * w1, p1y = v1.y - fy * w1;
+                const float p2x = v2.x - fx * w2, p2y = v2.y - fy * w2;
+                const float a0 = p1x * p2y - p1y * p2x;
+                const float a1 = p2x * p0y - p2y * p0x;
+                const float a2 = p0x * p1y - p0y * p1x;
+                const float at = a0 + a1 + a2;
+                const float iw = 1.0f / at;
+                const float b0 = a0 * iw, b1 = a1 * iw;
+                // ---- undo clamp / renormalise:  u = uc * s, v = vc * s, s = 1 / max(uc + vc, 1) ----
+                const float uc = fminf(fmaxf(b0, 0.0f), 1.0f), vc = fminf(fmaxf(b1, 0.0f), 1.0f);
+                float guc = g.x, gvc = g.y;
+                const float sum = uc + vc;
+                if (sum > 1.0f) {
+                    const float s = 1.0f / sum;
+                    const float dot = (uc * g.x + vc * g.y) * s * s;
+                    guc = g.x * s - dot;
+                    gvc = g.y * s - dot;
+                }
+                float gb0 = (b0 >= 0.0f && b0 <= 1.0f) ? guc : 0.0f;
+                float gb1 = (b1 >= 0.0f && b1 <= 1.0f) ? gvc : 0.0f;
+                // ---- reverse through the derivative outputs ----
+                float ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, giw = 0.f;
+                float gp0x = 0.f, gp0y = 0.f, gp1x = 0.f, gp1y = 0.f, gp2x = 0.f, gp2y = 0.f;
+                float gw0 = 0.f, gw1 = 0.f, gw2 = 0.f;
+                if (HAS_DDB) {
+                    const float da0x = w2 * p1y - w1 * p2y, da0y = w1 * p2x - w2 * p1x;
+                    const float da1x = w0 * p2y - w2 * p0y, da1y = w2 * p0x - w0 * p2x;
+                    const float da2x = w1 * p0y - w0 * p1y, da2y = w0 * p1x - w1 * p0x;
+                    const float datx = da0x + da1x + da2x, daty = da0y + da1y + da2y;
+                    const float hx0 = gd.x * sx, hy0 = gd.y * sy, hx1 = gd.z * sx, hy1 = gd.w * sy;
+                    // dudx = n0x * iw * sx,  n0x = da0x - b0 * datx   (same for the other three)
+                    const float n0x = da0x - b0 * datx, n0y = da0y - b0 * daty;
+                    const float n1x = da1x - b1 * datx, n1y = da1y - b1 * daty;
+                    giw += hx0 * n0x + hy0 * n0y + hx1 * n1x + hy1 * n1y;
+                    const float gn0x = hx0 * iw, gn0y = hy0 * iw, gn1x = hx1 * iw, gn1y = hy1 * iw;
+                    gb0 -= gn0x * datx + gn0y * daty;
+                    gb1 -= gn1x * datx + gn1y * daty;
+                    const float gdatx = -(gn0x * b0 + gn1x * b1), gdaty = -(gn0y * b0 + gn1y * b1);
+                    const float gda0x = gn0x + gdatx, gda0y = gn0y + gdaty;
+                    const float gda1x = gn1x + gdatx, gda1y = gn1y + gdaty;
+                    const float gda2x = gdatx, gda2y = gdaty;
+                    // da0x = w2*p1y - w1*p2y ; da0y = w1*p2x - w2*p1x
+                    gw2 += gda0x * p1y; gp1y += gda0x * w2; gw1 -= gda0x * p2y; gp2y -= gda0x * w1;
+                    gw1 += gda0y * p2x; gp2x += gda0y * w1; gw2 -= gda0y * p1x; gp1x -= gda0y * w2;
+                    // da1x = w0*p2y - w2*p0y ; da1y = w2*p0x - w0*p2x
+                    gw0 += gda1x * p2y; gp2y += gda1x * w0; gw2 -= gda1x * p0y; gp0y -= gda1x * w2;
+                    gw2 += gda1y * p0x; gp0x += gda1y * w2; gw0 -= gda1y * p2x; gp2x -= gda1y * w0;
+                    // da2x = w1*p0y - w0*p1y ; da2y = w0*p1x - w1*p0x
+                    gw1 += gda2x * p0y; gp0y += gda2x * w1; gw0 -= gda2x * p1y; gp1y -= gda2x * w0;
+                    gw0 += gda2y * p1x; gp1x += gda2y * w0; gw1 -= gda2y * p0x; gp0x -= gda2y * w1;
+                }
+                // b0 = a0 * iw ; b1 = a1 * iw
+                ga0 += gb0 * iw; ga1 += gb1 * iw;
+                giw += gb0 * a0 + gb1 * a1;
+                // iw = 1 / at ; at = a0 + a1 + a2
+                const float gat = -giw * iw * iw;
+                ga0 += gat; ga1 += gat; ga2 += gat;
+                // a0 = p1x*p2y - p1y*p2x ; a1 = p2x*p0y - p2y*p0x ; a2 = p0x*p1y - p0y*p1x
+                gp1x += ga0 * p2y; gp2y += ga0 * p1x; gp1y -= ga0 * p2x; gp2x -= ga0 * p1y;
+                gp2x += ga1 * p0y; gp0y += ga1 * p2x; gp2y -= ga1 * p0x; gp0x -= ga1 * p2y;
+                gp0x += ga2 * p1y; gp1y += ga2 * p0x; gp0y -= ga2 * p1x; gp1x -= ga2 * p0y;
+                // p_kx = x_k - fx * w_k ; p_ky = y_k - fy * w_k
+                g0[0] = gp0x; g0[1] = gp0y; g0[2] = gw0 - fx * gp0x - fy * gp0y;
+                g1[0] = gp1x; g1[1] = gp1y; g1[2] = gw1 - fx * gp1x - fy * gp1y;
+                g2[0] = gp2x; g2[1] = gp2y; g2[2] = gw2 - fx * gp2x - fy * gp2y;
+                key0 = i0; key1 = i1; key2 = i2;
+            }
+        }
+    }
+    // wave-uniform early out (most waves of an image see no gradient at all)
+    if (__ballot(key0 >= 0) == 0ull) return;
+    float *gp = grad_pos + (size_t)b * V * 4;
+    {
+        float *const d[3] = {gp + 4 * (size_t)max(key0, 0), gp + 4 * (size_t)max(key0, 0) + 1, gp + 4 * (size_t)max(key0, 0) + 3};
+        wave_group_atomic_add<3>(key0, d, g0);
+    }
+    {
+        float *const d[3] = {gp + 4 * (size_t)max(key1, 0), gp + 4 * (size_t)max(key1, 0) + 1, gp + 4 * (size_t)max(key1, 0) + 3};
+        wave_group_atomic_add<3>(key1, d, g1);
+    }
+    {
+        float *const d[3] = {gp + 4 * (size_t)max(key2, 0), gp + 4 * (size_t)max(key2, 0) + 1, gp + 4 * (size_t)max(key2, 0) + 3};
+        wave_group_atomic_add<3>(key2, d, g2);
+    }
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" size_t fpcdr_rasterize_scratch_bytes(int32_t B, int32_t T) {
+    if (B <= 0 || T <= 0) return 0;
+    size_t n = (size_t)B * (size_t)T;
+    return align_up(n * sizeof(TriRec), 256) + align_up(n * sizeof(TriBox), 256) + align_up((size_t)B * sizeof(ImgBox), 256);
+}
+
+extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->pos && p->tri && p->scratch && p->rast, "null pointer");
+    FPCDR_REQUIRE(p->B > 0 && p->V > 0 && p->T > 0 && p->H > 0 && p->W > 0, "sizes must be positive");
+    FPCDR_REQUIRE(p->H <= 32767 && p->W <= 32767, "resolution above 32767 is not supported");
+    FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
+    hipStream_t st = (hipStream_t)stream;
+    size_t n = (size_t)p->B * p->T;
+    char *s = (char *)p->scratch;
+    TriRec *recs = (TriRec *)s;
+    TriBox *boxes = (TriBox *)(s + align_up(n * sizeof(TriRec), 256));
+    ImgBox *ibox = (ImgBox *)((char *)boxes + align_up(n * sizeof(TriBox), 256));
+    hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
+    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv((long long)n, 256)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, ibox);
+    dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
+    if (p->rast_db)
+        hipLaunchKernelGGL(k_bins<true>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
+                           recs, boxes, ibox, (float4 *)p->rast, (float4 *)p->rast_db);
+    else
+        hipLaunchKernelGGL(k_bins<false>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
+                           recs, boxes, ibox, (float4 *)p->rast, (float4 *)nullptr);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_rasterize_bwd(const fpcdr_rasterize_bwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->pos && p->tri && p->rast && p->dy && p->grad_pos, "null pointer");
+    FPCDR_REQUIRE(p->B > 0 && p->V > 0 && p->T > 0 && p->H > 0 && p->W > 0, "sizes must be positive");
+    FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
+    if (p->ddb)
+        hipLaunchKernelGGL(k_grad<true>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, (const float4 *)p->rast,
+                           (const float4 *)p->dy, (const float4 *)p->ddb, p->B, p->V, p->T, p->H, p->W, p->grad_pos);
+    else
+        hipLaunchKernelGGL(k_grad<false>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, (const float4 *)p->rast,
+                           (const float4 *)p->dy, (const float4 *)nullptr, p->B, p->V, p->T, p->H, p->W, p->grad_pos);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}

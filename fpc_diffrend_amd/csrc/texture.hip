@@ -1,0 +1,342 @@
+// texture forward / backward for gfx950 (MI355X).
+//
+// Performs the work of `dr.texture(tex[None], texc, filter_mode='linear')` (reference
+// src/torch/fit.py:158) and `dr.texture(tex[None], texc, texd, filter_mode='linear-mipmap-linear',
+// max_mip_level=n)` (fit.py:155); nvdiffrast op, absent from the reference tree.
+//
+// One pixel per lane.  The texture (reference: 1024 x 1024 x 1 = 4 MB, fit.py:439) and its mip chain
+// stay resident in L2 / Infinity Cache, so the forward pass streams uv in and colour out at HBM rate.
+// The backward pass is bounded by the f32 atomic rate into grad_tex, not by HBM: pixels whose
+// incoming gradient is exactly zero (every background pixel of the fit loop, since fit.py:161
+// overwrites them with a constant) issue no atomics at all.
+#include "common.h"
+
+namespace {
+
+struct TexLevels {
+    const float *tex[FPCDR_MAX_MIP + 1];
+    float *grad[FPCDR_MAX_MIP + 1];
+};
+
+__device__ __forceinline__ int wrap_i(int i, int n, int mode) {
+    if (mode == FPCDR_BOUNDARY_WRAP) {
+        int r = i % n;
+        return r < 0 ? r + n : r;
+    }
+    return min(max(i, 0), n - 1);
+}
+
+__device__ __forceinline__ float prep_coord(float u, int mode) {
+    if (mode == FPCDR_BOUNDARY_WRAP) return u - floorf(u);
+    return fminf(fmaxf(u, 0.0f), 1.0f);
+}
+
+struct Taps {
+    int i00, i10, i01, i11;  // element offsets (texel index * C) within one texture image
+    float fx, fy;
+};
+
+__device__ __forceinline__ Taps make_taps(float u, float v, int Ht, int Wt, int C, int mode) {
+    const float x = prep_coord(u, mode) * (float)Wt - 0.5f;
+    const float y = prep_coord(v, mode) * (float)Ht - 0.5f;
+    const float x0f = floorf(x), y0f = floorf(y);
+    Taps t;
+    t.fx = x - x0f;
+    t.fy = y - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int ix0 = wrap_i(x0, Wt, mode), ix1 = wrap_i(x0 + 1, Wt, mode);
+    const int iy0 = wrap_i(y0, Ht, mode), iy1 = wrap_i(y0 + 1, Ht, mode);
+    t.i00 = (iy0 * Wt + ix0) * C; t.i10 = (iy0 * Wt + ix1) * C;
+    t.i01 = (iy1 * Wt + ix0) * C; t.i11 = (iy1 * Wt + ix1) * C;
+    return t;
+}
+
+__device__ __forceinline__ float bilerp(const float *tx, const Taps &t, int c) {
+    const float t00 = tx[t.i00 + c], t10 = tx[t.i10 + c], t01 = tx[t.i01 + c], t11 = tx[t.i11 + c];
+    const float top = t00 + (t10 - t00) * t.fx;
+    const float bot = t01 + (t11 - t01) * t.fx;
+    return top + (bot - top) * t.fy;
+}
+
+// level of detail from the uv footprint; returns the unclamped level, outputs the pieces the backward needs
+struct Lod { float level, l2, rt, df, bq, dudx, dudy, dvdx, dvdy; };
+
+__device__ __forceinline__ Lod compute_lod(float4 d, int Ht, int Wt, float bias) {
+    Lod L;
+    L.dudx = d.x * (float)Wt; L.dudy = d.y * (float)Wt; L.dvdx = d.z * (float)Ht; L.dvdy = d.w * (float)Ht;
+    const float A = L.dudx * L.dudx + L.dudy * L.dudy;
+    const float Bq = L.dudx * L.dvdx + L.dudy * L.dvdy;
+    const float Cc = L.dvdx * L.dvdx + L.dvdy * L.dvdy;
+    const float tr = 0.5f * (A + Cc);
+    L.df = 0.5f * (A - Cc);
+    L.bq = Bq;
+    L.rt = sqrtf(L.df * L.df + Bq * Bq + 1e-30f);
+    L.l2 = tr + L.rt;
+    L.level = 0.5f * log2f(fmaxf(L.l2, 1e-30f)) + bias;
+    return L;
+}
+
+__global__ void __launch_bounds__(256) k_tex_fwd(TexLevels lv, int n_levels, const float2 *__restrict__ uv,
+                                                 const float4 *__restrict__ uv_da, const float *__restrict__ bias,
+                                                 long long npix_img, int B, int Bt, int Ht, int Wt, int C, int filter,
+                                                 int boundary, float *__restrict__ out) {
+    const long long total = npix_img * B;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float2 q = uv[i];
+        const int b = Bt > 1 ? (int)(i / npix_img) : 0;
+        float *o = out + i * C;
+        if (filter == FPCDR_FILTER_NEAREST) {
+            const float x = prep_coord(q.x, boundary) * (float)Wt - 0.5f, y = prep_coord(q.y, boundary) * (float)Ht - 0.5f;
+            const int ix = wrap_i((int)floorf(x + 0.5f), Wt, boundary), iy = wrap_i((int)floorf(y + 0.5f), Ht, boundary);
+            const float *tx = lv.tex[0] + (size_t)b * Ht * Wt * C + ((size_t)iy * Wt + ix) * C;
+            for (int c = 0; c < C; ++c) o[c] = tx[c];
+        } else if (filter == FPCDR_FILTER_LINEAR) {
+            const Taps t = make_taps(q.x, q.y, Ht, Wt, C, boundary);
+            const float *tx = lv.tex[0] + (size_t)b * Ht * Wt * C;
+            for (int c = 0; c < C; ++c) o[c] = bilerp(tx, t, c);
+        } else {
+            float level = bias ? bias[i] : 0.0f;
+            if (uv_da) level = compute_lod(uv_da[i], Ht, Wt, level).level;
+            level = fminf(fmaxf(level, 0.0f), (float)n_levels);
+            int l0;
+            float fl = 0.0f;
+            if (filter == FPCDR_FILTER_LINEAR_MIPMAP_NEAREST) {
+                l0 = min((int)floorf(level + 0.5f), n_levels);
+            } else {
+                l0 = min((int)floorf(level), n_levels);
+                fl = level - (float)l0;
+            }
+            const int h0 = Ht >> l0, w0 = Wt >> l0;
+            const Taps t0 = make_taps(q.x, q.y, h0, w0, C, boundary);
+            const float *tx0 = lv.tex[l0] + (size_t)b * h0 * w0 * C;
+            if (filter == FPCDR_FILTER_LINEAR_MIPMAP_NEAREST) {
+                for (int c = 0; c < C; ++c) o[c] = bilerp(tx0, t0, c);
+            } else {
+                const int l1 = min(l0 + 1, n_levels);
+                const int h1 = Ht >> l1, w1 = Wt >> l1;
+                const Taps t1 = make_taps(q.x, q.y, h1, w1, C, boundary);
+                const float *tx1 = lv.tex[l1] + (size_t)b * h1 * w1 * C;
+                for (int c = 0; c < C; ++c) {
+                    const float c0 = bilerp(tx0, t0, c), c1 = bilerp(tx1, t1, c);
+                    o[c] = c0 + (c1 - c0) * fl;
+                }
+            }
+        }
+    }
+}
+
+// scatter dy * weight into the four taps of one level and return (d out / d fx, d out / d fy) summed over channels
+__device__ __forceinline__ void taps_bwd(const float *tx, float *gtx, const Taps &t, const float *g, float scale, int C,
+                                         float &gfx, float &gfy) {
+    const float w00 = (1.0f - t.fx) * (1.0f - t.fy), w10 = t.fx * (1.0f - t.fy), w01 = (1.0f - t.fx) * t.fy, w11 = t.fx * t.fy;
+    for (int c = 0; c < C; ++c) {
+        const float gc = g[c] * scale;
+        const float t00 = tx[t.i00 + c], t10 = tx[t.i10 + c], t01 = tx[t.i01 + c], t11 = tx[t.i11 + c];
+        gfx += gc * ((t10 - t00) * (1.0f - t.fy) + (t11 - t01) * t.fy);
+        gfy += gc * ((t01 + (t11 - t01) * t.fx) - (t00 + (t10 - t00) * t.fx));
+        if (gtx && gc != 0.0f) {
+            atomicAdd(gtx + t.i00 + c, gc * w00);
+            atomicAdd(gtx + t.i10 + c, gc * w10);
+            atomicAdd(gtx + t.i01 + c, gc * w01);
+            atomicAdd(gtx + t.i11 + c, gc * w11);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tex_bwd(TexLevels lv, int n_levels, const float2 *__restrict__ uv,
+                                                 const float4 *__restrict__ uv_da, const float *__restrict__ bias,
+                                                 const float *__restrict__ dy, long long npix_img, int B, int Bt, int Ht,
+                                                 int Wt, int C, int filter, int boundary, float2 *__restrict__ grad_uv,
+                                                 float4 *__restrict__ grad_uv_da, float *__restrict__ grad_bias) {
+    const long long total = npix_img * B;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float *g = dy + i * C;
+        bool any = false;
+        for (int c = 0; c < C; ++c) any |= (g[c] != 0.0f);
+        float2 guv = make_float2(0.f, 0.f);
+        float4 gda = make_float4(0.f, 0.f, 0.f, 0.f);
+        float gbias = 0.f;
+        if (any) {
+            const float2 q = uv[i];
+            const int b = Bt > 1 ? (int)(i / npix_img) : 0;
+            // clamp mode: no uv gradient outside [0,1] (torch.clamp semantics of the oracle)
+            const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(q.x >= 0.0f && q.x <= 1.0f)) ? 0.0f : 1.0f;
+            const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(q.y >= 0.0f && q.y <= 1.0f)) ? 0.0f : 1.0f;
+            if (filter == FPCDR_FILTER_NEAREST) {
+                if (lv.grad[0]) {
+                    const float x = prep_coord(q.x, boundary) * (float)Wt - 0.5f, y = prep_coord(q.y, boundary) * (float)Ht - 0.5f;
+                    const int ix = wrap_i((int)floorf(x + 0.5f), Wt, boundary), iy = wrap_i((int)floorf(y + 0.5f), Ht, boundary);
+                    float *gt = lv.grad[0] + (size_t)b * Ht * Wt * C + ((size_t)iy * Wt + ix) * C;
+                    for (int c = 0; c < C; ++c)
+                        if (g[c] != 0.0f) atomicAdd(gt + c, g[c]);
+                }
+            } else if (filter == FPCDR_FILTER_LINEAR) {
+                const Taps t = make_taps(q.x, q.y, Ht, Wt, C, boundary);
+                const size_t img = (size_t)b * Ht * Wt * C;
+                float gfx = 0.f, gfy = 0.f;
+                taps_bwd(lv.tex[0] + img, lv.grad[0] ? lv.grad[0] + img : nullptr, t, g, 1.0f, C, gfx, gfy);
+                guv = make_float2(gfx * (float)Wt * mu, gfy * (float)Ht * mv);
+            } else {
+                float raw = bias ? bias[i] : 0.0f;
+                Lod L;
+                if (uv_da) { L = compute_lod(uv_da[i], Ht, Wt, raw); raw = L.level; }
+                const float level = fminf(fmaxf(raw, 0.0f), (float)n_levels);
+                int l0;
+                float fl = 0.0f;
+                const bool trilinear = (filter == FPCDR_FILTER_LINEAR_MIPMAP_LINEAR);
+                if (!trilinear) {
+                    l0 = min((int)floorf(level + 0.5f), n_levels);
+                } else {
+                    l0 = min((int)floorf(level), n_levels);
+                    fl = level - (float)l0;
+                }
+                const int h0 = Ht >> l0, w0 = Wt >> l0;
+                const Taps t0 = make_taps(q.x, q.y, h0, w0, C, boundary);
+                const size_t img0 = (size_t)b * h0 * w0 * C;
+                float gfx = 0.f, gfy = 0.f;
+                taps_bwd(lv.tex[l0] + img0, lv.grad[l0] ? lv.grad[l0] + img0 : nullptr, t0, g, 1.0f - fl, C, gfx, gfy);
+                float gu = gfx * (float)w0, gv = gfy * (float)h0;
+                if (trilinear) {
+                    const int l1 = min(l0 + 1, n_levels);
+                    const int h1 = Ht >> l1, w1 = Wt >> l1;
+                    const Taps t1 = make_taps(q.x, q.y, h1, w1, C, boundary);
+                    const size_t img1 = (size_t)b * h1 * w1 * C;
+                    float gfx1 = 0.f, gfy1 = 0.f;
+                    taps_bwd(lv.tex[l1] + img1, lv.grad[l1] ? lv.grad[l1] + img1 : nullptr, t1, g, fl, C, gfx1, gfy1);
+                    gu += gfx1 * (float)w1;
+                    gv += gfy1 * (float)h1;
+                    // d out / d fl = sum_c g_c (c1 - c0);  level clamp passes gradient inside [0, n_levels]
+                    float gfl = 0.f;
+                    for (int c = 0; c < C; ++c) gfl += g[c] * (bilerp(lv.tex[l1] + img1, t1, c) - bilerp(lv.tex[l0] + img0, t0, c));
+                    const float glevel = (raw >= 0.0f && raw <= (float)n_levels) ? gfl : 0.0f;
+                    gbias = glevel;
+                    if (uv_da) {
+                        // level = 0.5 log2(max(l2, eps)) + bias ; l2 = tr + rt ; rt = sqrt(df^2 + bq^2 + eps)
+                        const float gl2 = (L.l2 >= 1e-30f) ? glevel * 0.5f / (L.l2 * 0.6931471805599453f) : 0.0f;
+                        const float gdf = gl2 * L.df / L.rt, gbq = gl2 * L.bq / L.rt;
+                        const float gA = 0.5f * gl2 + 0.5f * gdf, gC = 0.5f * gl2 - 0.5f * gdf;
+                        const float g_dudx = 2.0f * L.dudx * gA + L.dvdx * gbq;
+                        const float g_dudy = 2.0f * L.dudy * gA + L.dvdy * gbq;
+                        const float g_dvdx = 2.0f * L.dvdx * gC + L.dudx * gbq;
+                        const float g_dvdy = 2.0f * L.dvdy * gC + L.dudy * gbq;
+                        gda = make_float4(g_dudx * (float)Wt, g_dudy * (float)Wt, g_dvdx * (float)Ht, g_dvdy * (float)Ht);
+                    }
+                }
+                guv = make_float2(gu * mu, gv * mv);
+            }
+        }
+        if (grad_uv) grad_uv[i] = guv;
+        if (grad_uv_da) grad_uv_da[i] = gda;
+        if (grad_bias) grad_bias[i] = gbias;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mip_down(const float *__restrict__ src, float *__restrict__ dst, int N, int Ht,
+                                                  int Wt, int C) {
+    const int ho = Ht / 2, wo = Wt / 2;
+    const long long total = (long long)N * ho * wo * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int x = (int)(r % wo); r /= wo;
+        const int y = (int)(r % ho);
+        const int n = (int)(r / ho);
+        const float *s = src + (((size_t)n * Ht + 2 * y) * Wt + 2 * x) * C + c;
+        dst[i] = (s[0] + s[C] + s[(size_t)Wt * C] + s[(size_t)Wt * C + C]) * 0.25f;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mip_down_bwd(const float *__restrict__ gdst, float *__restrict__ gsrc, int N, int Ht,
+                                                      int Wt, int C) {
+    const int ho = Ht / 2, wo = Wt / 2;
+    const long long total = (long long)N * Ht * Wt * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int x = (int)(r % Wt); r /= Wt;
+        const int y = (int)(r % Ht);
+        const int n = (int)(r / Ht);
+        gsrc[i] += 0.25f * gdst[(((size_t)n * ho + y / 2) * wo + x / 2) * C + c];
+    }
+}
+
+int grid_for(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+int check_common(int B, int H, int W, int Bt, int Ht, int Wt, int C, int n_levels, int filter, int boundary) {
+    if (!(B > 0 && H > 0 && W > 0 && Ht > 0 && Wt > 0 && C > 0)) return 1;
+    if (!(Bt == 1 || Bt == B)) return 2;
+    if (n_levels < 0 || n_levels > FPCDR_MAX_MIP) return 3;
+    if (filter < FPCDR_FILTER_NEAREST || filter > FPCDR_FILTER_LINEAR_MIPMAP_LINEAR) return 4;
+    if (boundary != FPCDR_BOUNDARY_WRAP && boundary != FPCDR_BOUNDARY_CLAMP) return 5;
+    if ((long long)Ht * Wt * C > 0x7fffffffLL) return 6;
+    for (int l = 0; l < n_levels; ++l)
+        if (((Ht >> l) & 1) || ((Wt >> l) & 1)) return 7;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int fpcdr_mip_downsample(const float *src, float *dst, int32_t N, int32_t Ht, int32_t Wt, int32_t C, void *stream) {
+    FPCDR_REQUIRE(src && dst, "null pointer");
+    FPCDR_REQUIRE(N > 0 && Ht >= 2 && Wt >= 2 && C > 0 && !(Ht & 1) && !(Wt & 1), "level must have even, positive size");
+    hipLaunchKernelGGL(k_mip_down, dim3(grid_for((long long)N * (Ht / 2) * (Wt / 2) * C)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, N, Ht, Wt, C);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_mip_downsample_bwd(const float *grad_dst, float *grad_src, int32_t N, int32_t Ht, int32_t Wt, int32_t C,
+                                        void *stream) {
+    FPCDR_REQUIRE(grad_dst && grad_src, "null pointer");
+    FPCDR_REQUIRE(N > 0 && Ht >= 2 && Wt >= 2 && C > 0 && !(Ht & 1) && !(Wt & 1), "level must have even, positive size");
+    hipLaunchKernelGGL(k_mip_down_bwd, dim3(grid_for((long long)N * Ht * Wt * C)), dim3(256), 0, (hipStream_t)stream, grad_dst,
+                       grad_src, N, Ht, Wt, C);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_texture_fwd(const fpcdr_texture_fwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->tex[0] && p->uv && p->out, "null pointer");
+    int rc = check_common(p->B, p->H, p->W, p->Bt, p->Ht, p->Wt, p->C, p->n_levels, p->filter_mode, p->boundary_mode);
+    FPCDR_REQUIRE(rc == 0, "bad sizes / modes");
+    const bool mip = p->filter_mode >= FPCDR_FILTER_LINEAR_MIPMAP_NEAREST;
+    FPCDR_REQUIRE(mip || p->n_levels == 0, "n_levels must be 0 for non-mip filters");
+    TexLevels lv;
+    for (int l = 0; l <= FPCDR_MAX_MIP; ++l) {
+        lv.tex[l] = l <= p->n_levels ? p->tex[l] : nullptr;
+        lv.grad[l] = nullptr;
+        if (l <= p->n_levels) FPCDR_REQUIRE(p->tex[l] != nullptr, "missing mip level");
+    }
+    const long long npix = (long long)p->H * p->W;
+    hipLaunchKernelGGL(k_tex_fwd, dim3(grid_for(npix * p->B)), dim3(256), 0, (hipStream_t)stream, lv, p->n_levels,
+                       (const float2 *)p->uv, mip ? (const float4 *)p->uv_da : nullptr, mip ? p->mip_level_bias : nullptr, npix,
+                       p->B, p->Bt, p->Ht, p->Wt, p->C, p->filter_mode, p->boundary_mode, p->out);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_texture_bwd(const fpcdr_texture_bwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->tex[0] && p->uv && p->dy, "null pointer");
+    int rc = check_common(p->B, p->H, p->W, p->Bt, p->Ht, p->Wt, p->C, p->n_levels, p->filter_mode, p->boundary_mode);
+    FPCDR_REQUIRE(rc == 0, "bad sizes / modes");
+    const bool mip = p->filter_mode >= FPCDR_FILTER_LINEAR_MIPMAP_NEAREST;
+    FPCDR_REQUIRE(mip || p->n_levels == 0, "n_levels must be 0 for non-mip filters");
+    TexLevels lv;
+    for (int l = 0; l <= FPCDR_MAX_MIP; ++l) {
+        lv.tex[l] = l <= p->n_levels ? p->tex[l] : nullptr;
+        lv.grad[l] = l <= p->n_levels ? p->grad_tex[l] : nullptr;
+        if (l <= p->n_levels) FPCDR_REQUIRE(p->tex[l] != nullptr, "missing mip level");
+    }
+    const long long npix = (long long)p->H * p->W;
+    hipLaunchKernelGGL(k_tex_bwd, dim3(grid_for(npix * p->B)), dim3(256), 0, (hipStream_t)stream, lv, p->n_levels,
+                       (const float2 *)p->uv, mip ? (const float4 *)p->uv_da : nullptr, mip ? p->mip_level_bias : nullptr, p->dy,
+                       npix, p->B, p->Bt, p->Ht, p->Wt, p->C, p->filter_mode, p->boundary_mode, (float2 *)p->grad_uv,
+                       mip ? (float4 *)p->grad_uv_da : nullptr, mip ? p->grad_mip_level_bias : nullptr);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}

@@ -1,0 +1,466 @@
+"""
+nvdiffrast-compatible operator API over the gfx950 HIP kernels (C ABI: include/fpcdr.h).
+
+The reference's fit loop calls exactly these names on `import nvdiffrast.torch as dr`
+(reference src/torch/fit.py:13):
+
+    dr.RasterizeGLContext(device='cuda')                                   fit.py:484
+    dr.rasterize(glctx, pos_clip, pos_idx, resolution=(H, W))              fit.py:151
+    dr.interpolate(uv[None], rast, uv_idx[, rast_db=..., diff_attrs='all']) fit.py:154, 157
+    dr.texture(tex[None], texc[, texd], filter_mode=..., max_mip_level=..) fit.py:155, 158
+    dr.antialias(colour, rast, pos_clip, pos_idx)                          fit.py:160
+
+so `import fpc_diffrend_amd.ops as dr` lets the reference's render() (fit.py:134-162) run
+unchanged.  Signatures, argument meaning, defaults and error behaviour follow nvdiffrast's
+documented API; arguments the reference never passes are accepted with upstream defaults.
+Only instanced mode (pos [B,V,4]) is implemented; range mode raises NotImplementedError.
+
+PyTorch is plumbing here: it owns the HBM buffers (including kernel scratch, so lifetimes follow
+autograd), supplies the stream, and runs autograd bookkeeping.  All pixel work happens in
+libfpcdr.so; there is no CPU or eager-torch fallback.
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+
+__all__ = ['RasterizeGLContext', 'RasterizeCudaContext', 'RasterizeHipContext', 'rasterize', 'interpolate', 'texture',
+           'texture_construct_mip', 'antialias', 'antialias_construct_topology_hash']
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _check_tensor(name, t, dtype, dims=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a GPU tensor (got device {t.device}); the raster ops have no CPU path")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must have dtype {dtype} (got {t.dtype})")
+    if dims is not None and t.dim() != dims:
+        raise ValueError(f"{name} must have {dims} dimensions (got shape {tuple(t.shape)})")
+
+
+# ----------------------------------------------------------------------------------------------
+# contexts
+# ----------------------------------------------------------------------------------------------
+
+class RasterizeHipContext:
+    """Rasteriser context.  Stateless on the device side (the library keeps no state between calls);
+    holds the device and whether rast_db is produced.  `RasterizeGLContext` / `RasterizeCudaContext`
+    are aliases so reference code constructing either keeps working (reference fit.py:484)."""
+
+    def __init__(self, output_db=True, mode='automatic', device=None):
+        assert output_db is True or output_db is False
+        assert mode in ('automatic', 'manual')
+        self.output_db = output_db
+        self.mode = mode
+        if device is None:
+            self.device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
+        else:
+            self.device = torch.device(device)
+            if self.device.type == 'cuda' and self.device.index is None and torch.cuda.is_available():
+                self.device = torch.device('cuda', torch.cuda.current_device())
+        _lib.load()  # fail loudly here if the HIP extension is missing
+
+    # nvdiffrast GL-context API surface (no-ops: there is no GL context to bind)
+    def set_context(self):
+        pass
+
+    def release_context(self):
+        pass
+
+
+RasterizeGLContext = RasterizeHipContext
+RasterizeCudaContext = RasterizeHipContext
+
+
+# ----------------------------------------------------------------------------------------------
+# rasterize
+# ----------------------------------------------------------------------------------------------
+
+class _rasterize_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, tri, H, W, output_db, grad_db):
+        lib = _lib.load()
+        B, V, _ = pos.shape
+        T = tri.shape[0]
+        dev = pos.device
+        rast = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
+        rast_db = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev) if output_db else None
+        scratch = torch.empty(lib.fpcdr_rasterize_scratch_bytes(B, T), dtype=torch.uint8, device=dev)
+        p = _lib.RasterizeFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch),
+                              rast=_ptr(rast), rast_db=_ptr(rast_db))
+        _lib.check(lib.fpcdr_rasterize_fwd(ctypes.byref(p), _stream()))
+        ctx.save_for_backward(pos, tri, rast)
+        ctx.grad_db = bool(grad_db and output_db)
+        if rast_db is None:
+            rast_db = torch.zeros(B, H, W, 0, dtype=torch.float32, device=dev)
+        return rast, rast_db
+
+    @staticmethod
+    def backward(ctx, dy, ddb):
+        lib = _lib.load()
+        pos, tri, rast = ctx.saved_tensors
+        B, V, _ = pos.shape
+        _, H, W, _ = rast.shape
+        g_pos = torch.zeros_like(pos)
+        dy = dy.contiguous()
+        ddb = ddb.contiguous() if (ctx.grad_db and ddb is not None and ddb.numel() > 0) else None
+        p = _lib.RasterizeBwd(pos=_ptr(pos), tri=_ptr(tri), rast=_ptr(rast), dy=_ptr(dy), ddb=_ptr(ddb), B=B, V=V,
+                              T=tri.shape[0], H=H, W=W, grad_pos=_ptr(g_pos))
+        _lib.check(lib.fpcdr_rasterize_bwd(ctypes.byref(p), _stream()))
+        return g_pos, None, None, None, None, None
+
+
+def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
+    """Rasterize triangles.  pos [B,V,4] clip space f32, tri [T,3] i32, resolution (H, W).
+
+    Returns (rast [B,H,W,4] = (u, v, z/w, triangle_id + 1), rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY)).
+    """
+    assert isinstance(glctx, RasterizeHipContext), "glctx must be a Rasterize*Context"
+    if ranges is not None or (isinstance(pos, torch.Tensor) and pos.dim() == 2):
+        raise NotImplementedError("range mode (pos [V,4] + ranges) is not implemented; use instanced mode pos [B,V,4]")
+    assert grad_db is True or grad_db is False
+    resolution = tuple(int(r) for r in resolution)
+    assert len(resolution) == 2 and resolution[0] > 0 and resolution[1] > 0, "resolution must be (height, width)"
+    _check_tensor('pos', pos, torch.float32, 3)
+    _check_tensor('tri', tri, torch.int32, 2)
+    if pos.shape[2] != 4 or pos.shape[0] < 1 or pos.shape[1] < 1:
+        raise ValueError(f"pos must have shape [>0, >0, 4] (got {tuple(pos.shape)})")
+    if tri.shape[1] != 3 or tri.shape[0] < 1:
+        raise ValueError(f"tri must have shape [>0, 3] (got {tuple(tri.shape)})")
+    if glctx.device is not None and pos.device != glctx.device:
+        raise ValueError(f"pos is on {pos.device} but the context was created for {glctx.device}")
+    return _rasterize_func.apply(pos.contiguous(), tri.contiguous(), resolution[0], resolution[1], glctx.output_db,
+                                 grad_db)
+
+
+# ----------------------------------------------------------------------------------------------
+# interpolate
+# ----------------------------------------------------------------------------------------------
+
+def _diff_array(diff_list):
+    arr = (ctypes.c_int32 * _lib.MAX_ATTR)()
+    for i, k in enumerate(diff_list):
+        arr[i] = k
+    return arr
+
+
+class _interpolate_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attr, rast, tri, rast_db, diff_list):
+        lib = _lib.load()
+        B, H, W, _ = rast.shape
+        Ba, Vt, A = attr.shape
+        n_diff = len(diff_list)
+        dev = rast.device
+        out = torch.empty(B, H, W, A, dtype=torch.float32, device=dev)
+        out_da = torch.empty(B, H, W, 2 * n_diff, dtype=torch.float32, device=dev)
+        p = _lib.InterpolateFwd(attr=_ptr(attr), rast=_ptr(rast), tri=_ptr(tri), rast_db=_ptr(rast_db) if n_diff else None,
+                                B=B, H=H, W=W, Ba=Ba, Vt=Vt, A=A, T=tri.shape[0], n_diff=n_diff,
+                                diff_idx=_diff_array(diff_list), out=_ptr(out), out_da=_ptr(out_da) if n_diff else None)
+        _lib.check(lib.fpcdr_interpolate_fwd(ctypes.byref(p), _stream()))
+        ctx.save_for_backward(attr, rast, tri, rast_db if n_diff else None)
+        ctx.diff_list = diff_list
+        return out, out_da
+
+    @staticmethod
+    def backward(ctx, dy, dda):
+        lib = _lib.load()
+        attr, rast, tri, rast_db = ctx.saved_tensors
+        B, H, W, _ = rast.shape
+        Ba, Vt, A = attr.shape
+        diff_list = ctx.diff_list
+        n_diff = len(diff_list)
+        dev = rast.device
+        need_attr = ctx.needs_input_grad[0]
+        g_attr = torch.zeros_like(attr) if need_attr else None
+        g_rast = torch.empty_like(rast)
+        g_db = torch.empty_like(rast_db) if n_diff else None
+        dy = dy.contiguous()
+        if n_diff:
+            dda = dda.contiguous() if dda is not None else torch.zeros(B, H, W, 2 * n_diff, dtype=torch.float32, device=dev)
+        p = _lib.InterpolateBwd(attr=_ptr(attr), rast=_ptr(rast), tri=_ptr(tri), rast_db=_ptr(rast_db) if n_diff else None,
+                                dy=_ptr(dy), dda=_ptr(dda) if n_diff else None, B=B, H=H, W=W, Ba=Ba, Vt=Vt, A=A,
+                                T=tri.shape[0], n_diff=n_diff, diff_idx=_diff_array(diff_list), grad_attr=_ptr(g_attr),
+                                grad_rast=_ptr(g_rast), grad_rast_db=_ptr(g_db))
+        _lib.check(lib.fpcdr_interpolate_bwd(ctypes.byref(p), _stream()))
+        return g_attr, g_rast, None, g_db, None
+
+
+def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+    """Interpolate vertex attributes.  attr [1|B,Vt,A], rast [B,H,W,4], tri [T,3] -> (out [B,H,W,A], out_da [B,H,W,2D])."""
+    _check_tensor('attr', attr, torch.float32)
+    _check_tensor('rast', rast, torch.float32, 4)
+    _check_tensor('tri', tri, torch.int32, 2)
+    if attr.dim() == 2:
+        raise NotImplementedError("range mode (attr [Vt,A]) is not implemented; use instanced mode attr [1|B,Vt,A]")
+    if attr.dim() != 3:
+        raise ValueError(f"attr must have shape [1|B,Vt,A] (got {tuple(attr.shape)})")
+    if rast.shape[3] != 4:
+        raise ValueError("rast must have shape [B,H,W,4]")
+    if attr.shape[0] not in (1, rast.shape[0]):
+        raise ValueError(f"attr minibatch ({attr.shape[0]}) must be 1 or match rast ({rast.shape[0]})")
+    if tri.shape[1] != 3:
+        raise ValueError("tri must have shape [T,3]")
+    A = attr.shape[2]
+    if diff_attrs is None or rast_db is None:
+        diff_list = []
+        if diff_attrs is not None and rast_db is None:
+            raise ValueError("diff_attrs given but rast_db is None")
+    elif isinstance(diff_attrs, str):
+        if diff_attrs != 'all':
+            raise ValueError("diff_attrs must be None, 'all' or a list of attribute indices")
+        diff_list = list(range(A))
+    else:
+        diff_list = [int(i) for i in diff_attrs]
+        if any(i < 0 or i >= A for i in diff_list):
+            raise ValueError("diff_attrs index out of range")
+    if len(diff_list) > _lib.MAX_ATTR:
+        raise ValueError(f"at most {_lib.MAX_ATTR} attributes may have pixel differentials")
+    if diff_list:
+        _check_tensor('rast_db', rast_db, torch.float32, 4)
+        if rast_db.shape != rast.shape:
+            raise ValueError("rast_db must have the same shape as rast")
+        rast_db = rast_db.contiguous()
+    else:
+        rast_db = None
+    return _interpolate_func.apply(attr.contiguous(), rast.contiguous(), tri.contiguous(), rast_db, diff_list)
+
+
+# ----------------------------------------------------------------------------------------------
+# texture
+# ----------------------------------------------------------------------------------------------
+
+def _num_mip_levels(Ht, Wt, max_mip_level):
+    n = 0
+    h, w = Ht, Wt
+    while (max_mip_level is None or n < max_mip_level) and h % 2 == 0 and w % 2 == 0 and h >= 2 and w >= 2:
+        h //= 2
+        w //= 2
+        n += 1
+        if n >= _lib.MAX_MIP:
+            break
+    return n
+
+
+def _build_mips(tex, n_levels):
+    lib = _lib.load()
+    chain = [tex]
+    for _ in range(n_levels):
+        src = chain[-1]
+        N, h, w, C = src.shape
+        dst = torch.empty(N, h // 2, w // 2, C, dtype=torch.float32, device=tex.device)
+        _lib.check(lib.fpcdr_mip_downsample(_ptr(src), _ptr(dst), N, h, w, C, _stream()))
+        chain.append(dst)
+    return chain
+
+
+def texture_construct_mip(tex, max_mip_level=None, cube_mode=False):
+    """Pre-build a mip stack for `texture(..., mip=...)`.  Returns a list of tensors (level 1..n)."""
+    if cube_mode:
+        raise NotImplementedError("cube maps are not implemented")
+    _check_tensor('tex', tex, torch.float32, 4)
+    n = _num_mip_levels(tex.shape[1], tex.shape[2], max_mip_level)
+    with torch.no_grad():
+        return _build_mips(tex.contiguous(), n)[1:]
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * (_lib.MAX_MIP + 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+class _texture_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tex, uv, uv_da, bias, filter_mode, boundary_mode, n_levels, *mips):
+        lib = _lib.load()
+        B, H, W, _ = uv.shape
+        Bt, Ht, Wt, C = tex.shape
+        chain = [tex] + list(mips) if mips else _build_mips(tex, n_levels)
+        out = torch.empty(B, H, W, C, dtype=torch.float32, device=uv.device)
+        p = _lib.TextureFwd(tex=_ptr_array(chain), n_levels=n_levels, uv=_ptr(uv), uv_da=_ptr(uv_da),
+                            mip_level_bias=_ptr(bias), B=B, H=H, W=W, Bt=Bt, Ht=Ht, Wt=Wt, C=C,
+                            filter_mode=filter_mode, boundary_mode=boundary_mode, out=_ptr(out))
+        _lib.check(lib.fpcdr_texture_fwd(ctypes.byref(p), _stream()))
+        ctx.save_for_backward(tex, uv, uv_da, bias, *chain[1:])
+        ctx.cfg = (filter_mode, boundary_mode, n_levels)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        tex, uv, uv_da, bias = ctx.saved_tensors[:4]
+        chain = [tex] + list(ctx.saved_tensors[4:])
+        filter_mode, boundary_mode, n_levels = ctx.cfg
+        B, H, W, _ = uv.shape
+        Bt, Ht, Wt, C = tex.shape
+        need_tex = ctx.needs_input_grad[0]
+        g_levels = [torch.zeros_like(t) if need_tex else None for t in chain]
+        g_uv = torch.empty_like(uv) if ctx.needs_input_grad[1] else None
+        g_da = torch.empty_like(uv_da) if (uv_da is not None and ctx.needs_input_grad[2]) else None
+        g_bias = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[3]) else None
+        dy = dy.contiguous()
+        p = _lib.TextureBwd(tex=_ptr_array(chain), n_levels=n_levels, uv=_ptr(uv), uv_da=_ptr(uv_da),
+                            mip_level_bias=_ptr(bias), dy=_ptr(dy), B=B, H=H, W=W, Bt=Bt, Ht=Ht, Wt=Wt, C=C,
+                            filter_mode=filter_mode, boundary_mode=boundary_mode, grad_tex=_ptr_array(g_levels),
+                            grad_uv=_ptr(g_uv), grad_uv_da=_ptr(g_da), grad_mip_level_bias=_ptr(g_bias))
+        _lib.check(lib.fpcdr_texture_bwd(ctypes.byref(p), _stream()))
+        if need_tex:
+            # collapse the mip gradients down to level 0
+            for l in range(n_levels, 0, -1):
+                N, h, w, _ = chain[l - 1].shape
+                _lib.check(lib.fpcdr_mip_downsample_bwd(_ptr(g_levels[l]), _ptr(g_levels[l - 1]), N, h, w, C, _stream()))
+        return (g_levels[0], g_uv, g_da, g_bias, None, None, None) + (None,) * (len(chain) - 1)
+
+
+def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='auto', boundary_mode='wrap',
+            max_mip_level=None):
+    """Texture lookup.  tex [1|B,Ht,Wt,C], uv [B,H,W,2], uv_da [B,H,W,4] -> [B,H,W,C]."""
+    if filter_mode == 'auto':
+        filter_mode = 'linear-mipmap-linear' if (uv_da is not None or mip_level_bias is not None) else 'linear'
+    if filter_mode not in _lib.FILTER:
+        raise ValueError(f"unknown filter_mode '{filter_mode}'")
+    if boundary_mode == 'cube':
+        raise NotImplementedError("cube maps are not implemented")
+    if boundary_mode == 'zero':
+        raise NotImplementedError("boundary_mode='zero' is not implemented")
+    if boundary_mode not in _lib.BOUNDARY:
+        raise ValueError(f"unknown boundary_mode '{boundary_mode}'")
+    _check_tensor('tex', tex, torch.float32, 4)
+    _check_tensor('uv', uv, torch.float32, 4)
+    if uv.shape[3] != 2:
+        raise ValueError("uv must have shape [B,H,W,2]")
+    if tex.shape[0] not in (1, uv.shape[0]):
+        raise ValueError(f"tex minibatch ({tex.shape[0]}) must be 1 or match uv ({uv.shape[0]})")
+    mipped = filter_mode in ('linear-mipmap-nearest', 'linear-mipmap-linear')
+    n_levels = 0
+    mips = ()
+    if mipped:
+        if uv_da is None and mip_level_bias is None:
+            raise ValueError("mipmapped filter modes need uv_da and/or mip_level_bias")
+        if uv_da is not None:
+            _check_tensor('uv_da', uv_da, torch.float32, 4)
+            if uv_da.shape != uv.shape[:3] + (4,):
+                raise ValueError("uv_da must have shape [B,H,W,4]")
+            uv_da = uv_da.contiguous()
+        if mip_level_bias is not None:
+            _check_tensor('mip_level_bias', mip_level_bias, torch.float32, 3)
+            if mip_level_bias.shape != uv.shape[:3]:
+                raise ValueError("mip_level_bias must have shape [B,H,W]")
+            mip_level_bias = mip_level_bias.contiguous()
+        if mip is not None:
+            mips = tuple(m.contiguous() for m in mip)
+            n_levels = len(mips)
+            if max_mip_level is not None:
+                n_levels = min(n_levels, int(max_mip_level))
+                mips = mips[:n_levels]
+        else:
+            n_levels = _num_mip_levels(tex.shape[1], tex.shape[2], max_mip_level)
+    else:
+        uv_da = None
+        mip_level_bias = None
+    return _texture_func.apply(tex.contiguous(), uv.contiguous(), uv_da, mip_level_bias, _lib.FILTER[filter_mode],
+                               _lib.BOUNDARY[boundary_mode], n_levels, *mips)
+
+
+# ----------------------------------------------------------------------------------------------
+# antialias
+# ----------------------------------------------------------------------------------------------
+
+_topology_cache = OrderedDict()
+_TOPOLOGY_CACHE_SIZE = 16
+
+
+def antialias_construct_topology_hash(tri):
+    """Edge adjacency of `tri` ([T,3] i32): adj [T,3] i32 (see include/fpcdr.h).  Built on the GPU."""
+    _check_tensor('tri', tri, torch.int32, 2)
+    lib = _lib.load()
+    tri = tri.contiguous()
+    T = tri.shape[0]
+    scratch = torch.empty(lib.fpcdr_topology_scratch_bytes(T), dtype=torch.uint8, device=tri.device)
+    adj = torch.empty(T, 3, dtype=torch.int32, device=tri.device)
+    _lib.check(lib.fpcdr_topology_build(_ptr(tri), T, _ptr(scratch), _ptr(adj), _stream()))
+    return adj
+
+
+def _cached_topology(tri):
+    key = (tri.data_ptr(), tri._version, tuple(tri.shape), str(tri.device))
+    hit = _topology_cache.get(key)
+    if hit is not None:
+        _topology_cache.move_to_end(key)
+        return hit[1]
+    adj = antialias_construct_topology_hash(tri)
+    _topology_cache[key] = (tri, adj)  # holding `tri` keeps its storage (and so the key) alive
+    while len(_topology_cache) > _TOPOLOGY_CACHE_SIZE:
+        _topology_cache.popitem(last=False)
+    return adj
+
+
+class _antialias_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, rast, pos, tri, adj, boost):
+        lib = _lib.load()
+        B, H, W, C = color.shape
+        V, T = pos.shape[1], tri.shape[0]
+        dev = color.device
+        out = torch.empty_like(color)
+        sil = torch.empty(B, T, dtype=torch.uint8, device=dev)
+        flags = torch.empty(lib.fpcdr_antialias_flags_bytes(B, H, W) // 8, dtype=torch.int64, device=dev)
+        p = _lib.AntialiasFwd(color=_ptr(color), rast=_ptr(rast), pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), B=B, H=H,
+                              W=W, C=C, V=V, T=T, sil=_ptr(sil), flags=_ptr(flags), out=_ptr(out))
+        _lib.check(lib.fpcdr_antialias_fwd(ctypes.byref(p), _stream()))
+        ctx.save_for_backward(color, rast, pos, tri, adj, sil, flags)
+        ctx.boost = float(boost)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        color, rast, pos, tri, adj, sil, flags = ctx.saved_tensors
+        B, H, W, C = color.shape
+        V, T = pos.shape[1], tri.shape[0]
+        g_color = torch.empty_like(color)
+        g_pos = torch.zeros_like(pos)
+        dy = dy.contiguous()
+        p = _lib.AntialiasBwd(color=_ptr(color), rast=_ptr(rast), pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), dy=_ptr(dy),
+                              B=B, H=H, W=W, C=C, V=V, T=T, sil=_ptr(sil), flags=_ptr(flags),
+                              pos_gradient_boost=ctx.boost, grad_color=_ptr(g_color), grad_pos=_ptr(g_pos))
+        _lib.check(lib.fpcdr_antialias_bwd(ctypes.byref(p), _stream()))
+        return g_color, None, g_pos, None, None, None
+
+
+def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
+    """Silhouette antialiasing.  color [B,H,W,C], rast [B,H,W,4], pos [B,V,4], tri [T,3] -> [B,H,W,C]."""
+    _check_tensor('color', color, torch.float32, 4)
+    _check_tensor('rast', rast, torch.float32, 4)
+    _check_tensor('pos', pos, torch.float32)
+    _check_tensor('tri', tri, torch.int32, 2)
+    if pos.dim() == 2:
+        raise NotImplementedError("range mode (pos [V,4]) is not implemented; use instanced mode pos [B,V,4]")
+    if pos.dim() != 3 or pos.shape[2] != 4:
+        raise ValueError("pos must have shape [B,V,4]")
+    if color.shape[:3] != rast.shape[:3] or rast.shape[3] != 4:
+        raise ValueError("color [B,H,W,C] and rast [B,H,W,4] must agree in B, H, W")
+    if pos.shape[0] != color.shape[0]:
+        raise ValueError("pos minibatch must match color")
+    tri = tri.contiguous()
+    if topology_hash is None:
+        adj = _cached_topology(tri)
+    else:
+        adj = topology_hash
+        _check_tensor('topology_hash', adj, torch.int32, 2)
+        if adj.shape != tri.shape:
+            raise ValueError("topology_hash does not belong to this tri tensor")
+    return _antialias_func.apply(color.contiguous(), rast.contiguous(), pos.contiguous(), tri, adj, pos_gradient_boost)

@@ -1,0 +1,206 @@
+/*
+ * fpcdr.h -- C ABI of the MI355X (gfx950) differentiable-raster path.
+ *
+ * Drop-in boundary.  In the reference the four operators are Python calls
+ * into the third-party package nvdiffrast (reference src/torch/fit.py:13); the reference itself
+ * has no FFI.  Each entry point below states the reference call site whose work it performs; the
+ * Python binding that preserves the nvdiffrast signatures is fpc_diffrend_amd/ops.py and the
+ * binding a maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types: device pointers are void-free typed pointers into HBM, the
+ *     stream is passed as void* (a hipStream_t); every launch is asynchronous on that stream;
+ *   - the CALLER owns every buffer, including scratch; the library allocates nothing and keeps no
+ *     state between calls (re-entrant, any number of devices / streams);
+ *   - all tensors are contiguous, float32 / int32, NHWC images with row 0 = bottom scanline;
+ *   - gradient outputs documented "accumulated" are added to with atomics and must be zeroed (or
+ *     hold a running sum) on entry; all other outputs are fully overwritten;
+ *   - return value 0 = launched, otherwise an FPCDR_E* code; fpcdr_last_error() gives the
+ *     message (thread-local).  No exception crosses the boundary.
+ */
+#ifndef FPCDR_H
+#define FPCDR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPCDR_ABI_VERSION 1
+
+enum {
+    FPCDR_OK = 0,
+    FPCDR_EINVAL = 1,   /* bad argument (null pointer, non-positive size, unsupported mode) */
+    FPCDR_ELAUNCH = 2   /* the HIP runtime refused the launch */
+};
+
+int fpcdr_abi_version(void);
+const char *fpcdr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* rasterize -- dr.rasterize(glctx, pos, tri, resolution)        reference fit.py:151 (ctx :484) */
+/* ------------------------------------------------------------------------------------------ */
+
+/* bytes of scratch fpcdr_rasterize_fwd needs for B images of T triangles */
+size_t fpcdr_rasterize_scratch_bytes(int32_t B, int32_t T);
+
+typedef struct {
+    const float *pos;     /* [B,V,4] clip-space positions */
+    const int32_t *tri;   /* [T,3] */
+    int32_t B, V, T, H, W;
+    void *scratch;        /* fpcdr_rasterize_scratch_bytes(B,T) bytes, 16-byte aligned */
+    float *rast;          /* out [B,H,W,4] = (u, v, z/w, triangle index + 1; 0 = empty) */
+    float *rast_db;       /* out [B,H,W,4] = (du/dx, du/dy, dv/dx, dv/dy) per pixel, or NULL */
+} fpcdr_rasterize_fwd_params;
+int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *stream);
+
+typedef struct {
+    const float *pos;     /* [B,V,4] */
+    const int32_t *tri;   /* [T,3] */
+    const float *rast;    /* [B,H,W,4] forward output */
+    const float *dy;      /* [B,H,W,4] dL/d rast (only .x .y are used: z/w and id carry no gradient) */
+    const float *ddb;     /* [B,H,W,4] dL/d rast_db, or NULL */
+    int32_t B, V, T, H, W;
+    float *grad_pos;      /* [B,V,4] accumulated (x, y, w components; z receives nothing) */
+} fpcdr_rasterize_bwd_params;
+int fpcdr_rasterize_bwd(const fpcdr_rasterize_bwd_params *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* interpolate -- dr.interpolate(attr, rast, tri[, rast_db, diff_attrs])  reference fit.py:154,157 */
+/* ------------------------------------------------------------------------------------------ */
+
+#define FPCDR_MAX_ATTR 32
+
+typedef struct {
+    const float *attr;    /* [Ba,Vt,A], Ba = 1 (broadcast) or B */
+    const float *rast;    /* [B,H,W,4] */
+    const int32_t *tri;   /* [T,3] index buffer of attr (e.g. uv_idx) */
+    const float *rast_db; /* [B,H,W,4] or NULL when n_diff == 0 */
+    int32_t B, H, W, Ba, Vt, A, T;
+    int32_t n_diff;                     /* number of attributes with pixel differentials */
+    int32_t diff_idx[FPCDR_MAX_ATTR];   /* their indices into A (diff_attrs='all' -> 0..A-1) */
+    float *out;           /* out [B,H,W,A] */
+    float *out_da;        /* out [B,H,W,2*n_diff] = (da/dx, da/dy) per selected attribute, or NULL */
+} fpcdr_interpolate_fwd_params;
+int fpcdr_interpolate_fwd(const fpcdr_interpolate_fwd_params *p, void *stream);
+
+typedef struct {
+    const float *attr, *rast;
+    const int32_t *tri;
+    const float *rast_db;
+    const float *dy;      /* [B,H,W,A] */
+    const float *dda;     /* [B,H,W,2*n_diff] or NULL */
+    int32_t B, H, W, Ba, Vt, A, T;
+    int32_t n_diff;
+    int32_t diff_idx[FPCDR_MAX_ATTR];
+    float *grad_attr;     /* [Ba,Vt,A] accumulated, or NULL (attr needs no gradient, as in fit.py:431) */
+    float *grad_rast;     /* out [B,H,W,4] (.z .w are written as 0) */
+    float *grad_rast_db;  /* out [B,H,W,4], or NULL when n_diff == 0 */
+} fpcdr_interpolate_bwd_params;
+int fpcdr_interpolate_bwd(const fpcdr_interpolate_bwd_params *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* texture -- dr.texture(tex, uv[, uv_da], filter_mode, boundary_mode, max_mip_level)             */
+/*                                                                   reference fit.py:155,158    */
+/* ------------------------------------------------------------------------------------------ */
+
+enum { FPCDR_FILTER_NEAREST = 0, FPCDR_FILTER_LINEAR = 1, FPCDR_FILTER_LINEAR_MIPMAP_NEAREST = 2,
+       FPCDR_FILTER_LINEAR_MIPMAP_LINEAR = 3 };
+enum { FPCDR_BOUNDARY_WRAP = 0, FPCDR_BOUNDARY_CLAMP = 1 };
+#define FPCDR_MAX_MIP 16
+
+/* level l+1 [N,Ht/2,Wt/2,C] = 2x2 box filter of level l [N,Ht,Wt,C] (Ht, Wt even) */
+int fpcdr_mip_downsample(const float *src, float *dst, int32_t N, int32_t Ht, int32_t Wt, int32_t C, void *stream);
+/* gradient of the above: grad_src [N,Ht,Wt,C] += 0.25 * grad_dst of its 2x2 parent (plain add, not atomic) */
+int fpcdr_mip_downsample_bwd(const float *grad_dst, float *grad_src, int32_t N, int32_t Ht, int32_t Wt, int32_t C,
+                             void *stream);
+
+typedef struct {
+    const float *tex[FPCDR_MAX_MIP + 1];  /* tex[0] = [Bt,Ht,Wt,C]; tex[l] = level l of the chain */
+    int32_t n_levels;                     /* number of mip levels beyond level 0 (0 for non-mip filters) */
+    const float *uv;                      /* [B,H,W,2] */
+    const float *uv_da;                   /* [B,H,W,4] = (du/dx,du/dy,dv/dx,dv/dy) or NULL */
+    const float *mip_level_bias;          /* [B,H,W] or NULL */
+    int32_t B, H, W, Bt, Ht, Wt, C;
+    int32_t filter_mode, boundary_mode;
+    float *out;                           /* out [B,H,W,C] */
+} fpcdr_texture_fwd_params;
+int fpcdr_texture_fwd(const fpcdr_texture_fwd_params *p, void *stream);
+
+typedef struct {
+    const float *tex[FPCDR_MAX_MIP + 1];
+    int32_t n_levels;
+    const float *uv, *uv_da, *mip_level_bias;
+    const float *dy;                      /* [B,H,W,C] */
+    int32_t B, H, W, Bt, Ht, Wt, C;
+    int32_t filter_mode, boundary_mode;
+    float *grad_tex[FPCDR_MAX_MIP + 1];   /* per level, accumulated; grad_tex[0] may be NULL (tex needs no grad) */
+    float *grad_uv;                       /* out [B,H,W,2] or NULL */
+    float *grad_uv_da;                    /* out [B,H,W,4] or NULL */
+    float *grad_mip_level_bias;           /* out [B,H,W] or NULL */
+} fpcdr_texture_bwd_params;
+int fpcdr_texture_bwd(const fpcdr_texture_bwd_params *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* antialias -- dr.antialias(color, rast, pos, tri)                       reference fit.py:160   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Edge adjacency of an index buffer, built once per `tri` tensor (nvdiffrast's "topology hash").
+ * adj[t][e], e = edge opposite to corner e (joins corners (e+1)%3 and (e+2)%3):
+ *    >= 0  vertex index opposite to the edge in the one other triangle sharing it
+ *    -1    boundary edge (no other triangle)      -2  shared by more than two triangles */
+size_t fpcdr_topology_scratch_bytes(int32_t T);
+int fpcdr_topology_build(const int32_t *tri, int32_t T, void *scratch, int32_t *adj /* out [T,3] */, void *stream);
+
+/* words (uint64) per flag bit-plane row */
+#define FPCDR_AA_ROW_WORDS(W) (((W) + 63) / 64)
+/* bytes of the flag planes written by the forward pass and read by the backward pass */
+size_t fpcdr_antialias_flags_bytes(int32_t B, int32_t H, int32_t W);
+
+typedef struct {
+    const float *color;   /* [B,H,W,C] */
+    const float *rast;    /* [B,H,W,4] */
+    const float *pos;     /* [B,V,4] */
+    const int32_t *tri;   /* [T,3] */
+    const int32_t *adj;   /* [T,3] from fpcdr_topology_build */
+    int32_t B, H, W, C, V, T;
+    uint8_t *sil;         /* scratch+saved [B,T]: per image, bit e set = edge e of t is a silhouette edge */
+    uint64_t *flags;      /* saved, fpcdr_antialias_flags_bytes(): plane 0 = pair (p, p+x) blended, plane 1 = (p, p+y) */
+    float *out;           /* out [B,H,W,C] */
+} fpcdr_antialias_fwd_params;
+int fpcdr_antialias_fwd(const fpcdr_antialias_fwd_params *p, void *stream);
+
+typedef struct {
+    const float *color, *rast, *pos;
+    const int32_t *tri, *adj;
+    const float *dy;      /* [B,H,W,C] */
+    int32_t B, H, W, C, V, T;
+    const uint8_t *sil;   /* from the forward pass */
+    const uint64_t *flags;
+    float pos_gradient_boost;
+    float *grad_color;    /* out [B,H,W,C] */
+    float *grad_pos;      /* [B,V,4] accumulated (x, y, w) */
+} fpcdr_antialias_bwd_params;
+int fpcdr_antialias_bwd(const fpcdr_antialias_bwd_params *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* blend -- V = v_base + Bmat . w     reference fit.py:115-122 (prior), :58-62 (free)            */
+/* ------------------------------------------------------------------------------------------ */
+
+/* out[f][i] = v_base[i] + sum_k Bmat[i][k] * w[f][k]     (f32 MFMA, exact f32 accumulation)
+ *   v_base [M] (may be NULL = 0), Bmat [M,K] row-major, w [F,K], out [F,M]                      */
+int fpcdr_blend_fwd(const float *v_base, const float *Bmat, const float *w, float *out, int32_t M, int32_t K,
+                    int32_t F, void *stream);
+/* grad_w[f][k] += sum_i grad_out[f][i] * Bmat[i][k]  (accumulated: zero grad_w first)           */
+int fpcdr_blend_bwd_w(const float *Bmat, const float *grad_out, float *grad_w, int32_t M, int32_t K, int32_t F,
+                      void *stream);
+/* grad_B[i][k] = sum_f grad_out[f][i] * w[f][k]      (free-form basis m3, reference fit.py:60; overwritten) */
+int fpcdr_blend_bwd_basis(const float *w, const float *grad_out, float *grad_B, int32_t M, int32_t K, int32_t F,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPCDR_H */

@@ -1,0 +1,61 @@
+"""Shared builders for the parity tests (seeded synthetic inputs; nothing reads /root/reference)."""
+import numpy as np
+import torch
+
+from fpc_diffrend_amd import camera, scene
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def scene_mvps(sc, cam_ids, frames=None):
+    """mvp [len(frames)*len(cam_ids),4,4] float32 for the ground-truth pose of `frames` (frame-major)."""
+    out = []
+    T = camera.translate(0.0, 170.0, 0.0)
+    frames = [None] if frames is None else frames
+    for f in frames:
+        for c in cam_ids:
+            cam = sc.cams[c]
+            P = camera.intrinsic_to_projection(cam['intr'])
+            MV = camera.extrinsic_to_modelview(cam['rot'], cam['trans_calib'])
+            m = MV @ T
+            if f is not None:
+                R = camera.unitquat_to_rotmat(torch.tensor(sc.q_gt[f])).numpy()
+                Rt = np.eye(4, dtype=np.float32)
+                Rt[:3, :3] = R
+                Rt[:3, 3] = sc.t_gt[f]
+                m = Rt @ m
+            out.append((P @ m).astype(np.float32))
+    return torch.tensor(np.stack(out))
+
+
+def clip_positions(sc, cam_ids, frames=None, jitter=0.0, seed=0):
+    """pos_clip [B,V,4] for the base mesh (+ blendshape ground truth per frame)."""
+    mvps = scene_mvps(sc, cam_ids, frames)
+    V = sc.n_vertices
+    if frames is None:
+        verts = torch.tensor(sc.v_base.reshape(1, V, 3))
+    else:
+        vb = torch.tensor(sc.v_base)
+        Bm = torch.tensor(sc.blendshapes)
+        w = torch.tensor(sc.weights_gt[frames])
+        verts = (vb[None] + w @ Bm.t()).reshape(len(frames), V, 3)
+    if jitter:
+        g = torch.Generator().manual_seed(seed)
+        verts = verts + jitter * torch.randn(verts.shape, generator=g)
+    return camera.transform_clip(mvps, verts), mvps
+
+
+def random_soup(B, T, seed, spread=1.2, size=0.5, wmin=0.5, wmax=3.0):
+    """Random triangle soup in clip space, many overlaps, mixed facing, some off-screen; V = 3T."""
+    g = torch.Generator().manual_seed(seed)
+    c = (torch.rand(B, T, 1, 2, generator=g) * 2 - 1) * spread
+    xy = c + (torch.rand(B, T, 3, 2, generator=g) * 2 - 1) * size
+    z = (torch.rand(B, T, 3, 1, generator=g) * 2 - 1) * 0.9
+    w = torch.rand(B, T, 3, 1, generator=g) * (wmax - wmin) + wmin
+    pos = torch.cat([xy * w, z * w, w], dim=-1).reshape(B, T * 3, 4).contiguous()
+    tri = torch.arange(T * 3, dtype=torch.int32).reshape(T, 3)
+    return pos, tri

@@ -1,0 +1,207 @@
+"""
+GPU parity tests: HIP kernels (through the C ABI, via fpc_diffrend_amd.ops) against the CPU oracle on
+the same seeded inputs.  Bars (BASELINE.json north_star): integer triangle-id / coverage buffers
+bit-exact; float tensors within 1e-4 relative L2.  The oracle is this build's own restatement
+(parity unpinned vs nvdiffrast).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import clip_positions, random_soup, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dr():
+    import fpc_diffrend_amd.ops as dr
+    return dr
+
+
+@pytest.fixture(scope="module")
+def ctx(dr):
+    return dr.RasterizeGLContext(device='cuda')
+
+
+def _ids(rast):
+    return rast[..., 3].to(torch.int32).cpu()
+
+
+@pytest.mark.parametrize("res,T,seed", [((64, 64), 40, 0), ((200, 136), 300, 1), ((97, 131), 1500, 2), ((256, 256), 5000, 3)])
+def test_rasterize_soup_ids_bit_exact(dr, ctx, oracle_ops, res, T, seed):
+    pos, tri = random_soup(2, T, seed)
+    rast, db = dr.rasterize(ctx, pos.cuda(), tri.cuda(), res)
+    ids_ref = oracle_ops.rasterize_ids(pos, tri, res)
+    assert torch.equal(_ids(rast), ids_ref)
+    r_ref, db_ref = oracle_ops.rasterize(pos, tri, res)
+    assert rel_l2(rast[..., :3], r_ref[..., :3]) < TOL
+    assert rel_l2(db, db_ref) < TOL
+
+
+def test_rasterize_mesh_cfg1(dr, ctx, oracle_ops):
+    from fpc_diffrend_amd import scene
+    sc = scene.cfg('cfg1')
+    pos, _ = clip_positions(sc, [0, 3, 8], frames=[0, 1])
+    tri = torch.tensor(sc.pos_idx)
+    rast, db = dr.rasterize(ctx, pos.cuda(), tri.cuda(), sc.resolution)
+    assert torch.equal(_ids(rast), oracle_ops.rasterize_ids(pos, tri, sc.resolution))
+    r_ref, db_ref = oracle_ops.rasterize(pos, tri, sc.resolution)
+    assert rel_l2(rast, r_ref) < TOL
+    assert rel_l2(db, db_ref) < TOL
+
+
+def test_rasterize_backward(dr, ctx, oracle_ops):
+    pos, tri = random_soup(2, 200, 5)
+    res = (96, 80)
+    g = torch.Generator().manual_seed(1)
+    gy = torch.randn(2, res[0], res[1], 4, generator=g)
+    gdb = torch.randn(2, res[0], res[1], 4, generator=g) * 0.1
+    p_ref = pos.clone().requires_grad_(True)
+    r, d = oracle_ops.rasterize(p_ref, tri, res)
+    ((r * gy).sum() + (d * gdb).sum()).backward()
+    p_gpu = pos.cuda().requires_grad_(True)
+    r2, d2 = dr.rasterize(ctx, p_gpu, tri.cuda(), res)
+    ((r2 * gy.cuda()).sum() + (d2 * gdb.cuda()).sum()).backward()
+    assert rel_l2(p_gpu.grad, p_ref.grad) < TOL
+    # without db gradient
+    p_ref.grad = None
+    p_gpu.grad = None
+    r, d = oracle_ops.rasterize(p_ref, tri, res, grad_db=False)
+    ((r * gy).sum() + (d * gdb).sum()).backward()
+    r2, d2 = dr.rasterize(ctx, p_gpu, tri.cuda(), res, grad_db=False)
+    ((r2 * gy.cuda()).sum() + (d2 * gdb.cuda()).sum()).backward()
+    assert rel_l2(p_gpu.grad, p_ref.grad) < TOL
+
+
+@pytest.mark.parametrize("A,Ba,diff", [(2, 1, None), (2, 1, 'all'), (3, 2, [2, 0]), (5, 1, 'all')])
+def test_interpolate_fwd_bwd(dr, ctx, oracle_ops, A, Ba, diff):
+    pos, tri = random_soup(2, 150, 7)
+    res = (72, 88)
+    g = torch.Generator().manual_seed(2)
+    Vt = 3 * 150
+    attr = torch.randn(Ba, Vt, A, generator=g)
+    r_ref, db_ref = oracle_ops.rasterize(pos, tri, res)
+    r_ref = r_ref.detach().requires_grad_(True)
+    db_ref = db_ref.detach().requires_grad_(True)
+    a_ref = attr.clone().requires_grad_(True)
+    o, oda = oracle_ops.interpolate(a_ref, r_ref, tri, rast_db=db_ref if diff else None, diff_attrs=diff)
+    gy = torch.randn(o.shape, generator=g)
+    gda = torch.randn(oda.shape, generator=g)
+    ((o * gy).sum() + (oda * gda).sum()).backward()
+
+    r_gpu = r_ref.detach().cuda().requires_grad_(True)
+    db_gpu = db_ref.detach().cuda().requires_grad_(True)
+    a_gpu = attr.cuda().requires_grad_(True)
+    o2, oda2 = dr.interpolate(a_gpu, r_gpu, tri.cuda(), rast_db=db_gpu if diff else None, diff_attrs=diff)
+    assert o2.shape == o.shape and oda2.shape == oda.shape
+    ((o2 * gy.cuda()).sum() + (oda2 * gda.cuda()).sum()).backward()
+    assert rel_l2(o2, o) < TOL
+    if oda.numel():
+        assert rel_l2(oda2, oda) < TOL
+    assert rel_l2(a_gpu.grad, a_ref.grad) < TOL
+    assert rel_l2(r_gpu.grad, r_ref.grad) < TOL
+    if diff:
+        assert rel_l2(db_gpu.grad, db_ref.grad) < TOL
+
+
+@pytest.mark.parametrize("mode,C,Bt,boundary", [('linear', 1, 1, 'wrap'), ('linear', 3, 2, 'clamp'), ('nearest', 1, 1, 'wrap'),
+                                               ('linear-mipmap-linear', 1, 1, 'wrap'), ('linear-mipmap-linear', 3, 1, 'clamp'),
+                                               ('linear-mipmap-nearest', 2, 1, 'wrap')])
+def test_texture_fwd_bwd(dr, oracle_ops, mode, C, Bt, boundary):
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 40, 56
+    tex = torch.rand(Bt, 32, 64, C, generator=g)
+    uv = torch.rand(B, H, W, 2, generator=g) * 1.6 - 0.3
+    uv_da = (torch.rand(B, H, W, 4, generator=g) - 0.5) * 0.2
+    mip = 'mipmap' in mode
+    gy = torch.randn(B, H, W, C, generator=g)
+    gy[0, :5] = 0.0  # exercises the zero-gradient skip
+    t_ref = tex.clone().requires_grad_(True)
+    uv_ref = uv.clone().requires_grad_(True)
+    da_ref = uv_da.clone().requires_grad_(True)
+    kw = dict(filter_mode=mode, boundary_mode=boundary)
+    if mip:
+        kw['max_mip_level'] = 4
+    o = oracle_ops.texture(t_ref, uv_ref, da_ref if mip else None, **kw)
+    (o * gy).sum().backward()
+    t_gpu = tex.cuda().requires_grad_(True)
+    uv_gpu = uv.cuda().requires_grad_(True)
+    da_gpu = uv_da.cuda().requires_grad_(True)
+    o2 = dr.texture(t_gpu, uv_gpu, da_gpu if mip else None, **kw)
+    (o2 * gy.cuda()).sum().backward()
+    assert rel_l2(o2, o) < TOL
+    assert rel_l2(t_gpu.grad, t_ref.grad) < TOL
+    if mode != 'nearest':
+        assert rel_l2(uv_gpu.grad, uv_ref.grad) < 5e-4  # bilinear derivative is discontinuous at texel borders
+    if mode == 'linear-mipmap-linear':
+        assert rel_l2(da_gpu.grad, da_ref.grad) < 5e-4
+
+
+def _aa_inputs(sc_name='cfg1', cams=(0, 4), C=1, seed=0):
+    from fpc_diffrend_amd import scene
+    sc = scene.cfg(sc_name)
+    pos, _ = clip_positions(sc, list(cams), frames=[0])
+    tri = torch.tensor(sc.pos_idx)
+    g = torch.Generator().manual_seed(seed)
+    color = torch.rand(pos.shape[0], sc.resolution[0], sc.resolution[1], C, generator=g)
+    return sc, pos, tri, color
+
+
+@pytest.mark.parametrize("C", [1, 3, 2])
+def test_antialias_fwd_bwd_mesh(dr, ctx, oracle_ops, C):
+    sc, pos, tri, color = _aa_inputs(C=C)
+    rast_ref, _ = oracle_ops.rasterize(pos, tri, sc.resolution)
+    rast_ref = rast_ref.detach()
+    g = torch.Generator().manual_seed(9)
+    gy = torch.randn(color.shape, generator=g)
+    c_ref = color.clone().requires_grad_(True)
+    p_ref = pos.clone().requires_grad_(True)
+    o, flags = oracle_ops.antialias(c_ref, rast_ref, p_ref, tri, return_flags=True)
+    (o * gy).sum().backward()
+    assert int((flags > 0).sum()) > 20, "test scene must contain silhouette pairs"
+
+    c_gpu = color.cuda().requires_grad_(True)
+    p_gpu = pos.cuda().requires_grad_(True)
+    o2 = dr.antialias(c_gpu, rast_ref.cuda(), p_gpu, tri.cuda())
+    (o2 * gy.cuda()).sum().backward()
+    assert rel_l2(o2, o) < TOL
+    assert rel_l2(c_gpu.grad, c_ref.grad) < TOL
+    assert rel_l2(p_gpu.grad, p_ref.grad) < TOL
+
+
+def test_antialias_soup(dr, ctx, oracle_ops):
+    # open geometry: every edge is a boundary edge -> many silhouette pairs, incl. against background
+    pos, tri = random_soup(2, 60, 11, size=0.6)
+    res = (120, 104)
+    rast_ref, _ = oracle_ops.rasterize(pos, tri, res)
+    rast_ref = rast_ref.detach()
+    g = torch.Generator().manual_seed(4)
+    color = torch.rand(2, res[0], res[1], 3, generator=g)
+    gy = torch.randn(color.shape, generator=g)
+    c_ref = color.clone().requires_grad_(True)
+    p_ref = pos.clone().requires_grad_(True)
+    o = oracle_ops.antialias(c_ref, rast_ref, p_ref, tri)
+    (o * gy).sum().backward()
+    c_gpu = color.cuda().requires_grad_(True)
+    p_gpu = pos.cuda().requires_grad_(True)
+    o2 = dr.antialias(c_gpu, rast_ref.cuda(), p_gpu, tri.cuda())
+    (o2 * gy.cuda()).sum().backward()
+    assert float((o - color).abs().sum()) > 1.0
+    assert rel_l2(o2, o) < TOL
+    assert rel_l2(c_gpu.grad, c_ref.grad) < TOL
+    assert rel_l2(p_gpu.grad, p_ref.grad) < 5e-4
+
+
+def test_topology_matches_oracle(dr, oracle_ops):
+    from fpc_diffrend_amd import scene
+    sc = scene.cfg('cfg1')
+    tri = torch.tensor(sc.pos_idx)
+    # open the mesh (drop triangles) and add a non-manifold fin
+    tri = torch.cat([tri[40:], torch.tensor([[1, 2, 500], [1, 2, 501]], dtype=torch.int32)])
+    adj = dr.antialias_construct_topology_hash(tri.cuda()).cpu()
+    cnt, oth = oracle_ops.edge_table(tri)
+    expect = torch.where(cnt == 1, torch.full_like(oth, -1), torch.where(cnt == 2, oth, torch.full_like(oth, -2)))
+    assert torch.equal(adj, expect)

@@ -1,0 +1,251 @@
+"""
+CPU tests of the oracle itself (no GPU).  The reference has no tests or golden vectors for the four
+raster ops (they live in the absent nvdiffrast), so the oracle is validated by
+construction: an independent brute-force statement of the raster rules, forward invariants, and
+finite differences of every autograd backward in float64-free central differences.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import clip_positions, random_soup
+
+
+def brute_force_ids(pos, tri, H, W):
+    """Third, independent statement of raster rules R1-R6 with Python big ints / fractions."""
+    from fractions import Fraction
+    import math
+    B = pos.shape[0]
+    out = np.zeros((B, H, W), dtype=np.int32)
+    p = pos.numpy().astype(np.float64)
+    for b in range(B):
+        best = {}
+        for t, (i0, i1, i2) in enumerate(tri.numpy().tolist()):
+            vs = [p[b, i0], p[b, i1], p[b, i2]]
+            if not all(v[3] > 0 for v in vs):
+                continue
+            X, Y, zw = [], [], []
+            bad = False
+            for v in vs:
+                xs, ys = v[0] / v[3], v[1] / v[3]
+                fx = math.floor((xs * 0.5 + 0.5) * (W * 256) + 0.5)
+                fy = math.floor((ys * 0.5 + 0.5) * (H * 256) + 0.5)
+                if abs(fx) > 2 ** 24 or abs(fy) > 2 ** 24:
+                    bad = True
+                X.append(int(fx)); Y.append(int(fy)); zw.append(v[2] / v[3])
+            if bad:
+                continue
+            D = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0])
+            if D == 0:
+                continue
+            s = 1 if D > 0 else -1
+            q = [z / float(abs(D)) for z in zw]
+            for py in range(H):
+                Py = py * 256 + 128
+                if Py < min(Y) or Py > max(Y):
+                    continue
+                for px in range(W):
+                    Px = px * 256 + 128
+                    if Px < min(X) or Px > max(X):
+                        continue
+                    E = []
+                    inside = True
+                    for a, c in ((1, 2), (2, 0), (0, 1)):
+                        dx, dy = (X[c] - X[a]) * s, (Y[c] - Y[a]) * s
+                        e = dx * (Py - Y[a]) - dy * (Px - X[a])
+                        own = dy > 0 or (dy == 0 and dx < 0)
+                        if e < 0 or (e == 0 and not own):
+                            inside = False
+                        E.append(e)
+                    if not inside:
+                        continue
+                    d = (float(E[0]) * q[0] + float(E[1]) * q[1]) + float(E[2]) * q[2]
+                    if not (-1.0 <= d <= 1.0):
+                        continue
+                    if (py, px) not in best or d < best[(py, px)][0]:
+                        best[(py, px)] = (d, t)
+        for (py, px), (_, t) in best.items():
+            out[b, py, px] = t + 1
+    return torch.from_numpy(out)
+
+
+def test_raster_ids_vs_brute_force(oracle_ops):
+    pos, tri = random_soup(1, 25, 0)
+    ids = oracle_ops.rasterize_ids(pos, tri, (24, 20))
+    assert torch.equal(ids, brute_force_ids(pos, tri, 24, 20))
+    assert int((ids > 0).sum()) > 50
+
+
+def test_raster_fill_rule_shared_edges(oracle_ops):
+    # a quad split into two triangles, vertices on exact pixel centres: every covered pixel exactly once
+    H = W = 16
+
+    def ndc(px):  # pixel centre -> ndc
+        return (2 * px + 1) / W - 1
+
+    corners = [(2, 2), (12, 2), (12, 12), (2, 12)]
+    pos = torch.tensor([[[ndc(x), ndc(y), 0.0, 1.0] for x, y in corners]], dtype=torch.float32)
+    for tri in ([[0, 1, 2], [0, 2, 3]], [[0, 2, 1], [0, 2, 3]], [[1, 2, 3], [1, 3, 0]]):
+        t = torch.tensor(tri, dtype=torch.int32)
+        ids = oracle_ops.rasterize_ids(pos, t, (H, W))
+        cov = (ids > 0).sum().item()
+        # top-left style rule: 10 x 10 pixel centres inside the closed square minus two owned-out sides
+        assert cov == 100, cov
+        both = torch.stack([oracle_ops.rasterize_ids(pos, t[i:i + 1], (H, W)) > 0 for i in range(2)]).sum(0)
+        assert both.max().item() == 1  # no pixel claimed by both triangles
+        assert torch.equal(both > 0, ids > 0)
+
+
+def test_raster_depth_and_ties(oracle_ops):
+    H = W = 8
+    full = [[-3.0, -3.0], [3.0, -3.0], [0.0, 3.0]]
+
+    def tri_at(z):
+        return [[x, y, z, 1.0] for x, y in full]
+
+    pos = torch.tensor([tri_at(0.5) + tri_at(-0.2) + tri_at(-0.2) + tri_at(1.5)], dtype=torch.float32)
+    tri = torch.arange(12, dtype=torch.int32).reshape(4, 3)
+    ids = oracle_ops.rasterize_ids(pos, tri, (H, W))
+    assert (ids == 2).all()  # nearest wins; exact tie -> lower index; z/w = 1.5 is clipped
+    # w <= 0 drops the triangle
+    pos2 = pos.clone()
+    pos2[0, 3:9, 3] = -1.0
+    assert (oracle_ops.rasterize_ids(pos2, tri, (H, W)) == 1).all()
+
+
+def test_rasterize_barycentrics_reproduce_attributes(oracle_ops):
+    pos, tri = random_soup(2, 40, 3)
+    res = (40, 48)
+    rast, db = oracle_ops.rasterize(pos, tri, res)
+    m = rast[..., 3] > 0
+    u, v = rast[..., 0][m], rast[..., 1][m]
+    assert (u >= 0).all() and (v >= 0).all() and (u + v <= 1 + 1e-6).all()
+    # barycentric weights sum to one: a constant attribute is reproduced exactly; empty pixels give zero
+    out, _ = oracle_ops.interpolate(torch.ones(1, pos.shape[1], 1), rast, tri)
+    assert torch.allclose(out[..., 0][m], torch.ones_like(u), atol=1e-6)
+    assert (out[..., 0][~m] == 0).all()
+    # db: finite difference of u across neighbouring pixels of the same triangle
+    ids = rast[..., 3]
+    same = (ids[:, :, 1:] == ids[:, :, :-1]) & (ids[:, :, 1:] > 0)
+    fd = (rast[:, :, 1:, 0] - rast[:, :, :-1, 0])[same]
+    an = 0.5 * (db[:, :, 1:, 0] + db[:, :, :-1, 0])[same]
+    inner = (rast[:, :, 1:, 0][same] > 1e-3) & (rast[:, :, :-1, 0][same] > 1e-3) & (rast[:, :, 1:, 1][same] > 1e-3) & (rast[:, :, :-1, 1][same] > 1e-3)
+    # u is a rational (not linear) function of the pixel under perspective: compare to first order
+    err = (fd[inner] - an[inner]).abs() / (an[inner].abs() + 1e-3)
+    assert err.median() < 1e-2 and (err < 0.15).float().mean() > 0.95
+
+
+def _fd_check(f, x, g, eps, n=12, seed=0, rtol=3e-2, atol=1e-3):
+    """central differences of sum(f(x) * g) along random coordinates vs autograd"""
+    x = x.clone().requires_grad_(True)
+    y = f(x)
+    (y * g).sum().backward()
+    grad = x.grad.reshape(-1)
+    rng = np.random.default_rng(seed)
+    nz = torch.nonzero(grad.abs() > 10 * atol).reshape(-1)
+    assert nz.numel() > 0, "no gradient to check"
+    picks = nz[rng.integers(0, nz.numel(), size=n)]
+    ok = 0
+    for i in picks.tolist():
+        xp = x.detach().clone().reshape(-1)
+        xm = xp.clone()
+        xp[i] += eps
+        xm[i] -= eps
+        fd = ((f(xp.reshape(x.shape)) * g).sum() - (f(xm.reshape(x.shape)) * g).sum()) / (2 * eps)
+        if abs(fd.item() - grad[i].item()) <= atol + rtol * abs(grad[i].item()):
+            ok += 1
+    # a perturbation may flip a visibility / texel decision in rare cases: allow a small miss rate
+    assert ok >= n - 2, f"finite differences disagree with autograd ({ok}/{n})"
+
+
+def test_fd_rasterize_interpolate_chain(oracle_ops):
+    pos, tri = random_soup(1, 30, 5, spread=0.6, size=0.8)
+    res = (20, 20)
+    g = torch.Generator().manual_seed(0)
+    attr = torch.randn(1, 90, 3, generator=g)
+    ids0 = oracle_ops.rasterize_ids(pos, tri, res)
+    interior = torch.ones_like(ids0, dtype=torch.bool)
+    gy = torch.randn(1, 20, 20, 3, generator=g)
+
+    def f(p):
+        # freeze visibility so that finite differences see a smooth function
+        bidx, yy, xx, t, u, v, zw, db = oracle_ops._bary(p.float(), tri, ids0, 20, 20)
+        rast = torch.zeros(1, 20, 20, 4).index_put((bidx, yy, xx), torch.stack([u, v, zw, (t + 1).float()], 1))
+        out, _ = oracle_ops.interpolate(attr, rast, tri)
+        return out
+
+    _fd_check(f, pos, gy, 1e-3)
+
+
+def test_fd_texture(oracle_ops):
+    g = torch.Generator().manual_seed(1)
+    tex = torch.rand(1, 8, 8, 2, generator=g)
+    uv = torch.rand(1, 6, 6, 2, generator=g)
+    da = (torch.rand(1, 6, 6, 4, generator=g) - 0.5) * 0.8
+    gy = torch.randn(1, 6, 6, 2, generator=g)
+    _fd_check(lambda x: oracle_ops.texture(tex, x, filter_mode='linear'), uv, gy, 1e-3)
+    _fd_check(lambda x: oracle_ops.texture(x, uv, filter_mode='linear'), tex, gy, 1e-2)
+    _fd_check(lambda x: oracle_ops.texture(tex, uv, x, filter_mode='linear-mipmap-linear'), da, gy, 1e-3)
+    _fd_check(lambda x: oracle_ops.texture(x, uv, da, filter_mode='linear-mipmap-linear'), tex, gy, 1e-2)
+    # constant texture -> constant output, any filter
+    const = torch.full((1, 8, 8, 1), 0.37)
+    for mode in ('nearest', 'linear', 'linear-mipmap-linear', 'linear-mipmap-nearest'):
+        o = oracle_ops.texture(const, uv * 3 - 1, da if 'mip' in mode else None, filter_mode=mode)
+        assert torch.allclose(o, torch.full_like(o, 0.37), atol=1e-6)
+
+
+def test_antialias_invariants_and_fd(oracle_ops):
+    # single triangle over a background: axis-aligned-ish edge moves the blended pixel linearly
+    H = W = 16
+    pos = torch.tensor([[[-0.5, -0.8, 0.0, 1.0], [0.52, -0.7, 0.0, 1.0], [0.1, 0.75, 0.0, 1.0]]], dtype=torch.float32)
+    tri = torch.tensor([[0, 1, 2]], dtype=torch.int32)
+    rast, _ = oracle_ops.rasterize(pos, tri, (H, W))
+    color = torch.where(rast[..., 3:] > 0, torch.tensor(1.0), torch.tensor(0.0)).expand(1, H, W, 1).contiguous()
+    out, flags = oracle_ops.antialias(color, rast, pos, tri, return_flags=True)
+    assert int((flags > 0).sum()) > 5
+    assert ((out >= -1e-6) & (out <= 1 + 1e-6)).all()
+    # uniform colour -> identity
+    flat = torch.full((1, H, W, 1), 0.3)
+    assert torch.equal(oracle_ops.antialias(flat, rast, pos, tri), flat)
+    # coverage estimate: AA'd mask area is closer to the exact triangle area than the binary mask
+    tri_area = 0.5 * abs((0.52 + 0.5) * (0.75 + 0.8) - (0.1 + 0.5) * (-0.7 + 0.8)) * (W / 2) * (H / 2)
+    assert abs(out.sum().item() - tri_area) < abs(color.sum().item() - tri_area) + 1e-6
+    # finite differences on positions (the silhouette gradient) and colours
+    g = torch.Generator().manual_seed(2)
+    col = torch.rand(1, H, W, 2, generator=g)
+    gy = torch.randn(1, H, W, 2, generator=g)
+    rast = rast.detach()
+    _fd_check(lambda p: oracle_ops.antialias(col, rast, p, tri), pos, gy, 1e-4, atol=2e-3)
+    _fd_check(lambda c: oracle_ops.antialias(c, rast, pos, tri), col, gy, 1e-2)
+
+
+def test_antialias_closed_mesh_interior_untouched(oracle_ops):
+    from fpc_diffrend_amd import scene
+    sc = scene.cfg('cfg1')
+    pos, _ = clip_positions(sc, [3])
+    tri = torch.tensor(sc.pos_idx)
+    rast, _ = oracle_ops.rasterize(pos, tri, sc.resolution)
+    g = torch.Generator().manual_seed(0)
+    color = torch.rand(1, 256, 256, 1, generator=g)
+    out, flags = oracle_ops.antialias(color, rast, pos, tri, return_flags=True)
+    changed = (out != color)[..., 0]
+    assert changed.sum() > 50
+    # every changed pixel lies on the silhouette: it or a 4-neighbour is background
+    ids = rast[..., 3]
+    bg = ids == 0
+    near_bg = bg.clone()
+    near_bg[:, 1:] |= bg[:, :-1]; near_bg[:, :-1] |= bg[:, 1:]
+    near_bg[:, :, 1:] |= bg[:, :, :-1]; near_bg[:, :, :-1] |= bg[:, :, 1:]
+    assert (changed & ~near_bg).sum() == 0
+
+
+def test_edge_table(oracle_ops):
+    tri = torch.tensor([[0, 1, 2], [2, 1, 3], [1, 0, 4], [0, 1, 5]], dtype=torch.int32)
+    cnt, oth = oracle_ops.edge_table(tri)
+    # edge (0,1) is shared by three triangles -> count 3, no "other"
+    assert cnt[0, 2] == 3 and oth[0, 2] == -1
+    # edge (1,2): triangles 0 (opp 0) and 1 (opp 3)
+    assert cnt[0, 0] == 2 and oth[0, 0] == 3
+    assert cnt[1, 2] == 2 and oth[1, 2] == 0
+    # boundary
+    assert cnt[1, 0] == 1 and oth[1, 0] == -1
