@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""
+bench.py -- fit-loop throughput of the MI355X-native differentiable-raster path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg1|cfg5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" = one optimisation step of the fit loop over this rank's batch: blend (MFMA) -> MVP chain ->
+transform_clip -> rasterize -> interpolate -> texture -> antialias -> background + pixel loss, the whole
+backward, the gradient all-reduce and Adam (reference src/torch/fit.py:524-618, batched).  The default
+workload is BASELINE.json's configs[2] (9 views x 1080p, ~150 blendshapes, ~30k triangles, textured +
+antialias forward/backward, 32 frames per GPU, Adam on weights + pose + texture): the configuration the
+metric "fit-loop frames/sec (9-view 1080p)" and the 8-GPU config (32 frames/GPU) are quoted on.
+`--workload cfg2` runs configs[1] (single frame, rasterize + interpolate only).  One "frame" = all 9
+views of one time-frame.  Inputs (mesh, blendshapes, texture, 8-bit reference images) are synthetic and
+resident in HBM before the timed region.  Weak scaling: every rank owns 32 frames.
+
+Rank 0 prints ONE JSON line; see DESIGN.md section 6 for the roofline / cpu_baseline accounting.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+# algorithmic bytes per pixel, C = colour channels, fp32, op-boundary tensors read / written once
+# (SURVEY.md section 8d / BASELINE.md section 2).  rasterize forward writes rast only (rast_db is not
+# materialised when mip-mapping is off); pixel_loss: colour + rast + 8-bit ref in, grad out.
+def algorithmic_bytes_per_px(C, with_db):
+    return {
+        "fpcdr_rasterize_fwd": 16 + (16 if with_db else 0),
+        "fpcdr_rasterize_bwd": 32 + (16 if with_db else 0),
+        "fpcdr_interpolate_fwd": 24 + (32 if with_db else 0),
+        "fpcdr_interpolate_bwd": 40 + (48 if with_db else 0),
+        "fpcdr_texture_fwd": 8 + 4 * C + (16 if with_db else 0),
+        "fpcdr_texture_bwd": 16 + 4 * C + (32 if with_db else 0),
+        "fpcdr_antialias_fwd": 16 + 8 * C,
+        "fpcdr_antialias_bwd": 8 * C,
+        "fpcdr_pixel_loss": 4 * C + 16 + 1 + 4 * C,
+    }
+
+
+def cpu_baseline(sc, seconds_budget=30.0):
+    """The oracle fit step (PyTorch-CPU software raster, cpu_baseline.kind = 'port') on the host cores, on a
+    bounded sample of the same workload: ONE 1080p image (1 frame x 1 view) per step."""
+    from oracle import fit as ofit
+    from oracle import ops as oops
+    oops.build()
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    dt, n_img, used = ofit.timed_steps(sc, cams=[3], frame_ids=[0], steps=1, threads=threads)
+    steps = 1
+    if dt < seconds_budget / 3:
+        k = max(1, int(seconds_budget / 3 / dt))
+        dt, n_img, used = ofit.timed_steps(sc, cams=[3], frame_ids=[0], steps=k, threads=threads)
+        steps = k
+    n_views = 9
+    return {"value": (n_img / n_views) / dt, "unit": "frames/s", "cores": used, "kind": "port",
+            "sample": f"{steps} full fit step(s) (forward + backward + Adam) of 1 frame x 1 view at "
+                      f"{sc.resolution[1]}x{sc.resolution[0]} on the same mesh/rig, {dt:.2f} s per image, scaled linearly to "
+                      f"{n_views} views per frame; wall {time.perf_counter() - t0:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--frames-per-gpu", type=int, default=0)
+    ap.add_argument("--channels", type=int, default=1)
+    ap.add_argument("--mip", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    from fpc_diffrend_amd import _lib, dist as fdist, fit, scene
+
+    rank, world, local_rank = fdist.init()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    _lib.load()
+
+    fpg = args.frames_per_gpu or {"cfg1": 4, "cfg2": 1, "cfg3": 32, "cfg5": 4}[args.workload]
+    n_frames = fpg * world
+    sc = scene.cfg(args.workload, n_frames=n_frames)
+    if args.channels != 1:
+        import numpy as np
+        sc.texture = np.repeat(sc.texture, args.channels, axis=2)[:, :, :args.channels].copy()
+    cfg = fit.FitConfig(max_iter=80000, enable_mip=args.mip, frames_per_step=0, init_texture="random")
+    if args.workload == "cfg2":
+        cfg.optimize_texture = False
+    bucket = None
+    fitter = fit.Fitter(sc, cfg, device=device, rank=rank, world=world)
+    bucket = fdist.GradBucket(fitter.params, device)
+    fitter.reduce_fn = bucket if world > 1 else None
+    H, W = fitter.resolution
+    n_cam = len(fitter.cam_idxs)
+    C = sc.texture.shape[2]
+
+    for _ in range(args.warmup):
+        fitter.step()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = _lib.KernelTimer()
+    torch.cuda.synchronize()
+    fdist.barrier()
+    torch.cuda.synchronize()
+    _lib.TIMER = timer
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(args.steps):
+        loss = fitter.step()
+    torch.cuda.synchronize()
+    fdist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.TIMER = None
+    elapsed = fdist.max_over_ranks(elapsed, device)
+
+    frames_total = fpg * world * args.steps
+    value = frames_total / elapsed
+    out = {
+        "metric": "fit-loop frames/sec (9-view 1080p)" if args.workload in ("cfg2", "cfg3") else f"fit-loop frames/sec ({args.workload})",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {n_cam}-view {W}x{H}, K={sc.blendshapes.shape[1]} blendshapes, "
+                               f"T={sc.pos_idx.shape[0]} triangles, {fpg} frames/GPU/step ({fpg * n_cam} images), "
+                               f"textured C={C} + antialias fwd/bwd{' + mip' if args.mip else ''}, Adam on weights+pose+texture",
+                   "frames_per_gpu": fpg, "views": n_cam, "resolution": [H, W], "triangles": int(sc.pos_idx.shape[0]),
+                   "blendshapes": int(sc.blendshapes.shape[1]), "texture": list(sc.texture.shape),
+                   "parallelism": f"dp{world} (frames sharded, one RCCL all-reduce of {bucket.nbytes / 1e6:.1f} MB per step)"},
+        "final_loss": float(loss) if loss is not None else None,
+    }
+    if rank == 0 and timer is not None:
+        summ = timer.summary()
+        bpp = algorithmic_bytes_per_px(C, args.mip)
+        npix = fpg * n_cam * H * W
+        table = {}
+        for name, (calls, ms) in summ.items():
+            per = ms / max(calls, 1)
+            row = {"calls": calls, "avg_ms": per}
+            if name in bpp:
+                row["algorithmic_GBps"] = bpp[name] * npix / (per * 1e-3) / 1e9
+                row["bytes_per_px"] = bpp[name]
+            table[name] = row
+        out["kernels"] = table
+        px_ops = {k: v for k, v in table.items() if "algorithmic_GBps" in v}
+        if px_ops:
+            dom = max(px_ops, key=lambda k: px_ops[k]["avg_ms"] * px_ops[k]["calls"])
+            a = px_ops[dom]["algorithmic_GBps"]
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": a / HBM_PEAK_GBS, "traffic": None}
+            if "fpcdr_antialias_bwd" in px_ops:
+                a = px_ops["fpcdr_antialias_bwd"]["algorithmic_GBps"]
+                out["roofline_antialias_bwd"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": a / HBM_PEAK_GBS}
+            gpu_ms = sum(v["avg_ms"] * v["calls"] for v in table.values()) / args.steps
+            out["fpcdr_ms_per_step"] = gpu_ms
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(sc)
+        except Exception as e:  # the baseline must never take the measurement down
+            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {e!r}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

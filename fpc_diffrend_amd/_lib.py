@@ -67,6 +67,12 @@ class AntialiasBwd(ctypes.Structure):
                 ("pos_gradient_boost", ctypes.c_float), ("grad_color", _p), ("grad_pos", _p)]
 
 
+class PixelLoss(ctypes.Structure):
+    _fields_ = [("color", _p), ("rast", _p), ("ref", _p), ("B", _i), ("H", _i), ("W", _i), ("C", _i),
+                ("bg", ctypes.c_float), ("color_scale", ctypes.c_float), ("grad_scale", ctypes.c_float),
+                ("loss_sum", _p), ("grad_color", _p)]
+
+
 # every symbol include/fpcdr.h declares: name -> (restype, argtypes)
 _sz = ctypes.c_size_t
 _int = ctypes.c_int
@@ -90,6 +96,7 @@ SYMBOLS = {
     "fpcdr_blend_fwd": (_int, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_blend_bwd_w": (_int, [_p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_blend_bwd_basis": (_int, [_p, _p, _p, _i, _i, _i, _p]),
+    "fpcdr_pixel_loss": (_int, [ctypes.POINTER(PixelLoss), _p]),
 }
 
 _lib = None
@@ -121,6 +128,43 @@ def load():
         raise RuntimeError(f"libfpcdr.so ABI version {ver} != binding {ABI_VERSION}; rebuild the extension")
     _lib = lib
     return lib
+
+
+class KernelTimer:
+    """Per-entry-point device time, measured with HIP events recorded on the launch stream (torch's current
+    stream, the one every fpcdr_* launch goes to).  Used by bench.py for the roofline figures."""
+
+    def __init__(self):
+        self.records = {}
+
+    def add(self, name, e0, e1):
+        self.records.setdefault(name, []).append((e0, e1))
+
+    def summary(self):
+        """name -> (calls, total milliseconds); synchronises."""
+        import torch
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.records.items()}
+
+
+TIMER = None  # set to a KernelTimer() to time every C-ABI call
+
+
+def call(name, *args):
+    """Invoke one C-ABI entry point, raise on a non-zero return code."""
+    fn = getattr(load(), name)
+    t = TIMER
+    if t is not None:
+        import torch
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        t.add(name, e0, e1)
+    else:
+        rc = fn(*args)
+    check(rc)
 
 
 def check(rc):

@@ -339,7 +339,6 @@ __global__ void __launch_bounds__(256) k_aa_bwd(const float *__restrict__ color,
             [&](float t, int Px, int Py, int Qx, int Qy, int va, int vb, const EdgeEval &ev, float s) {
                 const bool far = t >= 0.5f;
                 const int rx = far ? Qx : Px, ry = far ? Qy : Py;
-                const int ox = far ? Px : Qx, oy = far ? Py : Qy;
                 const float amt = far ? t - 0.5f : 0.5f - t;
                 const size_t roff = img + (size_t)ry * W + rx;
                 const float *gr = dy + roff * C;

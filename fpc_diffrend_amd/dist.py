@@ -1,0 +1,99 @@
+"""
+Data-parallel plumbing: one process per GPU, frames sharded contiguously over ranks, parameters
+replicated, ONE RCCL all-reduce (sum) of a single flat f32 gradient bucket per Adam step over xGMI.
+
+The reference is single-process / single-GPU: this is a capability of the
+build, designed from the path's structure (section 8e): every (frame, view) image is an independent
+render; frames interact only through the shared parameters, so the gradient sum is the one real
+exchange step.  Payload in prior mode (F = 256, K = 150, 1024^2 x 1 texture): ~1.15 M floats = 4.6 MB
+-- latency-bound on 7 x 153 GB/s xGMI links, so no overlap machinery is needed; weak-scaling
+efficiency hinges on equal pixels per rank.
+
+Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests (world_size 2).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+    Returns (rank, world, local_rank).  A single process (no env) returns (0, 1, 0) without a process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, 0
+    rank = int(os.environ["RANK"])
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+class GradBucket:
+    """Flat gradient bucket.  `bucket(params)` packs every existing .grad into one contiguous f32 buffer,
+    all-reduces it (sum) and unpacks -- exactly one collective per optimisation step."""
+
+    def __init__(self, params, device):
+        self.all_params = list(params)
+        self.device = device
+        self.calls = 0
+        self._layout(None)
+
+    def _layout(self, sig):
+        # only parameters that are being optimised travel (combined mode enables more half-way, fit.py:603-608)
+        self.sig = tuple(p.requires_grad for p in self.all_params) if sig is None else sig
+        self.params = [p for p in self.all_params if p.requires_grad]
+        self.sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(max(sum(self.sizes), 1), dtype=torch.float32, device=self.device)
+
+    def __call__(self, params=None):
+        sig = tuple(p.requires_grad for p in self.all_params)
+        if sig != self.sig:
+            self._layout(sig)
+        off = 0
+        for p, n in zip(self.params, self.sizes):
+            if p.grad is not None:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            else:
+                self.flat[off:off + n].zero_()
+            off += n
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.calls += 1
+        off = 0
+        for p, n in zip(self.params, self.sizes):
+            if p.grad is not None:
+                p.grad.copy_(self.flat[off:off + n].view_as(p.grad))
+            else:
+                p.grad = self.flat[off:off + n].view_as(p).clone()
+            off += n
+
+    @property
+    def nbytes(self):
+        return self.flat.numel() * 4
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

@@ -99,7 +99,7 @@ class _rasterize_func(torch.autograd.Function):
         scratch = torch.empty(lib.fpcdr_rasterize_scratch_bytes(B, T), dtype=torch.uint8, device=dev)
         p = _lib.RasterizeFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch),
                               rast=_ptr(rast), rast_db=_ptr(rast_db))
-        _lib.check(lib.fpcdr_rasterize_fwd(ctypes.byref(p), _stream()))
+        _lib.call("fpcdr_rasterize_fwd", ctypes.byref(p), _stream())
         ctx.save_for_backward(pos, tri, rast)
         ctx.grad_db = bool(grad_db and output_db)
         if rast_db is None:
@@ -117,7 +117,7 @@ class _rasterize_func(torch.autograd.Function):
         ddb = ddb.contiguous() if (ctx.grad_db and ddb is not None and ddb.numel() > 0) else None
         p = _lib.RasterizeBwd(pos=_ptr(pos), tri=_ptr(tri), rast=_ptr(rast), dy=_ptr(dy), ddb=_ptr(ddb), B=B, V=V,
                               T=tri.shape[0], H=H, W=W, grad_pos=_ptr(g_pos))
-        _lib.check(lib.fpcdr_rasterize_bwd(ctypes.byref(p), _stream()))
+        _lib.call("fpcdr_rasterize_bwd", ctypes.byref(p), _stream())
         return g_pos, None, None, None, None, None
 
 
@@ -168,7 +168,7 @@ class _interpolate_func(torch.autograd.Function):
         p = _lib.InterpolateFwd(attr=_ptr(attr), rast=_ptr(rast), tri=_ptr(tri), rast_db=_ptr(rast_db) if n_diff else None,
                                 B=B, H=H, W=W, Ba=Ba, Vt=Vt, A=A, T=tri.shape[0], n_diff=n_diff,
                                 diff_idx=_diff_array(diff_list), out=_ptr(out), out_da=_ptr(out_da) if n_diff else None)
-        _lib.check(lib.fpcdr_interpolate_fwd(ctypes.byref(p), _stream()))
+        _lib.call("fpcdr_interpolate_fwd", ctypes.byref(p), _stream())
         ctx.save_for_backward(attr, rast, tri, rast_db if n_diff else None)
         ctx.diff_list = diff_list
         return out, out_da
@@ -193,7 +193,7 @@ class _interpolate_func(torch.autograd.Function):
                                 dy=_ptr(dy), dda=_ptr(dda) if n_diff else None, B=B, H=H, W=W, Ba=Ba, Vt=Vt, A=A,
                                 T=tri.shape[0], n_diff=n_diff, diff_idx=_diff_array(diff_list), grad_attr=_ptr(g_attr),
                                 grad_rast=_ptr(g_rast), grad_rast_db=_ptr(g_db))
-        _lib.check(lib.fpcdr_interpolate_bwd(ctypes.byref(p), _stream()))
+        _lib.call("fpcdr_interpolate_bwd", ctypes.byref(p), _stream())
         return g_attr, g_rast, None, g_db, None
 
 
@@ -260,7 +260,7 @@ def _build_mips(tex, n_levels):
         src = chain[-1]
         N, h, w, C = src.shape
         dst = torch.empty(N, h // 2, w // 2, C, dtype=torch.float32, device=tex.device)
-        _lib.check(lib.fpcdr_mip_downsample(_ptr(src), _ptr(dst), N, h, w, C, _stream()))
+        _lib.call("fpcdr_mip_downsample", _ptr(src), _ptr(dst), N, h, w, C, _stream())
         chain.append(dst)
     return chain
 
@@ -293,7 +293,7 @@ class _texture_func(torch.autograd.Function):
         p = _lib.TextureFwd(tex=_ptr_array(chain), n_levels=n_levels, uv=_ptr(uv), uv_da=_ptr(uv_da),
                             mip_level_bias=_ptr(bias), B=B, H=H, W=W, Bt=Bt, Ht=Ht, Wt=Wt, C=C,
                             filter_mode=filter_mode, boundary_mode=boundary_mode, out=_ptr(out))
-        _lib.check(lib.fpcdr_texture_fwd(ctypes.byref(p), _stream()))
+        _lib.call("fpcdr_texture_fwd", ctypes.byref(p), _stream())
         ctx.save_for_backward(tex, uv, uv_da, bias, *chain[1:])
         ctx.cfg = (filter_mode, boundary_mode, n_levels)
         return out
@@ -316,12 +316,12 @@ class _texture_func(torch.autograd.Function):
                             mip_level_bias=_ptr(bias), dy=_ptr(dy), B=B, H=H, W=W, Bt=Bt, Ht=Ht, Wt=Wt, C=C,
                             filter_mode=filter_mode, boundary_mode=boundary_mode, grad_tex=_ptr_array(g_levels),
                             grad_uv=_ptr(g_uv), grad_uv_da=_ptr(g_da), grad_mip_level_bias=_ptr(g_bias))
-        _lib.check(lib.fpcdr_texture_bwd(ctypes.byref(p), _stream()))
+        _lib.call("fpcdr_texture_bwd", ctypes.byref(p), _stream())
         if need_tex:
             # collapse the mip gradients down to level 0
             for l in range(n_levels, 0, -1):
                 N, h, w, _ = chain[l - 1].shape
-                _lib.check(lib.fpcdr_mip_downsample_bwd(_ptr(g_levels[l]), _ptr(g_levels[l - 1]), N, h, w, C, _stream()))
+                _lib.call("fpcdr_mip_downsample_bwd", _ptr(g_levels[l]), _ptr(g_levels[l - 1]), N, h, w, C, _stream())
         return (g_levels[0], g_uv, g_da, g_bias, None, None, None) + (None,) * (len(chain) - 1)
 
 
@@ -391,7 +391,7 @@ def antialias_construct_topology_hash(tri):
     T = tri.shape[0]
     scratch = torch.empty(lib.fpcdr_topology_scratch_bytes(T), dtype=torch.uint8, device=tri.device)
     adj = torch.empty(T, 3, dtype=torch.int32, device=tri.device)
-    _lib.check(lib.fpcdr_topology_build(_ptr(tri), T, _ptr(scratch), _ptr(adj), _stream()))
+    _lib.call("fpcdr_topology_build", _ptr(tri), T, _ptr(scratch), _ptr(adj), _stream())
     return adj
 
 
@@ -420,7 +420,7 @@ class _antialias_func(torch.autograd.Function):
         flags = torch.empty(lib.fpcdr_antialias_flags_bytes(B, H, W) // 8, dtype=torch.int64, device=dev)
         p = _lib.AntialiasFwd(color=_ptr(color), rast=_ptr(rast), pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), B=B, H=H,
                               W=W, C=C, V=V, T=T, sil=_ptr(sil), flags=_ptr(flags), out=_ptr(out))
-        _lib.check(lib.fpcdr_antialias_fwd(ctypes.byref(p), _stream()))
+        _lib.call("fpcdr_antialias_fwd", ctypes.byref(p), _stream())
         ctx.save_for_backward(color, rast, pos, tri, adj, sil, flags)
         ctx.boost = float(boost)
         return out
@@ -437,7 +437,7 @@ class _antialias_func(torch.autograd.Function):
         p = _lib.AntialiasBwd(color=_ptr(color), rast=_ptr(rast), pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), dy=_ptr(dy),
                               B=B, H=H, W=W, C=C, V=V, T=T, sil=_ptr(sil), flags=_ptr(flags),
                               pos_gradient_boost=ctx.boost, grad_color=_ptr(g_color), grad_pos=_ptr(g_pos))
-        _lib.check(lib.fpcdr_antialias_bwd(ctypes.byref(p), _stream()))
+        _lib.call("fpcdr_antialias_bwd", ctypes.byref(p), _stream())
         return g_color, None, g_pos, None, None, None
 
 

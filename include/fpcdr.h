@@ -200,6 +200,25 @@ int fpcdr_blend_bwd_w(const float *Bmat, const float *grad_out, float *grad_w, i
 int fpcdr_blend_bwd_basis(const float *w, const float *grad_out, float *grad_B, int32_t M, int32_t K, int32_t F,
                           void *stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* background composite + L2 pixel loss        reference fit.py:161 and the pixel term of :579   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* loss_sum += sum over pixels, channels of (ref - color_scale * c)^2, c = covered ? color : bg
+ * grad_color = grad_scale * d(that sum)/d color  (0 at uncovered pixels); one pass.              */
+typedef struct {
+    const float *color;    /* [B,H,W,C] */
+    const float *rast;     /* [B,H,W,4]; covered = rast.w > 0 */
+    const uint8_t *ref;    /* [B,H,W] 8-bit reference image, broadcast over C (reference: greyscale, C = 1) */
+    int32_t B, H, W, C;
+    float bg;              /* background colour, reference 45/255 */
+    float color_scale;     /* reference 255 */
+    float grad_scale;      /* 1 / (number of elements of the global mean) */
+    double *loss_sum;      /* accumulated, one f64 */
+    float *grad_color;     /* out [B,H,W,C], or NULL */
+} fpcdr_pixel_loss_params;
+int fpcdr_pixel_loss(const fpcdr_pixel_loss_params *p, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

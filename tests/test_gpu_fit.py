@@ -1,0 +1,92 @@
+"""GPU: the fit-loop pieces around the four ops -- MFMA blend, fused pixel loss, the whole smoke step vs the
+oracle, and that a few Adam steps reduce the loss."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("M,K,F", [(1542, 10, 4), (4500, 150, 32), (999, 70, 5), (3 * 15002, 150, 32)])
+def test_blend_mfma_fwd_bwd(M, K, F):
+    from fpc_diffrend_amd import fit
+    g = torch.Generator().manual_seed(0)
+    vb, Bm, w = torch.randn(M, generator=g), torch.randn(M, K, generator=g), torch.randn(F, K, generator=g)
+    go = torch.randn(F, M, generator=g)
+    vb_r, Bm_r, w_r = (x.double().requires_grad_(True) for x in (vb, Bm, w))
+    out_r = vb_r[None] + w_r @ Bm_r.t()
+    (out_r * go.double()).sum().backward()
+    vb_g, Bm_g, w_g = (x.cuda().requires_grad_(True) for x in (vb, Bm, w))
+    out = fit.blend_batched(vb_g, Bm_g, w_g)
+    (out * go.cuda()).sum().backward()
+    assert rel_l2(out, out_r) < 1e-6
+    assert rel_l2(w_g.grad, w_r.grad) < 1e-5
+    assert rel_l2(Bm_g.grad, Bm_r.grad) < 1e-6
+    assert rel_l2(vb_g.grad, vb_r.grad) < 1e-6
+
+
+def test_blend_reference_forms_match_torch():
+    from fpc_diffrend_amd import fit
+    g = torch.Generator().manual_seed(1)
+    M, K, F = 300, 12, 6
+    v = torch.randn(M, generator=g).cuda()
+    maps = {'local': torch.randn(F, F, generator=g).cuda()}
+    mi = {'local': torch.randn(K, F, generator=g).cuda()}
+    ds = {'local': torch.randn(M, K, generator=g).cuda()}
+    m1, m2, m3 = torch.randn(F, F, generator=g).cuda(), torch.randn(F, F, generator=g).cuda(), torch.randn(M, F, generator=g).cuda()
+    e = torch.zeros(F).cuda()
+    e[2] = 1.0
+    ref = v + ds['local'] @ (mi['local'] @ (maps['local'] @ e))          # reference fit.py:115-119
+    assert rel_l2(fit.blend(v, maps, mi, ds, e), ref) < 1e-5
+    ref_free = v + m3 @ (m2 @ (m1 @ e))                                   # reference fit.py:58-62
+    assert rel_l2(fit.blend_free(v, m1, m2, m3, e), ref_free) < 1e-5
+    ref_c = ref + 0.5 * (m3 @ (m2 @ (m1 @ e)))                            # reference fit.py:88-99
+    assert rel_l2(fit.blend_combined(v, m1, m2, m3, maps, mi, ds, e, learned_coefficient=0.5), ref_c) < 1e-5
+
+
+def test_pixel_loss_fused_equals_reference_chain():
+    from fpc_diffrend_amd import fit
+    g = torch.Generator().manual_seed(2)
+    B, H, W, C = 3, 37, 53, 1
+    colour = torch.rand(B, H, W, C, generator=g).cuda().requires_grad_(True)
+    rast = torch.zeros(B, H, W, 4)
+    rast[..., 3] = (torch.rand(B, H, W, generator=g) > 0.4).float() * 7
+    rast = rast.cuda()
+    ref = torch.randint(0, 141, (B, H, W), generator=g, dtype=torch.uint8).cuda()
+    col = torch.where(rast[..., 3:] > 0, colour, torch.tensor(fit.BACKGROUND).cuda())     # reference fit.py:161
+    loss = torch.mean((ref[..., None].float() - col * 255) ** 2)                            # reference fit.py:579
+    loss.backward()
+    s, grad = fit.pixel_loss_fused(colour, rast, ref)
+    assert abs(float(s[0]) / colour.numel() - float(loss)) < 1e-3 * float(loss)
+    assert rel_l2(grad, colour.grad) < 1e-6
+
+
+def test_smoke_step_matches_oracle(oracle_ops):
+    from fpc_diffrend_amd import fit, scene
+    from oracle import fit as ofit
+    sc = scene.cfg('cfg1', n_frames=2)
+    res = fit.smoke_step(sc, device='cuda:0')
+    ref = ofit.smoke_step(sc)
+    assert torch.equal(res['ids'].cpu(), ref['ids'])
+    for k in ('image', 'grad_w', 'grad_tex', 'grad_pose'):
+        assert rel_l2(res[k], ref[k]) < TOL, k
+    assert abs(float(res['loss']) - float(ref['loss'])) < 1e-4 * float(ref['loss'])
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_fit_reduces_loss(fused):
+    from fpc_diffrend_amd import fit, scene
+    sc = scene.cfg('cfg1', n_frames=4)
+    cfg = fit.FitConfig(max_iter=40, cam_idxs=(0, 3, 6), lr_base=2e-2, lr_t=1e-3, lr_q=1e-4, fused_loss=fused,
+                        weight_laplacian=0.0)
+    ft = fit.Fitter(sc, cfg, device='cuda')
+    losses = [float(ft.step()) for _ in range(40)]
+    assert np.isfinite(losses).all()
+    assert losses[-1] < 0.7 * losses[0], losses
+    w = ft.weights().cpu().numpy()
+    w_gt = sc.weights_gt
+    # activations move towards the hidden ground truth
+    assert np.abs(w - w_gt).mean() < np.abs(w_gt).mean()

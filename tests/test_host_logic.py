@@ -1,0 +1,140 @@
+"""CPU tests (no GPU): host-side mirrors of the reference against the committed golden fixtures, the
+synthetic scene generator, and that the C-ABI library loads and exports every symbol include/fpcdr.h declares."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from fpc_diffrend_amd import camera, scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def cam_gold():
+    with open(os.path.join(GOLD, "camera_golden.json")) as f:
+        return json.load(f)
+
+
+def test_camera_matrices_match_reference_golden(cam_gold):
+    # golden: outputs of the reference's camera.intrinsic_to_projection / extrinsic_to_modelview
+    # (reference camera.py:27-66) on its own calibration.json, captured by tests/golden/make_golden.py
+    assert len(cam_gold["cameras"]) == 9
+    for name, c in cam_gold["cameras"].items():
+        intr = np.asarray(c["intrinsic"], dtype=np.float32)
+        rot = np.asarray(c["rotation"], dtype=np.float32)
+        trans = np.asarray(c["translation"], dtype=np.float32)
+        P = camera.intrinsic_to_projection(intr)
+        MV = camera.extrinsic_to_modelview(rot, trans)
+        assert P.dtype == np.float32 and str(MV.dtype) == c["MV_dtype"]
+        np.testing.assert_array_equal(P, np.asarray(c["P"], dtype=np.float32))
+        np.testing.assert_array_equal(MV, np.asarray(c["MV"], dtype=np.float32))
+    # known answers recorded in SURVEY.md section 8c for pod2primary
+    c = cam_gold["cameras"]["pod2primary"]
+    P = camera.intrinsic_to_projection(np.asarray(c["intrinsic"], dtype=np.float32))
+    assert abs(P[0, 0] - 12.08315) < 1e-4 and abs(P[1, 1] - 8.954283) < 1e-5
+    assert abs(P[2, 2] + 1.0001) < 1e-6 and abs(P[2, 3] + 0.020001) < 1e-7
+
+
+def test_small_camera_helpers_match_golden(cam_gold):
+    np.testing.assert_array_equal(camera.translate(0.0, 170.0, 0.0), np.asarray(cam_gold["translate_0_170_0"], dtype=np.float32))
+    np.testing.assert_array_equal(camera.default_projection(), np.asarray(cam_gold["default_projection"], dtype=np.float32))
+    np.testing.assert_array_equal(camera.default_modelview(), np.asarray(cam_gold["default_modelview"], dtype=np.float32))
+    np.testing.assert_allclose(camera.rotate_x(0.3), np.asarray(cam_gold["rotate_x_0p3"], dtype=np.float32), atol=1e-7)
+    np.testing.assert_allclose(camera.rotate_y(0.3), np.asarray(cam_gold["rotate_y_0p3"], dtype=np.float32), atol=1e-7)
+
+
+def test_rig_file_equals_golden_inputs(cam_gold):
+    rig = camera.load_rig()
+    assert [r['cam'] for r in rig] == list(cam_gold["cameras"].keys())
+    for r in rig:
+        c = cam_gold["cameras"][r['cam']]
+        np.testing.assert_array_equal(r['rot'], np.asarray(c["rotation"], dtype=np.float32))
+        np.testing.assert_array_equal(r['trans_calib'], np.asarray(c["translation"], dtype=np.float32))
+
+
+def test_transform_clip_and_rigid():
+    g = torch.Generator().manual_seed(0)
+    pos = torch.randn(7, 3, generator=g)
+    mvp = torch.randn(4, 4, generator=g)
+    out = camera.transform_clip(mvp, pos)
+    assert out.shape == (1, 7, 4)
+    ref = torch.cat([pos, torch.ones(7, 1)], 1) @ mvp.t()       # reference camera.py:21-22
+    assert torch.allclose(out[0], ref)
+    assert torch.allclose(camera.transform_clip(mvp.numpy(), pos), out)
+    # batched: 2 vertex buffers x 3 views each
+    posb = torch.randn(2, 7, 3, generator=g)
+    mv = torch.randn(6, 4, 4, generator=g)
+    ob = camera.transform_clip(mv, posb)
+    assert ob.shape == (6, 7, 4)
+    for b in range(6):
+        assert torch.allclose(ob[b], torch.cat([posb[b // 3], torch.ones(7, 1)], 1) @ mv[b].t(), atol=1e-6)
+    # rigid_grad: reference camera.py:128-132
+    R = camera.unitquat_to_rotmat(torch.tensor([0.0, 0.0, 0.0, 1.0]))
+    assert torch.equal(R, torch.eye(3))
+    Rt = camera.rigid_grad(torch.tensor([1.0, 2.0, 3.0]), R)
+    assert torch.equal(Rt, torch.tensor(camera.translate(1, 2, 3)))
+    # quaternion: 90 degrees about z (XYZW)
+    s = float(np.sqrt(0.5))
+    Rz = camera.unitquat_to_rotmat(torch.tensor([0.0, 0.0, s, s]))
+    assert torch.allclose(Rz, torch.tensor([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]]), atol=1e-6)
+    # gradients flow
+    t = torch.zeros(3, requires_grad=True)
+    q = torch.tensor([0.0, 0.0, 0.0, 1.0], requires_grad=True)
+    camera.rigid_grad(t, camera.unitquat_to_rotmat(q)).sum().backward()
+    assert t.grad is not None and q.grad is not None
+
+
+def test_scene_generator_matches_config_sizes():
+    sc = scene.cfg('cfg1')
+    assert sc.pos_idx.shape == (1024, 3) and sc.n_vertices == 514 and sc.blendshapes.shape == (1542, 10)
+    assert sc.uv.shape[0] > sc.n_vertices and sc.uv_idx.shape == sc.pos_idx.shape
+    assert sc.uv_idx.max() < sc.uv.shape[0] and sc.pos_idx.max() < sc.n_vertices
+    assert sc.texture.shape == (256, 256, 1) and 0 <= sc.texture.min() and sc.texture.max() <= 1
+    assert len(sc.cams) == 9
+    # deterministic
+    sc2 = scene.cfg('cfg1')
+    np.testing.assert_array_equal(sc.blendshapes, sc2.blendshapes)
+    np.testing.assert_array_equal(sc.texture, sc2.texture)
+    # closed manifold: every edge shared by exactly two triangles
+    from oracle import ops as O
+    O.build()
+    cnt, _ = O.edge_table(torch.tensor(sc.pos_idx))
+    assert (cnt == 2).all()
+    v, t, uv, tuv = scene.make_mesh(*scene.MESH_30K)
+    assert t.shape[0] == 30000 and v.shape[0] == 15002
+    # the head projects inside every camera's frame
+    from helpers import clip_positions
+    pos, _ = clip_positions(sc, list(range(9)))
+    ndc = pos[..., :2] / pos[..., 3:]
+    assert (pos[..., 3] > 0).all() and ndc.abs().max() < 1.0
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from fpc_diffrend_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    header = open(os.path.join(ROOT, "include", "fpcdr.h")).read()
+    declared = set(re.findall(r"\b(fpcdr_[a-z0-9_]+)\s*\(", header))
+    declared = {d for d in declared if not d.endswith("_params")}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported"
+    assert _lib.load().fpcdr_abi_version() == _lib.ABI_VERSION
+    # struct sizes agree with the C layout (spot check via the compiler)
+    assert ctypes.sizeof(_lib.RasterizeFwd) == 64
+    assert ctypes.sizeof(_lib.InterpolateFwd) == 4 * 8 + 8 * 4 + 32 * 4 + 2 * 8
+
+
+def test_ops_reject_cpu_tensors_and_missing_gpu():
+    import fpc_diffrend_amd.ops as dr
+    with pytest.raises((ValueError, RuntimeError)):
+        dr.interpolate(torch.zeros(1, 3, 2), torch.zeros(1, 4, 4, 4), torch.zeros(1, 3, dtype=torch.int32))
+    with pytest.raises(ValueError):
+        dr.texture(torch.zeros(1, 4, 4, 1), torch.zeros(1, 4, 4, 2), filter_mode='bogus')

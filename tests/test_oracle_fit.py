@@ -1,0 +1,35 @@
+"""CPU: the oracle fit step (BASELINE.json configs[0]: 1-view 256x256, 10 blendshapes, 1k triangles, PyTorch-CPU
+software raster) runs end to end and its loss goes down -- the plumbing the CPU baseline and smoke() rely on."""
+import torch
+
+from fpc_diffrend_amd import scene
+from oracle import fit as ofit
+
+
+def test_oracle_fit_cfg1_descends(oracle_ops):
+    sc = scene.cfg('cfg1', n_frames=2)
+    st = ofit.State(sc, cams=[3])
+    # targets: ground truth rendered by the oracle itself, 8 bit, clipped to [0,140] (reference fit.py:531)
+    gt = ofit.State(sc, cams=[3])
+    with torch.no_grad():
+        gt.M1.copy_(torch.eye(2))
+        gt.M2.copy_(torch.tensor(sc.weights_gt).t())
+        gt.per_frame_t.copy_(torch.tensor(sc.t_gt))
+        gt.per_frame_q.copy_(torch.tensor(sc.q_gt))
+        _, img, _ = ofit.forward(gt, torch.arange(2), torch.zeros(2, 1, 256, 256, dtype=torch.uint8))
+        targets = torch.clamp(torch.round(img[..., 0] * 255), 0, 140).to(torch.uint8).reshape(2, 1, 256, 256)
+    with torch.no_grad():
+        st.M1.copy_(torch.eye(2))
+        st.M2.zero_()
+    opt = torch.optim.Adam([st.M2, st.per_frame_t], lr=2e-2)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        loss, _, _ = ofit.forward(st, torch.arange(2), targets)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+    r = ofit.smoke_step(sc)
+    assert all(torch.isfinite(v).all() for k, v in r.items())
+    assert r['grad_w'].abs().max() > 0 and r['grad_tex'].abs().max() > 0 and r['grad_pose'].abs().max() > 0
