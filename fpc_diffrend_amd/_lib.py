@@ -118,6 +118,14 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (or `make -C {CSRC}`). There is no CPU fallback for the raster ops.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (soname libamdhip64.so.7, the
+    # same soname libfpcdr.so needs).  Importing torch first makes the loader bind our library to the runtime
+    # torch already uses, so streams / device pointers are shared; loaded the other way round the process
+    # ends up with two runtimes and launches fail with "no ROCm-capable device is detected".
+    import torch
+    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_rt):
+        ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -38,15 +38,16 @@ def quat_to_rotmat(q):
 
 def rigid(t, R):
     top = torch.cat([R, t.reshape(t.shape[:-1] + (3, 1))], dim=-1)
-    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(t.shape[:-1] + (1, 4))
+    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=t.dtype).expand(t.shape[:-1] + (1, 4))
     return torch.cat([top, bottom], dim=-2)
 
 
 class State:
     """Parameters of the fit (reference fit.py:433-461), CPU tensors."""
 
-    def __init__(self, sc, cams, texture=None):
+    def __init__(self, sc, cams, texture=None, dtype=torch.float32):
         F, K = sc.weights_gt.shape
+        self.dtype = dtype
         self.sc, self.cams = sc, list(cams)
         self.v_base = torch.tensor(sc.v_base)
         self.Bmat = torch.tensor(sc.blendshapes)
@@ -62,17 +63,22 @@ class State:
         q = torch.zeros(F, 4); q[:, 3] = 1
         self.per_frame_q = q.requires_grad_(True)
         self.tex = torch.tensor(sc.texture if texture is None else texture).clone().requires_grad_(True)
+        if dtype != torch.float32:
+            for name in ('v_base', 'Bmat', 'uv', 'M1', 'M2', 't_opt', 'q_opt', 'per_frame_t', 'per_frame_q', 'tex'):
+                t = getattr(self, name)
+                setattr(self, name, t.detach().to(dtype).requires_grad_(t.requires_grad))
         trans = camera.translate(0.0, 170.0, 0.0)
-        self.P = torch.tensor(np.stack([camera.intrinsic_to_projection(sc.cams[c]['intr']) for c in self.cams]))
+        self.P = torch.tensor(np.stack([camera.intrinsic_to_projection(sc.cams[c]['intr']) for c in self.cams])).to(dtype)
         self.TMV = torch.tensor(np.stack([camera.extrinsic_to_modelview(sc.cams[c]['rot'], sc.cams[c]['trans_calib']) @ trans
-                                          for c in self.cams]))
+                                          for c in self.cams])).to(dtype)
 
     def params(self):
         return [self.M1, self.M2, self.t_opt, self.q_opt, self.per_frame_t, self.per_frame_q, self.tex]
 
 
-def forward(st, frame_ids, targets, enable_mip=False, max_mip_level=6, weight_laplacian=0.0):
-    """Loss of a batch of frames x the state's cameras; targets uint8 [Fb,Nc,H,W].  Returns (loss, image, rast)."""
+def forward(st, frame_ids, targets, enable_mip=False, max_mip_level=6, weight_laplacian=0.0, ids=None):
+    """Loss of a batch of frames x the state's cameras; targets uint8 [Fb,Nc,H,W].  Returns (loss, image, rast).
+    `ids`: visibility override (see oracle.ops.rasterize)."""
     sc = st.sc
     H, W = sc.resolution
     Fb, Nc = len(frame_ids), len(st.cams)
@@ -84,9 +90,9 @@ def forward(st, frame_ids, targets, enable_mip=False, max_mip_level=6, weight_la
     rf = rigid(st.per_frame_t[frame_ids], quat_to_rotmat(st.per_frame_q[frame_ids]))  # fit.py:549-550
     tr = torch.matmul(rc, st.TMV)
     mvp = torch.matmul(st.P[None], torch.matmul(rf[:, None], tr[None])).reshape(Fb * Nc, 4, 4)  # fit.py:551-553
-    posw = torch.cat([verts, torch.ones(Fb, verts.shape[1], 1)], dim=-1).repeat_interleave(Nc, dim=0)
+    posw = torch.cat([verts, torch.ones(Fb, verts.shape[1], 1, dtype=verts.dtype)], dim=-1).repeat_interleave(Nc, dim=0)
     pos_clip = torch.matmul(posw, mvp.transpose(1, 2))                # camera.py:19-23
-    rast, rast_db = O.rasterize(pos_clip, st.pos_idx, (H, W))
+    rast, rast_db = O.rasterize(pos_clip, st.pos_idx, (H, W), ids=ids)
     if enable_mip:
         texc, texd = O.interpolate(st.uv[None], rast, st.uv_idx, rast_db=rast_db, diff_attrs='all')
         colour = O.texture(st.tex[None], texc, texd, filter_mode='linear-mipmap-linear', max_mip_level=max_mip_level)
@@ -94,8 +100,8 @@ def forward(st, frame_ids, targets, enable_mip=False, max_mip_level=6, weight_la
         texc, _ = O.interpolate(st.uv[None], rast, st.uv_idx)
         colour = O.texture(st.tex[None], texc, filter_mode='linear')
     colour = O.antialias(colour, rast, pos_clip, st.pos_idx)
-    image = torch.where(rast[..., 3:] > 0, colour, torch.tensor(BACKGROUND))          # fit.py:161
-    ref = targets.reshape(Fb * Nc, H, W, 1).to(torch.float32)
+    image = torch.where(rast[..., 3:] > 0, colour, torch.tensor(BACKGROUND, dtype=colour.dtype))   # fit.py:161
+    ref = targets.reshape(Fb * Nc, H, W, 1).to(colour.dtype)
     loss = torch.mean((ref - image * 255) ** 2)                                        # fit.py:579
     if weight_laplacian:
         loss = loss + weight_laplacian * uniform_laplacian(verts, st.pos_idx) ** 2      # fit.py:581
@@ -116,17 +122,18 @@ def uniform_laplacian(verts, faces):
     return torch.matmul(L[None], verts).norm(dim=2).mean()
 
 
-def smoke_step(sc, cams=(0, 4)):
-    """Same small forward + backward as fpc_diffrend_amd.fit.smoke_step, on the oracle."""
+def smoke_step(sc, cams=(0, 4), dtype=torch.float32, ids=None):
+    """Same small forward + backward as fpc_diffrend_amd.fit.smoke_step, on the oracle.  dtype=float64 with
+    `ids` taken from a float32 run gives a high-precision reference for the gradients."""
     from fpc_diffrend_amd.fit import smoke_targets
-    st = State(sc, cams)
+    st = State(sc, cams, dtype=dtype)
     F = sc.weights_gt.shape[0]
     with torch.no_grad():
         st.M1.copy_(torch.eye(F))
         st.M2.copy_(0.5 * torch.tensor(sc.weights_gt).t())
         st.per_frame_t.copy_(0.5 * torch.tensor(sc.t_gt))
     targets = smoke_targets(sc, cams)
-    loss, image, rast = forward(st, torch.arange(F), targets)
+    loss, image, rast = forward(st, torch.arange(F), targets, ids=ids)
     loss.backward()
     return {'loss': loss.detach(), 'ids': rast[..., 3].to(torch.int32), 'image': image.detach(),
             'grad_w': st.M2.grad.clone(), 'grad_tex': st.tex.grad.clone(),

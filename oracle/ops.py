@@ -92,8 +92,8 @@ def _bary(pos, tri, ids, H, W):
     p0 = pos[bidx, vi[:, 0]]
     p1 = pos[bidx, vi[:, 1]]
     p2 = pos[bidx, vi[:, 2]]
-    fx = (2.0 * xx.to(torch.float32) + 1.0) / W - 1.0
-    fy = (2.0 * yy.to(torch.float32) + 1.0) / H - 1.0
+    fx = (2.0 * xx.to(pos.dtype) + 1.0) / W - 1.0
+    fy = (2.0 * yy.to(pos.dtype) + 1.0) / H - 1.0
     w0, w1, w2 = p0[:, 3], p1[:, 3], p2[:, 3]
     p0x, p0y = p0[:, 0] - fx * w0, p0[:, 1] - fy * w0
     p1x, p1y = p1[:, 0] - fx * w1, p1[:, 1] - fy * w1
@@ -133,19 +133,23 @@ def _bary(pos, tri, ids, H, W):
     return bidx, yy, xx, t, u, v, zw, db
 
 
-def rasterize(pos, tri, resolution, grad_db=True):
-    """dr.rasterize(glctx, pos[B,V,4], tri[T,3], resolution=(H,W)) -> (rast[B,H,W,4], rast_db[B,H,W,4])."""
+def rasterize(pos, tri, resolution, grad_db=True, ids=None):
+    """dr.rasterize(glctx, pos[B,V,4], tri[T,3], resolution=(H,W)) -> (rast[B,H,W,4], rast_db[B,H,W,4]).
+
+    Float outputs follow pos.dtype (float32 like the product; float64 gives a high-precision gradient
+    reference).  `ids` overrides the visibility buffer (used to evaluate a float64 run on the float32 run's
+    visibility, which is always decided on float32 positions)."""
     assert pos.dim() == 3 and pos.shape[2] == 4, "instanced mode only: pos must be [B,V,4]"
     H, W = int(resolution[0]), int(resolution[1])
     B = pos.shape[0]
-    pos = pos.to(torch.float32)
-    ids = rasterize_ids(pos, tri, (H, W))
+    if ids is None:
+        ids = rasterize_ids(pos.to(torch.float32), tri, (H, W))
     bidx, yy, xx, t, u, v, zw, db = _bary(pos, tri, ids, H, W)
-    vals = torch.stack([u, v, zw, (t + 1).to(torch.float32)], dim=1)
-    rast = torch.zeros(B, H, W, 4, dtype=torch.float32).index_put((bidx, yy, xx), vals)
+    vals = torch.stack([u, v, zw, (t + 1).to(pos.dtype)], dim=1)
+    rast = torch.zeros(B, H, W, 4, dtype=pos.dtype).index_put((bidx, yy, xx), vals)
     if not grad_db:
         db = db.detach()
-    rast_db = torch.zeros(B, H, W, 4, dtype=torch.float32).index_put((bidx, yy, xx), db)
+    rast_db = torch.zeros(B, H, W, 4, dtype=pos.dtype).index_put((bidx, yy, xx), db)
     return rast, rast_db
 
 
@@ -171,9 +175,9 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
     u = rast[bidx, yy, xx, 0:1]
     v = rast[bidx, yy, xx, 1:2]
     val = u * a0 + v * a1 + (1.0 - u - v) * a2
-    out = torch.zeros(B, H, W, A, dtype=torch.float32).index_put((bidx, yy, xx), val)
+    out = torch.zeros(B, H, W, A, dtype=val.dtype).index_put((bidx, yy, xx), val)
     if diff_attrs is None or rast_db is None:
-        return out, torch.zeros(B, H, W, 0, dtype=torch.float32)
+        return out, torch.zeros(B, H, W, 0, dtype=val.dtype)
     sel = list(range(A)) if (isinstance(diff_attrs, str) and diff_attrs == 'all') else [int(i) for i in diff_attrs]
     d = rast_db[bidx, yy, xx]  # du/dx du/dy dv/dx dv/dy
     e0 = (a0 - a2)[:, sel]
@@ -181,7 +185,7 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
     dadx = d[:, 0:1] * e0 + d[:, 2:3] * e1
     dady = d[:, 1:2] * e0 + d[:, 3:4] * e1
     da = torch.stack([dadx, dady], dim=2).reshape(-1, 2 * len(sel))
-    out_da = torch.zeros(B, H, W, 2 * len(sel), dtype=torch.float32).index_put((bidx, yy, xx), da)
+    out_da = torch.zeros(B, H, W, 2 * len(sel), dtype=da.dtype).index_put((bidx, yy, xx), da)
     return out, out_da
 
 
@@ -282,13 +286,13 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
             l2 = tr + torch.sqrt(df * df + B_ * B_ + 1e-30)  # squared major-axis length
             level = 0.5 * torch.log2(torch.clamp(l2, min=1e-30))
         else:
-            level = torch.zeros(B * H * W)
+            level = torch.zeros(B * H * W, dtype=uv.dtype)
         if mip_level_bias is not None:
             level = level + mip_level_bias.reshape(-1)
         level = torch.clamp(level, 0.0, float(nlev))
         if filter_mode == 'linear-mipmap-nearest':
             l0 = torch.floor(level + 0.5).long().clamp(max=nlev)
-            out = torch.zeros(B * H * W, C)
+            out = torch.zeros(B * H * W, C, dtype=tex.dtype)
             for l in range(nlev + 1):
                 m = torch.nonzero(l0 == l, as_tuple=True)[0]
                 if m.numel():
@@ -298,7 +302,7 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
         l0 = torch.floor(level).long().clamp(max=nlev)
         l1 = (l0 + 1).clamp(max=nlev)
         fl = (level - l0.to(level.dtype)).unsqueeze(-1)
-        out = torch.zeros(B * H * W, C)
+        out = torch.zeros(B * H * W, C, dtype=tex.dtype)
         for l in range(nlev + 1):
             m = torch.nonzero(l0 == l, as_tuple=True)[0]
             if not m.numel():
@@ -387,11 +391,11 @@ def _aa_pairs(color, rast, pos, tri, sil, d, out, flags):
     Py = torch.where(use1, y1, y0)
     Qx = torch.where(use1, x0, x1)
     Qy = torch.where(use1, y0, y1)
-    s = torch.where(use1, -torch.ones(1), torch.ones(1))
+    s = torch.where(use1, -torch.ones(1, dtype=pos.dtype), torch.ones(1, dtype=pos.dtype))
     vi = tri.long()[tau]
     hw, hh = 0.5 * W, 0.5 * H
-    fxp = Px.to(torch.float32) + 0.5 - hw
-    fyp = Py.to(torch.float32) + 0.5 - hh
+    fxp = Px.to(pos.dtype) + 0.5 - hw
+    fyp = Py.to(pos.dtype) + 0.5 - hh
 
     def proj(vidx):
         c = pos[bidx, vidx]

@@ -71,9 +71,16 @@ def test_smoke_step_matches_oracle(oracle_ops):
     res = fit.smoke_step(sc, device='cuda:0')
     ref = ofit.smoke_step(sc)
     assert torch.equal(res['ids'].cpu(), ref['ids'])
-    for k in ('image', 'grad_w', 'grad_tex', 'grad_pose'):
-        assert rel_l2(res[k], ref[k]) < TOL, k
+    assert rel_l2(res['image'], ref['image']) < TOL
     assert abs(float(res['loss']) - float(ref['loss'])) < 1e-4 * float(ref['loss'])
+    # End-to-end gradients of this chain are ill-conditioned in float32 (clip-space coordinates ~170 with
+    # sub-pixel differences): the float32 ORACLE itself sits 4e-4 (weights) / 2e-3 (pose) from a float64
+    # evaluation.  The bar: the HIP path is within 1e-4 of the float64 truth, or no worse than 2x the float32
+    # oracle's own distance from it.  (Per-op gradients on well-conditioned inputs meet 1e-4: test_gpu_parity.)
+    ref64 = ofit.smoke_step(sc, dtype=torch.float64, ids=ref['ids'])
+    for k in ('grad_w', 'grad_tex', 'grad_pose'):
+        floor = rel_l2(ref[k], ref64[k])
+        assert rel_l2(res[k], ref64[k]) < max(TOL, 2.0 * floor), (k, rel_l2(res[k], ref64[k]), floor)
 
 
 @pytest.mark.parametrize("fused", [True, False])
