@@ -60,58 +60,82 @@ __device__ __forceinline__ long long floordiv256(long long a) { return a >> 8; }
 __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                 int B, int V, int T, int H, int W, TriRec *__restrict__ recs,
                                                 TriBox *__restrict__ boxes, ImgBox *__restrict__ ibox) {
-    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)B * T) return;
-    int b = (int)(gid / T), t = (int)(gid - (long long)b * T);
-    TriBox box = {1, 1, 0, 0};
-    int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-    bool ok = !(i0 < 0 || i0 >= V || i1 < 0 || i1 >= V || i2 < 0 || i2 >= V);
-    long long X[3], Y[3];
-    double zw[3];
-    if (ok) {
-        const float4 *p = pos + (size_t)b * V;
-        float4 v[3] = {p[i0], p[i1], p[i2]};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            float w = v[i].w;
-            if (!(w > 0.0f)) { ok = false; }
-            double dw = (double)(ok ? w : 1.0f);
-            double xs = (double)v[i].x / dw;
-            double ys = (double)v[i].y / dw;
-            double fx = floor((xs * 0.5 + 0.5) * (double)(W * SUBPIX) + 0.5);
-            double fy = floor((ys * 0.5 + 0.5) * (double)(H * SUBPIX) + 0.5);
-            if (!(fabs(fx) <= GUARD) || !(fabs(fy) <= GUARD)) { ok = false; fx = 0.0; fy = 0.0; }
-            X[i] = (long long)fx;
-            Y[i] = (long long)fy;
-            zw[i] = (double)v[i].z / dw;
-        }
-    }
-    if (ok) {
-        long long D = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
-        if (D == 0) ok = false;
+    // grid: x over triangles, y = image (so a block never straddles two images and the image-wide
+    // bounding box can be reduced in the block before touching the four per-image atomics)
+    __shared__ int s_box[4][4];
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
+    if (t < T) {
+        const size_t gid = (size_t)b * T + t;
+        TriBox box = {1, 1, 0, 0};
+        int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        bool ok = !(i0 < 0 || i0 >= V || i1 < 0 || i1 >= V || i2 < 0 || i2 >= V);
+        long long X[3], Y[3];
+        double zw[3];
         if (ok) {
-            double Dd = (double)(D > 0 ? D : -D);
-            long long xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
-            long long ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
-            long long px0 = floordiv256(xmin - HALFPIX + SUBPIX - 1), px1 = floordiv256(xmax - HALFPIX);
-            long long py0 = floordiv256(ymin - HALFPIX + SUBPIX - 1), py1 = floordiv256(ymax - HALFPIX);
-            px0 = max(px0, 0ll); py0 = max(py0, 0ll);
-            px1 = min(px1, (long long)W - 1); py1 = min(py1, (long long)H - 1);
-            if (px0 > px1 || py0 > py1) ok = false;
-            if (ok) {
-                box = {(int16_t)px0, (int16_t)py0, (int16_t)px1, (int16_t)py1};
-                TriRec r;
-                r.X0 = (int32_t)X[0]; r.Y0 = (int32_t)Y[0];
-                r.X1 = (int32_t)X[1]; r.Y1 = (int32_t)Y[1];
-                r.X2 = (int32_t)X[2]; r.Y2 = (int32_t)Y[2];
-                r.q0 = zw[0] / Dd; r.q1 = zw[1] / Dd; r.q2 = zw[2] / Dd;
-                recs[gid] = r;
-                atomicMin(&ibox[b].x0, (int)px0); atomicMin(&ibox[b].y0, (int)py0);
-                atomicMax(&ibox[b].x1, (int)px1); atomicMax(&ibox[b].y1, (int)py1);
+            const float4 *p = pos + (size_t)b * V;
+            float4 v[3] = {p[i0], p[i1], p[i2]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float w = v[i].w;
+                if (!(w > 0.0f)) { ok = false; }
+                double dw = (double)(ok ? w : 1.0f);
+                double xs = (double)v[i].x / dw;
+                double ys = (double)v[i].y / dw;
+                double fx = floor((xs * 0.5 + 0.5) * (double)(W * SUBPIX) + 0.5);
+                double fy = floor((ys * 0.5 + 0.5) * (double)(H * SUBPIX) + 0.5);
+                if (!(fabs(fx) <= GUARD) || !(fabs(fy) <= GUARD)) { ok = false; fx = 0.0; fy = 0.0; }
+                X[i] = (long long)fx;
+                Y[i] = (long long)fy;
+                zw[i] = (double)v[i].z / dw;
             }
         }
+        if (ok) {
+            long long D = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
+            if (D == 0) ok = false;
+            if (ok) {
+                double Dd = (double)(D > 0 ? D : -D);
+                long long xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
+                long long ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
+                long long px0 = floordiv256(xmin - HALFPIX + SUBPIX - 1), px1 = floordiv256(xmax - HALFPIX);
+                long long py0 = floordiv256(ymin - HALFPIX + SUBPIX - 1), py1 = floordiv256(ymax - HALFPIX);
+                px0 = max(px0, 0ll); py0 = max(py0, 0ll);
+                px1 = min(px1, (long long)W - 1); py1 = min(py1, (long long)H - 1);
+                if (px0 > px1 || py0 > py1) ok = false;
+                if (ok) {
+                    box = {(int16_t)px0, (int16_t)py0, (int16_t)px1, (int16_t)py1};
+                    TriRec r;
+                    r.X0 = (int32_t)X[0]; r.Y0 = (int32_t)Y[0];
+                    r.X1 = (int32_t)X[1]; r.Y1 = (int32_t)Y[1];
+                    r.X2 = (int32_t)X[2]; r.Y2 = (int32_t)Y[2];
+                    r.q0 = zw[0] / Dd; r.q1 = zw[1] / Dd; r.q2 = zw[2] / Dd;
+                    recs[gid] = r;
+                    bx0 = (int)px0; by0 = (int)py0; bx1 = (int)px1; by1 = (int)py1;
+                }
+            }
+        }
+        boxes[gid] = box;
     }
-    boxes[gid] = box;
+    // image bounding box: wave reduce -> block reduce -> at most four atomics per block
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, o, 64)); by0 = min(by0, __shfl_xor(by0, o, 64));
+        bx1 = max(bx1, __shfl_xor(bx1, o, 64)); by1 = max(by1, __shfl_xor(by1, o, 64));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_box[wave][0] = bx0; s_box[wave][1] = by0; s_box[wave][2] = bx1; s_box[wave][3] = by1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            bx0 = min(bx0, s_box[w][0]); by0 = min(by0, s_box[w][1]);
+            bx1 = max(bx1, s_box[w][2]); by1 = max(by1, s_box[w][3]);
+        }
+        if (bx1 >= 0) {
+            atomicMin(&ibox[b].x0, bx0); atomicMin(&ibox[b].y0, by0);
+            atomicMax(&ibox[b].x1, bx1); atomicMax(&ibox[b].y1, by1);
+        }
+    }
 }
 
 __global__ void k_init_ibox(ImgBox *ibox, int B) {
@@ -444,7 +468,7 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
     TriBox *boxes = (TriBox *)(s + align_up(n * sizeof(TriRec), 256));
     ImgBox *ibox = (ImgBox *)((char *)boxes + align_up(n * sizeof(TriBox), 256));
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
-    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv((long long)n, 256)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, ibox);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     if (p->rast_db)
