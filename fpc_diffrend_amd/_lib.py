@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfpcdr.so")
+LIB_PATH = os.environ.get("FPCDR_LIB_PATH") or os.path.join(_HERE, "libfpcdr.so")  # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
 MAX_ATTR = 32

@@ -110,12 +110,16 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
                     r.X1 = (int32_t)X[1]; r.Y1 = (int32_t)Y[1];
                     r.X2 = (int32_t)X[2]; r.Y2 = (int32_t)Y[2];
                     r.q0 = zw[0] / Dd; r.q1 = zw[1] / Dd; r.q2 = zw[2] / Dd;
+#ifndef AB_NO_RECS
                     recs[gid] = r;
+#endif
                     bx0 = (int)px0; by0 = (int)py0; bx1 = (int)px1; by1 = (int)py1;
                 }
             }
         }
+#ifndef AB_NO_BOXES
         boxes[gid] = box;
+#endif
     }
     // image bounding box: wave reduce -> block reduce -> at most four atomics per block
 #pragma unroll
@@ -131,7 +135,11 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
             bx0 = min(bx0, s_box[w][0]); by0 = min(by0, s_box[w][1]);
             bx1 = max(bx1, s_box[w][2]); by1 = max(by1, s_box[w][3]);
         }
+#ifdef AB_NO_ATOMICS
+        if (bx1 >= 0 && blockIdx.x == 0) {
+#else
         if (bx1 >= 0) {
+#endif
             atomicMin(&ibox[b].x0, bx0); atomicMin(&ibox[b].y0, by0);
             atomicMax(&ibox[b].x1, bx1); atomicMax(&ibox[b].y1, by1);
         }
