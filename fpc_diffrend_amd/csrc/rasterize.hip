@@ -59,9 +59,12 @@ __device__ __forceinline__ long long floordiv256(long long a) { return a >> 8; }
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                 int B, int V, int T, int H, int W, TriRec *__restrict__ recs,
-                                                TriBox *__restrict__ boxes, ImgBox *__restrict__ ibox) {
-    // grid: x over triangles, y = image (so a block never straddles two images and the image-wide
-    // bounding box can be reduced in the block before touching the four per-image atomics)
+                                                TriBox *__restrict__ boxes, TriBox *__restrict__ cboxes,
+                                                ImgBox *__restrict__ ibox) {
+    // grid: x over 256-triangle chunks, y = image.  A block never straddles two images, so the union of
+    // its triangles' bounding boxes can be reduced in the block: it is stored as the CHUNK box (meshes
+    // keep neighbouring triangles at neighbouring indices, so a bin later skips most chunks with one
+    // test) and folded into the image box with at most four atomics per block.
     __shared__ int s_box[4][4];
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,16 +113,12 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
                     r.X1 = (int32_t)X[1]; r.Y1 = (int32_t)Y[1];
                     r.X2 = (int32_t)X[2]; r.Y2 = (int32_t)Y[2];
                     r.q0 = zw[0] / Dd; r.q1 = zw[1] / Dd; r.q2 = zw[2] / Dd;
-#ifndef AB_NO_RECS
                     recs[gid] = r;
-#endif
                     bx0 = (int)px0; by0 = (int)py0; bx1 = (int)px1; by1 = (int)py1;
                 }
             }
         }
-#ifndef AB_NO_BOXES
         boxes[gid] = box;
-#endif
     }
     // image bounding box: wave reduce -> block reduce -> at most four atomics per block
 #pragma unroll
@@ -135,14 +134,13 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
             bx0 = min(bx0, s_box[w][0]); by0 = min(by0, s_box[w][1]);
             bx1 = max(bx1, s_box[w][2]); by1 = max(by1, s_box[w][3]);
         }
-#ifdef AB_NO_ATOMICS
-        if (bx1 >= 0 && blockIdx.x == 0) {
-#else
+        TriBox cb = {1, 1, 0, 0};
         if (bx1 >= 0) {
-#endif
+            cb = {(int16_t)bx0, (int16_t)by0, (int16_t)bx1, (int16_t)by1};
             atomicMin(&ibox[b].x0, bx0); atomicMin(&ibox[b].y0, by0);
             atomicMax(&ibox[b].x1, bx1); atomicMax(&ibox[b].y1, by1);
         }
+        cboxes[(size_t)b * gridDim.x + blockIdx.x] = cb;
     }
 }
 
@@ -188,9 +186,11 @@ __device__ __forceinline__ Shade shade_pixel(float4 v0, float4 v1, float4 v2, fl
 template <bool WRITE_DB>
 __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               int V, int T, int H, int W, const TriRec *__restrict__ recs,
-                                              const TriBox *__restrict__ boxes, const ImgBox *__restrict__ ibox,
-                                              float4 *__restrict__ rast, float4 *__restrict__ rast_db) {
+                                              const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
+                                              const ImgBox *__restrict__ ibox, float4 *__restrict__ rast,
+                                              float4 *__restrict__ rast_db) {
     __shared__ EdgeRec s_tri[BATCH];
+    __shared__ int s_clist[256];        // live chunks of the current segment (ascending)
     __shared__ unsigned long long s_mask[NTILES][BATCH / 64];
     __shared__ int s_list[2 * BATCH];   // pending triangle indices (ascending); first BATCH = current batch
     __shared__ int s_wave_cnt[2][4];
@@ -214,19 +214,45 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
         const TriBox *bx = boxes + (size_t)b * T;
         const TriRec *rc = recs + (size_t)b * T;
         const int n_chunks = (T + 255) / 256;
+        const TriBox *cbx = cboxes + (size_t)b * n_chunks;
         int pending = 0;  // block-uniform: entries waiting in s_list
-        for (int chunk = 0; chunk <= n_chunks; ++chunk) {
-            const bool last = (chunk == n_chunks);
-            // ---- scan 256 bounding boxes, append hits in ascending order ----
+        int it = 0;       // block-uniform: scan iterations done (parity selects the s_wave_cnt buffer)
+        for (int seg = 0; seg <= n_chunks; seg += 256) {
+          // ---- which of the next 256 chunks touch this bin?  (one box test per chunk) ----
+          int n_live = 0;
+          const bool flush_seg = (seg + 256 > n_chunks);   // last segment: flush what is pending at its end
+          {
+              const int c = seg + tid;
+              bool live = false;
+              if (c < n_chunks) {
+                  const TriBox q = cbx[c];
+                  live = (q.x0 <= q.x1) && !(q.x1 < bin_x0 || q.x0 > bin_x1 || q.y1 < bin_y0 || q.y0 > bin_y1);
+              }
+              const unsigned long long bal = __ballot(live);
+              int *cnt = s_wave_cnt[it & 1];
+              ++it;
+              if (lane == 0) cnt[wave] = __popcll(bal);
+              __syncthreads();
+              const int c0 = cnt[0], c1 = cnt[1], c2 = cnt[2], c3 = cnt[3];
+              const int base = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+              if (live) s_clist[base + __popcll(bal & ((1ull << lane) - 1ull))] = c;
+              n_live = c0 + c1 + c2 + c3;
+              __syncthreads();
+          }
+          for (int ci = 0; ci <= n_live; ++ci) {
+            const bool last = flush_seg && (ci == n_live);
+            if (ci == n_live && !last) break;
+            // ---- scan the 256 bounding boxes of one live chunk, append hits in ascending order ----
             if (!last) {
-                const int t = chunk * 256 + tid;
+                const int t = s_clist[ci] * 256 + tid;
                 bool hit = false;
                 if (t < T) {
                     const TriBox q = bx[t];
                     hit = (q.x0 <= q.x1) && !(q.x1 < bin_x0 || q.x0 > bin_x1 || q.y1 < bin_y0 || q.y0 > bin_y1);
                 }
                 const unsigned long long bal = __ballot(hit);
-                int *cnt = s_wave_cnt[chunk & 1];
+                int *cnt = s_wave_cnt[it & 1];
+                ++it;
                 if (lane == 0) cnt[wave] = __popcll(bal);
                 __syncthreads();
                 const int c0 = cnt[0], c1 = cnt[1], c2 = cnt[2], c3 = cnt[3];
@@ -309,6 +335,7 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
                 if (tid < rest) s_list[tid] = moved;
                 pending = rest;
             }
+          }
         }
     }
 
@@ -460,7 +487,9 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 extern "C" size_t fpcdr_rasterize_scratch_bytes(int32_t B, int32_t T) {
     if (B <= 0 || T <= 0) return 0;
     size_t n = (size_t)B * (size_t)T;
-    return align_up(n * sizeof(TriRec), 256) + align_up(n * sizeof(TriBox), 256) + align_up((size_t)B * sizeof(ImgBox), 256);
+    size_t nc = (size_t)B * (size_t)((T + 255) / 256);
+    return align_up(n * sizeof(TriRec), 256) + align_up(n * sizeof(TriBox), 256) + align_up(nc * sizeof(TriBox), 256) +
+           align_up((size_t)B * sizeof(ImgBox), 256);
 }
 
 extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *stream) {
@@ -474,17 +503,19 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
     char *s = (char *)p->scratch;
     TriRec *recs = (TriRec *)s;
     TriBox *boxes = (TriBox *)(s + align_up(n * sizeof(TriRec), 256));
-    ImgBox *ibox = (ImgBox *)((char *)boxes + align_up(n * sizeof(TriBox), 256));
+    TriBox *cboxes = (TriBox *)((char *)boxes + align_up(n * sizeof(TriBox), 256));
+    const size_t nc = (size_t)p->B * (size_t)fpcdr_cdiv(p->T, 256);
+    ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, ibox);
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     if (p->rast_db)
         hipLaunchKernelGGL(k_bins<true>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
-                           recs, boxes, ibox, (float4 *)p->rast, (float4 *)p->rast_db);
+                           recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)p->rast_db);
     else
         hipLaunchKernelGGL(k_bins<false>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
-                           recs, boxes, ibox, (float4 *)p->rast, (float4 *)nullptr);
+                           recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }
