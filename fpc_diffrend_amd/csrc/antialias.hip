@@ -18,9 +18,10 @@
 //              deterministic, and HBM traffic is the algorithmic 16 + 8C bytes per pixel.  The wave
 //              (64 consecutive pixels of a row) publishes two 64-bit ballot words: pair (p,p+x) /
 //              (p,p+y) blended.
-//   k_aa_bwd   reads those two bit planes (2 bits per pixel): waves without a flagged pair copy dy to
-//              grad_colour -- the HBM-bound bulk, 8C bytes per pixel; flagged pixels re-evaluate their
-//              pairs, gather their colour-gradient corrections and scatter d(alpha)/d(pos) sparsely.
+//   backward   grad_colour = dy is one device-to-device copy (the HBM-bound bulk, 8C bytes per pixel);
+//              k_aa_bwd_fix then scans the two bit planes (2 bits per pixel) and only where a pair was
+//              blended re-evaluates it, rewrites the affected pixels' grad_colour in gather form and
+//              scatters d(alpha)/d(pos) sparsely.
 #include "common.h"
 
 namespace {
@@ -294,43 +295,56 @@ __global__ void __launch_bounds__(256) k_aa_fwd(const float *__restrict__ color,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward, sparse part.  The bulk (grad_colour = dy) is a device-to-device copy issued before this kernel;
+// here each wave scans 64 consecutive flag words (= 4096 pixels, 2 KB of flags) and, for the few words
+// that carry a blended pair, turns into one lane per pixel of that 64-pixel span: a flagged pixel re-evaluates
+// its pairs, rewrites its OWN grad_colour entry completely (gather form: dy + corrections, plain store, no
+// atomics, deterministic) and the owner of each pair scatters d(alpha)/d(pos).
 template <int CS>
-__global__ void __launch_bounds__(256) k_aa_bwd(const float *__restrict__ color, const float4 *__restrict__ rast,
-                                                const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
-                                                const uint8_t *__restrict__ sil, const float *__restrict__ dy, int B, int H,
-                                                int W, int C_dyn, int V, int T, const unsigned long long *__restrict__ flags,
-                                                float boost, float *__restrict__ grad_color, float *__restrict__ grad_pos) {
+__global__ void __launch_bounds__(256) k_aa_bwd_fix(const float *__restrict__ color, const float4 *__restrict__ rast,
+                                                    const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                    const uint8_t *__restrict__ sil, const float *__restrict__ dy, int B, int H,
+                                                    int W, int C_dyn, int V, int T, const unsigned long long *__restrict__ flags,
+                                                    float boost, float *__restrict__ grad_color, float *__restrict__ grad_pos) {
     const int C = CS > 0 ? CS : C_dyn;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wave, b = blockIdx.z;
-    if (y >= H) return;
     const int Wq = FPCDR_AA_ROW_WORDS(W);
     const size_t plane = (size_t)B * H * Wq;
-    const size_t wi = ((size_t)b * H + y) * Wq + blockIdx.x;
-    // wave-uniform flag words: own row (x pairs, y pairs), word to the left, row below (y pairs)
-    const unsigned long long fx = flags[wi], fy = flags[plane + wi];
-    const unsigned long long fxl = blockIdx.x > 0 ? flags[wi - 1] : 0ull;
-    const unsigned long long fyd = y > 0 ? flags[plane + wi - Wq] : 0ull;
-    const bool wave_any = (fx | fy | fyd | (fxl >> 63)) != 0ull;
-    if (x >= W) return;
-    const size_t img = (size_t)b * H * W;
-    const size_t off = img + (size_t)y * W + x;
-    const float *g = dy + off * C;
-    float *go = grad_color + off * C;
-    if (!wave_any) {
-        if (CS > 0) {
-#pragma unroll
-            for (int c = 0; c < CS; ++c) go[c] = g[c];
-        } else {
-            for (int c = 0; c < C; ++c) go[c] = g[c];
-        }
-        return;
+    const size_t wi_l = ((size_t)blockIdx.x * 4 + wave) * 64 + lane;
+    unsigned long long w_fx = 0ull, w_fy = 0ull, w_fxl = 0ull, w_fyd = 0ull;
+    int w_wq = 0, w_y = 0, w_b = 0;
+    if (wi_l < plane) {
+        w_wq = (int)(wi_l % Wq);
+        const size_t row = wi_l / Wq;
+        w_y = (int)(row % H);
+        w_b = (int)(row / H);
+        w_fx = flags[wi_l];
+        w_fy = flags[plane + wi_l];
+        if (w_wq > 0) w_fxl = flags[wi_l - 1];
+        if (w_y > 0) w_fyd = flags[plane + wi_l - Wq];
     }
+    unsigned long long todo = __ballot((w_fx | w_fy | w_fyd | (w_fxl >> 63)) != 0ull);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const unsigned long long fx = __shfl(w_fx, src, 64), fy = __shfl(w_fy, src, 64);
+        const unsigned long long fxl = __shfl(w_fxl, src, 64), fyd = __shfl(w_fyd, src, 64);
+        const int b = __shfl(w_b, src, 64), y = __shfl(w_y, src, 64);
+        const int x = __shfl(w_wq, src, 64) * 64 + lane;
+        if (x >= W) continue;
     const bool own_x = (fx >> lane) & 1ull, own_y = (fy >> lane) & 1ull;
     const bool left_x = lane > 0 ? ((fx >> (lane - 1)) & 1ull) : ((fxl >> 63) & 1ull);
     const bool down_y = (fyd >> lane) & 1ull;
-    for (int c = 0; c < C; ++c) go[c] = g[c];
-    if (!(own_x | own_y | left_x | down_y)) return;
+    if (!(own_x | own_y | left_x | down_y)) continue;
+    const size_t img = (size_t)b * H * W;
+    const size_t off = img + (size_t)y * W + x;
+    const float *g = dy + off * C;
+    float go_[CS > 0 ? CS : 1];
+    float *go = CS > 0 ? go_ : grad_color + off * C;   // generic C accumulates in place (already holds dy)
+    if (CS > 0) {
+#pragma unroll
+        for (int c = 0; c < CS; ++c) go_[c] = g[c];
+    }
     AAGeom geo = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
     float *gp = grad_pos + (size_t)b * V * 4;
     const float2 me = load_zid(rast, off);
@@ -377,6 +391,11 @@ __global__ void __launch_bounds__(256) k_aa_bwd(const float *__restrict__ color,
     if (own_y) visit(x, y, 1, me, load_zid(rast, off + W), true);
     if (left_x) visit(x - 1, y, 0, load_zid(rast, off - 1), me, false);
     if (down_y) visit(x, y - 1, 1, load_zid(rast, off - W), me, false);
+    if (CS > 0) {
+#pragma unroll
+        for (int c = 0; c < CS; ++c) grad_color[off * C + c] = go_[c];
+    }
+    }
 }
 
 }  // namespace
@@ -432,12 +451,18 @@ extern "C" int fpcdr_antialias_bwd(const fpcdr_antialias_bwd_params *p, void *st
     FPCDR_REQUIRE(p->color && p->rast && p->pos && p->tri && p->adj && p->dy && p->sil && p->flags && p->grad_color && p->grad_pos,
                   "null pointer");
     FPCDR_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->C > 0 && p->V > 0 && p->T > 0, "sizes must be positive");
-    FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 4) <= 65535, "image batch / height too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 4), p->B);
-#define LAUNCH_BWD(CS)                                                                                                   \
-    hipLaunchKernelGGL(k_aa_bwd<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, \
-                       p->tri, p->sil, p->dy, p->B, p->H, p->W, p->C, p->V, p->T, (const unsigned long long *)p->flags,  \
+    // bulk: grad_colour = dy (8C bytes per pixel, the HBM-bound part), then the sparse fix-up
+    const size_t bytes = (size_t)p->B * p->H * p->W * p->C * sizeof(float);
+    if (hipMemcpyAsync(p->grad_color, p->dy, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        fpcdr_set_error("fpcdr_antialias_bwd: device copy failed");
+        return FPCDR_ELAUNCH;
+    }
+    const size_t words = (size_t)p->B * p->H * FPCDR_AA_ROW_WORDS(p->W);
+    dim3 grid(fpcdr_cdiv((long long)words, 256));
+#define LAUNCH_BWD(CS)                                                                                                       \
+    hipLaunchKernelGGL(k_aa_bwd_fix<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, \
+                       p->tri, p->sil, p->dy, p->B, p->H, p->W, p->C, p->V, p->T, (const unsigned long long *)p->flags,      \
                        p->pos_gradient_boost, p->grad_color, p->grad_pos)
     if (p->C == 1) LAUNCH_BWD(1);
     else if (p->C == 3) LAUNCH_BWD(3);

@@ -51,8 +51,24 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int Ht, int Wt, int 
     return t;
 }
 
-__device__ __forceinline__ float bilerp(const float *tx, const Taps &t, int c) {
-    const float t00 = tx[t.i00 + c], t10 = tx[t.i10 + c], t01 = tx[t.i01 + c], t11 = tx[t.i11 + c];
+// two horizontally adjacent texels in one 8-byte gather (4-byte aligned): the gather rate, not HBM, bounds
+// the texture kernels, so halving the number of gather instructions matters
+typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ void load_taps(const float *tx, const Taps &t, int c, int C, float &t00, float &t10, float &t01,
+                                          float &t11) {
+    if (C == 1 && t.i10 == t.i00 + 1) {   // no wrap between the two columns
+        const float2_u a = *reinterpret_cast<const float2_u *>(tx + t.i00);
+        const float2_u b = *reinterpret_cast<const float2_u *>(tx + t.i01);
+        t00 = a.x; t10 = a.y; t01 = b.x; t11 = b.y;
+    } else {
+        t00 = tx[t.i00 + c]; t10 = tx[t.i10 + c]; t01 = tx[t.i01 + c]; t11 = tx[t.i11 + c];
+    }
+}
+
+__device__ __forceinline__ float bilerp(const float *tx, const Taps &t, int c, int C) {
+    float t00, t10, t01, t11;
+    load_taps(tx, t, c, C, t00, t10, t01, t11);
     const float top = t00 + (t10 - t00) * t.fx;
     const float bot = t01 + (t11 - t01) * t.fx;
     return top + (bot - top) * t.fy;
@@ -78,9 +94,10 @@ __device__ __forceinline__ Lod compute_lod(float4 d, int Ht, int Wt, float bias)
 
 __global__ void __launch_bounds__(256) k_tex_fwd(TexLevels lv, int n_levels, const float2 *__restrict__ uv,
                                                  const float4 *__restrict__ uv_da, const float *__restrict__ bias,
-                                                 long long npix_img, int B, int Bt, int Ht, int Wt, int C, int filter,
+                                                 int H, int W, int B, int Bt, int Ht, int Wt, int C, int filter,
                                                  int boundary, float *__restrict__ out) {
-    const long long total = npix_img * B;
+    // forward: 64 consecutive pixels of a row per wave, grid-stride (streams uv in / colour out in full lines)
+    const long long npix_img = (long long)H * W, total = npix_img * B;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const float2 q = uv[i];
         const int b = Bt > 1 ? (int)(i / npix_img) : 0;
@@ -93,7 +110,7 @@ __global__ void __launch_bounds__(256) k_tex_fwd(TexLevels lv, int n_levels, con
         } else if (filter == FPCDR_FILTER_LINEAR) {
             const Taps t = make_taps(q.x, q.y, Ht, Wt, C, boundary);
             const float *tx = lv.tex[0] + (size_t)b * Ht * Wt * C;
-            for (int c = 0; c < C; ++c) o[c] = bilerp(tx, t, c);
+            for (int c = 0; c < C; ++c) o[c] = bilerp(tx, t, c, C);
         } else {
             float level = bias ? bias[i] : 0.0f;
             if (uv_da) level = compute_lod(uv_da[i], Ht, Wt, level).level;
@@ -110,14 +127,14 @@ __global__ void __launch_bounds__(256) k_tex_fwd(TexLevels lv, int n_levels, con
             const Taps t0 = make_taps(q.x, q.y, h0, w0, C, boundary);
             const float *tx0 = lv.tex[l0] + (size_t)b * h0 * w0 * C;
             if (filter == FPCDR_FILTER_LINEAR_MIPMAP_NEAREST) {
-                for (int c = 0; c < C; ++c) o[c] = bilerp(tx0, t0, c);
+                for (int c = 0; c < C; ++c) o[c] = bilerp(tx0, t0, c, C);
             } else {
                 const int l1 = min(l0 + 1, n_levels);
                 const int h1 = Ht >> l1, w1 = Wt >> l1;
                 const Taps t1 = make_taps(q.x, q.y, h1, w1, C, boundary);
                 const float *tx1 = lv.tex[l1] + (size_t)b * h1 * w1 * C;
                 for (int c = 0; c < C; ++c) {
-                    const float c0 = bilerp(tx0, t0, c), c1 = bilerp(tx1, t1, c);
+                    const float c0 = bilerp(tx0, t0, c, C), c1 = bilerp(tx1, t1, c, C);
                     o[c] = c0 + (c1 - c0) * fl;
                 }
             }
@@ -131,7 +148,8 @@ __device__ __forceinline__ void taps_bwd(const float *tx, float *gtx, const Taps
     const float w00 = (1.0f - t.fx) * (1.0f - t.fy), w10 = t.fx * (1.0f - t.fy), w01 = (1.0f - t.fx) * t.fy, w11 = t.fx * t.fy;
     for (int c = 0; c < C; ++c) {
         const float gc = g[c] * scale;
-        const float t00 = tx[t.i00 + c], t10 = tx[t.i10 + c], t01 = tx[t.i01 + c], t11 = tx[t.i11 + c];
+        float t00, t10, t01, t11;
+        load_taps(tx, t, c, C, t00, t10, t01, t11);
         gfx += gc * ((t10 - t00) * (1.0f - t.fy) + (t11 - t01) * t.fy);
         gfy += gc * ((t01 + (t11 - t01) * t.fx) - (t00 + (t10 - t00) * t.fx));
         if (gtx && gc != 0.0f) {
@@ -145,11 +163,15 @@ __device__ __forceinline__ void taps_bwd(const float *tx, float *gtx, const Taps
 
 __global__ void __launch_bounds__(256) k_tex_bwd(TexLevels lv, int n_levels, const float2 *__restrict__ uv,
                                                  const float4 *__restrict__ uv_da, const float *__restrict__ bias,
-                                                 const float *__restrict__ dy, long long npix_img, int B, int Bt, int Ht,
+                                                 const float *__restrict__ dy, int H, int W, int B, int Bt, int Ht,
                                                  int Wt, int C, int filter, int boundary, float2 *__restrict__ grad_uv,
                                                  float4 *__restrict__ grad_uv_da, float *__restrict__ grad_bias) {
-    const long long total = npix_img * B;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    // backward: one wave = a 16 x 4 pixel tile (block 16 x 16) so that the lanes' atomics land on neighbouring
+    // texels of a few texture rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = blockIdx.x * 16 + (lane & 15), py = blockIdx.y * 16 + wave * 4 + (lane >> 4);
+    if (px < W && py < H) {
+        const long long i = ((long long)blockIdx.z * H + py) * W + px;
         const float *g = dy + i * C;
         bool any = false;
         for (int c = 0; c < C; ++c) any |= (g[c] != 0.0f);
@@ -158,7 +180,7 @@ __global__ void __launch_bounds__(256) k_tex_bwd(TexLevels lv, int n_levels, con
         float gbias = 0.f;
         if (any) {
             const float2 q = uv[i];
-            const int b = Bt > 1 ? (int)(i / npix_img) : 0;
+            const int b = Bt > 1 ? (int)blockIdx.z : 0;
             // clamp mode: no uv gradient outside [0,1] (torch.clamp semantics of the oracle)
             const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(q.x >= 0.0f && q.x <= 1.0f)) ? 0.0f : 1.0f;
             const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(q.y >= 0.0f && q.y <= 1.0f)) ? 0.0f : 1.0f;
@@ -207,7 +229,7 @@ __global__ void __launch_bounds__(256) k_tex_bwd(TexLevels lv, int n_levels, con
                     gv += gfy1 * (float)h1;
                     // d out / d fl = sum_c g_c (c1 - c0);  level clamp passes gradient inside [0, n_levels]
                     float gfl = 0.f;
-                    for (int c = 0; c < C; ++c) gfl += g[c] * (bilerp(lv.tex[l1] + img1, t1, c) - bilerp(lv.tex[l0] + img0, t0, c));
+                    for (int c = 0; c < C; ++c) gfl += g[c] * (bilerp(lv.tex[l1] + img1, t1, c, C) - bilerp(lv.tex[l0] + img0, t0, c, C));
                     const float glevel = (raw >= 0.0f && raw <= (float)n_levels) ? gfl : 0.0f;
                     gbias = glevel;
                     if (uv_da) {
@@ -311,9 +333,8 @@ extern "C" int fpcdr_texture_fwd(const fpcdr_texture_fwd_params *p, void *stream
         lv.grad[l] = nullptr;
         if (l <= p->n_levels) FPCDR_REQUIRE(p->tex[l] != nullptr, "missing mip level");
     }
-    const long long npix = (long long)p->H * p->W;
-    hipLaunchKernelGGL(k_tex_fwd, dim3(grid_for(npix * p->B)), dim3(256), 0, (hipStream_t)stream, lv, p->n_levels,
-                       (const float2 *)p->uv, mip ? (const float4 *)p->uv_da : nullptr, mip ? p->mip_level_bias : nullptr, npix,
+    hipLaunchKernelGGL(k_tex_fwd, dim3(grid_for((long long)p->B * p->H * p->W)), dim3(256), 0, (hipStream_t)stream, lv, p->n_levels,
+                       (const float2 *)p->uv, mip ? (const float4 *)p->uv_da : nullptr, mip ? p->mip_level_bias : nullptr, p->H, p->W,
                        p->B, p->Bt, p->Ht, p->Wt, p->C, p->filter_mode, p->boundary_mode, p->out);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
@@ -332,10 +353,11 @@ extern "C" int fpcdr_texture_bwd(const fpcdr_texture_bwd_params *p, void *stream
         lv.grad[l] = l <= p->n_levels ? p->grad_tex[l] : nullptr;
         if (l <= p->n_levels) FPCDR_REQUIRE(p->tex[l] != nullptr, "missing mip level");
     }
-    const long long npix = (long long)p->H * p->W;
-    hipLaunchKernelGGL(k_tex_bwd, dim3(grid_for(npix * p->B)), dim3(256), 0, (hipStream_t)stream, lv, p->n_levels,
+    FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 16) <= 65535, "image batch / height too large for one launch");
+    dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
+    hipLaunchKernelGGL(k_tex_bwd, grid, dim3(256), 0, (hipStream_t)stream, lv, p->n_levels,
                        (const float2 *)p->uv, mip ? (const float4 *)p->uv_da : nullptr, mip ? p->mip_level_bias : nullptr, p->dy,
-                       npix, p->B, p->Bt, p->Ht, p->Wt, p->C, p->filter_mode, p->boundary_mode, (float2 *)p->grad_uv,
+                       p->H, p->W, p->B, p->Bt, p->Ht, p->Wt, p->C, p->filter_mode, p->boundary_mode, (float2 *)p->grad_uv,
                        mip ? (float4 *)p->grad_uv_da : nullptr, mip ? p->grad_mip_level_bias : nullptr);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
