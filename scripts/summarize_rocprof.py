@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel_stats / kernel_trace / counter_collection) into a small text summary
+that is committed under profiles/.   python scripts/summarize_rocprof.py <rocprof_out_dir> [more dirs] > profiles/x.txt"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    return name.split("(")[0][:70]
+
+
+for d in sys.argv[1:]:
+    print(f"== {d}")
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        print(f"-- kernel stats ({os.path.basename(f)}): name, calls, total_ms, avg_us, pct")
+        for r in rows[:24]:
+            print(f"{short(r['Name']):72s} {int(r['Calls']):6d} {float(r['TotalDurationNs']) / 1e6:10.3f} "
+                  f"{float(r['AverageNs']) / 1e3:10.1f} {float(r['Percentage']):6.2f}")
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        agg = defaultdict(lambda: defaultdict(list))
+        for r in rows:
+            agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+        print(f"-- counters ({os.path.basename(f)}): kernel, counter, dispatches, mean value per dispatch")
+        for k, cs in sorted(agg.items()):
+            if not any(x in k for x in ("k_", "Cijk")):
+                continue
+            for c, v in cs.items():
+                print(f"{k:72s} {c:14s} {len(v):5d} {sum(v) / len(v):16.1f}")
