@@ -31,4 +31,4 @@ for d in sys.argv[1:]:
             if not any(x in k for x in ("k_", "Cijk")):
                 continue
             for c, v in cs.items():
-                print(f"{k:72s} {c:14s} {len(v):5d} {sum(v) / len(v):16.1f}")
+                print(f"{k:72s} {c:14s} {len(v):5d} {sum(v) / len(v):16.1f} (max {max(v):.1f})")
