@@ -6,13 +6,13 @@
 // software pipeline designed for CDNA4:
 //
 //   k_setup   one thread per (image, triangle): clip -> 24.8 fixed point (double arithmetic, rules
-//             R1-R3 of DESIGN.md), writes a 48-byte record + an 8-byte pixel bounding box, and folds
-//             the image-wide bounding box with integer atomics.
+//             R1-R3 of DESIGN.md) and the float32 depth plane of R6; writes a 40-byte record + an 8-byte
+//             pixel bounding box, the 256-triangle chunk box and folds the image-wide bounding box.
 //   k_bins    one 256-thread workgroup per 64x64-pixel bin.  The bin scans the image's bounding
 //             boxes (8 B per triangle, L2 resident), keeps the overlapping triangles IN ORDER in
 //             LDS, 256 at a time, expands them to edge equations in LDS and marks which of the bin's
 //             64 8x8 tiles each one touches (bit masks in LDS).  Each wave owns 16 tiles, one pixel
-//             per lane: coverage by exact int64 edge functions, depth in double, winner kept in
+//             per lane: coverage by exact integer edge functions, depth by a float32 plane, winner kept in
 //             registers -- no global atomics, no per-pixel depth buffer in HBM, and the result does
 //             not depend on scheduling (ascending triangle order + strict "<").  The same wave then
 //             shades its pixels (perspective-correct barycentrics and their screen-space derivatives
@@ -20,8 +20,8 @@
 //   k_grad    one thread per pixel: recomputes the shading terms, chains (dL/du, dL/dv, dL/d db) to
 //             the three clip-space vertices and scatters with wave-level pre-reduction by vertex.
 //
-// Arithmetic that decides integer outputs uses only + - * / floor on IEEE doubles / int64 and is
-// compiled with -ffp-contract=off, so it agrees bit for bit with oracle/raster_ref.c.
+// Arithmetic that decides integer outputs uses only + - * / floor on IEEE doubles, exact integers and
+// explicit fmaf, and is compiled with -ffp-contract=off, so it agrees bit for bit with oracle/raster_ref.c.
 #include "common.h"
 
 namespace {
@@ -31,15 +31,17 @@ constexpr int HALFPIX = 128;
 constexpr double GUARD = 16777216.0;  // 2^24
 
 constexpr int BIN = 64;          // pixels per bin side
-constexpr int TILE = 8;          // pixels per tile side (one wave = one tile = 64 lanes)
+constexpr int TILE = 16;         // pixels per tile side; a wave covers a tile with 4 pixels per lane (2x2 quads of 8x8)
+constexpr int QUAD = 8;
 constexpr int TILES_X = BIN / TILE;
-constexpr int NTILES = TILES_X * TILES_X;   // 64 tiles per bin
+constexpr int NTILES = TILES_X * TILES_X;   // 16 tiles per bin
 constexpr int BATCH = 256;       // triangles expanded in LDS at a time (= block size)
-constexpr int TILES_PER_WAVE = NTILES / 4;  // 16
+constexpr int TILES_PER_WAVE = NTILES / 4;  // 4 (x 4 pixels per lane = 16 pixels of state per lane)
 
-struct __attribute__((aligned(16))) TriRec {  // 48 bytes
-    int32_t X0, Y0, X1, Y1, X2, Y2;
-    double q0, q1, q2;
+struct __attribute__((aligned(8))) TriRec {  // 40 bytes
+    int32_t X0, Y0, X1, Y1, X2, Y2;   // snapped vertices (R2)
+    float zA, zB, z0;                 // depth plane anchored at vertex 0 (R6)
+    int32_t pad;
 };
 struct __attribute__((aligned(8))) TriBox {  // inclusive pixel bbox; x0 > x1 = dropped
     int16_t x0, y0, x1, y1;
@@ -48,11 +50,21 @@ struct ImgBox { int32_t x0, y0, x1, y1; };  // folded with atomicMin/atomicMax
 
 struct __attribute__((aligned(16))) EdgeRec {  // LDS, 80 bytes
     int32_t A0, B0, A1, B1, A2, B2;
-    int32_t nb;       // bit e set: edge e does NOT own ties (E == 0 is outside)
+    int32_t nb;       // bit e (0..2) set: edge e does NOT own ties (E == 0 is outside); bit 3: small triangle
     int32_t id;       // triangle index
-    long long C0, C1, C2;   // biased: C - nb_e
-    double q0, q1, q2;
+    union {
+        long long C[3];                              // general path: biased constants C_e - nb_e (int64)
+        struct { int32_t X1, Y1, X2, Y2, X0, Y0; } v;  // small path: anchor vertex of edge 0, 1, 2
+    };
+    float zA, zB, z0;   // depth plane (R6), anchored at (X0, Y0)
+    int32_t X0, Y0;     // (also for the general path, whose union holds C[])
+    int32_t pad[3];
 };
+static_assert(sizeof(EdgeRec) == 96, "EdgeRec layout");
+// A triangle whose extent is at most 64 pixels in x and y takes the 32-bit path: for every pixel of a tile its
+// bounding box touches, |P - anchor| <= 16384 + 2048 sub-pixel units and |A|,|B| <= 16384, so each edge
+// function fits in int32 and the products fit v_mad_i32_i24.  Same integers, fewer and full-rate instructions.
+constexpr int SMALL_EXTENT = 16384;
 
 __device__ __forceinline__ long long floordiv256(long long a) { return a >> 8; }  // arithmetic shift = floor
 
@@ -98,7 +110,7 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
             long long D = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
             if (D == 0) ok = false;
             if (ok) {
-                double Dd = (double)(D > 0 ? D : -D);
+                const double Dd = (double)D;
                 long long xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
                 long long ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
                 long long px0 = floordiv256(xmin - HALFPIX + SUBPIX - 1), px1 = floordiv256(xmax - HALFPIX);
@@ -112,7 +124,11 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
                     r.X0 = (int32_t)X[0]; r.Y0 = (int32_t)Y[0];
                     r.X1 = (int32_t)X[1]; r.Y1 = (int32_t)Y[1];
                     r.X2 = (int32_t)X[2]; r.Y2 = (int32_t)Y[2];
-                    r.q0 = zw[0] / Dd; r.q1 = zw[1] / Dd; r.q2 = zw[2] / Dd;
+                    const double dz1 = zw[1] - zw[0], dz2 = zw[2] - zw[0];
+                    r.zA = (float)((dz1 * (double)(Y[2] - Y[0]) - dz2 * (double)(Y[1] - Y[0])) / Dd);
+                    r.zB = (float)((dz2 * (double)(X[1] - X[0]) - dz1 * (double)(X[2] - X[0])) / Dd);
+                    r.z0 = (float)zw[0];
+                    r.pad = 0;
                     recs[gid] = r;
                     bx0 = (int)px0; by0 = (int)py0; bx1 = (int)px1; by1 = (int)py1;
                 }
@@ -183,6 +199,64 @@ __device__ __forceinline__ Shade shade_pixel(float4 v0, float4 v1, float4 v2, fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fine raster of one 16x16 tile against the triangles of the current batch whose bit is set in `mrow`.  Each lane
+// owns FOUR pixels of the tile -- (lx,ly) in each 8x8 quadrant -- so one LDS fetch of a triangle feeds four
+// independent coverage / depth chains (the loop is latency-bound, not ALU-bound).  (Px,Py) is the lane's sample
+// point in quadrant 0; quadrant q adds (q&1, q>>1) * 8 pixels.  SMALL selects the 32-bit path (SMALL_EXTENT).
+template <bool SMALL>
+__device__ __forceinline__ void fine_tile(const unsigned long long *mrow, const EdgeRec *s_tri, int Px, int Py, float (&bd)[4],
+                                          int (&bi)[4]) {
+    constexpr int STEP = QUAD * SUBPIX;   // 2048 sub-pixel units between quadrants
+    for (int wd = 0; wd < BATCH / 64; ++wd) {
+        unsigned long long m = mrow[wd];
+        const unsigned int mlo = __builtin_amdgcn_readfirstlane((unsigned int)m);
+        const unsigned int mhi = __builtin_amdgcn_readfirstlane((unsigned int)(m >> 32));
+        m = ((unsigned long long)mhi << 32) | mlo;
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const EdgeRec &e = s_tri[wd * 64 + j];
+            const int nb = e.nb;
+            const int id = e.id;
+            const float zA = e.zA, zB = e.zB, z0 = e.z0;
+            const int rx = Px - e.X0, ry = Py - e.Y0;   // offset from the depth plane's anchor (quadrant 0)
+            if (SMALL) {
+                // E'_e = A (Px - Xa) + B (Py - Ya) - nb_e in int32 with 24-bit multiplies; other quadrants by addition
+                const int A0 = e.A0, B0 = e.B0, A1 = e.A1, B1 = e.B1, A2 = e.A2, B2 = e.B2;
+                const int b0 = __mul24(A0, Px - e.v.X1) + __mul24(B0, Py - e.v.Y1) - (nb & 1);
+                const int b1 = __mul24(A1, Px - e.v.X2) + __mul24(B1, Py - e.v.Y2) - ((nb >> 1) & 1);
+                const int b2 = __mul24(A2, rx) + __mul24(B2, ry) - ((nb >> 2) & 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int E0 = b0 + ((q & 1) ? A0 * STEP : 0) + ((q >> 1) ? B0 * STEP : 0);
+                    const int E1 = b1 + ((q & 1) ? A1 * STEP : 0) + ((q >> 1) ? B1 * STEP : 0);
+                    const int E2 = b2 + ((q & 1) ? A2 * STEP : 0) + ((q >> 1) ? B2 * STEP : 0);
+                    if ((E0 | E1 | E2) >= 0) {
+                        const float d = __fmaf_rn(zA, (float)(rx + (q & 1) * STEP), __fmaf_rn(zB, (float)(ry + (q >> 1) * STEP), z0));
+                        if (d >= -1.0f && d <= 1.0f && d < bd[q]) { bd[q] = d; bi[q] = id; }
+                    }
+                }
+            } else {
+                const long long A0 = e.A0, B0 = e.B0, A1 = e.A1, B1 = e.B1, A2 = e.A2, B2 = e.B2;
+                const long long b0 = A0 * Px + (B0 * Py + e.C[0]);
+                const long long b1 = A1 * Px + (B1 * Py + e.C[1]);
+                const long long b2 = A2 * Px + (B2 * Py + e.C[2]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long long E0 = b0 + ((q & 1) ? A0 * STEP : 0) + ((q >> 1) ? B0 * STEP : 0);
+                    const long long E1 = b1 + ((q & 1) ? A1 * STEP : 0) + ((q >> 1) ? B1 * STEP : 0);
+                    const long long E2 = b2 + ((q & 1) ? A2 * STEP : 0) + ((q >> 1) ? B2 * STEP : 0);
+                    if ((E0 | E1 | E2) >= 0) {
+                        const float d = __fmaf_rn(zA, (float)(rx + (q & 1) * STEP), __fmaf_rn(zB, (float)(ry + (q >> 1) * STEP), z0));
+                        if (d >= -1.0f && d <= 1.0f && d < bd[q]) { bd[q] = d; bi[q] = id; }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 template <bool WRITE_DB>
 __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               int V, int T, int H, int W, const TriRec *__restrict__ recs,
@@ -191,7 +265,8 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
                                               float4 *__restrict__ rast_db) {
     __shared__ EdgeRec s_tri[BATCH];
     __shared__ int s_clist[256];        // live chunks of the current segment (ascending)
-    __shared__ unsigned long long s_mask[NTILES][BATCH / 64];
+    __shared__ unsigned long long s_mask[2][NTILES][BATCH / 64];   // [0] small triangles, [1] the rest
+    __shared__ int s_any_large;
     __shared__ int s_list[2 * BATCH];   // pending triangle indices (ascending); first BATCH = current batch
     __shared__ int s_wave_cnt[2][4];
 
@@ -201,16 +276,19 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lx = lane & 7, ly = lane >> 3;
 
-    double best_d[TILES_PER_WAVE];
-    int best_id[TILES_PER_WAVE];
+    float best_d[TILES_PER_WAVE][4];
+    int best_id[TILES_PER_WAVE][4];
 #pragma unroll
-    for (int k = 0; k < TILES_PER_WAVE; ++k) { best_d[k] = 2.0; best_id[k] = -1; }
+    for (int k = 0; k < TILES_PER_WAVE; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { best_d[k][q] = 2.0f; best_id[k][q] = -1; }
 
     const ImgBox ib = ibox[b];
     const bool bin_live = !(ib.x1 < bin_x0 || ib.x0 > bin_x1 || ib.y1 < bin_y0 || ib.y0 > bin_y1);
 
     if (bin_live) {
-        for (int k = tid; k < NTILES * (BATCH / 64); k += 256) (&s_mask[0][0])[k] = 0ull;
+        for (int k = tid; k < 2 * NTILES * (BATCH / 64); k += 256) (&s_mask[0][0][0])[k] = 0ull;
+        if (tid == 0) s_any_large = 0;
         const TriBox *bx = boxes + (size_t)b * T;
         const TriRec *rc = recs + (size_t)b * T;
         const int n_chunks = (T + 255) / 256;
@@ -268,69 +346,74 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
                 if (tid < n) {
                     const int t = s_list[tid];
                     const TriRec r = rc[t];
-                    long long X0 = r.X0, Y0 = r.Y0, X1 = r.X1, Y1 = r.Y1, X2 = r.X2, Y2 = r.Y2;
-                    long long D = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
-                    long long s = D > 0 ? 1 : -1;
-                    EdgeRec e;
-                    long long A, Bc;
-                    int nb = 0;
-                    // edge 0: (1,2)  edge 1: (2,0)  edge 2: (0,1)
-                    A = -(Y2 - Y1) * s; Bc = (X2 - X1) * s;
-                    e.A0 = (int32_t)A; e.B0 = (int32_t)Bc;
-                    { bool own = (-A > 0) || (A == 0 && Bc < 0); nb |= own ? 0 : 1; e.C0 = -(A * X1 + Bc * Y1) - (own ? 0 : 1); }
-                    A = -(Y0 - Y2) * s; Bc = (X0 - X2) * s;
-                    e.A1 = (int32_t)A; e.B1 = (int32_t)Bc;
-                    { bool own = (-A > 0) || (A == 0 && Bc < 0); nb |= own ? 0 : 2; e.C1 = -(A * X2 + Bc * Y2) - (own ? 0 : 1); }
-                    A = -(Y1 - Y0) * s; Bc = (X1 - X0) * s;
-                    e.A2 = (int32_t)A; e.B2 = (int32_t)Bc;
-                    { bool own = (-A > 0) || (A == 0 && Bc < 0); nb |= own ? 0 : 4; e.C2 = -(A * X0 + Bc * Y0) - (own ? 0 : 1); }
-                    e.nb = nb; e.id = t;
-                    e.q0 = r.q0; e.q1 = r.q1; e.q2 = r.q2;
-                    s_tri[tid] = e;
                     const TriBox q = bx[t];
-                    int tx0 = (max((int)q.x0, bin_x0) - bin_x0) >> 3, tx1 = (min((int)q.x1, bin_x1) - bin_x0) >> 3;
-                    int ty0 = (max((int)q.y0, bin_y0) - bin_y0) >> 3, ty1 = (min((int)q.y1, bin_y1) - bin_y0) >> 3;
-                    unsigned long long bit = 1ull << (tid & 63);
+                    EdgeRec e;
+                    e.id = t;
+                    e.zA = r.zA; e.zB = r.zB; e.z0 = r.z0;
+                    e.X0 = r.X0; e.Y0 = r.Y0;
+                    const int ext_x = max(r.X0, max(r.X1, r.X2)) - min(r.X0, min(r.X1, r.X2));
+                    const int ext_y = max(r.Y0, max(r.Y1, r.Y2)) - min(r.Y0, min(r.Y1, r.Y2));
+                    const bool small = ext_x <= SMALL_EXTENT && ext_y <= SMALL_EXTENT;
+                    int nb = 0;
+                    // edge 0: (1,2)  edge 1: (2,0)  edge 2: (0,1);  A = -(Yb - Ya) s, B = (Xb - Xa) s
+                    if (small) {   // everything fits in int32
+                        const int D = (r.X1 - r.X0) * (r.Y2 - r.Y0) - (r.Y1 - r.Y0) * (r.X2 - r.X0);
+                        const int sg = D > 0 ? 1 : -1;
+                        e.A0 = -(r.Y2 - r.Y1) * sg; e.B0 = (r.X2 - r.X1) * sg;
+                        e.A1 = -(r.Y0 - r.Y2) * sg; e.B1 = (r.X0 - r.X2) * sg;
+                        e.A2 = -(r.Y1 - r.Y0) * sg; e.B2 = (r.X1 - r.X0) * sg;
+                        nb = 8;
+                        e.v.X1 = r.X1; e.v.Y1 = r.Y1; e.v.X2 = r.X2; e.v.Y2 = r.Y2; e.v.X0 = r.X0; e.v.Y0 = r.Y0;
+                    } else {
+                        s_any_large = 1;
+                        const long long X0 = r.X0, Y0 = r.Y0, X1 = r.X1, Y1 = r.Y1, X2 = r.X2, Y2 = r.Y2;
+                        const long long D = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
+                        const long long sg = D > 0 ? 1 : -1;
+                        e.A0 = (int32_t)(-(Y2 - Y1) * sg); e.B0 = (int32_t)((X2 - X1) * sg);
+                        e.A1 = (int32_t)(-(Y0 - Y2) * sg); e.B1 = (int32_t)((X0 - X2) * sg);
+                        e.A2 = (int32_t)(-(Y1 - Y0) * sg); e.B2 = (int32_t)((X1 - X0) * sg);
+                    }
+                    // R5 tie rule: an edge owns E == 0 iff its direction (dx,dy) = (B,-A) has dy > 0, or dy == 0 and dx < 0
+                    nb |= ((-e.A0 > 0) || (e.A0 == 0 && e.B0 < 0)) ? 0 : 1;
+                    nb |= ((-e.A1 > 0) || (e.A1 == 0 && e.B1 < 0)) ? 0 : 2;
+                    nb |= ((-e.A2 > 0) || (e.A2 == 0 && e.B2 < 0)) ? 0 : 4;
+                    if (!small) {
+                        e.C[0] = -((long long)e.A0 * r.X1 + (long long)e.B0 * r.Y1) - (nb & 1);
+                        e.C[1] = -((long long)e.A1 * r.X2 + (long long)e.B1 * r.Y2) - ((nb >> 1) & 1);
+                        e.C[2] = -((long long)e.A2 * r.X0 + (long long)e.B2 * r.Y0) - ((nb >> 2) & 1);
+                    }
+                    e.nb = nb;
+                    s_tri[tid] = e;
+                    const int tx0 = (max((int)q.x0, bin_x0) - bin_x0) >> 4, tx1 = (min((int)q.x1, bin_x1) - bin_x0) >> 4;
+                    const int ty0 = (max((int)q.y0, bin_y0) - bin_y0) >> 4, ty1 = (min((int)q.y1, bin_y1) - bin_y0) >> 4;
+                    const unsigned long long bit = 1ull << (tid & 63);
                     for (int ty = ty0; ty <= ty1; ++ty)
-                        for (int tx = tx0; tx <= tx1; ++tx) atomicOr(&s_mask[ty * TILES_X + tx][tid >> 6], bit);
+                        for (int tx = tx0; tx <= tx1; ++tx) atomicOr(&s_mask[small ? 0 : 1][ty * TILES_X + tx][tid >> 6], bit);
                 }
                 __syncthreads();
-                // ---- fine raster: this wave's 16 tiles, one pixel per lane ----
+                // ---- fine raster: this wave's 4 tiles of 16x16, four pixels per lane ----
 #pragma unroll
                 for (int k = 0; k < TILES_PER_WAVE; ++k) {
                     const int tile = wave * TILES_PER_WAVE + k;
-                    const int px = bin_x0 + (tile & 7) * TILE + lx, py = bin_y0 + (tile >> 3) * TILE + ly;
-                    const int Px = px * SUBPIX + HALFPIX, Py = py * SUBPIX + HALFPIX;
-                    double bd = best_d[k];
-                    int bi = best_id[k];
-                    for (int wd = 0; wd < BATCH / 64; ++wd) {
-                        unsigned long long m = s_mask[tile][wd];
-                        unsigned int mlo = __builtin_amdgcn_readfirstlane((unsigned int)m);
-                        unsigned int mhi = __builtin_amdgcn_readfirstlane((unsigned int)(m >> 32));
-                        m = ((unsigned long long)mhi << 32) | mlo;
-                        while (m) {
-                            const int j = __builtin_ctzll(m);
-                            m &= m - 1;
-                            const EdgeRec &e = s_tri[wd * 64 + j];
-                            long long E0 = (long long)e.A0 * Px + ((long long)e.B0 * Py + e.C0);
-                            long long E1 = (long long)e.A1 * Px + ((long long)e.B1 * Py + e.C1);
-                            long long E2 = (long long)e.A2 * Px + ((long long)e.B2 * Py + e.C2);
-                            if ((E0 | E1 | E2) >= 0) {
-                                const int nb = e.nb;
-                                E0 += (nb & 1); E1 += ((nb >> 1) & 1); E2 += ((nb >> 2) & 1);
-                                double d = ((double)E0 * e.q0 + (double)E1 * e.q1) + (double)E2 * e.q2;
-                                if (d >= -1.0 && d <= 1.0 && d < bd) { bd = d; bi = e.id; }
-                            }
-                        }
+                    const int px = bin_x0 + (tile & 3) * TILE + lx, py = bin_y0 + (tile >> 2) * TILE + ly;
+                    asm volatile("" ::: "memory");   // keep the 16 tiles' LDS mask loads from being hoisted together
+                    fine_tile<true>(s_mask[0][tile], s_tri, px * SUBPIX + HALFPIX, py * SUBPIX + HALFPIX, best_d[k], best_id[k]);
+                }
+                if (s_any_large) {   // block-uniform; large triangles are rare on the meshes this path is built for
+#pragma unroll
+                    for (int k = 0; k < TILES_PER_WAVE; ++k) {
+                        const int tile = wave * TILES_PER_WAVE + k;
+                        const int px = bin_x0 + (tile & 3) * TILE + lx, py = bin_y0 + (tile >> 2) * TILE + ly;
+                        asm volatile("" ::: "memory");
+                        fine_tile<false>(s_mask[1][tile], s_tri, px * SUBPIX + HALFPIX, py * SUBPIX + HALFPIX, best_d[k], best_id[k]);
                     }
-                    best_d[k] = bd;
-                    best_id[k] = bi;
                 }
                 __syncthreads();
                 // ---- retire the batch: shift the remaining pending entries down, clear masks ----
                 const int rest = pending - n;
                 int moved = (tid < rest) ? s_list[n + tid] : 0;
-                for (int k = tid; k < NTILES * (BATCH / 64); k += 256) (&s_mask[0][0])[k] = 0ull;
+                for (int k = tid; k < 2 * NTILES * (BATCH / 64); k += 256) (&s_mask[0][0][0])[k] = 0ull;
+                if (tid == 0) s_any_large = 0;
                 __syncthreads();
                 if (tid < rest) s_list[tid] = moved;
                 pending = rest;
@@ -345,21 +428,24 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
 #pragma unroll
     for (int k = 0; k < TILES_PER_WAVE; ++k) {
         const int tile = wave * TILES_PER_WAVE + k;
-        const int px = bin_x0 + (tile & 7) * TILE + lx, py = bin_y0 + (tile >> 3) * TILE + ly;
-        if (px >= W || py >= H) continue;
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int t = best_id[k];
-        if (t >= 0) {
-            const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-            const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
-            const float fy = (2.0f * (float)py + 1.0f) / (float)H - 1.0f;
-            Shade s = shade_pixel(p[i0], p[i1], p[i2], fx, fy, sx, sy);
-            o = make_float4(s.u, s.v, s.zw, (float)(t + 1));
-            d = make_float4(s.dudx, s.dudy, s.dvdx, s.dvdy);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int px = bin_x0 + (tile & 3) * TILE + (q & 1) * QUAD + lx, py = bin_y0 + (tile >> 2) * TILE + (q >> 1) * QUAD + ly;
+            if (px >= W || py >= H) continue;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int t = best_id[k][q];
+            if (t >= 0) {
+                const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+                const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
+                const float fy = (2.0f * (float)py + 1.0f) / (float)H - 1.0f;
+                Shade s = shade_pixel(p[i0], p[i1], p[i2], fx, fy, sx, sy);
+                o = make_float4(s.u, s.v, s.zw, (float)(t + 1));
+                d = make_float4(s.dudx, s.dudy, s.dvdx, s.dvdy);
+            }
+            const size_t off = ((size_t)b * H + py) * W + px;
+            rast[off] = o;
+            if (WRITE_DB) rast_db[off] = d;
         }
-        const size_t off = ((size_t)b * H + py) * W + px;
-        rast[off] = o;
-        if (WRITE_DB) rast_db[off] = d;
     }
 }
 

@@ -126,6 +126,11 @@ def blend_combined(v_base, m1, m2, m3, maps, maps_intermediate, datasets, frames
 def render_layers(glctx, mtx, pos, pos_idx, uv, uv_idx, tex, resolution, enable_mip, max_mip_level):
     """The op chain of reference render() up to and including antialias; returns (colour, rast_out)."""
     pos_clip = camera.transform_clip(mtx, pos)
+    return render_from_clip(glctx, pos_clip, pos_idx, uv, uv_idx, tex, resolution, enable_mip, max_mip_level)
+
+
+def render_from_clip(glctx, pos_clip, pos_idx, uv, uv_idx, tex, resolution, enable_mip, max_mip_level):
+    """reference fit.py:151-160 (rasterize -> interpolate -> texture -> antialias) on given clip-space positions."""
     rast_out, rast_out_db = dr.rasterize(glctx, pos_clip, pos_idx, resolution=(resolution[0], resolution[1]))
     if enable_mip:
         texc, texd = dr.interpolate(uv[None, ...], rast_out, uv_idx, rast_db=rast_out_db, diff_attrs='all')
@@ -435,6 +440,17 @@ class Fitter:
         self.iteration += 1
         return loss
 
+    @torch.no_grad()
+    def init_near_truth(self, scale=0.8):
+        """Start at `scale` x the synthetic ground truth (prior mode): M1 = I, M2 = scale * W_gt^T, per-frame pose.
+        The checkered synthetic texture makes the pixel loss non-convex beyond about half a check."""
+        sc, dev = self.sc, self.device
+        self.maps['local'].copy_(torch.eye(self.n_frames, device=dev))
+        self.maps_intermediate['local'].copy_(scale * torch.tensor(sc.weights_gt, device=dev).t())
+        self.per_frame_t.copy_(scale * torch.tensor(sc.t_gt, device=dev))
+        # quaternions stay at the reference's identity start: its whole-tensor renormalisation (quirk Q3,
+        # fit.py:616-618) rescales every row by 1/sqrt(F), which only the identity survives unchanged
+
     # ------------------------------------------------------------------------------------------
     def weights(self):
         """Current blendshape activations [F,K] (prior mode): (M2 M1)^T."""
@@ -478,13 +494,20 @@ def smoke_step(sc, device='cuda:0', cams=(0, 4), mode='prior'):
         ft.maps_intermediate['local'].copy_(0.5 * torch.tensor(sc.weights_gt, device=ft.device).t())
         ft.per_frame_t.copy_(0.5 * torch.tensor(sc.t_gt, device=ft.device))
     frame_ids = torch.arange(0, F, device=ft.device)
-    loss = ft.loss_and_backward(frame_ids)
+    Nc = len(ft.cam_idxs)
+    verts = ft.vertices(frame_ids).reshape(F, -1, 3)
+    pos_clip = camera.transform_clip(ft.mvp(frame_ids), verts)
+    pos_clip.retain_grad()
+    colour, rast = render_from_clip(ft.glctx, pos_clip, ft.pos_idx, ft.uv, ft.uv_idx, ft.tex_opt, ft.resolution, False, 0)
+    ref = ft.targets.reshape(F * Nc, *ft.resolution)
+    sum_sq, g_colour = pixel_loss_fused(colour, rast, ref)
+    ft.optimizer.zero_grad(set_to_none=False)
+    torch.autograd.backward([colour], [g_colour])
+    loss = sum_sq[0].to(torch.float32) / colour.numel()
     with torch.no_grad():
-        verts = ft.vertices(frame_ids).reshape(F, -1, 3)
-        colour, rast = render_layers(ft.glctx, ft.mvp(frame_ids), verts, ft.pos_idx, ft.uv, ft.uv_idx, ft.tex_opt,
-                                     ft.resolution, False, 0)
         image = torch.where(rast[..., 3:] > 0, colour, torch.tensor(BACKGROUND, device=ft.device))
-    return {'loss': loss.detach(), 'ids': rast[..., 3].to(torch.int32), 'image': image,
+    return {'loss': loss.detach(), 'ids': rast[..., 3].to(torch.int32), 'image': image.detach(),
+            'pos_clip': pos_clip.detach(), 'grad_pos_clip': pos_clip.grad.clone(),
             'grad_w': ft.maps_intermediate['local'].grad.clone(), 'grad_tex': ft.tex_opt.grad.clone(),
             'grad_pose': torch.cat([ft.per_frame_t.grad.reshape(-1), ft.per_frame_q.grad.reshape(-1),
                                     ft.t_opt.grad.reshape(-1), ft.q_opt.grad.reshape(-1)])}

@@ -112,7 +112,8 @@ def make_blendshapes(verts, K, rng):
 
 
 def make_texture(Ht, Wt, C, rng):
-    """Value noise over three octaves plus a faint grid; [Ht,Wt,C] in [0,1]."""
+    """Value noise over three octaves plus a faint grid; [Ht,Wt,C] in [0.05, 0.5]: the reference clips its
+    reference images to [0,140] of 255 (fit.py:531), so a renderable target must stay below 140/255."""
     tex = np.zeros((Ht, Wt), dtype=np.float64)
     yy, xx = np.meshgrid(np.arange(Ht) / Ht, np.arange(Wt) / Wt, indexing='ij')
     for octave, amp in ((4, 0.5), (16, 0.3), (64, 0.2)):
@@ -128,7 +129,7 @@ def make_texture(Ht, Wt, C, rng):
     grid = ((np.floor(yy * 32) + np.floor(xx * 32)) % 2) * 0.12
     tex = np.clip(0.15 + 0.7 * tex + grid - 0.06, 0.0, 1.0)
     out = np.stack([np.clip(tex * (1.0 - 0.08 * c) + 0.03 * c, 0, 1) for c in range(C)], axis=-1)
-    return out.astype(np.float32)
+    return (0.05 + 0.45 * out).astype(np.float32)
 
 
 def make_cameras(resolution, fill=0.6, head_height=22.0, target=(0.0, 170.0, 0.0)):

@@ -76,11 +76,8 @@ class State:
         return [self.M1, self.M2, self.t_opt, self.q_opt, self.per_frame_t, self.per_frame_q, self.tex]
 
 
-def forward(st, frame_ids, targets, enable_mip=False, max_mip_level=6, weight_laplacian=0.0, ids=None):
-    """Loss of a batch of frames x the state's cameras; targets uint8 [Fb,Nc,H,W].  Returns (loss, image, rast).
-    `ids`: visibility override (see oracle.ops.rasterize)."""
-    sc = st.sc
-    H, W = sc.resolution
+def clip_positions(st, frame_ids):
+    """Blend + MVP chain + transform_clip (reference fit.py:541-564, camera.py:19-23): pos_clip [Fb*Nc,V,4]."""
     Fb, Nc = len(frame_ids), len(st.cams)
     # fit.py:115-122 with a one-hot e_f: column f of M1, then M2, then B
     w = torch.matmul(st.M2, st.M1[:, frame_ids])                     # [K,Fb]
@@ -91,7 +88,13 @@ def forward(st, frame_ids, targets, enable_mip=False, max_mip_level=6, weight_la
     tr = torch.matmul(rc, st.TMV)
     mvp = torch.matmul(st.P[None], torch.matmul(rf[:, None], tr[None])).reshape(Fb * Nc, 4, 4)  # fit.py:551-553
     posw = torch.cat([verts, torch.ones(Fb, verts.shape[1], 1, dtype=verts.dtype)], dim=-1).repeat_interleave(Nc, dim=0)
-    pos_clip = torch.matmul(posw, mvp.transpose(1, 2))                # camera.py:19-23
+    return torch.matmul(posw, mvp.transpose(1, 2)), verts          # camera.py:19-23
+
+
+def forward_from_clip(st, pos_clip, targets, enable_mip=False, max_mip_level=6, ids=None):
+    """reference fit.py:151-161 + pixel loss fit.py:579 on given clip positions.  Returns (loss, image, rast)."""
+    H, W = st.sc.resolution
+    B = pos_clip.shape[0]
     rast, rast_db = O.rasterize(pos_clip, st.pos_idx, (H, W), ids=ids)
     if enable_mip:
         texc, texd = O.interpolate(st.uv[None], rast, st.uv_idx, rast_db=rast_db, diff_attrs='all')
@@ -101,8 +104,16 @@ def forward(st, frame_ids, targets, enable_mip=False, max_mip_level=6, weight_la
         colour = O.texture(st.tex[None], texc, filter_mode='linear')
     colour = O.antialias(colour, rast, pos_clip, st.pos_idx)
     image = torch.where(rast[..., 3:] > 0, colour, torch.tensor(BACKGROUND, dtype=colour.dtype))   # fit.py:161
-    ref = targets.reshape(Fb * Nc, H, W, 1).to(colour.dtype)
+    ref = targets.reshape(B, H, W, 1).to(colour.dtype)
     loss = torch.mean((ref - image * 255) ** 2)                                        # fit.py:579
+    return loss, image, rast
+
+
+def forward(st, frame_ids, targets, enable_mip=False, max_mip_level=6, weight_laplacian=0.0, ids=None):
+    """Loss of a batch of frames x the state's cameras; targets uint8 [Fb,Nc,H,W].  Returns (loss, image, rast).
+    `ids`: visibility override (see oracle.ops.rasterize)."""
+    pos_clip, verts = clip_positions(st, frame_ids)
+    loss, image, rast = forward_from_clip(st, pos_clip, targets, enable_mip, max_mip_level, ids)
     if weight_laplacian:
         loss = loss + weight_laplacian * uniform_laplacian(verts, st.pos_idx) ** 2      # fit.py:581
     return loss, image, rast
@@ -122,23 +133,52 @@ def uniform_laplacian(verts, faces):
     return torch.matmul(L[None], verts).norm(dim=2).mean()
 
 
-def smoke_step(sc, cams=(0, 4), dtype=torch.float32, ids=None):
-    """Same small forward + backward as fpc_diffrend_amd.fit.smoke_step, on the oracle.  dtype=float64 with
-    `ids` taken from a float32 run gives a high-precision reference for the gradients."""
-    from fpc_diffrend_amd.fit import smoke_targets
+def _smoke_state(sc, cams, dtype):
     st = State(sc, cams, dtype=dtype)
     F = sc.weights_gt.shape[0]
     with torch.no_grad():
         st.M1.copy_(torch.eye(F))
         st.M2.copy_(0.5 * torch.tensor(sc.weights_gt).t())
         st.per_frame_t.copy_(0.5 * torch.tensor(sc.t_gt))
-    targets = smoke_targets(sc, cams)
-    loss, image, rast = forward(st, torch.arange(F), targets, ids=ids)
-    loss.backward()
-    return {'loss': loss.detach(), 'ids': rast[..., 3].to(torch.int32), 'image': image.detach(),
-            'grad_w': st.M2.grad.clone(), 'grad_tex': st.tex.grad.clone(),
+    return st, F
+
+
+def _grads(st):
+    return {'grad_w': st.M2.grad.clone(), 'grad_tex': st.tex.grad.clone() if st.tex.grad is not None else None,
             'grad_pose': torch.cat([st.per_frame_t.grad.reshape(-1), st.per_frame_q.grad.reshape(-1),
                                     st.t_opt.grad.reshape(-1), st.q_opt.grad.reshape(-1)])}
+
+
+def smoke_step(sc, cams=(0, 4), dtype=torch.float32, ids=None):
+    """Same small forward + backward as fpc_diffrend_amd.fit.smoke_step, end to end on the oracle."""
+    from fpc_diffrend_amd.fit import smoke_targets
+    st, F = _smoke_state(sc, cams, dtype)
+    loss, image, rast = forward(st, torch.arange(F), smoke_targets(sc, cams), ids=ids)
+    loss.backward()
+    out = {'loss': loss.detach(), 'ids': rast[..., 3].to(torch.int32), 'image': image.detach()}
+    out.update(_grads(st))
+    return out
+
+
+def smoke_from_clip(sc, pos_clip, cams=(0, 4), dtype=torch.float32, ids=None):
+    """Raster chain + loss on GIVEN clip positions (a leaf): the four ops are compared on bit-identical input.
+    Returns ids, image, loss and the gradients w.r.t. pos_clip and the texture."""
+    from fpc_diffrend_amd.fit import smoke_targets
+    st, _ = _smoke_state(sc, cams, dtype)
+    p = pos_clip.detach().to(dtype).clone().requires_grad_(True)
+    loss, image, rast = forward_from_clip(st, p, smoke_targets(sc, cams), ids=ids)
+    loss.backward()
+    return {'loss': loss.detach(), 'ids': rast[..., 3].to(torch.int32), 'image': image.detach(),
+            'grad_pos_clip': p.grad.clone(), 'grad_tex': st.tex.grad.clone()}
+
+
+def smoke_upstream(sc, grad_pos_clip, cams=(0, 4), dtype=torch.float64):
+    """Chain a given d loss / d pos_clip back through transform_clip, the MVP chain and the blend
+    (reference fit.py:541-564) on the CPU: the reference for the parameter gradients of the GPU chain."""
+    st, F = _smoke_state(sc, cams, dtype)
+    pos_clip, _ = clip_positions(st, torch.arange(F))
+    pos_clip.backward(grad_pos_clip.detach().to(dtype))
+    return _grads(st)
 
 
 def timed_steps(sc, cams, frame_ids, steps=1, threads=None):

@@ -72,7 +72,7 @@ def rasterize_ids(pos, tri, resolution, return_depth=False):
     t = np.ascontiguousarray(tri.detach().cpu().numpy(), dtype=np.int32)
     B, V, _ = p.shape
     ids = np.zeros((B, H, W), dtype=np.int32)
-    depth = np.zeros((B, H, W), dtype=np.float64) if return_depth else None
+    depth = np.zeros((B, H, W), dtype=np.float32) if return_depth else None
     rc = _lib().fpcdr_oracle_rasterize_ids(p.ctypes.data, t.ctypes.data, B, V, t.shape[0], H, W, ids.ctypes.data,
                                            depth.ctypes.data if return_depth else None)
     assert rc == 0

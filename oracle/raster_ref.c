@@ -26,9 +26,12 @@
  *   R5  E_ab(P) = s[(Xb-Xa)(Py-Ya) - (Yb-Ya)(Px-Xa)] for (a,b) = (1,2),(2,0),(0,1);
  *       covered iff every E >= 0, where an edge with E == 0 counts only if its
  *       normalised direction (dx,dy) has dy > 0, or dy == 0 and dx < 0;
- *   R6  depth = (E0*q0 + E1*q1) + E2*q2, q_i = (z_i/w_i) / |D| in double; fragments
- *       with depth outside [-1,1] are discarded; the smaller depth wins, ties go to
- *       the smaller triangle index.
+ *   R6  depth is a float32 plane through the snapped vertices, anchored at vertex 0 (like a
+ *       24-bit hardware depth buffer): with zw_i = z_i/w_i in double,
+ *         zA = ((zw1-zw0)(Y2-Y0) - (zw2-zw0)(Y1-Y0)) / D,  zB = ((zw2-zw0)(X1-X0) - (zw1-zw0)(X2-X0)) / D
+ *       rounded to float, depth(P) = fmaf(zA, (float)(Px-X0), fmaf(zB, (float)(Py-Y0), (float)zw0));
+ *       fragments with depth outside [-1,1] are discarded; the smaller depth wins, ties
+ *       go to the smaller triangle index.
  */
 #include <math.h>
 #include <stdint.h>
@@ -42,7 +45,8 @@
 typedef struct {
     int64_t A[3], B[3], C[3];
     int own[3];
-    double q[3];
+    float zA, zB, z0;
+    int64_t X0, Y0;
     int px0, px1, py0, py1;
 } tri_setup_t;
 
@@ -73,7 +77,13 @@ static int setup_triangle(const float *v0, const float *v1, const float *v2, int
     int64_t D = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
     if (D == 0) return 0; /* R3 */
     int64_t s = D > 0 ? 1 : -1;
-    double Dd = (double)(D > 0 ? D : -D);
+    double Dd = (double)D;
+    double dz1 = zw[1] - zw[0], dz2 = zw[2] - zw[0];
+    ts->zA = (float)((dz1 * (double)(Y[2] - Y[0]) - dz2 * (double)(Y[1] - Y[0])) / Dd);
+    ts->zB = (float)((dz2 * (double)(X[1] - X[0]) - dz1 * (double)(X[2] - X[0])) / Dd);
+    ts->z0 = (float)zw[0];
+    ts->X0 = X[0];
+    ts->Y0 = Y[0];
     int64_t xmin = X[0], xmax = X[0], ymin = Y[0], ymax = Y[0];
     for (int i = 1; i < 3; ++i) {
         if (X[i] < xmin) xmin = X[i];
@@ -102,7 +112,6 @@ static int setup_triangle(const float *v0, const float *v1, const float *v2, int
         ts->C[e] = -(A * X[a] + Bc * Y[a]);
         int64_t dx = Bc, dy = -A;
         ts->own[e] = (dy > 0) || (dy == 0 && dx < 0); /* R5 tie rule */
-        ts->q[e] = zw[e] / Dd;                        /* R6 */
     }
     return 1;
 }
@@ -111,12 +120,12 @@ static int setup_triangle(const float *v0, const float *v1, const float *v2, int
  * pos  [B][V][4] float32 clip-space positions
  * tri  [T][3]    int32
  * out_id    [B][H][W] int32   triangle index + 1, 0 = empty
- * out_depth [B][H][W] double  winning depth (may be NULL)
+ * out_depth [B][H][W] float   winning depth (may be NULL)
  */
 int fpcdr_oracle_rasterize_ids(const float *pos, const int32_t *tri, int B, int V, int T, int H,
-                               int W, int32_t *out_id, double *out_depth) {
+                               int W, int32_t *out_id, float *out_depth) {
     size_t npix = (size_t)H * W;
-    double *zbuf = (double *)malloc(npix * sizeof(double));
+    float *zbuf = (float *)malloc(npix * sizeof(float));
     if (!zbuf) return 1;
     for (int b = 0; b < B; ++b) {
         const float *p = pos + (size_t)b * V * 4;
@@ -140,8 +149,8 @@ int fpcdr_oracle_rasterize_ids(const float *pos, const int32_t *tri, int B, int 
                         if (E[e] < 0 || (E[e] == 0 && !ts.own[e])) inside = 0;
                     }
                     if (!inside) continue;
-                    double depth = ((double)E[0] * ts.q[0] + (double)E[1] * ts.q[1]) + (double)E[2] * ts.q[2];
-                    if (!(depth >= -1.0 && depth <= 1.0)) continue;
+                    float depth = fmaf(ts.zA, (float)(Px - ts.X0), fmaf(ts.zB, (float)(Py - ts.Y0), ts.z0)); /* R6 */
+                    if (!(depth >= -1.0f && depth <= 1.0f)) continue;
                     size_t o = (size_t)py * W + px;
                     if (depth < zbuf[o]) {
                         zbuf[o] = depth;
@@ -150,7 +159,7 @@ int fpcdr_oracle_rasterize_ids(const float *pos, const int32_t *tri, int B, int 
                 }
             }
         }
-        if (out_depth) memcpy(out_depth + (size_t)b * npix, zbuf, npix * sizeof(double));
+        if (out_depth) memcpy(out_depth + (size_t)b * npix, zbuf, npix * sizeof(float));
     }
     free(zbuf);
     return 0;

@@ -19,17 +19,22 @@ def test_oracle_fit_cfg1_descends(oracle_ops):
         _, img, _ = ofit.forward(gt, torch.arange(2), torch.zeros(2, 1, 256, 256, dtype=torch.uint8))
         targets = torch.clamp(torch.round(img[..., 0] * 255), 0, 140).to(torch.uint8).reshape(2, 1, 256, 256)
     with torch.no_grad():
+        # start inside the basin of the checkered texture: 80 % of the true activations / translation
         st.M1.copy_(torch.eye(2))
-        st.M2.zero_()
-    opt = torch.optim.Adam([st.M2, st.per_frame_t], lr=2e-2)
+        st.M2.copy_(0.8 * torch.tensor(sc.weights_gt).t())
+        st.per_frame_t.copy_(0.8 * torch.tensor(sc.t_gt))
+        st.per_frame_q.copy_(torch.tensor(sc.q_gt))
+        at_truth, _, _ = ofit.forward(gt, torch.arange(2), targets)
+    assert float(at_truth) < 0.1          # only 8-bit quantisation separates the ground truth from its target
+    opt = torch.optim.Adam([st.M2, st.per_frame_t], lr=5e-3)
     losses = []
     for _ in range(8):
         opt.zero_grad()
         loss, _, _ = ofit.forward(st, torch.arange(2), targets)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
-    assert losses[-1] < losses[0]
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.7 * losses[0], losses
     r = ofit.smoke_step(sc)
     assert all(torch.isfinite(v).all() for k, v in r.items())
     assert r['grad_w'].abs().max() > 0 and r['grad_tex'].abs().max() > 0 and r['grad_pose'].abs().max() > 0

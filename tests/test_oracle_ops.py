@@ -39,7 +39,11 @@ def brute_force_ids(pos, tri, H, W):
             if D == 0:
                 continue
             s = 1 if D > 0 else -1
-            q = [z / float(abs(D)) for z in zw]
+            f32 = np.float32
+            dz1, dz2 = zw[1] - zw[0], zw[2] - zw[0]
+            zA = f32((dz1 * float(Y[2] - Y[0]) - dz2 * float(Y[1] - Y[0])) / float(D))
+            zB = f32((dz2 * float(X[1] - X[0]) - dz1 * float(X[2] - X[0])) / float(D))
+            z0 = f32(zw[0])
             for py in range(H):
                 Py = py * 256 + 128
                 if Py < min(Y) or Py > max(Y):
@@ -59,7 +63,9 @@ def brute_force_ids(pos, tri, H, W):
                         E.append(e)
                     if not inside:
                         continue
-                    d = (float(E[0]) * q[0] + float(E[1]) * q[1]) + float(E[2]) * q[2]
+                    # fmaf chain in exact rational arithmetic, rounded once per fma to float32
+                    inner = f32(float(Fraction(float(zB)) * Fraction(float(f32(Py - Y[0]))) + Fraction(float(z0))))
+                    d = f32(float(Fraction(float(zA)) * Fraction(float(f32(Px - X[0]))) + Fraction(float(inner))))
                     if not (-1.0 <= d <= 1.0):
                         continue
                     if (py, px) not in best or d < best[(py, px)][0]:
