@@ -31,6 +31,18 @@ class RasterizeBwd(ctypes.Structure):
                 ("H", _i), ("W", _i), ("grad_pos", _p)]
 
 
+class RenderFwd(ctypes.Structure):
+    _fields_ = [("pos", _p), ("tri", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i), ("scratch", _p),
+                ("uv", _p), ("uv_tri", _p), ("Vt", _i), ("tex", _p), ("Ht", _i), ("Wt", _i), ("C", _i),
+                ("boundary_mode", _i), ("rast", _p), ("color", _p)]
+
+
+class RenderBwd(ctypes.Structure):
+    _fields_ = [("pos", _p), ("tri", _p), ("uv", _p), ("uv_tri", _p), ("tex", _p), ("rast", _p), ("dy", _p), ("B", _i),
+                ("V", _i), ("T", _i), ("H", _i), ("W", _i), ("Vt", _i), ("Ht", _i), ("Wt", _i), ("C", _i),
+                ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p)]
+
+
 class InterpolateFwd(ctypes.Structure):
     _fields_ = [("attr", _p), ("rast", _p), ("tri", _p), ("rast_db", _p), ("B", _i), ("H", _i), ("W", _i), ("Ba", _i),
                 ("Vt", _i), ("A", _i), ("T", _i), ("n_diff", _i), ("diff_idx", _i * MAX_ATTR), ("out", _p),
@@ -82,6 +94,8 @@ SYMBOLS = {
     "fpcdr_rasterize_scratch_bytes": (_sz, [_i, _i]),
     "fpcdr_rasterize_fwd": (_int, [ctypes.POINTER(RasterizeFwd), _p]),
     "fpcdr_rasterize_bwd": (_int, [ctypes.POINTER(RasterizeBwd), _p]),
+    "fpcdr_render_fwd": (_int, [ctypes.POINTER(RenderFwd), _p]),
+    "fpcdr_render_bwd": (_int, [ctypes.POINTER(RenderBwd), _p]),
     "fpcdr_interpolate_fwd": (_int, [ctypes.POINTER(InterpolateFwd), _p]),
     "fpcdr_interpolate_bwd": (_int, [ctypes.POINTER(InterpolateBwd), _p]),
     "fpcdr_mip_downsample": (_int, [_p, _p, _i, _i, _i, _i, _p]),

@@ -26,6 +26,8 @@
 
 namespace {
 
+#include "texsample.h"
+
 constexpr int SUBPIX = 256;
 constexpr int HALFPIX = 128;
 constexpr double GUARD = 16777216.0;  // 2^24
@@ -257,12 +259,22 @@ __device__ __forceinline__ void fine_tile(const unsigned long long *mrow, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-template <bool WRITE_DB>
+// SHADE: the fused render path (fpcdr_render_fwd) -- the wave that resolved a pixel also interpolates its
+// texture coordinate and taps the texture, so texc never exists in HBM.
+struct ShadeArgs {
+    const float2 *uv;        // [Vt] texture coordinates
+    const int32_t *uv_tri;   // [T,3]
+    const float *tex;        // [Ht,Wt,C]
+    float *color;            // out [B,H,W,C]
+    int Ht, Wt, C, boundary;
+};
+
+template <bool WRITE_DB, bool SHADE>
 __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               int V, int T, int H, int W, const TriRec *__restrict__ recs,
                                               const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
                                               const ImgBox *__restrict__ ibox, float4 *__restrict__ rast,
-                                              float4 *__restrict__ rast_db) {
+                                              float4 *__restrict__ rast_db, ShadeArgs sh) {
     __shared__ EdgeRec s_tri[BATCH];
     __shared__ int s_clist[256];        // live chunks of the current segment (ascending)
     __shared__ unsigned long long s_mask[2][NTILES][BATCH / 64];   // [0] small triangles, [1] the rest
@@ -445,8 +457,97 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
             const size_t off = ((size_t)b * H + py) * W + px;
             rast[off] = o;
             if (WRITE_DB) rast_db[off] = d;
+            if (SHADE) {
+                // interpolate (reference fit.py:157) + texture 'linear' (fit.py:158), same arithmetic as the stand-alone
+                // kernels; an empty pixel samples uv = (0,0) exactly as they do
+                float tu = 0.0f, tv = 0.0f;
+                if (t >= 0) {
+                    const float2 q0 = sh.uv[sh.uv_tri[3 * t]], q1 = sh.uv[sh.uv_tri[3 * t + 1]], q2 = sh.uv[sh.uv_tri[3 * t + 2]];
+                    const float w = 1.0f - o.x - o.y;
+                    tu = o.x * q0.x + o.y * q1.x + w * q2.x;
+                    tv = o.x * q0.y + o.y * q1.y + w * q2.y;
+                }
+                const Taps tp = make_taps(tu, tv, sh.Ht, sh.Wt, sh.C, sh.boundary);
+                for (int c = 0; c < sh.C; ++c) sh.color[off * sh.C + c] = bilerp(sh.tex, tp, c, sh.C);
+            }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of shade_pixel for one pixel: chains (dL/du, dL/dv) = (g.x, g.y) and, with HAS_DDB, dL/d(rast_db) = gd
+// to the (x, y, w) of the three clip-space vertices.
+template <bool HAS_DDB>
+__device__ __forceinline__ void shade_pixel_bwd(float4 v0, float4 v1, float4 v2, float fx, float fy, float sx, float sy, float4 g,
+                                                float4 gd, float (&g0)[3], float (&g1)[3], float (&g2)[3]) {
+    // ---- forward recompute ----
+    const float w0 = v0.w, w1 = v1.w, w2 = v2.w;
+    const float p0x = v0.x - fx * w0, p0y = v0.y - fy * w0;
+    const float p1x = v1.x - fx * w1, p1y = v1.y - fy * w1;
+    const float p2x = v2.x - fx * w2, p2y = v2.y - fy * w2;
+    const float a0 = p1x * p2y - p1y * p2x;
+    const float a1 = p2x * p0y - p2y * p0x;
+    const float a2 = p0x * p1y - p0y * p1x;
+    const float at = a0 + a1 + a2;
+    const float iw = 1.0f / at;
+    const float b0 = a0 * iw, b1 = a1 * iw;
+    // ---- undo clamp / renormalise:  u = uc * s, v = vc * s, s = 1 / max(uc + vc, 1) ----
+    const float uc = fminf(fmaxf(b0, 0.0f), 1.0f), vc = fminf(fmaxf(b1, 0.0f), 1.0f);
+    float guc = g.x, gvc = g.y;
+    const float sum = uc + vc;
+    if (sum > 1.0f) {
+        const float s = 1.0f / sum;
+        const float dot = (uc * g.x + vc * g.y) * s * s;
+        guc = g.x * s - dot;
+        gvc = g.y * s - dot;
+    }
+    float gb0 = (b0 >= 0.0f && b0 <= 1.0f) ? guc : 0.0f;
+    float gb1 = (b1 >= 0.0f && b1 <= 1.0f) ? gvc : 0.0f;
+    // ---- reverse through the derivative outputs ----
+    float ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, giw = 0.f;
+    float gp0x = 0.f, gp0y = 0.f, gp1x = 0.f, gp1y = 0.f, gp2x = 0.f, gp2y = 0.f;
+    float gw0 = 0.f, gw1 = 0.f, gw2 = 0.f;
+    if (HAS_DDB) {
+        const float da0x = w2 * p1y - w1 * p2y, da0y = w1 * p2x - w2 * p1x;
+        const float da1x = w0 * p2y - w2 * p0y, da1y = w2 * p0x - w0 * p2x;
+        const float da2x = w1 * p0y - w0 * p1y, da2y = w0 * p1x - w1 * p0x;
+        const float datx = da0x + da1x + da2x, daty = da0y + da1y + da2y;
+        const float hx0 = gd.x * sx, hy0 = gd.y * sy, hx1 = gd.z * sx, hy1 = gd.w * sy;
+        // dudx = n0x * iw * sx,  n0x = da0x - b0 * datx   (same for the other three)
+        const float n0x = da0x - b0 * datx, n0y = da0y - b0 * daty;
+        const float n1x = da1x - b1 * datx, n1y = da1y - b1 * daty;
+        giw += hx0 * n0x + hy0 * n0y + hx1 * n1x + hy1 * n1y;
+        const float gn0x = hx0 * iw, gn0y = hy0 * iw, gn1x = hx1 * iw, gn1y = hy1 * iw;
+        gb0 -= gn0x * datx + gn0y * daty;
+        gb1 -= gn1x * datx + gn1y * daty;
+        const float gdatx = -(gn0x * b0 + gn1x * b1), gdaty = -(gn0y * b0 + gn1y * b1);
+        const float gda0x = gn0x + gdatx, gda0y = gn0y + gdaty;
+        const float gda1x = gn1x + gdatx, gda1y = gn1y + gdaty;
+        const float gda2x = gdatx, gda2y = gdaty;
+        // da0x = w2*p1y - w1*p2y ; da0y = w1*p2x - w2*p1x
+        gw2 += gda0x * p1y; gp1y += gda0x * w2; gw1 -= gda0x * p2y; gp2y -= gda0x * w1;
+        gw1 += gda0y * p2x; gp2x += gda0y * w1; gw2 -= gda0y * p1x; gp1x -= gda0y * w2;
+        // da1x = w0*p2y - w2*p0y ; da1y = w2*p0x - w0*p2x
+        gw0 += gda1x * p2y; gp2y += gda1x * w0; gw2 -= gda1x * p0y; gp0y -= gda1x * w2;
+        gw2 += gda1y * p0x; gp0x += gda1y * w2; gw0 -= gda1y * p2x; gp2x -= gda1y * w0;
+        // da2x = w1*p0y - w0*p1y ; da2y = w0*p1x - w1*p0x
+        gw1 += gda2x * p0y; gp0y += gda2x * w1; gw0 -= gda2x * p1y; gp1y -= gda2x * w0;
+        gw0 += gda2y * p1x; gp1x += gda2y * w0; gw1 -= gda2y * p0x; gp0x -= gda2y * w1;
+    }
+    // b0 = a0 * iw ; b1 = a1 * iw
+    ga0 += gb0 * iw; ga1 += gb1 * iw;
+    giw += gb0 * a0 + gb1 * a1;
+    // iw = 1 / at ; at = a0 + a1 + a2
+    const float gat = -giw * iw * iw;
+    ga0 += gat; ga1 += gat; ga2 += gat;
+    // a0 = p1x*p2y - p1y*p2x ; a1 = p2x*p0y - p2y*p0x ; a2 = p0x*p1y - p0y*p1x
+    gp1x += ga0 * p2y; gp2y += ga0 * p1x; gp1y -= ga0 * p2x; gp2x -= ga0 * p1y;
+    gp2x += ga1 * p0y; gp0y += ga1 * p2x; gp2y -= ga1 * p0x; gp0x -= ga1 * p2y;
+    gp0x += ga2 * p1y; gp1y += ga2 * p0x; gp0y -= ga2 * p1x; gp1x -= ga2 * p0y;
+    // p_kx = x_k - fx * w_k ; p_ky = y_k - fy * w_k
+    g0[0] = gp0x; g0[1] = gp0y; g0[2] = gw0 - fx * gp0x - fy * gp0y;
+    g1[0] = gp1x; g1[1] = gp1y; g1[2] = gw1 - fx * gp1x - fy * gp1y;
+    g2[0] = gp2x; g2[1] = gp2y; g2[2] = gw2 - fx * gp2x - fy * gp2y;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -477,80 +578,100 @@ __global__ void __launch_bounds__(256) k_grad(const float4 *__restrict__ pos, co
                 const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
                 const float fy = (2.0f * (float)py + 1.0f) / (float)H - 1.0f;
                 const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
-                // ---- forward recompute ----
-                const float w0 = v0.w, w1 = v1.w, w2 = v2.w;
-                const float p0x = v0.x - fx * w0, p0y = v0.y - fy * w0;
-                const float p1x = v1.x - fx * w1, p1y = v1.y - fy * w1;
-                const float p2x = v2.x - fx * w2, p2y = v2.y - fy * w2;
-                const float a0 = p1x * p2y - p1y * p2x;
-                const float a1 = p2x * p0y - p2y * p0x;
-                const float a2 = p0x * p1y - p0y * p1x;
-                const float at = a0 + a1 + a2;
-                const float iw = 1.0f / at;
-                const float b0 = a0 * iw, b1 = a1 * iw;
-                // ---- undo clamp / renormalise:  u = uc * s, v = vc * s, s = 1 / max(uc + vc, 1) ----
-                const float uc = fminf(fmaxf(b0, 0.0f), 1.0f), vc = fminf(fmaxf(b1, 0.0f), 1.0f);
-                float guc = g.x, gvc = g.y;
-                const float sum = uc + vc;
-                if (sum > 1.0f) {
-                    const float s = 1.0f / sum;
-                    const float dot = (uc * g.x + vc * g.y) * s * s;
-                    guc = g.x * s - dot;
-                    gvc = g.y * s - dot;
-                }
-                float gb0 = (b0 >= 0.0f && b0 <= 1.0f) ? guc : 0.0f;
-                float gb1 = (b1 >= 0.0f && b1 <= 1.0f) ? gvc : 0.0f;
-                // ---- reverse through the derivative outputs ----
-                float ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, giw = 0.f;
-                float gp0x = 0.f, gp0y = 0.f, gp1x = 0.f, gp1y = 0.f, gp2x = 0.f, gp2y = 0.f;
-                float gw0 = 0.f, gw1 = 0.f, gw2 = 0.f;
-                if (HAS_DDB) {
-                    const float da0x = w2 * p1y - w1 * p2y, da0y = w1 * p2x - w2 * p1x;
-                    const float da1x = w0 * p2y - w2 * p0y, da1y = w2 * p0x - w0 * p2x;
-                    const float da2x = w1 * p0y - w0 * p1y, da2y = w0 * p1x - w1 * p0x;
-                    const float datx = da0x + da1x + da2x, daty = da0y + da1y + da2y;
-                    const float hx0 = gd.x * sx, hy0 = gd.y * sy, hx1 = gd.z * sx, hy1 = gd.w * sy;
-                    // dudx = n0x * iw * sx,  n0x = da0x - b0 * datx   (same for the other three)
-                    const float n0x = da0x - b0 * datx, n0y = da0y - b0 * daty;
-                    const float n1x = da1x - b1 * datx, n1y = da1y - b1 * daty;
-                    giw += hx0 * n0x + hy0 * n0y + hx1 * n1x + hy1 * n1y;
-                    const float gn0x = hx0 * iw, gn0y = hy0 * iw, gn1x = hx1 * iw, gn1y = hy1 * iw;
-                    gb0 -= gn0x * datx + gn0y * daty;
-                    gb1 -= gn1x * datx + gn1y * daty;
-                    const float gdatx = -(gn0x * b0 + gn1x * b1), gdaty = -(gn0y * b0 + gn1y * b1);
-                    const float gda0x = gn0x + gdatx, gda0y = gn0y + gdaty;
-                    const float gda1x = gn1x + gdatx, gda1y = gn1y + gdaty;
-                    const float gda2x = gdatx, gda2y = gdaty;
-                    // da0x = w2*p1y - w1*p2y ; da0y = w1*p2x - w2*p1x
-                    gw2 += gda0x * p1y; gp1y += gda0x * w2; gw1 -= gda0x * p2y; gp2y -= gda0x * w1;
-                    gw1 += gda0y * p2x; gp2x += gda0y * w1; gw2 -= gda0y * p1x; gp1x -= gda0y * w2;
-                    // da1x = w0*p2y - w2*p0y ; da1y = w2*p0x - w0*p2x
-                    gw0 += gda1x * p2y; gp2y += gda1x * w0; gw2 -= gda1x * p0y; gp0y -= gda1x * w2;
-                    gw2 += gda1y * p0x; gp0x += gda1y * w2; gw0 -= gda1y * p2x; gp2x -= gda1y * w0;
-                    // da2x = w1*p0y - w0*p1y ; da2y = w0*p1x - w1*p0x
-                    gw1 += gda2x * p0y; gp0y += gda2x * w1; gw0 -= gda2x * p1y; gp1y -= gda2x * w0;
-                    gw0 += gda2y * p1x; gp1x += gda2y * w0; gw1 -= gda2y * p0x; gp0x -= gda2y * w1;
-                }
-                // b0 = a0 * iw ; b1 = a1 * iw
-                ga0 += gb0 * iw; ga1 += gb1 * iw;
-                giw += gb0 * a0 + gb1 * a1;
-                // iw = 1 / at ; at = a0 + a1 + a2
-                const float gat = -giw * iw * iw;
-                ga0 += gat; ga1 += gat; ga2 += gat;
-                // a0 = p1x*p2y - p1y*p2x ; a1 = p2x*p0y - p2y*p0x ; a2 = p0x*p1y - p0y*p1x
-                gp1x += ga0 * p2y; gp2y += ga0 * p1x; gp1y -= ga0 * p2x; gp2x -= ga0 * p1y;
-                gp2x += ga1 * p0y; gp0y += ga1 * p2x; gp2y -= ga1 * p0x; gp0x -= ga1 * p2y;
-                gp0x += ga2 * p1y; gp1y += ga2 * p0x; gp0y -= ga2 * p1x; gp1x -= ga2 * p0y;
-                // p_kx = x_k - fx * w_k ; p_ky = y_k - fy * w_k
-                g0[0] = gp0x; g0[1] = gp0y; g0[2] = gw0 - fx * gp0x - fy * gp0y;
-                g1[0] = gp1x; g1[1] = gp1y; g1[2] = gw1 - fx * gp1x - fy * gp1y;
-                g2[0] = gp2x; g2[1] = gp2y; g2[2] = gw2 - fx * gp2x - fy * gp2y;
+                shade_pixel_bwd<HAS_DDB>(v0, v1, v2, fx, fy, sx, sy, g, gd, g0, g1, g2);
                 key0 = i0; key1 = i1; key2 = i2;
             }
         }
     }
     // wave-uniform early out (most waves of an image see no gradient at all)
     if (__ballot(key0 >= 0) == 0ull) return;
+    float *gp = grad_pos + (size_t)b * V * 4;
+    {
+        float *const d[3] = {gp + 4 * (size_t)max(key0, 0), gp + 4 * (size_t)max(key0, 0) + 1, gp + 4 * (size_t)max(key0, 0) + 3};
+        wave_group_atomic_add<3>(key0, d, g0);
+    }
+    {
+        float *const d[3] = {gp + 4 * (size_t)max(key1, 0), gp + 4 * (size_t)max(key1, 0) + 1, gp + 4 * (size_t)max(key1, 0) + 3};
+        wave_group_atomic_add<3>(key1, d, g1);
+    }
+    {
+        float *const d[3] = {gp + 4 * (size_t)max(key2, 0), gp + 4 * (size_t)max(key2, 0) + 1, gp + 4 * (size_t)max(key2, 0) + 3};
+        wave_group_atomic_add<3>(key2, d, g2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused backward of texture('linear') -> interpolate -> rasterize (reference fit.py:158,157,151) for the render
+// path: reads dL/d colour (4C B/px) and rast (16 B/px), writes nothing dense.  A covered pixel with a non-zero
+// gradient re-derives its texture coordinate, scatters into grad_tex (4C atomics), chains d colour / d uv through
+// the barycentrics to the three clip-space vertices and scatters into grad_pos (pre-reduced per wave by vertex).
+__global__ void __launch_bounds__(256) k_render_bwd(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                    const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
+                                                    const float *__restrict__ tex, const float4 *__restrict__ rast,
+                                                    const float *__restrict__ dy, int V, int T, int H, int W, int Ht, int Wt,
+                                                    int C, int boundary, float *__restrict__ grad_pos,
+                                                    float *__restrict__ grad_tex) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int b = blockIdx.z;
+    int key0 = -1, key1 = -1, key2 = -1;
+    float g0[3] = {0, 0, 0}, g1[3] = {0, 0, 0}, g2[3] = {0, 0, 0};
+    if (px < W && py < H) {
+        const size_t off = ((size_t)b * H + py) * W + px;
+        const float *g = dy + off * C;
+        bool any = false;
+        for (int c = 0; c < C; ++c) any |= (g[c] != 0.0f);
+        if (any) {
+            const float4 r = rast[off];
+            int t = (int)r.w - 1;
+            if (t >= T) t = -1;
+            // texture backward; an empty pixel sampled uv = (0,0) in the forward pass and scatters there
+            float2 q0 = make_float2(0.f, 0.f), q1 = q0, q2 = q0;
+            float tu = 0.0f, tv = 0.0f;
+            if (t >= 0) {
+                q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]];
+                const float w = 1.0f - r.x - r.y;
+                tu = r.x * q0.x + r.y * q1.x + w * q2.x;
+                tv = r.x * q0.y + r.y * q1.y + w * q2.y;
+            }
+            const Taps tp = make_taps(tu, tv, Ht, Wt, C, boundary);
+            const float w00 = (1.0f - tp.fx) * (1.0f - tp.fy), w10 = tp.fx * (1.0f - tp.fy);
+            const float w01 = (1.0f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
+            float gfx = 0.f, gfy = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float gc = g[c];
+                float t00, t10, t01, t11;
+                load_taps(tex, tp, c, C, t00, t10, t01, t11);
+                gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
+                gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
+                if (grad_tex && gc != 0.0f) {
+                    atomicAdd(grad_tex + tp.i00 + c, gc * w00);
+                    atomicAdd(grad_tex + tp.i10 + c, gc * w10);
+                    atomicAdd(grad_tex + tp.i01 + c, gc * w01);
+                    atomicAdd(grad_tex + tp.i11 + c, gc * w11);
+                }
+            }
+            if (t >= 0 && grad_pos) {
+                const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
+                const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv >= 0.0f && tv <= 1.0f)) ? 0.0f : 1.0f;
+                const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
+                // interpolate backward: d uv / d (u, v)
+                const float gu = gtu * (q0.x - q2.x) + gtv * (q0.y - q2.y);
+                const float gv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
+                if (gu != 0.0f || gv != 0.0f) {
+                    const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+                    const float4 *p = pos + (size_t)b * V;
+                    const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
+                    const float fy = (2.0f * (float)py + 1.0f) / (float)H - 1.0f;
+                    shade_pixel_bwd<false>(p[i0], p[i1], p[i2], fx, fy, 2.0f / (float)W, 2.0f / (float)H,
+                                           make_float4(gu, gv, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), g0, g1, g2);
+                    key0 = i0; key1 = i1; key2 = i2;
+                }
+            }
+        }
+    }
+    if (!grad_pos || __ballot(key0 >= 0) == 0ull) return;
     float *gp = grad_pos + (size_t)b * V * 4;
     {
         float *const d[3] = {gp + 4 * (size_t)max(key0, 0), gp + 4 * (size_t)max(key0, 0) + 1, gp + 4 * (size_t)max(key0, 0) + 3};
@@ -597,11 +718,11 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     if (p->rast_db)
-        hipLaunchKernelGGL(k_bins<true>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
-                           recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)p->rast_db);
+        hipLaunchKernelGGL((k_bins<true, false>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
+                           recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)p->rast_db, ShadeArgs{});
     else
-        hipLaunchKernelGGL(k_bins<false>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
-                           recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr);
+        hipLaunchKernelGGL((k_bins<false, false>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
+                           recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr, ShadeArgs{});
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }
@@ -619,6 +740,48 @@ extern "C" int fpcdr_rasterize_bwd(const fpcdr_rasterize_bwd_params *p, void *st
     else
         hipLaunchKernelGGL(k_grad<false>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, (const float4 *)p->rast,
                            (const float4 *)p->dy, (const float4 *)nullptr, p->B, p->V, p->T, p->H, p->W, p->grad_pos);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->pos && p->tri && p->scratch && p->rast && p->uv && p->uv_tri && p->tex && p->color, "null pointer");
+    FPCDR_REQUIRE(p->B > 0 && p->V > 0 && p->T > 0 && p->H > 0 && p->W > 0 && p->Ht > 0 && p->Wt > 0 && p->C > 0,
+                  "sizes must be positive");
+    FPCDR_REQUIRE(p->H <= 32767 && p->W <= 32767 && p->B <= 65535, "resolution / batch too large");
+    FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
+    FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C <= 0x7fffffffLL, "texture too large");
+    hipStream_t st = (hipStream_t)stream;
+    size_t n = (size_t)p->B * p->T;
+    char *s = (char *)p->scratch;
+    TriRec *recs = (TriRec *)s;
+    TriBox *boxes = (TriBox *)(s + align_up(n * sizeof(TriRec), 256));
+    TriBox *cboxes = (TriBox *)((char *)boxes + align_up(n * sizeof(TriBox), 256));
+    const size_t nc = (size_t)p->B * (size_t)fpcdr_cdiv(p->T, 256);
+    ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
+    hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
+    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
+    dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
+    ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode};
+    hipLaunchKernelGGL((k_bins<false, true>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
+                       recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr, sh);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_render_bwd(const fpcdr_render_bwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->pos && p->tri && p->uv && p->uv_tri && p->tex && p->rast && p->dy, "null pointer");
+    FPCDR_REQUIRE(p->grad_pos || p->grad_tex, "nothing to compute");
+    FPCDR_REQUIRE(p->B > 0 && p->V > 0 && p->T > 0 && p->H > 0 && p->W > 0 && p->Ht > 0 && p->Wt > 0 && p->C > 0,
+                  "sizes must be positive");
+    FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
+    dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
+    hipLaunchKernelGGL(k_render_bwd, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)p->pos, p->tri,
+                       (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->dy, p->V, p->T, p->H, p->W, p->Ht,
+                       p->Wt, p->C, p->boundary_mode, p->grad_pos, p->grad_tex);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }

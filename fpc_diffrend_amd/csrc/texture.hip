@@ -13,66 +13,12 @@
 
 namespace {
 
+#include "texsample.h"
+
 struct TexLevels {
     const float *tex[FPCDR_MAX_MIP + 1];
     float *grad[FPCDR_MAX_MIP + 1];
 };
-
-__device__ __forceinline__ int wrap_i(int i, int n, int mode) {
-    if (mode == FPCDR_BOUNDARY_WRAP) {
-        int r = i % n;
-        return r < 0 ? r + n : r;
-    }
-    return min(max(i, 0), n - 1);
-}
-
-__device__ __forceinline__ float prep_coord(float u, int mode) {
-    if (mode == FPCDR_BOUNDARY_WRAP) return u - floorf(u);
-    return fminf(fmaxf(u, 0.0f), 1.0f);
-}
-
-struct Taps {
-    int i00, i10, i01, i11;  // element offsets (texel index * C) within one texture image
-    float fx, fy;
-};
-
-__device__ __forceinline__ Taps make_taps(float u, float v, int Ht, int Wt, int C, int mode) {
-    const float x = prep_coord(u, mode) * (float)Wt - 0.5f;
-    const float y = prep_coord(v, mode) * (float)Ht - 0.5f;
-    const float x0f = floorf(x), y0f = floorf(y);
-    Taps t;
-    t.fx = x - x0f;
-    t.fy = y - y0f;
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    const int ix0 = wrap_i(x0, Wt, mode), ix1 = wrap_i(x0 + 1, Wt, mode);
-    const int iy0 = wrap_i(y0, Ht, mode), iy1 = wrap_i(y0 + 1, Ht, mode);
-    t.i00 = (iy0 * Wt + ix0) * C; t.i10 = (iy0 * Wt + ix1) * C;
-    t.i01 = (iy1 * Wt + ix0) * C; t.i11 = (iy1 * Wt + ix1) * C;
-    return t;
-}
-
-// two horizontally adjacent texels in one 8-byte gather (4-byte aligned): the gather rate, not HBM, bounds
-// the texture kernels, so halving the number of gather instructions matters
-typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));
-
-__device__ __forceinline__ void load_taps(const float *tx, const Taps &t, int c, int C, float &t00, float &t10, float &t01,
-                                          float &t11) {
-    if (C == 1 && t.i10 == t.i00 + 1) {   // no wrap between the two columns
-        const float2_u a = *reinterpret_cast<const float2_u *>(tx + t.i00);
-        const float2_u b = *reinterpret_cast<const float2_u *>(tx + t.i01);
-        t00 = a.x; t10 = a.y; t01 = b.x; t11 = b.y;
-    } else {
-        t00 = tx[t.i00 + c]; t10 = tx[t.i10 + c]; t01 = tx[t.i01 + c]; t11 = tx[t.i11 + c];
-    }
-}
-
-__device__ __forceinline__ float bilerp(const float *tx, const Taps &t, int c, int C) {
-    float t00, t10, t01, t11;
-    load_taps(tx, t, c, C, t00, t10, t01, t11);
-    const float top = t00 + (t10 - t00) * t.fx;
-    const float bot = t01 + (t11 - t01) * t.fx;
-    return top + (bot - top) * t.fy;
-}
 
 // level of detail from the uv footprint; returns the unclamped level, outputs the pieces the backward needs
 struct Lod { float level, l2, rt, df, bq, dudx, dudy, dvdx, dvdy; };

@@ -123,14 +123,19 @@ def blend_combined(v_base, m1, m2, m3, maps, maps_intermediate, datasets, frames
 # render -- reference fit.py:134-162
 # ----------------------------------------------------------------------------------------------
 
-def render_layers(glctx, mtx, pos, pos_idx, uv, uv_idx, tex, resolution, enable_mip, max_mip_level):
+def render_layers(glctx, mtx, pos, pos_idx, uv, uv_idx, tex, resolution, enable_mip, max_mip_level, fused=False):
     """The op chain of reference render() up to and including antialias; returns (colour, rast_out)."""
     pos_clip = camera.transform_clip(mtx, pos)
-    return render_from_clip(glctx, pos_clip, pos_idx, uv, uv_idx, tex, resolution, enable_mip, max_mip_level)
+    return render_from_clip(glctx, pos_clip, pos_idx, uv, uv_idx, tex, resolution, enable_mip, max_mip_level, fused)
 
 
-def render_from_clip(glctx, pos_clip, pos_idx, uv, uv_idx, tex, resolution, enable_mip, max_mip_level):
-    """reference fit.py:151-160 (rasterize -> interpolate -> texture -> antialias) on given clip-space positions."""
+def render_from_clip(glctx, pos_clip, pos_idx, uv, uv_idx, tex, resolution, enable_mip, max_mip_level, fused=False):
+    """reference fit.py:151-160 (rasterize -> interpolate -> texture -> antialias) on given clip-space positions.
+    fused=True (non-mip only) runs the first three as one kernel pair (ops.render_textured): same values."""
+    if fused and not enable_mip:
+        colour, rast_out = dr.render_textured(glctx, pos_clip, pos_idx, uv, uv_idx, tex, resolution)
+        colour = dr.antialias(colour, rast_out, pos_clip, pos_idx)
+        return colour, rast_out
     rast_out, rast_out_db = dr.rasterize(glctx, pos_clip, pos_idx, resolution=(resolution[0], resolution[1]))
     if enable_mip:
         texc, texd = dr.interpolate(uv[None, ...], rast_out, uv_idx, rast_db=rast_out_db, diff_attrs='all')
@@ -229,6 +234,7 @@ class FitConfig:
     optimize_texture: bool = True
     init_texture: str = "truth"     # 'truth' | 'random' (reference: np.random.uniform when no texpath, fit.py:438)
     fused_loss: bool = True         # False = reference-style torch.where + torch.mean chain
+    fused_render: bool = True       # rasterize + interpolate + texture as one kernel pair (non-mip); False = four separate ops
 
 
 def setup_dataset(blendshapes, n_frames, device):
@@ -391,7 +397,7 @@ class Fitter:
         vtx_pos_split = vtx_pos.reshape(Fb, -1, 3)
         mvp = self.mvp(frame_ids)
         colour, rast_out = render_layers(self.glctx, mvp, vtx_pos_split, self.pos_idx, self.uv, self.uv_idx, self.tex_opt,
-                                         self.resolution, cfg.enable_mip, cfg.max_mip_level)
+                                         self.resolution, cfg.enable_mip, cfg.max_mip_level, cfg.fused_render)
         ref = self.targets[frame_ids - self.frame_lo].reshape(Fb * Nc, *self.resolution)
         n_img_global = Fb * Nc * self.world
         # regularisers (fit.py:578-595): evaluated on this rank's meshes, averaged over all ranks

@@ -27,7 +27,7 @@ import torch
 from . import _lib
 
 __all__ = ['RasterizeGLContext', 'RasterizeCudaContext', 'RasterizeHipContext', 'rasterize', 'interpolate', 'texture',
-           'texture_construct_mip', 'antialias', 'antialias_construct_topology_hash']
+           'texture_construct_mip', 'antialias', 'antialias_construct_topology_hash', 'render_textured']
 
 
 def _stream():
@@ -142,6 +142,68 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
         raise ValueError(f"pos is on {pos.device} but the context was created for {glctx.device}")
     return _rasterize_func.apply(pos.contiguous(), tri.contiguous(), resolution[0], resolution[1], glctx.output_db,
                                  grad_db)
+
+
+# ----------------------------------------------------------------------------------------------
+# fused render (extension; not part of the nvdiffrast surface)
+# ----------------------------------------------------------------------------------------------
+
+class _render_textured_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, tri, uv, uv_tri, tex, H, W, boundary):
+        lib = _lib.load()
+        B, V, _ = pos.shape
+        T = tri.shape[0]
+        Ht, Wt, C = tex.shape
+        dev = pos.device
+        rast = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
+        color = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
+        scratch = torch.empty(lib.fpcdr_rasterize_scratch_bytes(B, T), dtype=torch.uint8, device=dev)
+        p = _lib.RenderFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
+                           uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C, boundary_mode=boundary,
+                           rast=_ptr(rast), color=_ptr(color))
+        _lib.call("fpcdr_render_fwd", ctypes.byref(p), _stream())
+        ctx.save_for_backward(pos, tri, uv, uv_tri, tex, rast)
+        ctx.boundary = boundary
+        ctx.mark_non_differentiable(rast)
+        return color, rast
+
+    @staticmethod
+    def backward(ctx, dy, _drast):
+        pos, tri, uv, uv_tri, tex, rast = ctx.saved_tensors
+        B, V, _ = pos.shape
+        _, H, W, _ = rast.shape
+        Ht, Wt, C = tex.shape
+        g_pos = torch.zeros_like(pos) if ctx.needs_input_grad[0] else None
+        g_tex = torch.zeros_like(tex) if ctx.needs_input_grad[4] else None
+        if g_pos is None and g_tex is None:
+            return (None,) * 8
+        dy = dy.contiguous()
+        p = _lib.RenderBwd(pos=_ptr(pos), tri=_ptr(tri), uv=_ptr(uv), uv_tri=_ptr(uv_tri), tex=_ptr(tex), rast=_ptr(rast),
+                           dy=_ptr(dy), B=B, V=V, T=tri.shape[0], H=H, W=W, Vt=uv.shape[0], Ht=Ht, Wt=Wt, C=C,
+                           boundary_mode=ctx.boundary, grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex))
+        _lib.call("fpcdr_render_bwd", ctypes.byref(p), _stream())
+        return g_pos, None, None, None, g_tex, None, None, None
+
+
+def render_textured(glctx, pos, tri, uv, uv_tri, tex, resolution, boundary_mode='wrap'):
+    """rasterize -> interpolate(uv) -> texture('linear') in one pass (the non-mip branch of the reference's render(),
+    fit.py:151,157,158).  pos [B,V,4], tri [T,3], uv [Vt,2], uv_tri [T,3], tex [Ht,Wt,C].  Returns (colour [B,H,W,C],
+    rast [B,H,W,4]); values equal the three separate calls, the texture-coordinate image never reaches HBM, and the
+    backward pass scatters straight into grad_tex and grad_pos.  rast carries no gradient here (use `rasterize` for that)."""
+    assert isinstance(glctx, RasterizeHipContext)
+    _check_tensor('pos', pos, torch.float32, 3)
+    _check_tensor('tri', tri, torch.int32, 2)
+    _check_tensor('uv', uv, torch.float32, 2)
+    _check_tensor('uv_tri', uv_tri, torch.int32, 2)
+    _check_tensor('tex', tex, torch.float32, 3)
+    if uv.shape[1] != 2 or uv_tri.shape != tri.shape or pos.shape[2] != 4 or tri.shape[1] != 3:
+        raise ValueError("shapes: pos [B,V,4], tri [T,3], uv [Vt,2], uv_tri [T,3], tex [Ht,Wt,C]")
+    if boundary_mode not in _lib.BOUNDARY:
+        raise ValueError(f"unknown boundary_mode '{boundary_mode}'")
+    H, W = int(resolution[0]), int(resolution[1])
+    return _render_textured_func.apply(pos.contiguous(), tri.contiguous(), uv.contiguous(), uv_tri.contiguous(),
+                                       tex.contiguous(), H, W, _lib.BOUNDARY[boundary_mode])
 
 
 # ----------------------------------------------------------------------------------------------

@@ -68,6 +68,44 @@ typedef struct {
 int fpcdr_rasterize_bwd(const fpcdr_rasterize_bwd_params *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* render -- rasterize + interpolate(uv) + texture('linear') fused   reference fit.py:151,157,158 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* The non-mip branch of the reference's render() up to the antialias call, in one pass: the wave that resolves
+ * a pixel also interpolates its texture coordinate and taps the texture, so texc never exists in HBM
+ * (20 B/px written instead of 52 read+written).  Results are identical to the three separate calls.
+ * scratch: fpcdr_rasterize_scratch_bytes(B, T).                                                    */
+typedef struct {
+    const float *pos;       /* [B,V,4] */
+    const int32_t *tri;     /* [T,3] */
+    int32_t B, V, T, H, W;
+    void *scratch;
+    const float *uv;        /* [Vt,2] texture coordinates (one set, broadcast over B: reference uv[None]) */
+    const int32_t *uv_tri;  /* [T,3] */
+    int32_t Vt;
+    const float *tex;       /* [Ht,Wt,C] (one texture, broadcast over B: reference tex[None]) */
+    int32_t Ht, Wt, C, boundary_mode;
+    float *rast;            /* out [B,H,W,4] */
+    float *color;           /* out [B,H,W,C] */
+} fpcdr_render_fwd_params;
+int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream);
+
+/* Backward of the above: dy = dL/d color; reads dy and rast, writes nothing dense. */
+typedef struct {
+    const float *pos;
+    const int32_t *tri;
+    const float *uv;
+    const int32_t *uv_tri;
+    const float *tex;
+    const float *rast;      /* forward output */
+    const float *dy;        /* [B,H,W,C] */
+    int32_t B, V, T, H, W, Vt, Ht, Wt, C, boundary_mode;
+    float *grad_pos;        /* [B,V,4] accumulated, or NULL */
+    float *grad_tex;        /* [Ht,Wt,C] accumulated, or NULL */
+} fpcdr_render_bwd_params;
+int fpcdr_render_bwd(const fpcdr_render_bwd_params *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* interpolate -- dr.interpolate(attr, rast, tri[, rast_db, diff_attrs])  reference fit.py:154,157 */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -110,3 +110,53 @@ def test_fit_reduces_loss(fused):
     assert losses[-1] < 0.5 * losses[0], losses
     # the active blendshapes' weights move towards the hidden ground truth
     assert np.abs(ft.weights().cpu().numpy() - sc.weights_gt)[act].mean() < w0
+
+
+@pytest.mark.parametrize("C,boundary", [(1, 'wrap'), (3, 'clamp')])
+def test_fused_render_equals_separate_ops(C, boundary):
+    """ops.render_textured == rasterize -> interpolate -> texture('linear'): bitwise forward, gradients to tolerance."""
+    import fpc_diffrend_amd.ops as dr
+    from fpc_diffrend_amd import scene
+    from helpers import clip_positions
+    sc = scene.cfg('cfg1', n_frames=2)
+    pos, _ = clip_positions(sc, [0, 3, 7], frames=[0, 1])
+    dev = 'cuda'
+    tri = torch.tensor(sc.pos_idx, device=dev)
+    uv = torch.tensor(sc.uv, device=dev) * 1.3 - 0.1          # exercise the boundary mode
+    uv_idx = torch.tensor(sc.uv_idx, device=dev)
+    g = torch.Generator().manual_seed(0)
+    tex0 = torch.rand(64, 48, C, generator=g)
+    gy = torch.randn(pos.shape[0], sc.resolution[0], sc.resolution[1], C, generator=g).to(dev)
+    ctx = dr.RasterizeGLContext(device=dev)
+
+    p1 = pos.to(dev).requires_grad_(True)
+    t1 = tex0.to(dev).requires_grad_(True)
+    rast, _ = dr.rasterize(ctx, p1, tri, sc.resolution)
+    texc, _ = dr.interpolate(uv[None], rast, uv_idx)
+    col = dr.texture(t1[None], texc, filter_mode='linear', boundary_mode=boundary)
+    (col * gy).sum().backward()
+
+    p2 = pos.to(dev).requires_grad_(True)
+    t2 = tex0.to(dev).requires_grad_(True)
+    col2, rast2 = dr.render_textured(ctx, p2, tri, uv, uv_idx, t2, sc.resolution, boundary_mode=boundary)
+    (col2 * gy).sum().backward()
+    assert torch.equal(rast2, rast)
+    assert torch.equal(col2, col)
+    # (the corner texel collects the random gradients of every empty pixel: float32 atomic order noise ~1e-4)
+    assert rel_l2(t2.grad, t1.grad) < 1e-3
+    assert rel_l2(p2.grad, p1.grad) < 1e-4
+
+
+def test_fitter_fused_and_unfused_paths_agree():
+    from fpc_diffrend_amd import fit, scene
+    sc = scene.cfg('cfg1', n_frames=2)
+    grads = []
+    for fused in (True, False):
+        cfg = fit.FitConfig(max_iter=10, cam_idxs=(0, 5), fused_render=fused, weight_laplacian=10.0)
+        ft = fit.Fitter(sc, cfg, device='cuda')
+        ft.init_near_truth(0.7)
+        loss = ft.loss_and_backward(torch.arange(0, 2, device='cuda'))
+        grads.append((float(loss), ft.maps_intermediate['local'].grad.clone(), ft.tex_opt.grad.clone(), ft.per_frame_t.grad.clone()))
+    assert abs(grads[0][0] - grads[1][0]) < 1e-5 * abs(grads[1][0])
+    for a, b in zip(grads[0][1:], grads[1][1:]):
+        assert rel_l2(a, b) < 1e-4
