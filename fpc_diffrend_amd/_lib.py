@@ -43,6 +43,18 @@ class RenderBwd(ctypes.Structure):
                 ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p)]
 
 
+class AaLossFwd(ctypes.Structure):
+    _fields_ = [("color", _p), ("rast", _p), ("pos", _p), ("tri", _p), ("adj", _p), ("ref", _p), ("B", _i), ("H", _i),
+                ("W", _i), ("C", _i), ("V", _i), ("T", _i), ("bg", ctypes.c_float), ("color_scale", ctypes.c_float),
+                ("grad_scale", ctypes.c_float), ("sil", _p), ("flags", _p), ("grad_aa", _p), ("loss_sum", _p)]
+
+
+class RenderAaBwd(ctypes.Structure):
+    _fields_ = [("pos", _p), ("tri", _p), ("uv", _p), ("uv_tri", _p), ("tex", _p), ("rast", _p), ("color", _p),
+                ("grad_aa", _p), ("sil", _p), ("flags", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i),
+                ("Vt", _i), ("Ht", _i), ("Wt", _i), ("C", _i), ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p)]
+
+
 class InterpolateFwd(ctypes.Structure):
     _fields_ = [("attr", _p), ("rast", _p), ("tri", _p), ("rast_db", _p), ("B", _i), ("H", _i), ("W", _i), ("Ba", _i),
                 ("Vt", _i), ("A", _i), ("T", _i), ("n_diff", _i), ("diff_idx", _i * MAX_ATTR), ("out", _p),
@@ -96,6 +108,8 @@ SYMBOLS = {
     "fpcdr_rasterize_bwd": (_int, [ctypes.POINTER(RasterizeBwd), _p]),
     "fpcdr_render_fwd": (_int, [ctypes.POINTER(RenderFwd), _p]),
     "fpcdr_render_bwd": (_int, [ctypes.POINTER(RenderBwd), _p]),
+    "fpcdr_aa_loss_fwd": (_int, [ctypes.POINTER(AaLossFwd), _p]),
+    "fpcdr_render_aa_bwd": (_int, [ctypes.POINTER(RenderAaBwd), _p]),
     "fpcdr_interpolate_fwd": (_int, [ctypes.POINTER(InterpolateFwd), _p]),
     "fpcdr_interpolate_bwd": (_int, [ctypes.POINTER(InterpolateBwd), _p]),
     "fpcdr_mip_downsample": (_int, [_p, _p, _i, _i, _i, _i, _p]),

@@ -1,0 +1,333 @@
+// Fused pixel objective of the fit loop for gfx950 (MI355X): everything between the clip-space positions and
+// the scalar pixel loss of reference src/torch/fit.py:151-161 + :579, as three kernels instead of nine:
+//
+//   fpcdr_render_fwd (rasterize.hip)  rasterize + interpolate + texture      -> rast, colour        20 B/px
+//   fpcdr_aa_loss_fwd (this file)     antialias + background + pixel loss    -> d loss / d aa, flags 25 B/px
+//   fpcdr_render_aa_bwd (this file)   antialias bwd + texture bwd + interpolate bwd + rasterize bwd  20 B/px
+//
+// versus 217 B/px for the separate operators (C = 1).  The antialiased colour, the texture-coordinate image and
+// every intermediate gradient image never reach HBM.  Values equal the separate operators' (same device
+// functions); the separate operators remain the nvdiffrast-compatible API and the parity reference.
+#include "common.h"
+
+namespace {
+
+#include "texsample.h"
+#include "raster_math.h"
+#include "aa_pairs.h"
+
+// ------------------------------------------------------------------------------------------------
+// antialias forward (gather form, see antialias.hip) + background composite + squared error, one pixel per lane.
+// Writes d(sum of squares * grad_scale)/d(antialiased colour) and the two flag bit planes; reduces the loss.
+template <int CS>
+__global__ void __launch_bounds__(256) k_aa_loss(const float *__restrict__ color, const float4 *__restrict__ rast,
+                                                 const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                 const uint8_t *__restrict__ sil, const uint8_t *__restrict__ ref, int B, int H,
+                                                 int W, int V, int T, float bg, float color_scale, float grad_scale,
+                                                 unsigned long long *__restrict__ flags, float *__restrict__ g_aa,
+                                                 double *__restrict__ loss_sum) {
+    __shared__ float s_part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wave, b = blockIdx.z;
+    const int Wq = FPCDR_AA_ROW_WORDS(W);
+    bool fx_flag = false, fy_flag = false;
+    float lsum = 0.0f;
+    if (y < H) {
+        if (x < W) {
+            const size_t img = (size_t)b * H * W;
+            const size_t off = img + (size_t)y * W + x;
+            const float2 me = load_zid(rast, off);
+            const int id = (int)me.y;
+            const bool hasR = x + 1 < W, hasL = x > 0, hasU = y + 1 < H, hasD = y > 0;
+            const float2 nR = hasR ? load_zid(rast, off + 1) : me;
+            const float2 nL = hasL ? load_zid(rast, off - 1) : me;
+            const float2 nU = hasU ? load_zid(rast, off + W) : me;
+            const float2 nD = hasD ? load_zid(rast, off - W) : me;
+            float acc[CS];
+            const float *cme = color + off * CS;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) acc[c] = cme[c];
+            const bool disc = ((int)nR.y != id) | ((int)nL.y != id) | ((int)nU.y != id) | ((int)nD.y != id);
+            if (disc) {
+                AAGeom g = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
+                auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own, bool &flag) {
+                    if ((int)p0.y == (int)p1.y) return;
+                    bool hit = for_active_edges(g, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
+                        [&](float t, int Px, int Py, int Qx, int Qy, int, int, const EdgeEval &, float) {
+                            const bool far = t >= 0.5f;
+                            const int rx = far ? Qx : Px, ry = far ? Qy : Py;
+                            if (rx != x || ry != y) return;
+                            const int ox = far ? Px : Qx, oy = far ? Py : Qy;
+                            const float amt = far ? t - 0.5f : 0.5f - t;
+                            const float *co = color + (img + (size_t)oy * W + ox) * CS;
+#pragma unroll
+                            for (int c = 0; c < CS; ++c) acc[c] += amt * (co[c] - cme[c]);
+                        });
+                    if (own && hit) flag = true;
+                };
+                bool dummy = false;
+                if (hasR) visit(x, y, 0, me, nR, true, fx_flag);
+                if (hasU) visit(x, y, 1, me, nU, true, fy_flag);
+                if (hasL) visit(x - 1, y, 0, nL, me, false, dummy);
+                if (hasD) visit(x, y - 1, 1, nD, me, false, dummy);
+            }
+            // background (fit.py:161) + squared error (fit.py:579) and its gradient
+            const bool covered = id > 0;
+            const float r = (float)ref[off];
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                const float col = covered ? acc[c] : bg;
+                const float d = r - col * color_scale;
+                lsum += d * d;
+                g_aa[off * CS + c] = covered ? (-2.0f * color_scale * grad_scale) * d : 0.0f;
+            }
+        }
+        const unsigned long long bx = __ballot(fx_flag), by = __ballot(fy_flag);
+        if (lane == 0) {
+            const size_t plane = (size_t)B * H * Wq;
+            const size_t wi = ((size_t)b * H + y) * Wq + blockIdx.x;
+            flags[wi] = bx;
+            flags[plane + wi] = by;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
+    if (lane == 0) s_part[wave] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (double)s_part[0] + (double)s_part[1] + (double)s_part[2] + (double)s_part[3];
+        if (tot != 0.0) atomicAdd(loss_sum, tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the whole pixel objective for one pixel per lane (8x8 tile per wave):
+//   g_c = g_aa + antialias corrections (gather form, only where a flag bit says a pair was blended)
+//   texture bwd: scatter into grad_tex;  interpolate bwd;  rasterize bwd: scatter into grad_pos
+//   + the antialias op's own d alpha / d pos for the pairs this pixel owns.
+template <int CS>
+__global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                       const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
+                                                       const float *__restrict__ tex, const float4 *__restrict__ rast,
+                                                       const float *__restrict__ color, const float *__restrict__ g_aa,
+                                                       const uint8_t *__restrict__ sil,
+                                                       const unsigned long long *__restrict__ flags, int B, int V, int T, int H,
+                                                       int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
+                                                       float *__restrict__ grad_tex) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int b = blockIdx.z;
+    int key0 = -1, key1 = -1, key2 = -1;
+    float g0[3] = {0, 0, 0}, g1[3] = {0, 0, 0}, g2[3] = {0, 0, 0};
+    float *gp = grad_pos + (size_t)b * V * 4;
+    if (x < W && y < H) {
+        const int Wq = FPCDR_AA_ROW_WORDS(W);
+        const size_t plane = (size_t)B * H * Wq;
+        const size_t wi = ((size_t)b * H + y) * Wq + (x >> 6);
+        const int bit = x & 63;
+        const unsigned long long fxw = flags[wi], fyw = flags[plane + wi];
+        const bool own_x = (fxw >> bit) & 1ull, own_y = (fyw >> bit) & 1ull;
+        const bool left_x = bit > 0 ? ((fxw >> (bit - 1)) & 1ull) : (x > 0 ? ((flags[wi - 1] >> 63) & 1ull) : false);
+        const bool down_y = y > 0 ? ((flags[plane + wi - Wq] >> bit) & 1ull) : false;
+        const size_t img = (size_t)b * H * W;
+        const size_t off = img + (size_t)y * W + x;
+        float go[CS];
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < CS; ++c) { go[c] = g_aa[off * CS + c]; any |= (go[c] != 0.0f); }
+        if (own_x | own_y | left_x | down_y) {
+            // antialias backward for this pixel (see k_aa_bwd_fix in antialias.hip)
+            AAGeom geo = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
+            const float2 me = load_zid(rast, off);
+            auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own) {
+                for_active_edges(geo, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
+                    [&](float t, int Px, int Py, int Qx, int Qy, int va, int vb, const EdgeEval &ev, float s) {
+                        const bool far = t >= 0.5f;
+                        const int rx = far ? Qx : Px, ry = far ? Qy : Py;
+                        const float amt = far ? t - 0.5f : 0.5f - t;
+                        const float *gr = g_aa + (img + (size_t)ry * W + rx) * CS;
+                        if (rx == x && ry == y) {
+#pragma unroll
+                            for (int c = 0; c < CS; ++c) go[c] -= amt * gr[c];
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < CS; ++c) go[c] += amt * gr[c];
+                        }
+                        if (!own) return;
+                        const float *cP = color + (img + (size_t)Py * W + Px) * CS;
+                        const float *cQ = color + (img + (size_t)Qy * W + Qx) * CS;
+                        float G = 0.f;
+#pragma unroll
+                        for (int c = 0; c < CS; ++c) G += gr[c] * (cP[c] - cQ[c]);
+                        if (G == 0.0f) return;
+                        const float Ld = d == 0 ? ev.Lx : ev.Ly;
+                        const float gLz = -G / (s * Ld);
+                        const float gLd = -G * t / Ld;
+                        const float gLx = d == 0 ? gLd : 0.0f, gLy = d == 0 ? 0.0f : gLd;
+                        float g_qax = 0.f, g_qay = 0.f, g_wa = 0.f, g_qbx = 0.f, g_qby = 0.f, g_wb = 0.f;
+                        g_qay += gLx * ev.wb; g_wb += gLx * ev.qay; g_wa -= gLx * ev.qby; g_qby -= gLx * ev.wa;
+                        g_wa += gLy * ev.qbx; g_qbx += gLy * ev.wa; g_qax -= gLy * ev.wb; g_wb -= gLy * ev.qax;
+                        g_qax += gLz * ev.qby; g_qby += gLz * ev.qax; g_qay -= gLz * ev.qbx; g_qbx -= gLz * ev.qay;
+                        const float fxp = (float)Px + 0.5f - geo.hw, fyp = (float)Py + 0.5f - geo.hh;
+                        atomicAdd(gp + 4 * (size_t)va + 0, g_qax * geo.hw);
+                        atomicAdd(gp + 4 * (size_t)va + 1, g_qay * geo.hh);
+                        atomicAdd(gp + 4 * (size_t)va + 3, g_wa - fxp * g_qax - fyp * g_qay);
+                        atomicAdd(gp + 4 * (size_t)vb + 0, g_qbx * geo.hw);
+                        atomicAdd(gp + 4 * (size_t)vb + 1, g_qby * geo.hh);
+                        atomicAdd(gp + 4 * (size_t)vb + 3, g_wb - fxp * g_qbx - fyp * g_qby);
+                    });
+            };
+            if (own_x) visit(x, y, 0, me, load_zid(rast, off + 1), true);
+            if (own_y) visit(x, y, 1, me, load_zid(rast, off + W), true);
+            if (left_x) visit(x - 1, y, 0, load_zid(rast, off - 1), me, false);
+            if (down_y) visit(x, y - 1, 1, load_zid(rast, off - W), me, false);
+            any = false;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) any |= (go[c] != 0.0f);
+        }
+        if (any) {
+            const float4 r = rast[off];
+            int t = (int)r.w - 1;
+            if (t >= T) t = -1;
+            float2 q0 = make_float2(0.f, 0.f), q1 = q0, q2 = q0;
+            float tu = 0.0f, tv = 0.0f;
+            if (t >= 0) {
+                q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]];
+                const float w = 1.0f - r.x - r.y;
+                tu = r.x * q0.x + r.y * q1.x + w * q2.x;
+                tv = r.x * q0.y + r.y * q1.y + w * q2.y;
+            }
+            const Taps tp = make_taps(tu, tv, Ht, Wt, CS, boundary);
+            const float w00 = (1.0f - tp.fx) * (1.0f - tp.fy), w10 = tp.fx * (1.0f - tp.fy);
+            const float w01 = (1.0f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
+            float gfx = 0.f, gfy = 0.f;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                const float gc = go[c];
+                float t00, t10, t01, t11;
+                load_taps(tex, tp, c, CS, t00, t10, t01, t11);
+                gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
+                gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
+                if (grad_tex && gc != 0.0f) {
+                    atomicAdd(grad_tex + tp.i00 + c, gc * w00);
+                    atomicAdd(grad_tex + tp.i10 + c, gc * w10);
+                    atomicAdd(grad_tex + tp.i01 + c, gc * w01);
+                    atomicAdd(grad_tex + tp.i11 + c, gc * w11);
+                }
+            }
+            if (t >= 0) {
+                const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
+                const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv >= 0.0f && tv <= 1.0f)) ? 0.0f : 1.0f;
+                const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
+                const float gu = gtu * (q0.x - q2.x) + gtv * (q0.y - q2.y);
+                const float gv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
+                if (gu != 0.0f || gv != 0.0f) {
+                    const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+                    const float4 *p = pos + (size_t)b * V;
+                    const float fx = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
+                    const float fy = (2.0f * (float)y + 1.0f) / (float)H - 1.0f;
+                    shade_pixel_bwd<false>(p[i0], p[i1], p[i2], fx, fy, 2.0f / (float)W, 2.0f / (float)H,
+                                           make_float4(gu, gv, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), g0, g1, g2);
+                    key0 = i0; key1 = i1; key2 = i2;
+                }
+            }
+        }
+    }
+    if (__ballot(key0 >= 0) == 0ull) return;
+    {
+        float *const d[3] = {gp + 4 * (size_t)max(key0, 0), gp + 4 * (size_t)max(key0, 0) + 1, gp + 4 * (size_t)max(key0, 0) + 3};
+        wave_group_atomic_add<3>(key0, d, g0);
+    }
+    {
+        float *const d[3] = {gp + 4 * (size_t)max(key1, 0), gp + 4 * (size_t)max(key1, 0) + 1, gp + 4 * (size_t)max(key1, 0) + 3};
+        wave_group_atomic_add<3>(key1, d, g1);
+    }
+    {
+        float *const d[3] = {gp + 4 * (size_t)max(key2, 0), gp + 4 * (size_t)max(key2, 0) + 1, gp + 4 * (size_t)max(key2, 0) + 3};
+        wave_group_atomic_add<3>(key2, d, g2);
+    }
+}
+
+// per-image silhouette classification (same arithmetic as k_sil in antialias.hip)
+__global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                              const int32_t *__restrict__ adj, int B, int V, int T, float hw, float hh,
+                                              uint8_t *__restrict__ sil) {
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * T) return;
+    const int b = (int)(gid / T), t = (int)(gid - (long long)b * T);
+    const float4 *p = pos + (size_t)b * V;
+    int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    unsigned int bits = 0;
+    bool ok = true;
+    for (int k = 0; k < 3; ++k) ok &= (vi[k] >= 0 && vi[k] < V);
+    if (ok) {
+        float qx[3], qy[3], qw[3];
+        for (int k = 0; k < 3; ++k) {
+            const float4 c = p[vi[k]];
+            qx[k] = c.x * hw; qy[k] = c.y * hh; qw[k] = c.w;
+        }
+        for (int e = 0; e < 3; ++e) {
+            const int ad = adj[3 * t + e];
+            if (ad == -1) { bits |= 1u << e; continue; }
+            if (ad < 0 || ad >= V) continue;
+            const int a = (e + 1) % 3, bb = (e + 2) % 3;
+            const float Lx = qy[a] * qw[bb] - qw[a] * qy[bb];
+            const float Ly = qw[a] * qx[bb] - qx[a] * qw[bb];
+            const float Lz = qx[a] * qy[bb] - qy[a] * qx[bb];
+            const float so = Lx * qx[e] + Ly * qy[e] + Lz * qw[e];
+            const float4 c = p[ad];
+            const float sp = Lx * (c.x * hw) + Ly * (c.y * hh) + Lz * c.w;
+            if ((so > 0.0f && sp > 0.0f) || (so < 0.0f && sp < 0.0f)) bits |= 1u << e;
+        }
+    }
+    sil[gid] = (uint8_t)bits;
+}
+
+}  // namespace
+
+extern "C" int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->color && p->rast && p->pos && p->tri && p->adj && p->ref && p->sil && p->flags && p->grad_aa && p->loss_sum,
+                  "null pointer");
+    FPCDR_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->C > 0 && p->V > 0 && p->T > 0, "sizes must be positive");
+    FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
+    FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 4) <= 65535, "image batch / height too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv((long long)p->B * p->T, 256)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                       p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil);
+    dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 4), p->B);
+#define LAUNCH(CS)                                                                                                         \
+    hipLaunchKernelGGL(k_aa_loss<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos,  \
+                       p->tri, p->sil, p->ref, p->B, p->H, p->W, p->V, p->T, p->bg, p->color_scale, p->grad_scale,         \
+                       (unsigned long long *)p->flags, p->grad_aa, p->loss_sum)
+    if (p->C == 1) LAUNCH(1);
+    else if (p->C == 3) LAUNCH(3);
+    else LAUNCH(4);
+#undef LAUNCH
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->pos && p->tri && p->uv && p->uv_tri && p->tex && p->rast && p->color && p->grad_aa && p->sil && p->flags &&
+                      p->grad_pos,
+                  "null pointer");
+    FPCDR_REQUIRE(p->B > 0 && p->V > 0 && p->T > 0 && p->H > 0 && p->W > 0 && p->Ht > 0 && p->Wt > 0 && p->C > 0,
+                  "sizes must be positive");
+    FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
+    FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
+    dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
+#define LAUNCH(CS)                                                                                                          \
+    hipLaunchKernelGGL(k_render_aa_bwd<CS>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)p->pos, p->tri,        \
+                       (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa, p->sil,     \
+                       (const unsigned long long *)p->flags, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt, p->boundary_mode,   \
+                       p->grad_pos, p->grad_tex)
+    if (p->C == 1) LAUNCH(1);
+    else if (p->C == 3) LAUNCH(3);
+    else LAUNCH(4);
+#undef LAUNCH
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}

@@ -27,6 +27,7 @@
 namespace {
 
 #include "texsample.h"
+#include "raster_math.h"
 
 constexpr int SUBPIX = 256;
 constexpr int HALFPIX = 128;
@@ -167,38 +168,6 @@ __global__ void k_init_ibox(ImgBox *ibox, int B) {
     if (i < B) ibox[i] = {0x7fffffff, 0x7fffffff, -1, -1};
 }
 
-// ---------------------------------------------------------------------------------------------
-// f32 shading of one pixel: perspective-correct barycentrics of vertices 0,1, z/w and (optionally)
-// the screen-space derivatives.  fx,fy = pixel centre in NDC.
-struct Shade { float u, v, zw, dudx, dudy, dvdx, dvdy; };
-
-__device__ __forceinline__ Shade shade_pixel(float4 v0, float4 v1, float4 v2, float fx, float fy, float sx, float sy) {
-    float p0x = v0.x - fx * v0.w, p0y = v0.y - fy * v0.w;
-    float p1x = v1.x - fx * v1.w, p1y = v1.y - fy * v1.w;
-    float p2x = v2.x - fx * v2.w, p2y = v2.y - fy * v2.w;
-    float a0 = p1x * p2y - p1y * p2x;
-    float a1 = p2x * p0y - p2y * p0x;
-    float a2 = p0x * p1y - p0y * p1x;
-    float at = a0 + a1 + a2;
-    float iw = 1.0f / at;
-    float b0 = a0 * iw, b1 = a1 * iw;
-    Shade s;
-    float zw = (a0 * v0.z + a1 * v1.z + a2 * v2.z) / (a0 * v0.w + a1 * v1.w + a2 * v2.w);
-    s.zw = fminf(fmaxf(zw, -1.0f), 1.0f);
-    float da0x = v2.w * p1y - v1.w * p2y, da0y = v1.w * p2x - v2.w * p1x;
-    float da1x = v0.w * p2y - v2.w * p0y, da1y = v2.w * p0x - v0.w * p2x;
-    float da2x = v1.w * p0y - v0.w * p1y, da2y = v0.w * p1x - v1.w * p0x;
-    float datx = da0x + da1x + da2x, daty = da0y + da1y + da2y;
-    s.dudx = (da0x - b0 * datx) * iw * sx;
-    s.dudy = (da0y - b0 * daty) * iw * sy;
-    s.dvdx = (da1x - b1 * datx) * iw * sx;
-    s.dvdy = (da1y - b1 * daty) * iw * sy;
-    float uc = fminf(fmaxf(b0, 0.0f), 1.0f), vc = fminf(fmaxf(b1, 0.0f), 1.0f);
-    float sc = 1.0f / fmaxf(uc + vc, 1.0f);
-    s.u = uc * sc;
-    s.v = vc * sc;
-    return s;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Fine raster of one 16x16 tile against the triangles of the current batch whose bit is set in `mrow`.  Each lane
@@ -472,82 +441,6 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
             }
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Backward of shade_pixel for one pixel: chains (dL/du, dL/dv) = (g.x, g.y) and, with HAS_DDB, dL/d(rast_db) = gd
-// to the (x, y, w) of the three clip-space vertices.
-template <bool HAS_DDB>
-__device__ __forceinline__ void shade_pixel_bwd(float4 v0, float4 v1, float4 v2, float fx, float fy, float sx, float sy, float4 g,
-                                                float4 gd, float (&g0)[3], float (&g1)[3], float (&g2)[3]) {
-    // ---- forward recompute ----
-    const float w0 = v0.w, w1 = v1.w, w2 = v2.w;
-    const float p0x = v0.x - fx * w0, p0y = v0.y - fy * w0;
-    const float p1x = v1.x - fx * w1, p1y = v1.y - fy * w1;
-    const float p2x = v2.x - fx * w2, p2y = v2.y - fy * w2;
-    const float a0 = p1x * p2y - p1y * p2x;
-    const float a1 = p2x * p0y - p2y * p0x;
-    const float a2 = p0x * p1y - p0y * p1x;
-    const float at = a0 + a1 + a2;
-    const float iw = 1.0f / at;
-    const float b0 = a0 * iw, b1 = a1 * iw;
-    // ---- undo clamp / renormalise:  u = uc * s, v = vc * s, s = 1 / max(uc + vc, 1) ----
-    const float uc = fminf(fmaxf(b0, 0.0f), 1.0f), vc = fminf(fmaxf(b1, 0.0f), 1.0f);
-    float guc = g.x, gvc = g.y;
-    const float sum = uc + vc;
-    if (sum > 1.0f) {
-        const float s = 1.0f / sum;
-        const float dot = (uc * g.x + vc * g.y) * s * s;
-        guc = g.x * s - dot;
-        gvc = g.y * s - dot;
-    }
-    float gb0 = (b0 >= 0.0f && b0 <= 1.0f) ? guc : 0.0f;
-    float gb1 = (b1 >= 0.0f && b1 <= 1.0f) ? gvc : 0.0f;
-    // ---- reverse through the derivative outputs ----
-    float ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, giw = 0.f;
-    float gp0x = 0.f, gp0y = 0.f, gp1x = 0.f, gp1y = 0.f, gp2x = 0.f, gp2y = 0.f;
-    float gw0 = 0.f, gw1 = 0.f, gw2 = 0.f;
-    if (HAS_DDB) {
-        const float da0x = w2 * p1y - w1 * p2y, da0y = w1 * p2x - w2 * p1x;
-        const float da1x = w0 * p2y - w2 * p0y, da1y = w2 * p0x - w0 * p2x;
-        const float da2x = w1 * p0y - w0 * p1y, da2y = w0 * p1x - w1 * p0x;
-        const float datx = da0x + da1x + da2x, daty = da0y + da1y + da2y;
-        const float hx0 = gd.x * sx, hy0 = gd.y * sy, hx1 = gd.z * sx, hy1 = gd.w * sy;
-        // dudx = n0x * iw * sx,  n0x = da0x - b0 * datx   (same for the other three)
-        const float n0x = da0x - b0 * datx, n0y = da0y - b0 * daty;
-        const float n1x = da1x - b1 * datx, n1y = da1y - b1 * daty;
-        giw += hx0 * n0x + hy0 * n0y + hx1 * n1x + hy1 * n1y;
-        const float gn0x = hx0 * iw, gn0y = hy0 * iw, gn1x = hx1 * iw, gn1y = hy1 * iw;
-        gb0 -= gn0x * datx + gn0y * daty;
-        gb1 -= gn1x * datx + gn1y * daty;
-        const float gdatx = -(gn0x * b0 + gn1x * b1), gdaty = -(gn0y * b0 + gn1y * b1);
-        const float gda0x = gn0x + gdatx, gda0y = gn0y + gdaty;
-        const float gda1x = gn1x + gdatx, gda1y = gn1y + gdaty;
-        const float gda2x = gdatx, gda2y = gdaty;
-        // da0x = w2*p1y - w1*p2y ; da0y = w1*p2x - w2*p1x
-        gw2 += gda0x * p1y; gp1y += gda0x * w2; gw1 -= gda0x * p2y; gp2y -= gda0x * w1;
-        gw1 += gda0y * p2x; gp2x += gda0y * w1; gw2 -= gda0y * p1x; gp1x -= gda0y * w2;
-        // da1x = w0*p2y - w2*p0y ; da1y = w2*p0x - w0*p2x
-        gw0 += gda1x * p2y; gp2y += gda1x * w0; gw2 -= gda1x * p0y; gp0y -= gda1x * w2;
-        gw2 += gda1y * p0x; gp0x += gda1y * w2; gw0 -= gda1y * p2x; gp2x -= gda1y * w0;
-        // da2x = w1*p0y - w0*p1y ; da2y = w0*p1x - w1*p0x
-        gw1 += gda2x * p0y; gp0y += gda2x * w1; gw0 -= gda2x * p1y; gp1y -= gda2x * w0;
-        gw0 += gda2y * p1x; gp1x += gda2y * w0; gw1 -= gda2y * p0x; gp0x -= gda2y * w1;
-    }
-    // b0 = a0 * iw ; b1 = a1 * iw
-    ga0 += gb0 * iw; ga1 += gb1 * iw;
-    giw += gb0 * a0 + gb1 * a1;
-    // iw = 1 / at ; at = a0 + a1 + a2
-    const float gat = -giw * iw * iw;
-    ga0 += gat; ga1 += gat; ga2 += gat;
-    // a0 = p1x*p2y - p1y*p2x ; a1 = p2x*p0y - p2y*p0x ; a2 = p0x*p1y - p0y*p1x
-    gp1x += ga0 * p2y; gp2y += ga0 * p1x; gp1y -= ga0 * p2x; gp2x -= ga0 * p1y;
-    gp2x += ga1 * p0y; gp0y += ga1 * p2x; gp2y -= ga1 * p0x; gp0x -= ga1 * p2y;
-    gp0x += ga2 * p1y; gp1y += ga2 * p0x; gp0y -= ga2 * p1x; gp1x -= ga2 * p0y;
-    // p_kx = x_k - fx * w_k ; p_ky = y_k - fy * w_k
-    g0[0] = gp0x; g0[1] = gp0y; g0[2] = gw0 - fx * gp0x - fy * gp0y;
-    g1[0] = gp1x; g1[1] = gp1y; g1[2] = gw1 - fx * gp1x - fy * gp1y;
-    g2[0] = gp2x; g2[1] = gp2y; g2[2] = gw2 - fx * gp2x - fy * gp2y;
 }
 
 // ---------------------------------------------------------------------------------------------

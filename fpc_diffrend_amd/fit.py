@@ -235,6 +235,7 @@ class FitConfig:
     init_texture: str = "truth"     # 'truth' | 'random' (reference: np.random.uniform when no texpath, fit.py:438)
     fused_loss: bool = True         # False = reference-style torch.where + torch.mean chain
     fused_render: bool = True       # rasterize + interpolate + texture as one kernel pair (non-mip); False = four separate ops
+    fused_objective: bool = True    # with fused_render and fused_loss: the whole pixel term as three kernels (ops.pixel_objective)
 
 
 def setup_dataset(blendshapes, n_frames, device):
@@ -334,6 +335,10 @@ class Fitter:
         self.targets = targets if targets is not None else self.render_targets()
 
     # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _n(frame_ids):
+        return frame_ids.stop - frame_ids.start if isinstance(frame_ids, slice) else len(frame_ids)
+
     def mvp(self, frame_ids):
         """mvp[f,c] = P_c . Rt(q_f,t_f) . Rt(q_c,t_c) . MV_c . T(0,170,0)   (fit.py:541-553), [Fb*Nc,4,4]."""
         rigid_cam = camera.rigid_grad(self.t_opt[self.cam_sel], camera.unitquat_to_rotmat(self.q_opt[self.cam_sel]))
@@ -343,15 +348,18 @@ class Fitter:
         return torch.matmul(self.proj[None], tr_pose).reshape(-1, 4, 4)
 
     def vertices(self, frame_ids, iteration=None):
-        """Blended vertex buffers [Fb,3V] for a batch of frames (fit.py:555-562)."""
-        onehot = torch.zeros(self.n_frames, len(frame_ids), dtype=torch.float32, device=self.device)
-        onehot[frame_ids, torch.arange(len(frame_ids), device=self.device)] = 1.0
-        if self.cfg.mode == 'prior':
-            return blend(self.v_base, self.maps, self.maps_intermediate, self.datasets, onehot)
+        """Blended vertex buffers [Fb,3V] for a batch of frames (fit.py:555-562).  The reference multiplies by a
+        one-hot frame vector (fit.py:536, 115-116); M e_f is column f of M, so the batch selects columns
+        (a slice -- no copy -- when the frames are a contiguous range)."""
+        if self.cfg.mode in ('prior', 'combined'):
+            mapped = torch.matmul(self.maps_intermediate['local'], self.maps['local'][:, frame_ids])     # [K,Fb]
+            out = blend_batched(self.v_base, self.datasets['local'], mapped.t())
+            if self.cfg.mode == 'prior':
+                return out
+        basis = torch.matmul(self.m2, self.m1[:, frame_ids])                                             # [F,Fb]
         if self.cfg.mode == 'free':
-            return blend_free(self.v_base, self.m1, self.m2, self.m3, onehot)
-        return blend_combined(self.v_base, self.m1, self.m2, self.m3, self.maps, self.maps_intermediate, self.datasets,
-                              onehot, learned_coefficient=0.5)
+            return blend_batched(self.v_base, self.m3, basis.t())
+        return out + 0.5 * blend_batched(None, self.m3, basis.t())    # learned_coefficient=0.5, fit.py:562
 
     @torch.no_grad()
     def render_targets(self, chunk=4):
@@ -381,7 +389,7 @@ class Fitter:
         n_local = self.frame_hi - self.frame_lo
         k = self.cfg.frames_per_step or n_local
         if k >= n_local:
-            return torch.arange(self.frame_lo, self.frame_hi, device=self.device)
+            return slice(self.frame_lo, self.frame_hi)     # the whole shard: views, no gathers
         sel = np.sort(self.rng.choice(n_local, size=k, replace=False)) + self.frame_lo
         return torch.tensor(sel, dtype=torch.long, device=self.device)
 
@@ -392,14 +400,21 @@ class Fitter:
         if cfg.mode == 'combined' and i > cfg.max_iter / 2:   # fit.py:603-608
             for m in (self.m1, self.m2, self.m3):
                 m.requires_grad = True
-        Fb, Nc = len(frame_ids), len(self.cam_idxs)
+        Fb, Nc = self._n(frame_ids), len(self.cam_idxs)
         vtx_pos = self.vertices(frame_ids)                            # [Fb,3V]
         vtx_pos_split = vtx_pos.reshape(Fb, -1, 3)
         mvp = self.mvp(frame_ids)
-        colour, rast_out = render_layers(self.glctx, mvp, vtx_pos_split, self.pos_idx, self.uv, self.uv_idx, self.tex_opt,
-                                         self.resolution, cfg.enable_mip, cfg.max_mip_level, cfg.fused_render)
-        ref = self.targets[frame_ids - self.frame_lo].reshape(Fb * Nc, *self.resolution)
+        ref = None
         n_img_global = Fb * Nc * self.world
+        local = slice(frame_ids.start - self.frame_lo, frame_ids.stop - self.frame_lo) if isinstance(frame_ids, slice) \
+            else frame_ids - self.frame_lo
+        ref = self.targets[local].reshape(Fb * Nc, *self.resolution)
+        C = self.tex_opt.shape[2]
+        n_total = n_img_global * self.resolution[0] * self.resolution[1] * C
+        one_shot = cfg.fused_objective and cfg.fused_render and cfg.fused_loss and not cfg.enable_mip and C in (1, 3, 4)
+        if not one_shot:
+            colour, rast_out = render_layers(self.glctx, mvp, vtx_pos_split, self.pos_idx, self.uv, self.uv_idx, self.tex_opt,
+                                             self.resolution, cfg.enable_mip, cfg.max_mip_level, cfg.fused_render)
         # regularisers (fit.py:578-595): evaluated on this rank's meshes, averaged over all ranks
         reg = torch.zeros((), dtype=torch.float32, device=self.device)
         if cfg.weight_meshedge:
@@ -415,9 +430,13 @@ class Fitter:
             mi = torch.matmul(self.maps_intermediate['local'], self.maps['local'][:, frame_ids])
             reg = reg + torch.mean(mi ** 2)
         reg = reg / self.world
-        self.optimizer.zero_grad(set_to_none=False)
-        if cfg.fused_loss:
-            n_total = n_img_global * self.resolution[0] * self.resolution[1] * colour.shape[3]
+        self.optimizer.zero_grad(set_to_none=True)
+        if one_shot:
+            pos_clip = camera.transform_clip(mvp, vtx_pos_split)
+            loss = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
+                                      n_total, BACKGROUND) + reg
+            loss.backward()
+        elif cfg.fused_loss:
             sum_sq, g_colour = pixel_loss_fused(colour, rast_out, ref, n_total)
             roots, seeds = [colour], [g_colour]
             if reg.requires_grad:
@@ -430,7 +449,7 @@ class Fitter:
             loss = torch.mean((ref[..., None].to(torch.float32) - col * 255) ** 2) / self.world + reg
             loss.backward()
         self.result[frame_ids] = vtx_pos.detach()
-        return loss
+        return loss.detach()
 
     def step(self):
         """One Adam step (fit.py:524-618): forward, backward, gradient all-reduce, update, schedule, renormalise."""

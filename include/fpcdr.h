@@ -105,6 +105,42 @@ typedef struct {
 } fpcdr_render_bwd_params;
 int fpcdr_render_bwd(const fpcdr_render_bwd_params *p, void *stream);
 
+/* antialias + background + pixel loss in one pass (reference fit.py:160, 161, 579): reads colour, rast and the 8-bit
+ * reference image, accumulates the sum of squares and writes d(grad_scale * sum)/d(antialiased colour); the
+ * antialiased image itself is never stored.  sil / flags as in fpcdr_antialias_fwd.  C in {1, 3, 4}.          */
+typedef struct {
+    const float *color;    /* [B,H,W,C] from fpcdr_render_fwd */
+    const float *rast;     /* [B,H,W,4] */
+    const float *pos;      /* [B,V,4] */
+    const int32_t *tri;    /* [T,3] */
+    const int32_t *adj;    /* [T,3] */
+    const uint8_t *ref;    /* [B,H,W] */
+    int32_t B, H, W, C, V, T;
+    float bg, color_scale, grad_scale;
+    uint8_t *sil;          /* scratch+saved [B,T] */
+    uint64_t *flags;       /* saved, fpcdr_antialias_flags_bytes() */
+    float *grad_aa;        /* out [B,H,W,C] */
+    double *loss_sum;      /* accumulated */
+} fpcdr_aa_loss_fwd_params;
+int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream);
+
+/* Backward of antialias + texture + interpolate + rasterize in one pass: reads grad_aa (4C B/px), rast (16 B/px) and
+ * the flag planes; scatters into grad_pos and grad_tex; writes nothing dense.                                 */
+typedef struct {
+    const float *pos;
+    const int32_t *tri;
+    const float *uv;
+    const int32_t *uv_tri;
+    const float *tex;
+    const float *rast, *color, *grad_aa;
+    const uint8_t *sil;
+    const uint64_t *flags;
+    int32_t B, V, T, H, W, Vt, Ht, Wt, C, boundary_mode;
+    float *grad_pos;       /* [B,V,4] accumulated */
+    float *grad_tex;       /* [Ht,Wt,C] accumulated, or NULL */
+} fpcdr_render_aa_bwd_params;
+int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* interpolate -- dr.interpolate(attr, rast, tri[, rast_db, diff_attrs])  reference fit.py:154,157 */
 /* ------------------------------------------------------------------------------------------ */

@@ -147,16 +147,24 @@ def test_fused_render_equals_separate_ops(C, boundary):
     assert rel_l2(p2.grad, p1.grad) < 1e-4
 
 
-def test_fitter_fused_and_unfused_paths_agree():
+@pytest.mark.parametrize("C", [1, 3])
+def test_fitter_fused_and_unfused_paths_agree(C):
+    """The three execution paths of the pixel term -- one-shot objective (3 kernels), fused render + separate
+    antialias / loss, and the four nvdiffrast-style ops + reference loss chain -- give the same loss and gradients."""
     from fpc_diffrend_amd import fit, scene
     sc = scene.cfg('cfg1', n_frames=2)
-    grads = []
-    for fused in (True, False):
-        cfg = fit.FitConfig(max_iter=10, cam_idxs=(0, 5), fused_render=fused, weight_laplacian=10.0)
+    if C != 1:
+        sc.texture = np.repeat(sc.texture, C, axis=2) * np.linspace(1.0, 0.6, C, dtype=np.float32)
+    results = []
+    for kw in (dict(), dict(fused_objective=False), dict(fused_objective=False, fused_render=False, fused_loss=False)):
+        cfg = fit.FitConfig(max_iter=10, cam_idxs=(0, 5), weight_laplacian=10.0, **kw)
         ft = fit.Fitter(sc, cfg, device='cuda')
         ft.init_near_truth(0.7)
         loss = ft.loss_and_backward(torch.arange(0, 2, device='cuda'))
-        grads.append((float(loss), ft.maps_intermediate['local'].grad.clone(), ft.tex_opt.grad.clone(), ft.per_frame_t.grad.clone()))
-    assert abs(grads[0][0] - grads[1][0]) < 1e-5 * abs(grads[1][0])
-    for a, b in zip(grads[0][1:], grads[1][1:]):
-        assert rel_l2(a, b) < 1e-4
+        results.append((float(loss), ft.maps_intermediate['local'].grad.clone(), ft.tex_opt.grad.clone(),
+                        ft.per_frame_t.grad.clone(), ft.t_opt.grad.clone()))
+    ref = results[-1]
+    for r in results[:-1]:
+        assert abs(r[0] - ref[0]) < 1e-5 * abs(ref[0])
+        for a, b in zip(r[1:], ref[1:]):
+            assert rel_l2(a, b) < 1e-4
