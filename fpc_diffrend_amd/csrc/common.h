@@ -66,3 +66,49 @@ __device__ __forceinline__ void wave_group_atomic_add(int key, float *const (&ds
         todo &= ~grp;
     }
 }
+
+// Full-wave (64 lanes) f32 sum with DPP row operations (VALU rate; __shfl_xor lowers to ds_bpermute, several
+// times slower).  gfx9 family: row_bcast15 / row_bcast31 exist.  The total is returned in every lane.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    // quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140,
+    // row_bcast15 = 0x142 (row_mask 0xA), row_bcast31 = 0x143 (row_mask 0xC)
+    int x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false)); x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false)); x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false)); x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false)); x = __float_as_int(v);
+    // after the four steps every lane holds the sum of its 16-lane row
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false)); x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Lanes of a wave that share `key` (>= 0) sum their N values; the group's first lane calls emit(key, sums).
+// Lanes with key < 0 do not participate.  Convergent: every lane of the wave must call it.
+template <int N, typename Emit>
+__device__ __forceinline__ void wave_group_reduce(int key, const float (&val)[N], Emit &&emit) {
+    unsigned long long todo = __ballot(key >= 0);
+    const int l = lane_id();
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __builtin_amdgcn_readlane(key, leader);
+        const unsigned long long grp = __ballot(key == k) & todo;
+        const bool mine = (grp >> l) & 1ull;
+        float sums[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) sums[i] = wave_sum_dpp(mine ? val[i] : 0.0f);
+        if (l == leader) emit(k, sums);
+        todo &= ~grp;
+    }
+}
+
+// Full-wave integer min / max with DPP (same structure as wave_sum_dpp); result in every lane.
+__device__ __forceinline__ int wave_min_dpp(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}

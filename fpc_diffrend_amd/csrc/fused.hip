@@ -101,10 +101,23 @@ __global__ void __launch_bounds__(256) k_aa_loss(const float *__restrict__ color
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward of the whole pixel objective for one pixel per lane (8x8 tile per wave):
+// Backward of the whole pixel objective, one pixel per lane, one 16x16-pixel tile per workgroup:
 //   g_c = g_aa + antialias corrections (gather form, only where a flag bit says a pair was blended)
-//   texture bwd: scatter into grad_tex;  interpolate bwd;  rasterize bwd: scatter into grad_pos
-//   + the antialias op's own d alpha / d pos for the pairs this pixel owns.
+//   texture bwd -> grad_tex;  interpolate bwd;  rasterize bwd -> grad_pos;  + the antialias op's own d alpha / d pos.
+//
+// Measured at cfg3 (r1): the arithmetic + streaming of this kernel take 3.8 ms; scattering with global f32 atomics
+// took 6 ms more (51 ms without any pre-reduction): scattered atomics retire at only ~15-70 G lanes/s chip-wide, so
+// what matters is HOW MANY lanes reach memory.  Two levels of on-chip summation therefore precede every global atomic:
+//   vertices  the lanes of a wave that shade the same triangle reduce their nine components with DPP row operations;
+//             the group leaders add into a 256-slot LDS table keyed by vertex id; one flush per workgroup
+//             (a 16x16 tile touches a few dozen vertices: ~2300 per-pixel adds -> ~100 global atomics);
+//   texels    a TEXW x TEXH LDS window anchored at the tile's smallest tap absorbs the four taps of every covered
+//             pixel and is flushed row-contiguously; taps outside it (uv seams; empty pixels, which sample
+//             uv = (0,0)) go straight to global memory.
+// 85 % of the workgroups of the face rig see no gradient and leave at the first barrier.
+constexpr int VSLOTS = 256;
+constexpr int TEXW = 48, TEXH = 48;
+
 template <int CS>
 __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
@@ -114,13 +127,18 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
                                                        const unsigned long long *__restrict__ flags, int B, int V, int T, int H,
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex) {
+    __shared__ int s_vkey[VSLOTS];
+    __shared__ float s_vacc[VSLOTS][4];
+    __shared__ float s_tex[TEXH * TEXW * CS];
+    __shared__ int s_org[2];   // smallest tap x, y of the tile (unwrapped texel coordinates)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
     const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int b = blockIdx.z;
-    int key0 = -1, key1 = -1, key2 = -1;
-    float g0[3] = {0, 0, 0}, g1[3] = {0, 0, 0}, g2[3] = {0, 0, 0};
     float *gp = grad_pos + (size_t)b * V * 4;
+    float go[CS];
+    bool any = false;
+    size_t off = 0;
     if (x < W && y < H) {
         const int Wq = FPCDR_AA_ROW_WORDS(W);
         const size_t plane = (size_t)B * H * Wq;
@@ -131,13 +149,11 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
         const bool left_x = bit > 0 ? ((fxw >> (bit - 1)) & 1ull) : (x > 0 ? ((flags[wi - 1] >> 63) & 1ull) : false);
         const bool down_y = y > 0 ? ((flags[plane + wi - Wq] >> bit) & 1ull) : false;
         const size_t img = (size_t)b * H * W;
-        const size_t off = img + (size_t)y * W + x;
-        float go[CS];
-        bool any = false;
+        off = img + (size_t)y * W + x;
 #pragma unroll
         for (int c = 0; c < CS; ++c) { go[c] = g_aa[off * CS + c]; any |= (go[c] != 0.0f); }
         if (own_x | own_y | left_x | down_y) {
-            // antialias backward for this pixel (see k_aa_bwd_fix in antialias.hip)
+            // antialias backward for this pixel (see k_aa_bwd_fix in antialias.hip); sparse: plain global atomics
             AAGeom geo = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
             const float2 me = load_zid(rast, off);
             auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own) {
@@ -186,66 +202,141 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
 #pragma unroll
             for (int c = 0; c < CS; ++c) any |= (go[c] != 0.0f);
         }
-        if (any) {
-            const float4 r = rast[off];
-            int t = (int)r.w - 1;
-            if (t >= T) t = -1;
-            float2 q0 = make_float2(0.f, 0.f), q1 = q0, q2 = q0;
-            float tu = 0.0f, tv = 0.0f;
-            if (t >= 0) {
-                q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]];
-                const float w = 1.0f - r.x - r.y;
-                tu = r.x * q0.x + r.y * q1.x + w * q2.x;
-                tv = r.x * q0.y + r.y * q1.y + w * q2.y;
-            }
-            const Taps tp = make_taps(tu, tv, Ht, Wt, CS, boundary);
-            const float w00 = (1.0f - tp.fx) * (1.0f - tp.fy), w10 = tp.fx * (1.0f - tp.fy);
-            const float w01 = (1.0f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
-            float gfx = 0.f, gfy = 0.f;
+    }
+    // most workgroups of an image see no gradient at all: leave before touching LDS
+    if (!__syncthreads_or(any ? 1 : 0)) return;
+
+    // ---- texture coordinate + taps of this pixel ----
+    int t = -1;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 q0 = make_float2(0.f, 0.f), q1 = q0, q2 = q0;
+    float tu = 0.0f, tv = 0.0f;
+    int ux0 = 0x7fffffff, uy0 = 0x7fffffff;   // unwrapped texel coordinates of tap (0,0)
+    Taps tp = {};
+    if (any) {
+        r = rast[off];
+        t = (int)r.w - 1;
+        if (t >= T) t = -1;
+        if (t >= 0) {
+            q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]];
+            const float w = 1.0f - r.x - r.y;
+            tu = r.x * q0.x + r.y * q1.x + w * q2.x;
+            tv = r.x * q0.y + r.y * q1.y + w * q2.y;
+        }
+        tp = make_taps(tu, tv, Ht, Wt, CS, boundary);
+    }
+    const bool windowed = any && t >= 0 && grad_tex != nullptr;   // empty pixels (uv = (0,0)) scatter directly
+    if (windowed) {
+        ux0 = (int)floorf(prep_coord(tu, boundary) * (float)Wt - 0.5f);
+        uy0 = (int)floorf(prep_coord(tv, boundary) * (float)Ht - 0.5f);
+    }
+    for (int k = threadIdx.x; k < VSLOTS; k += 256) {
+        s_vkey[k] = -1;
+        s_vacc[k][0] = 0.f; s_vacc[k][1] = 0.f; s_vacc[k][2] = 0.f; s_vacc[k][3] = 0.f;
+    }
+    for (int k = threadIdx.x; k < TEXH * TEXW * CS; k += 256) s_tex[k] = 0.0f;
+    if (threadIdx.x == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
+    __syncthreads();
+    {
+        const int mx = wave_min_dpp(ux0), my = wave_min_dpp(uy0);
+        if (lane == 0 && mx != 0x7fffffff) { atomicMin(&s_org[0], mx); atomicMin(&s_org[1], my); }
+    }
+    __syncthreads();
+    const int ox = s_org[0], oy = s_org[1];
+
+    int tkey = -1;
+    float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (any) {
+        const float w00 = (1.0f - tp.fx) * (1.0f - tp.fy), w10 = tp.fx * (1.0f - tp.fy);
+        const float w01 = (1.0f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
+        const int lx = ux0 - ox, ly = uy0 - oy;
+        const bool in_win = windowed && lx >= 0 && ly >= 0 && lx + 1 < TEXW && ly + 1 < TEXH;
+        float gfx = 0.f, gfy = 0.f;
 #pragma unroll
-            for (int c = 0; c < CS; ++c) {
-                const float gc = go[c];
-                float t00, t10, t01, t11;
-                load_taps(tex, tp, c, CS, t00, t10, t01, t11);
-                gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
-                gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
-                if (grad_tex && gc != 0.0f) {
+        for (int c = 0; c < CS; ++c) {
+            const float gc = go[c];
+            float t00, t10, t01, t11;
+            load_taps(tex, tp, c, CS, t00, t10, t01, t11);
+            gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
+            gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
+            if (grad_tex && gc != 0.0f) {
+                if (in_win) {
+                    float *w = s_tex + (ly * TEXW + lx) * CS + c;
+                    atomicAdd(w, gc * w00);
+                    atomicAdd(w + CS, gc * w10);
+                    atomicAdd(w + TEXW * CS, gc * w01);
+                    atomicAdd(w + TEXW * CS + CS, gc * w11);
+                } else {
                     atomicAdd(grad_tex + tp.i00 + c, gc * w00);
                     atomicAdd(grad_tex + tp.i10 + c, gc * w10);
                     atomicAdd(grad_tex + tp.i01 + c, gc * w01);
                     atomicAdd(grad_tex + tp.i11 + c, gc * w11);
                 }
             }
-            if (t >= 0) {
-                const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
-                const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv >= 0.0f && tv <= 1.0f)) ? 0.0f : 1.0f;
-                const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
-                const float gu = gtu * (q0.x - q2.x) + gtv * (q0.y - q2.y);
-                const float gv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
-                if (gu != 0.0f || gv != 0.0f) {
-                    const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-                    const float4 *p = pos + (size_t)b * V;
-                    const float fx = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
-                    const float fy = (2.0f * (float)y + 1.0f) / (float)H - 1.0f;
-                    shade_pixel_bwd<false>(p[i0], p[i1], p[i2], fx, fy, 2.0f / (float)W, 2.0f / (float)H,
-                                           make_float4(gu, gv, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), g0, g1, g2);
-                    key0 = i0; key1 = i1; key2 = i2;
-                }
+        }
+        if (t >= 0) {
+            const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
+            const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv >= 0.0f && tv <= 1.0f)) ? 0.0f : 1.0f;
+            const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
+            const float gu = gtu * (q0.x - q2.x) + gtv * (q0.y - q2.y);
+            const float gvv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
+            if (gu != 0.0f || gvv != 0.0f) {
+                const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+                const float4 *p = pos + (size_t)b * V;
+                const float fx = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
+                const float fy = (2.0f * (float)y + 1.0f) / (float)H - 1.0f;
+                float g0[3], g1[3], g2[3];
+                shade_pixel_bwd<false>(p[i0], p[i1], p[i2], fx, fy, 2.0f / (float)W, 2.0f / (float)H,
+                                       make_float4(gu, gvv, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), g0, g1, g2);
+                gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
+                gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
+                gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
+                tkey = t;
             }
         }
     }
-    if (__ballot(key0 >= 0) == 0ull) return;
-    {
-        float *const d[3] = {gp + 4 * (size_t)max(key0, 0), gp + 4 * (size_t)max(key0, 0) + 1, gp + 4 * (size_t)max(key0, 0) + 3};
-        wave_group_atomic_add<3>(key0, d, g0);
+    // ---- vertices: wave-level reduction per triangle, then the group leaders add into the LDS table ----
+    wave_group_reduce<9>(tkey, gv9, [&](int tt, const float (&sm)[9]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int key = tri[3 * tt + k];
+            unsigned int slot = ((unsigned int)key * 2654435761u) >> 24;   // 8 bits = VSLOTS
+            bool done = false;
+            for (int probe = 0; probe < VSLOTS && !done; ++probe) {
+                const int old = atomicCAS(&s_vkey[slot], -1, key);
+                if (old == -1 || old == key) {
+                    atomicAdd(&s_vacc[slot][0], sm[3 * k]); atomicAdd(&s_vacc[slot][1], sm[3 * k + 1]);
+                    atomicAdd(&s_vacc[slot][3], sm[3 * k + 2]);
+                    done = true;
+                }
+                slot = (slot + 1) & (VSLOTS - 1);
+            }
+            if (!done) {   // table full: straight to memory
+                atomicAdd(gp + 4 * (size_t)key + 0, sm[3 * k]); atomicAdd(gp + 4 * (size_t)key + 1, sm[3 * k + 1]);
+                atomicAdd(gp + 4 * (size_t)key + 3, sm[3 * k + 2]);
+            }
+        }
+    });
+    __syncthreads();
+    // ---- flush: lane = (slot, component), so the four dwords of a vertex are one contiguous 16-byte access ----
+    for (int k = threadIdx.x; k < VSLOTS * 4; k += 256) {
+        const int slot = k >> 2, comp = k & 3;
+        const int key = s_vkey[slot];
+        if (key >= 0) {
+            const float v = s_vacc[slot][comp];
+            if (v != 0.0f) atomicAdd(gp + 4 * (size_t)key + comp, v);
+        }
     }
-    {
-        float *const d[3] = {gp + 4 * (size_t)max(key1, 0), gp + 4 * (size_t)max(key1, 0) + 1, gp + 4 * (size_t)max(key1, 0) + 3};
-        wave_group_atomic_add<3>(key1, d, g1);
-    }
-    {
-        float *const d[3] = {gp + 4 * (size_t)max(key2, 0), gp + 4 * (size_t)max(key2, 0) + 1, gp + 4 * (size_t)max(key2, 0) + 3};
-        wave_group_atomic_add<3>(key2, d, g2);
+    if (grad_tex && ox != 0x7fffffff) {
+        for (int k = threadIdx.x; k < TEXH * TEXW * CS; k += 256) {
+            const float v = s_tex[k];
+            if (v != 0.0f) {
+                const int c = k % CS, cell = k / CS;
+                const int col = cell % TEXW, row = cell / TEXW;
+                const int gx = wrap_i(ox + col, Wt, boundary), gy = wrap_i(oy + row, Ht, boundary);
+                atomicAdd(grad_tex + ((size_t)gy * Wt + gx) * CS + c, v);
+            }
+        }
     }
 }
 

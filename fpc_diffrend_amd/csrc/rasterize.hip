@@ -406,6 +406,12 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
     // ---- shade + write (every pixel of the bin is written exactly once) ----
     const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
     const float4 *p = pos + (size_t)b * V;
+    Taps empty_tp = {};
+    float empty_col[4] = {0.f, 0.f, 0.f, 0.f};
+    if (SHADE) {
+        empty_tp = make_taps(0.0f, 0.0f, sh.Ht, sh.Wt, sh.C, sh.boundary);
+        for (int c = 0; c < min(sh.C, 4); ++c) empty_col[c] = bilerp(sh.tex, empty_tp, c, sh.C);
+    }
 #pragma unroll
     for (int k = 0; k < TILES_PER_WAVE; ++k) {
         const int tile = wave * TILES_PER_WAVE + k;
@@ -428,16 +434,17 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
             if (WRITE_DB) rast_db[off] = d;
             if (SHADE) {
                 // interpolate (reference fit.py:157) + texture 'linear' (fit.py:158), same arithmetic as the stand-alone
-                // kernels; an empty pixel samples uv = (0,0) exactly as they do
-                float tu = 0.0f, tv = 0.0f;
+                // kernels; an empty pixel samples uv = (0,0) exactly as they do (one tap set, hoisted out of the loops)
                 if (t >= 0) {
                     const float2 q0 = sh.uv[sh.uv_tri[3 * t]], q1 = sh.uv[sh.uv_tri[3 * t + 1]], q2 = sh.uv[sh.uv_tri[3 * t + 2]];
                     const float w = 1.0f - o.x - o.y;
-                    tu = o.x * q0.x + o.y * q1.x + w * q2.x;
-                    tv = o.x * q0.y + o.y * q1.y + w * q2.y;
+                    const float tu = o.x * q0.x + o.y * q1.x + w * q2.x;
+                    const float tv = o.x * q0.y + o.y * q1.y + w * q2.y;
+                    const Taps tp = make_taps(tu, tv, sh.Ht, sh.Wt, sh.C, sh.boundary);
+                    for (int c = 0; c < sh.C; ++c) sh.color[off * sh.C + c] = bilerp(sh.tex, tp, c, sh.C);
+                } else {
+                    for (int c = 0; c < sh.C; ++c) sh.color[off * sh.C + c] = c < 4 ? empty_col[c] : bilerp(sh.tex, empty_tp, c, sh.C);
                 }
-                const Taps tp = make_taps(tu, tv, sh.Ht, sh.Wt, sh.C, sh.boundary);
-                for (int c = 0; c < sh.C; ++c) sh.color[off * sh.C + c] = bilerp(sh.tex, tp, c, sh.C);
             }
         }
     }
