@@ -12,6 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 MAX_ATTR = 32
 MAX_MIP = 16
+LOSS_SLOTS = 256
 ABI_VERSION = 1
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
@@ -34,7 +35,7 @@ class RasterizeBwd(ctypes.Structure):
 class RenderFwd(ctypes.Structure):
     _fields_ = [("pos", _p), ("tri", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i), ("scratch", _p),
                 ("uv", _p), ("uv_tri", _p), ("Vt", _i), ("tex", _p), ("Ht", _i), ("Wt", _i), ("C", _i),
-                ("boundary_mode", _i), ("rast", _p), ("color", _p)]
+                ("boundary_mode", _i), ("rast", _p), ("color", _p), ("ibox", _p)]
 
 
 class RenderBwd(ctypes.Structure):
@@ -46,12 +47,12 @@ class RenderBwd(ctypes.Structure):
 class AaLossFwd(ctypes.Structure):
     _fields_ = [("color", _p), ("rast", _p), ("pos", _p), ("tri", _p), ("adj", _p), ("ref", _p), ("B", _i), ("H", _i),
                 ("W", _i), ("C", _i), ("V", _i), ("T", _i), ("bg", ctypes.c_float), ("color_scale", ctypes.c_float),
-                ("grad_scale", ctypes.c_float), ("sil", _p), ("flags", _p), ("grad_aa", _p), ("loss_sum", _p)]
+                ("grad_scale", ctypes.c_float), ("sil", _p), ("flags", _p), ("grad_aa", _p), ("ibox", _p), ("loss_sum", _p)]
 
 
 class RenderAaBwd(ctypes.Structure):
     _fields_ = [("pos", _p), ("tri", _p), ("uv", _p), ("uv_tri", _p), ("tex", _p), ("rast", _p), ("color", _p),
-                ("grad_aa", _p), ("sil", _p), ("flags", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i),
+                ("grad_aa", _p), ("sil", _p), ("flags", _p), ("ibox", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i),
                 ("Vt", _i), ("Ht", _i), ("Wt", _i), ("C", _i), ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p)]
 
 

@@ -25,22 +25,41 @@ __global__ void __launch_bounds__(256) k_aa_loss(const float *__restrict__ color
                                                  const uint8_t *__restrict__ sil, const uint8_t *__restrict__ ref, int B, int H,
                                                  int W, int V, int T, float bg, float color_scale, float grad_scale,
                                                  unsigned long long *__restrict__ flags, float *__restrict__ g_aa,
-                                                 double *__restrict__ loss_sum) {
+                                                 const int4 *__restrict__ ibox, double *__restrict__ loss_sum) {
     __shared__ float s_part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wave, b = blockIdx.z;
     const int Wq = FPCDR_AA_ROW_WORDS(W);
     bool fx_flag = false, fy_flag = false;
     float lsum = 0.0f;
-    if (y < H) {
+    bool far = false;   // sparse mode: this wave's 64x64 bin is farther than 64 px from the image's geometry
+    if (ibox) {
+        const int4 ib = ibox[b];
+        const int bx0 = blockIdx.x * 64, by0 = (y >> 6) << 6;
+        far = ib.z + 64 < bx0 || ib.x - 64 > bx0 + 63 || ib.w + 64 < by0 || ib.y - 64 > by0 + 63;
+    }
+    if (far) {
+        // nothing but background here: (ref - 255 bg)^2, no gradient, no flags (the caller zero-filled them)
+        if (y < H && x < W) {
+            const float d = (float)ref[((size_t)b * H + y) * W + x] - bg * color_scale;
+            lsum = (float)CS * d * d;
+        }
+    } else if (y < H) {
+        // every lane of the wave (also beyond W) takes part in the neighbour exchange
+        float2 me_w = make_float2(0.f, 0.f);
+        if (x < W) me_w = load_zid(rast, ((size_t)b * H + y) * W + x);
+        const float zr = __shfl_down(me_w.x, 1, 64), ir = __shfl_down(me_w.y, 1, 64);
+        const float zl = __shfl_up(me_w.x, 1, 64), il = __shfl_up(me_w.y, 1, 64);
         if (x < W) {
             const size_t img = (size_t)b * H * W;
             const size_t off = img + (size_t)y * W + x;
-            const float2 me = load_zid(rast, off);
+            const float2 me = me_w;
             const int id = (int)me.y;
             const bool hasR = x + 1 < W, hasL = x > 0, hasU = y + 1 < H, hasD = y > 0;
-            const float2 nR = hasR ? load_zid(rast, off + 1) : me;
-            const float2 nL = hasL ? load_zid(rast, off - 1) : me;
+            // left / right neighbours come from the neighbouring lanes' registers; only the two ends of the wave's
+            // 64-pixel span and the rows above / below are loaded
+            const float2 nR = !hasR ? me : (lane < 63 ? make_float2(zr, ir) : load_zid(rast, off + 1));
+            const float2 nL = !hasL ? me : (lane > 0 ? make_float2(zl, il) : load_zid(rast, off - 1));
             const float2 nU = hasU ? load_zid(rast, off + W) : me;
             const float2 nD = hasD ? load_zid(rast, off - W) : me;
             float acc[CS];
@@ -96,7 +115,8 @@ __global__ void __launch_bounds__(256) k_aa_loss(const float *__restrict__ color
     __syncthreads();
     if (threadIdx.x == 0) {
         const double tot = (double)s_part[0] + (double)s_part[1] + (double)s_part[2] + (double)s_part[3];
-        if (tot != 0.0) atomicAdd(loss_sum, tot);
+        const unsigned int slot = (blockIdx.x + 31u * blockIdx.y + 977u * blockIdx.z) % FPCDR_LOSS_SLOTS;
+        if (tot != 0.0) atomicAdd(loss_sum + slot, tot);
     }
 }
 
@@ -124,7 +144,8 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
                                                        const float *__restrict__ tex, const float4 *__restrict__ rast,
                                                        const float *__restrict__ color, const float *__restrict__ g_aa,
                                                        const uint8_t *__restrict__ sil,
-                                                       const unsigned long long *__restrict__ flags, int B, int V, int T, int H,
+                                                       const unsigned long long *__restrict__ flags,
+                                                       const int4 *__restrict__ ibox, int B, int V, int T, int H,
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex) {
     __shared__ int s_vkey[VSLOTS];
@@ -139,6 +160,11 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
     float go[CS];
     bool any = false;
     size_t off = 0;
+    if (ibox) {   // sparse mode: tiles farther than 64 px from the image's geometry carry no gradient (and no data)
+        const int4 ib = ibox[b];
+        const int bx0 = (blockIdx.x * 16) & ~63, by0 = (blockIdx.y * 16) & ~63;
+        if (ib.z + 64 < bx0 || ib.x - 64 > bx0 + 63 || ib.w + 64 < by0 || ib.y - 64 > by0 + 63) return;
+    }
     if (x < W && y < H) {
         const int Wq = FPCDR_AA_ROW_WORDS(W);
         const size_t plane = (size_t)B * H * Wq;
@@ -391,7 +417,7 @@ extern "C" int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream
 #define LAUNCH(CS)                                                                                                         \
     hipLaunchKernelGGL(k_aa_loss<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos,  \
                        p->tri, p->sil, p->ref, p->B, p->H, p->W, p->V, p->T, p->bg, p->color_scale, p->grad_scale,         \
-                       (unsigned long long *)p->flags, p->grad_aa, p->loss_sum)
+                       (unsigned long long *)p->flags, p->grad_aa, (const int4 *)p->ibox, p->loss_sum)
     if (p->C == 1) LAUNCH(1);
     else if (p->C == 3) LAUNCH(3);
     else LAUNCH(4);
@@ -413,7 +439,8 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
 #define LAUNCH(CS)                                                                                                          \
     hipLaunchKernelGGL(k_render_aa_bwd<CS>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)p->pos, p->tri,        \
                        (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa, p->sil,     \
-                       (const unsigned long long *)p->flags, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt, p->boundary_mode,   \
+                       (const unsigned long long *)p->flags, (const int4 *)p->ibox, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,   \
+                       p->boundary_mode,                                                                                        \
                        p->grad_pos, p->grad_tex)
     if (p->C == 1) LAUNCH(1);
     else if (p->C == 3) LAUNCH(3);

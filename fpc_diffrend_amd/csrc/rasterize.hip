@@ -236,6 +236,8 @@ struct ShadeArgs {
     const float *tex;        // [Ht,Wt,C]
     float *color;            // out [B,H,W,C]
     int Ht, Wt, C, boundary;
+    int sparse_margin;       // >= 0: bins farther than this many pixels from the image's bounding box write nothing
+    int4 *ibox_out;          // sparse mode: per-image bounding box for the consumers (fused.hip), else null
 };
 
 template <bool WRITE_DB, bool SHADE>
@@ -266,6 +268,13 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
 
     const ImgBox ib = ibox[b];
     const bool bin_live = !(ib.x1 < bin_x0 || ib.x0 > bin_x1 || ib.y1 < bin_y0 || ib.y0 > bin_y1);
+    if (SHADE && sh.sparse_margin >= 0) {
+        // sparse mode of the fused objective: nothing of this image lies within `margin` pixels of the bin, and no
+        // consumer will look at it (they apply the same test with a smaller margin)
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) sh.ibox_out[b] = make_int4(ib.x0, ib.y0, ib.x1, ib.y1);
+        const int m = sh.sparse_margin;
+        if (ib.x1 + m < bin_x0 || ib.x0 - m > bin_x1 || ib.y1 + m < bin_y0 || ib.y0 - m > bin_y1) return;
+    }
 
     if (bin_live) {
         for (int k = tid; k < 2 * NTILES * (BATCH / 64); k += 256) (&s_mask[0][0][0])[k] = 0ull;
@@ -664,7 +673,8 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
-    ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode};
+    ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
+                    p->ibox ? 2 * BIN : -1, (int4 *)p->ibox};
     hipLaunchKernelGGL((k_bins<false, true>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
                        recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr, sh);
     FPCDR_CHECK_LAUNCH();

@@ -236,6 +236,7 @@ class FitConfig:
     fused_loss: bool = True         # False = reference-style torch.where + torch.mean chain
     fused_render: bool = True       # rasterize + interpolate + texture as one kernel pair (non-mip); False = four separate ops
     fused_objective: bool = True    # with fused_render and fused_loss: the whole pixel term as three kernels (ops.pixel_objective)
+    sparse_objective: bool = True   # the three kernels skip image regions far from any geometry (same result)
 
 
 def setup_dataset(blendshapes, n_frames, device):
@@ -434,7 +435,7 @@ class Fitter:
         if one_shot:
             pos_clip = camera.transform_clip(mvp, vtx_pos_split)
             loss = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
-                                      n_total, BACKGROUND) + reg
+                                      n_total, BACKGROUND, sparse=cfg.sparse_objective) + reg
             loss.backward()
         elif cfg.fused_loss:
             sum_sq, g_colour = pixel_loss_fused(colour, rast_out, ref, n_total)

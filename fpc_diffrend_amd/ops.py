@@ -210,7 +210,7 @@ class _pixel_objective_func(torch.autograd.Function):
     """mean over n_total of (ref - 255 * where(covered, antialias(render(pos, tex)), bg))^2 as three kernels."""
 
     @staticmethod
-    def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary):
+    def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, sparse):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -219,48 +219,54 @@ class _pixel_objective_func(torch.autograd.Function):
         rast = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
         color = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
         scratch = torch.empty(lib.fpcdr_rasterize_scratch_bytes(B, T), dtype=torch.uint8, device=dev)
+        # sparse: image regions far from any geometry are neither written nor read by the three kernels
+        ibox = torch.empty(B, 4, dtype=torch.int32, device=dev) if sparse else None
         p = _lib.RenderFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
                            uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C, boundary_mode=boundary,
-                           rast=_ptr(rast), color=_ptr(color))
+                           rast=_ptr(rast), color=_ptr(color), ibox=_ptr(ibox))
         _lib.call("fpcdr_render_fwd", ctypes.byref(p), _stream())
         del scratch
         g_aa = torch.empty_like(color)
         sil = torch.empty(B, T, dtype=torch.uint8, device=dev)
-        flags = torch.empty(lib.fpcdr_antialias_flags_bytes(B, H, W) // 8, dtype=torch.int64, device=dev)
-        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        nflag = lib.fpcdr_antialias_flags_bytes(B, H, W) // 8
+        flags = (torch.zeros if sparse else torch.empty)(nflag, dtype=torch.int64, device=dev)
+        acc = torch.zeros(_lib.LOSS_SLOTS, dtype=torch.float64, device=dev)
         q = _lib.AaLossFwd(color=_ptr(color), rast=_ptr(rast), pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), ref=_ptr(ref), B=B,
                            H=H, W=W, C=C, V=V, T=T, bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
-                           flags=_ptr(flags), grad_aa=_ptr(g_aa), loss_sum=_ptr(acc))
+                           flags=_ptr(flags), grad_aa=_ptr(g_aa), ibox=_ptr(ibox), loss_sum=_ptr(acc))
         _lib.call("fpcdr_aa_loss_fwd", ctypes.byref(q), _stream())
-        ctx.save_for_backward(pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags)
+        ctx.save_for_backward(pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, ibox)
         ctx.boundary = boundary
-        return (acc[0] / n_total).to(torch.float32)
+        return (acc.sum() / n_total).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
-        pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags = ctx.saved_tensors
+        pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, ibox = ctx.saved_tensors
         B, V, _ = pos.shape
         _, H, W, _ = rast.shape
         Ht, Wt, C = tex.shape
         g_pos = torch.zeros_like(pos)
         g_tex = torch.zeros_like(tex) if ctx.needs_input_grad[1] else None
         p = _lib.RenderAaBwd(pos=_ptr(pos), tri=_ptr(tri), uv=_ptr(uv), uv_tri=_ptr(uv_tri), tex=_ptr(tex), rast=_ptr(rast),
-                             color=_ptr(color), grad_aa=_ptr(g_aa), sil=_ptr(sil), flags=_ptr(flags), B=B, V=V, T=tri.shape[0],
+                             color=_ptr(color), grad_aa=_ptr(g_aa), sil=_ptr(sil), flags=_ptr(flags), ibox=_ptr(ibox), B=B, V=V,
+                             T=tri.shape[0],
                              H=H, W=W, Vt=uv.shape[0], Ht=Ht, Wt=Wt, C=C, boundary_mode=ctx.boundary, grad_pos=_ptr(g_pos),
                              grad_tex=_ptr(g_tex))
         _lib.call("fpcdr_render_aa_bwd", ctypes.byref(p), _stream())
         g_pos = g_pos * g if ctx.needs_input_grad[0] else None
         if g_tex is not None:
             g_tex = g_tex * g
-        return (g_pos, g_tex) + (None,) * 10
+        return (g_pos, g_tex) + (None,) * 11
 
 
 def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_total=None, background=45.0 / 255.0,
-                    boundary_mode='wrap'):
+                    boundary_mode='wrap', sparse=True):
     """The whole pixel term of the reference's loss (fit.py:151-161 + the first term of :579) for a minibatch,
     as three kernels:  mean((ref - 255 * where(rast.w > 0, antialias(texture(interpolate(rasterize(pos)))), bg))^2)
     over n_total elements (default: all of this call's).  pos [B,V,4], tex [Ht,Wt,C] (C in 1,3,4), ref_u8 [B,H,W] uint8.
-    Differentiable w.r.t. pos and tex; equals the chain of separate operators + pixel loss."""
+    Differentiable w.r.t. pos and tex; equals the chain of separate operators + pixel loss.
+    sparse=True: 64x64-pixel regions farther than 64 / 128 px from an image's geometry are skipped by all three
+    kernels (they can only contribute (ref - 255 bg)^2 to the loss, which is still added); same result."""
     assert isinstance(glctx, RasterizeHipContext)
     _check_tensor('pos', pos, torch.float32, 3)
     _check_tensor('tri', tri, torch.int32, 2)
@@ -277,7 +283,7 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     adj = _cached_topology(tri)
     n_total = n_total or pos.shape[0] * H * W * tex.shape[2]
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
-                                       ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode])
+                                       ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -87,6 +87,10 @@ typedef struct {
     int32_t Ht, Wt, C, boundary_mode;
     float *rast;            /* out [B,H,W,4] */
     float *color;           /* out [B,H,W,C] */
+    int32_t *ibox;          /* NULL = dense (every pixel of rast / color is written).  Otherwise out [B,4] = pixel bounding
+                               box (x0,y0,x1,y1) of each image's geometry, and SPARSE mode: 64x64-pixel bins farther than
+                               128 px from that box are not written at all -- only for consumers that apply the same test
+                               (fpcdr_aa_loss_fwd / fpcdr_render_aa_bwd with the same ibox) */
 } fpcdr_render_fwd_params;
 int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream);
 
@@ -105,6 +109,8 @@ typedef struct {
 } fpcdr_render_bwd_params;
 int fpcdr_render_bwd(const fpcdr_render_bwd_params *p, void *stream);
 
+#define FPCDR_LOSS_SLOTS 256
+
 /* antialias + background + pixel loss in one pass (reference fit.py:160, 161, 579): reads colour, rast and the 8-bit
  * reference image, accumulates the sum of squares and writes d(grad_scale * sum)/d(antialiased colour); the
  * antialiased image itself is never stored.  sil / flags as in fpcdr_antialias_fwd.  C in {1, 3, 4}.          */
@@ -119,8 +125,11 @@ typedef struct {
     float bg, color_scale, grad_scale;
     uint8_t *sil;          /* scratch+saved [B,T] */
     uint64_t *flags;       /* saved, fpcdr_antialias_flags_bytes() */
-    float *grad_aa;        /* out [B,H,W,C] */
-    double *loss_sum;      /* accumulated */
+    float *grad_aa;        /* out [B,H,W,C] (sparse mode: only within 64 px of the image's box) */
+    const int32_t *ibox;   /* NULL = dense, else [B,4] from fpcdr_render_fwd (sparse mode); flags must then be zero-filled
+                              by the caller, spans farther than 64 px from the box only add (ref - 255 bg)^2 to the loss */
+    double *loss_sum;      /* [FPCDR_LOSS_SLOTS] f64, accumulated: the loss is the sum of all slots (workgroups spread
+                              their partial sums over the slots instead of hammering one address) */
 } fpcdr_aa_loss_fwd_params;
 int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream);
 
@@ -135,6 +144,7 @@ typedef struct {
     const float *rast, *color, *grad_aa;
     const uint8_t *sil;
     const uint64_t *flags;
+    const int32_t *ibox;   /* NULL = dense, else [B,4] (sparse mode, as in the forward calls) */
     int32_t B, V, T, H, W, Vt, Ht, Wt, C, boundary_mode;
     float *grad_pos;       /* [B,V,4] accumulated */
     float *grad_tex;       /* [Ht,Wt,C] accumulated, or NULL */

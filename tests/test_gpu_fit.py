@@ -156,7 +156,8 @@ def test_fitter_fused_and_unfused_paths_agree(C):
     if C != 1:
         sc.texture = np.repeat(sc.texture, C, axis=2) * np.linspace(1.0, 0.6, C, dtype=np.float32)
     results = []
-    for kw in (dict(), dict(fused_objective=False), dict(fused_objective=False, fused_render=False, fused_loss=False)):
+    for kw in (dict(), dict(sparse_objective=False), dict(fused_objective=False),
+               dict(fused_objective=False, fused_render=False, fused_loss=False)):
         cfg = fit.FitConfig(max_iter=10, cam_idxs=(0, 5), weight_laplacian=10.0, **kw)
         ft = fit.Fitter(sc, cfg, device='cuda')
         ft.init_near_truth(0.7)
