@@ -122,6 +122,8 @@ SYMBOLS = {
     "fpcdr_antialias_flags_bytes": (_sz, [_i, _i, _i]),
     "fpcdr_antialias_fwd": (_int, [ctypes.POINTER(AntialiasFwd), _p]),
     "fpcdr_antialias_bwd": (_int, [ctypes.POINTER(AntialiasBwd), _p]),
+    "fpcdr_transform_clip_fwd": (_int, [_p, _p, _p, _i, _i, _i, _p]),
+    "fpcdr_transform_clip_bwd": (_int, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_blend_fwd": (_int, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_blend_bwd_w": (_int, [_p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_blend_bwd_basis": (_int, [_p, _p, _p, _i, _i, _i, _p]),

@@ -81,6 +81,34 @@ class _blend_func(torch.autograd.Function):
         return g_vb, g_B, g_w
 
 
+class _transform_clip_func(torch.autograd.Function):
+    """camera.transform_clip for a minibatch on the GPU (fpcdr_transform_clip_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, mvp, verts):
+        B, F, V = mvp.shape[0], verts.shape[0], verts.shape[1]
+        out = torch.empty(B, V, 4, dtype=torch.float32, device=verts.device)
+        _lib.call("fpcdr_transform_clip_fwd", _ptr(mvp), _ptr(verts), _ptr(out), F, B // F, V, _stream())
+        ctx.save_for_backward(mvp, verts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mvp, verts = ctx.saved_tensors
+        B, F, V = mvp.shape[0], verts.shape[0], verts.shape[1]
+        g = g.contiguous()
+        g_mvp = torch.zeros_like(mvp) if ctx.needs_input_grad[0] else None
+        g_verts = torch.empty_like(verts) if ctx.needs_input_grad[1] else None
+        _lib.call("fpcdr_transform_clip_bwd", _ptr(mvp), _ptr(verts), _ptr(g), _ptr(g_verts), _ptr(g_mvp), F, B // F, V, _stream())
+        return g_mvp, g_verts
+
+
+def transform_clip_batched(mvp, verts):
+    """mvp [F*Nc,4,4], verts [F,V,3] on the GPU -> pos_clip [F*Nc,V,4]; same values as camera.transform_clip."""
+    assert mvp.shape[0] % verts.shape[0] == 0
+    return _transform_clip_func.apply(mvp.contiguous(), verts.contiguous())
+
+
 def blend_batched(v_base, Bmat, w):
     """v_base [M], Bmat [M,K], w [F,K] -> [F,M] on the GPU matrix cores."""
     return _blend_func.apply(v_base.contiguous() if v_base is not None else None, Bmat.contiguous(), w.contiguous())
@@ -184,17 +212,40 @@ class MeshTopology:
         e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], axis=0)
         e = np.unique(np.sort(e, axis=1), axis=0)
         self.edges = torch.tensor(e, dtype=torch.long, device=device)
-        deg = np.bincount(e.reshape(-1), minlength=n_vertices).astype(np.float32)
+        deg = np.bincount(e.reshape(-1), minlength=n_vertices).astype(np.int64)
         self.inv_deg = torch.tensor(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0), dtype=torch.float32, device=device)
         self.n_vertices = n_vertices
+        # padded one-ring table [V, Dmax]; the pad index V points at an all-zero row appended to the vertex buffer
+        dmax = int(deg.max()) if deg.size else 0
+        nbr = np.full((n_vertices, max(dmax, 1)), n_vertices, dtype=np.int64)
+        fill = np.zeros(n_vertices, dtype=np.int64)
+        for a, b in e:
+            nbr[a, fill[a]] = b; fill[a] += 1
+            nbr[b, fill[b]] = a; fill[b] += 1
+        self.nbr = torch.tensor(nbr, dtype=torch.long, device=device)
+
+
+class _uniform_laplacian(torch.autograd.Function):
+    """L X with L = D^-1 A - I for a batch of vertex buffers [F,V,3].  Forward and backward are both GATHERS over the
+    static one-ring table (L^T = A D^-1 - I), so no scatter / index_put runs in the step."""
+
+    @staticmethod
+    def forward(ctx, verts, nbr, inv_deg):
+        ctx.save_for_backward(nbr, inv_deg)
+        pad = torch.cat([verts, torch.zeros_like(verts[:, :1])], dim=1)
+        return pad[:, nbr].sum(dim=2) * inv_deg[None, :, None] - verts
+
+    @staticmethod
+    def backward(ctx, g):
+        nbr, inv_deg = ctx.saved_tensors
+        gs = g * inv_deg[None, :, None]
+        pad = torch.cat([gs, torch.zeros_like(gs[:, :1])], dim=1)
+        return pad[:, nbr].sum(dim=2) - g, None, None
 
 
 def mesh_laplacian_smoothing(verts, topo):
     """Uniform Laplacian smoothing: mean_v || mean_{n in N(v)} x_n - x_v ||, averaged over meshes [F,V,3]."""
-    nbr = torch.zeros_like(verts)
-    i, j = topo.edges[:, 0], topo.edges[:, 1]
-    nbr = nbr.index_add(1, i, verts[:, j]).index_add(1, j, verts[:, i])
-    lap = nbr * topo.inv_deg[None, :, None] - verts
+    lap = _uniform_laplacian.apply(verts, topo.nbr, topo.inv_deg)
     return lap.norm(dim=2).mean()
 
 
@@ -413,9 +464,10 @@ class Fitter:
         C = self.tex_opt.shape[2]
         n_total = n_img_global * self.resolution[0] * self.resolution[1] * C
         one_shot = cfg.fused_objective and cfg.fused_render and cfg.fused_loss and not cfg.enable_mip and C in (1, 3, 4)
+        pos_clip = transform_clip_batched(mvp, vtx_pos_split)        # camera.transform_clip (camera.py:11-23), batched
         if not one_shot:
-            colour, rast_out = render_layers(self.glctx, mvp, vtx_pos_split, self.pos_idx, self.uv, self.uv_idx, self.tex_opt,
-                                             self.resolution, cfg.enable_mip, cfg.max_mip_level, cfg.fused_render)
+            colour, rast_out = render_from_clip(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt,
+                                                self.resolution, cfg.enable_mip, cfg.max_mip_level, cfg.fused_render)
         # regularisers (fit.py:578-595): evaluated on this rank's meshes, averaged over all ranks
         reg = torch.zeros((), dtype=torch.float32, device=self.device)
         if cfg.weight_meshedge:
@@ -433,7 +485,6 @@ class Fitter:
         reg = reg / self.world
         self.optimizer.zero_grad(set_to_none=True)
         if one_shot:
-            pos_clip = camera.transform_clip(mvp, vtx_pos_split)
             loss = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
                                       n_total, BACKGROUND, sparse=cfg.sparse_objective) + reg
             loss.backward()

@@ -270,6 +270,16 @@ typedef struct {
 int fpcdr_antialias_bwd(const fpcdr_antialias_bwd_params *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* transform_clip for a minibatch                                      reference camera.py:11-23 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* out[b][v] = mvp[b] . (verts[b / Nc][v], 1)      mvp [F*Nc,4,4] row-major, verts [F,V,3], out [F*Nc,V,4] */
+int fpcdr_transform_clip_fwd(const float *mvp, const float *verts, float *out, int32_t F, int32_t Nc, int32_t V, void *stream);
+/* grad_verts [F,V,3] (overwritten, may be NULL); grad_mvp [F*Nc,4,4] (accumulated: zero it first; may be NULL) */
+int fpcdr_transform_clip_bwd(const float *mvp, const float *verts, const float *grad_out, float *grad_verts, float *grad_mvp,
+                             int32_t F, int32_t Nc, int32_t V, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* blend -- V = v_base + Bmat . w     reference fit.py:115-122 (prior), :58-62 (free)            */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -169,3 +169,42 @@ def test_fitter_fused_and_unfused_paths_agree(C):
         assert abs(r[0] - ref[0]) < 1e-5 * abs(ref[0])
         for a, b in zip(r[1:], ref[1:]):
             assert rel_l2(a, b) < 1e-4
+
+
+def test_laplacian_gather_form_matches_dense():
+    from fpc_diffrend_amd import fit, scene
+    sc = scene.cfg('cfg1', n_frames=3)
+    topo = fit.MeshTopology(sc.pos_idx, sc.n_vertices, 'cuda')
+    g = torch.Generator().manual_seed(0)
+    verts = (torch.tensor(sc.v_base).reshape(1, -1, 3) + 0.1 * torch.randn(3, sc.n_vertices, 3, generator=g)).cuda()
+    v1 = verts.clone().requires_grad_(True)
+    l1 = fit.mesh_laplacian_smoothing(v1, topo)
+    l1.backward()
+    # dense restatement (pytorch3d mesh_laplacian_smoothing(method='uniform') semantics)
+    V = sc.n_vertices
+    A = torch.zeros(V, V, device='cuda')
+    A[topo.edges[:, 0], topo.edges[:, 1]] = 1
+    A[topo.edges[:, 1], topo.edges[:, 0]] = 1
+    L = A / A.sum(1, keepdim=True).clamp(min=1) - torch.eye(V, device='cuda')
+    v2 = verts.clone().requires_grad_(True)
+    l2 = torch.matmul(L[None], v2).norm(dim=2).mean()
+    l2.backward()
+    assert abs(float(l1) - float(l2)) < 1e-6 * abs(float(l2))
+    assert rel_l2(v1.grad, v2.grad) < 1e-5
+
+
+def test_transform_clip_kernel_matches_torch():
+    from fpc_diffrend_amd import camera, fit
+    g = torch.Generator().manual_seed(0)
+    F, Nc, V = 3, 4, 1000
+    mvp = torch.randn(F * Nc, 4, 4, generator=g).cuda().requires_grad_(True)
+    verts = torch.randn(F, V, 3, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(F * Nc, V, 4, generator=g).cuda()
+    ref = camera.transform_clip(mvp, verts)            # reference camera.py:19-23, batched torch.matmul
+    (ref * go).sum().backward()
+    gm, gv = mvp.grad.clone(), verts.grad.clone()
+    mvp.grad = None; verts.grad = None
+    out = fit.transform_clip_batched(mvp, verts)
+    (out * go).sum().backward()
+    assert rel_l2(out, ref) < 1e-6
+    assert rel_l2(mvp.grad, gm) < 1e-5 and rel_l2(verts.grad, gv) < 1e-6
