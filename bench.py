@@ -53,6 +53,20 @@ def algorithmic_bytes_per_px(C, with_db):
     }
 
 
+def measured_traffic(name, workload, n_images, C):
+    """HBM bytes per launch of one entry point from the committed rocprofv3 PMC passes (profiles/r01_traffic.json),
+    or None when no pass exists for this configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+        if t["workload"] != workload or t["images"] != n_images or t["channels"] != C:
+            return None
+        k = t["kernels"][name]
+        return (k["fetch_kb"] * k["fetch_factor"] + k["write_kb"]) * 1024.0
+    except Exception:
+        return None
+
+
 def standalone_op_sweep(fitter, reps=3):
     """HIP-event time of every nvdiffrast-style operator (the separate C-ABI calls) at the bench's batch size, outside
     the timed region: the fit loop itself runs the fused objective, so this is where the per-operator roofline
@@ -202,7 +216,7 @@ def main():
             dom = max(px_ops, key=lambda k: px_ops[k]["avg_ms"] * px_ops[k]["calls"])
             a = px_ops[dom]["algorithmic_GBps"]
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": a / HBM_PEAK_GBS, "traffic": None,
+                               "frac": a / HBM_PEAK_GBS, "traffic": measured_traffic(dom, args.workload, fpg * n_cam, C),
                                "note": "dense-equivalent algorithmic bytes (every pixel counted) / HIP-event time of the "
                                        "C-ABI call inside the timed region; the fused kernels are bounded by raster "
                                        "arithmetic and f32 atomics, not by HBM (DESIGN.md section 4.5)"}
@@ -214,6 +228,7 @@ def main():
                     a = st["fpcdr_antialias_bwd"]["algorithmic_GBps"]
                     out["roofline_antialias_bwd"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                      "frac": a / HBM_PEAK_GBS,
+                                                     "traffic": measured_traffic("fpcdr_antialias_bwd", args.workload, fpg * n_cam, C),
                                                      "note": "stand-alone dr.antialias backward at the same batch, outside the timed region"}
             except Exception as e:   # the sweep must never take the measurement down
                 out["kernels_standalone_ops"] = {"error": repr(e)}
