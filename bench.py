@@ -137,7 +137,7 @@ def main():
     rank, world, local_rank = fdist.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     _lib.load()
 

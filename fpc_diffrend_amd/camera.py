@@ -17,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+_DATA = os.path.dirname(os.path.abspath(__file__))
 
 
 def transform_clip(mvp, pos):

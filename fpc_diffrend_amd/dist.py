@@ -28,9 +28,10 @@ def init(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(local_rank)
+        backend = os.environ.get("FPCDR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        # one process per GPU; the modulo only matters when a test oversubscribes a box with fewer GPUs than ranks
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank

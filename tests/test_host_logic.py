@@ -138,3 +138,37 @@ def test_ops_reject_cpu_tensors_and_missing_gpu():
         dr.interpolate(torch.zeros(1, 3, 2), torch.zeros(1, 4, 4, 4), torch.zeros(1, 3, dtype=torch.int32))
     with pytest.raises(ValueError):
         dr.texture(torch.zeros(1, 4, 4, 1), torch.zeros(1, 4, 4, 2), filter_mode='bogus')
+
+
+def test_meshdata_matches_reference_golden(tmp_path):
+    # golden: what the reference's data.MeshData (data.py:7-39) parses from the fixture's OBJ text
+    from fpc_diffrend_amd import data
+    with open(os.path.join(GOLD, "meshdata_golden.json")) as f:
+        g = json.load(f)
+    p = tmp_path / "tiny.obj"
+    p.write_text(g["obj_text"])
+    md = data.MeshData(str(p))
+    for name in ("vertices", "uv", "faces", "fuv"):
+        got = getattr(md, name)
+        assert str(got.dtype) == g[name + "_dtype"]
+        np.testing.assert_array_equal(got, np.asarray(g[name], dtype=got.dtype))
+    # blendshape deltas (reference fit.py:199-220) and frame count helper (fit.py:29-43)
+    d = tmp_path / "bs"
+    d.mkdir()
+    (d / "a.obj").write_text("v 1 1 1\nv 2 0 0.5\nv 1 1 0\nv 0 1 -0.25\n")
+    B = data.load_blendshape_deltas(str(d), md.vertices)
+    assert B.shape == (12, 1) and B.dtype == np.float32
+    np.testing.assert_allclose(B[:3, 0], [1, 1, 1])
+    cams = tmp_path / "take"
+    for c in ("x_pod1primary", "x_pod2primary"):
+        (cams / c).mkdir(parents=True)
+        for i in range(3):
+            (cams / c / f"{c}_{i:02d}.tif").write_text("")
+    assert data.assert_num_frames(["x_pod1primary", "x_pod2primary"], str(cams)) == (3, 2)
+    rig = os.path.join(ROOT, "fpc_diffrend_amd", "rig9.json")
+    with open(rig) as f:
+        cal = {k: dict(v, distortion=[[0.0]] * 5) for k, v in json.load(f)["cameras"].items()}
+    cp = tmp_path / "calibration.json"
+    cp.write_text(json.dumps(cal))
+    look = data.load_calibration(str(cp), ["x_pod1primary", "x_pod2primary"])
+    assert look[1]['cam'] == "x_pod2primary" and look[1]['intr'].shape == (3, 3) and look[1]['trans_calib'].shape == (3, 1)
