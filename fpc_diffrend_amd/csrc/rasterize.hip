@@ -8,7 +8,7 @@
 //   k_setup   one thread per (image, triangle): clip -> 24.8 fixed point (double arithmetic, rules
 //             R1-R3 of DESIGN.md) and the float32 depth plane of R6; writes a 40-byte record + an 8-byte
 //             pixel bounding box, the 256-triangle chunk box and folds the image-wide bounding box.
-//   k_bins    one 256-thread workgroup per 64x64-pixel bin.  The bin scans the image's bounding
+//   k_bins    one 256-thread workgroup per 32x32-pixel bin (one 16x16 tile per wave, four pixels per lane).  The bin scans the image's bounding
 //             boxes (8 B per triangle, L2 resident), keeps the overlapping triangles IN ORDER in
 //             LDS, 256 at a time, expands them to edge equations in LDS and marks which of the bin's
 //             64 8x8 tiles each one touches (bit masks in LDS).  Each wave owns 16 tiles, one pixel
@@ -33,13 +33,17 @@ constexpr int SUBPIX = 256;
 constexpr int HALFPIX = 128;
 constexpr double GUARD = 16777216.0;  // 2^24
 
-constexpr int BIN = 64;          // pixels per bin side
+#ifndef FPCDR_BIN
+#define FPCDR_BIN 32   // measured at cfg3: 64 -> 5.2 ms, 32 -> 3.6 ms (fused forward): smaller bins balance the rim better
+#endif
+constexpr int BIN = FPCDR_BIN;   // pixels per bin side
 constexpr int TILE = 16;         // pixels per tile side; a wave covers a tile with 4 pixels per lane (2x2 quads of 8x8)
 constexpr int QUAD = 8;
 constexpr int TILES_X = BIN / TILE;
-constexpr int NTILES = TILES_X * TILES_X;   // 16 tiles per bin
+constexpr int NTILES = TILES_X * TILES_X;   // 4 tiles per bin
 constexpr int BATCH = 256;       // triangles expanded in LDS at a time (= block size)
-constexpr int TILES_PER_WAVE = NTILES / 4;  // 4 (x 4 pixels per lane = 16 pixels of state per lane)
+constexpr int TILES_PER_WAVE = NTILES / 4;  // 1 (x 4 pixels per lane)
+static_assert(TILES_PER_WAVE >= 1, "a bin needs at least one tile per wave");
 
 struct __attribute__((aligned(8))) TriRec {  // 40 bytes
     int32_t X0, Y0, X1, Y1, X2, Y2;   // snapped vertices (R2)
@@ -385,7 +389,7 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
 #pragma unroll
                 for (int k = 0; k < TILES_PER_WAVE; ++k) {
                     const int tile = wave * TILES_PER_WAVE + k;
-                    const int px = bin_x0 + (tile & 3) * TILE + lx, py = bin_y0 + (tile >> 2) * TILE + ly;
+                    const int px = bin_x0 + (tile % TILES_X) * TILE + lx, py = bin_y0 + (tile / TILES_X) * TILE + ly;
                     asm volatile("" ::: "memory");   // keep the 16 tiles' LDS mask loads from being hoisted together
                     fine_tile<true>(s_mask[0][tile], s_tri, px * SUBPIX + HALFPIX, py * SUBPIX + HALFPIX, best_d[k], best_id[k]);
                 }
@@ -393,7 +397,7 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
 #pragma unroll
                     for (int k = 0; k < TILES_PER_WAVE; ++k) {
                         const int tile = wave * TILES_PER_WAVE + k;
-                        const int px = bin_x0 + (tile & 3) * TILE + lx, py = bin_y0 + (tile >> 2) * TILE + ly;
+                        const int px = bin_x0 + (tile % TILES_X) * TILE + lx, py = bin_y0 + (tile / TILES_X) * TILE + ly;
                         asm volatile("" ::: "memory");
                         fine_tile<false>(s_mask[1][tile], s_tri, px * SUBPIX + HALFPIX, py * SUBPIX + HALFPIX, best_d[k], best_id[k]);
                     }
@@ -426,7 +430,7 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
         const int tile = wave * TILES_PER_WAVE + k;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int px = bin_x0 + (tile & 3) * TILE + (q & 1) * QUAD + lx, py = bin_y0 + (tile >> 2) * TILE + (q >> 1) * QUAD + ly;
+            const int px = bin_x0 + (tile % TILES_X) * TILE + (q & 1) * QUAD + lx, py = bin_y0 + (tile / TILES_X) * TILE + (q >> 1) * QUAD + ly;
             if (px >= W || py >= H) continue;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
             const int t = best_id[k][q];
@@ -674,7 +678,7 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
-                    p->ibox ? 2 * BIN : -1, (int4 *)p->ibox};
+                    p->ibox ? 160 : -1, (int4 *)p->ibox};   // consumers look at most 64 + 64 + 1 px beyond the box
     hipLaunchKernelGGL((k_bins<false, true>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
                        recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr, sh);
     FPCDR_CHECK_LAUNCH();
