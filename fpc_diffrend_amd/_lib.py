@@ -35,13 +35,13 @@ class RasterizeBwd(ctypes.Structure):
 class RenderFwd(ctypes.Structure):
     _fields_ = [("pos", _p), ("tri", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i), ("scratch", _p),
                 ("uv", _p), ("uv_tri", _p), ("Vt", _i), ("tex", _p), ("Ht", _i), ("Wt", _i), ("C", _i),
-                ("boundary_mode", _i), ("rast", _p), ("color", _p), ("ibox", _p)]
+                ("boundary_mode", _i), ("rast", _p), ("color", _p), ("tri_uv", _p), ("ibox", _p)]
 
 
 class RenderBwd(ctypes.Structure):
     _fields_ = [("pos", _p), ("tri", _p), ("uv", _p), ("uv_tri", _p), ("tex", _p), ("rast", _p), ("dy", _p), ("B", _i),
                 ("V", _i), ("T", _i), ("H", _i), ("W", _i), ("Vt", _i), ("Ht", _i), ("Wt", _i), ("C", _i),
-                ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p)]
+                ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p), ("tri_uv", _p)]
 
 
 class AaLossFwd(ctypes.Structure):
@@ -53,7 +53,8 @@ class AaLossFwd(ctypes.Structure):
 class RenderAaBwd(ctypes.Structure):
     _fields_ = [("pos", _p), ("tri", _p), ("uv", _p), ("uv_tri", _p), ("tex", _p), ("rast", _p), ("color", _p),
                 ("grad_aa", _p), ("sil", _p), ("flags", _p), ("ibox", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i),
-                ("Vt", _i), ("Ht", _i), ("Wt", _i), ("C", _i), ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p)]
+                ("Vt", _i), ("Ht", _i), ("Wt", _i), ("C", _i), ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p),
+                ("tri_uv", _p)]
 
 
 class InterpolateFwd(ctypes.Structure):

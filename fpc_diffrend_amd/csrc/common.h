@@ -85,21 +85,31 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 
 // Lanes of a wave that share `key` (>= 0) sum their N values; the group's first lane calls emit(key, sums).
 // Lanes with key < 0 do not participate.  Convergent: every lane of the wave must call it.
+// The sums are parked in the leader lanes' registers while the groups are walked, and ALL leaders emit together
+// afterwards: emitting inside the loop would run the (LDS / memory) latency of every group one after the other in a
+// single lane (measured: 2.5 ms of a 5.2 ms kernel).
 template <int N, typename Emit>
 __device__ __forceinline__ void wave_group_reduce(int key, const float (&val)[N], Emit &&emit) {
     unsigned long long todo = __ballot(key >= 0);
     const int l = lane_id();
+    float out[N];
+    bool is_leader = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = 0.0f;
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const int k = __builtin_amdgcn_readlane(key, leader);
         const unsigned long long grp = __ballot(key == k) & todo;
         const bool mine = (grp >> l) & 1ull;
-        float sums[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) sums[i] = wave_sum_dpp(mine ? val[i] : 0.0f);
-        if (l == leader) emit(k, sums);
+        for (int i = 0; i < N; ++i) {
+            const float sm = wave_sum_dpp(mine ? val[i] : 0.0f);
+            if (l == leader) out[i] = sm;
+        }
+        if (l == leader) is_leader = true;
         todo &= ~grp;
     }
+    if (is_leader) emit(key, out);
 }
 
 // Full-wave integer min / max with DPP (same structure as wave_sum_dpp); result in every lane.
@@ -112,3 +122,6 @@ __device__ __forceinline__ int wave_min_dpp(int v) {
     v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));
     return __builtin_amdgcn_readlane(v, 63);
 }
+
+// (An LDS-atomic variant of the per-group sums -- leaders store, members ds_add_f32 into a wave-private scratch --
+// was measured 75 % SLOWER than the DPP reductions above: same-address LDS float atomics serialise badly.)

@@ -242,6 +242,7 @@ struct ShadeArgs {
     int Ht, Wt, C, boundary;
     int sparse_margin;       // >= 0: bins farther than this many pixels from the image's bounding box write nothing
     int4 *ibox_out;          // sparse mode: per-image bounding box for the consumers (fused.hip), else null
+    const float2 *tri_uv;    // optional [T,3]: uv[uv_tri] pre-gathered
 };
 
 template <bool WRITE_DB, bool SHADE>
@@ -449,7 +450,9 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
                 // interpolate (reference fit.py:157) + texture 'linear' (fit.py:158), same arithmetic as the stand-alone
                 // kernels; an empty pixel samples uv = (0,0) exactly as they do (one tap set, hoisted out of the loops)
                 if (t >= 0) {
-                    const float2 q0 = sh.uv[sh.uv_tri[3 * t]], q1 = sh.uv[sh.uv_tri[3 * t + 1]], q2 = sh.uv[sh.uv_tri[3 * t + 2]];
+                    float2 q0, q1, q2;
+                    if (sh.tri_uv) { q0 = sh.tri_uv[3 * t]; q1 = sh.tri_uv[3 * t + 1]; q2 = sh.tri_uv[3 * t + 2]; }
+                    else { q0 = sh.uv[sh.uv_tri[3 * t]]; q1 = sh.uv[sh.uv_tri[3 * t + 1]]; q2 = sh.uv[sh.uv_tri[3 * t + 2]]; }
                     const float w = 1.0f - o.x - o.y;
                     const float tu = o.x * q0.x + o.y * q1.x + w * q2.x;
                     const float tv = o.x * q0.y + o.y * q1.y + w * q2.y;
@@ -523,7 +526,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const float4 *__restrict__ p
                                                     const float *__restrict__ tex, const float4 *__restrict__ rast,
                                                     const float *__restrict__ dy, int V, int T, int H, int W, int Ht, int Wt,
                                                     int C, int boundary, float *__restrict__ grad_pos,
-                                                    float *__restrict__ grad_tex) {
+                                                    float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
     const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
@@ -543,7 +546,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(const float4 *__restrict__ p
             float2 q0 = make_float2(0.f, 0.f), q1 = q0, q2 = q0;
             float tu = 0.0f, tv = 0.0f;
             if (t >= 0) {
-                q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]];
+                if (tri_uv) { q0 = tri_uv[3 * t]; q1 = tri_uv[3 * t + 1]; q2 = tri_uv[3 * t + 2]; }
+                else { q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]]; }
                 const float w = 1.0f - r.x - r.y;
                 tu = r.x * q0.x + r.y * q1.x + w * q2.x;
                 tv = r.x * q0.y + r.y * q1.y + w * q2.y;
@@ -678,7 +682,7 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
-                    p->ibox ? 160 : -1, (int4 *)p->ibox};   // consumers look at most 64 + 64 + 1 px beyond the box
+                    p->ibox ? 160 : -1, (int4 *)p->ibox, (const float2 *)p->tri_uv};   // consumers look at most 64 + 64 + 1 px beyond the box
     hipLaunchKernelGGL((k_bins<false, true>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
                        recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr, sh);
     FPCDR_CHECK_LAUNCH();
@@ -695,7 +699,7 @@ extern "C" int fpcdr_render_bwd(const fpcdr_render_bwd_params *p, void *stream) 
     dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
     hipLaunchKernelGGL(k_render_bwd, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)p->pos, p->tri,
                        (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->dy, p->V, p->T, p->H, p->W, p->Ht,
-                       p->Wt, p->C, p->boundary_mode, p->grad_pos, p->grad_tex);
+                       p->Wt, p->C, p->boundary_mode, p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }

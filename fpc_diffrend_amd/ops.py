@@ -159,9 +159,10 @@ class _render_textured_func(torch.autograd.Function):
         rast = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
         color = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
         scratch = torch.empty(lib.fpcdr_rasterize_scratch_bytes(B, T), dtype=torch.uint8, device=dev)
+        tri_uv = uv[uv_tri.long()].contiguous()      # [T,3,2], static per mesh
         p = _lib.RenderFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
                            uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C, boundary_mode=boundary,
-                           rast=_ptr(rast), color=_ptr(color))
+                           rast=_ptr(rast), color=_ptr(color), tri_uv=_ptr(tri_uv))
         _lib.call("fpcdr_render_fwd", ctypes.byref(p), _stream())
         ctx.save_for_backward(pos, tri, uv, uv_tri, tex, rast)
         ctx.boundary = boundary
@@ -181,7 +182,7 @@ class _render_textured_func(torch.autograd.Function):
         dy = dy.contiguous()
         p = _lib.RenderBwd(pos=_ptr(pos), tri=_ptr(tri), uv=_ptr(uv), uv_tri=_ptr(uv_tri), tex=_ptr(tex), rast=_ptr(rast),
                            dy=_ptr(dy), B=B, V=V, T=tri.shape[0], H=H, W=W, Vt=uv.shape[0], Ht=Ht, Wt=Wt, C=C,
-                           boundary_mode=ctx.boundary, grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex))
+                           boundary_mode=ctx.boundary, grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex), tri_uv=None)
         _lib.call("fpcdr_render_bwd", ctypes.byref(p), _stream())
         return g_pos, None, None, None, g_tex, None, None, None
 
@@ -221,9 +222,10 @@ class _pixel_objective_func(torch.autograd.Function):
         scratch = torch.empty(lib.fpcdr_rasterize_scratch_bytes(B, T), dtype=torch.uint8, device=dev)
         # sparse: image regions far from any geometry are neither written nor read by the three kernels
         ibox = torch.empty(B, 4, dtype=torch.int32, device=dev) if sparse else None
+        tri_uv = uv[uv_tri.long()].contiguous()      # [T,3,2], static per mesh: saves a dependent load per pixel
         p = _lib.RenderFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
                            uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C, boundary_mode=boundary,
-                           rast=_ptr(rast), color=_ptr(color), ibox=_ptr(ibox))
+                           rast=_ptr(rast), color=_ptr(color), tri_uv=_ptr(tri_uv), ibox=_ptr(ibox))
         _lib.call("fpcdr_render_fwd", ctypes.byref(p), _stream())
         del scratch
         g_aa = torch.empty_like(color)
@@ -235,13 +237,13 @@ class _pixel_objective_func(torch.autograd.Function):
                            H=H, W=W, C=C, V=V, T=T, bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
                            flags=_ptr(flags), grad_aa=_ptr(g_aa), ibox=_ptr(ibox), loss_sum=_ptr(acc))
         _lib.call("fpcdr_aa_loss_fwd", ctypes.byref(q), _stream())
-        ctx.save_for_backward(pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, ibox)
+        ctx.save_for_backward(pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, ibox, tri_uv)
         ctx.boundary = boundary
         return (acc.sum() / n_total).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
-        pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, ibox = ctx.saved_tensors
+        pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, ibox, tri_uv = ctx.saved_tensors
         B, V, _ = pos.shape
         _, H, W, _ = rast.shape
         Ht, Wt, C = tex.shape
@@ -251,7 +253,7 @@ class _pixel_objective_func(torch.autograd.Function):
                              color=_ptr(color), grad_aa=_ptr(g_aa), sil=_ptr(sil), flags=_ptr(flags), ibox=_ptr(ibox), B=B, V=V,
                              T=tri.shape[0],
                              H=H, W=W, Vt=uv.shape[0], Ht=Ht, Wt=Wt, C=C, boundary_mode=ctx.boundary, grad_pos=_ptr(g_pos),
-                             grad_tex=_ptr(g_tex))
+                             grad_tex=_ptr(g_tex), tri_uv=_ptr(tri_uv))
         _lib.call("fpcdr_render_aa_bwd", ctypes.byref(p), _stream())
         g_pos = g_pos * g if ctx.needs_input_grad[0] else None
         if g_tex is not None:

@@ -87,6 +87,7 @@ typedef struct {
     int32_t Ht, Wt, C, boundary_mode;
     float *rast;            /* out [B,H,W,4] */
     float *color;           /* out [B,H,W,C] */
+    const float *tri_uv;    /* optional [T,3,2]: uv[uv_tri] gathered once per mesh (saves one dependent load per pixel); NULL = look up */
     int32_t *ibox;          /* NULL = dense (every pixel of rast / color is written).  Otherwise out [B,4] = pixel bounding
                                box (x0,y0,x1,y1) of each image's geometry, and SPARSE mode: 64x64-pixel bins farther than
                                128 px from that box are not written at all -- only for consumers that apply the same test
@@ -106,6 +107,7 @@ typedef struct {
     int32_t B, V, T, H, W, Vt, Ht, Wt, C, boundary_mode;
     float *grad_pos;        /* [B,V,4] accumulated, or NULL */
     float *grad_tex;        /* [Ht,Wt,C] accumulated, or NULL */
+    const float *tri_uv;    /* optional [T,3,2], as in fpcdr_render_fwd */
 } fpcdr_render_bwd_params;
 int fpcdr_render_bwd(const fpcdr_render_bwd_params *p, void *stream);
 
@@ -148,6 +150,7 @@ typedef struct {
     int32_t B, V, T, H, W, Vt, Ht, Wt, C, boundary_mode;
     float *grad_pos;       /* [B,V,4] accumulated */
     float *grad_tex;       /* [Ht,Wt,C] accumulated, or NULL */
+    const float *tri_uv;   /* optional [T,3,2], as in fpcdr_render_fwd */
 } fpcdr_render_aa_bwd_params;
 int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *stream);
 
