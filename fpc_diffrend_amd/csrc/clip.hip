@@ -67,7 +67,41 @@ __global__ void __launch_bounds__(256) k_clip_bwd_mvp(const float *__restrict__ 
         }
 }
 
+// Uniform-Laplacian gather over a static, padded one-ring table (reference regulariser, fit.py:581 via pytorch3d):
+//   mode 0 (forward):   out[f][v] = inv_deg[v] * sum_n x[f][n] - x[f][v]            (L x,   L = D^-1 A - I)
+//   mode 1 (backward):  out[f][v] = sum_n inv_deg[n] * x[f][n] - x[f][v]            (L^T x, L^T = A D^-1 - I)
+// nbr [V,D] holds neighbour indices, entries >= V are padding.  Both directions are gathers: no atomics.
+__global__ void __launch_bounds__(256) k_lap_gather(const float *__restrict__ x, const int32_t *__restrict__ nbr,
+                                                    const float *__restrict__ inv_deg, int V, int D, int mode,
+                                                    float *__restrict__ out) {
+    const int f = blockIdx.y;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float *xf = x + (size_t)f * V * 3;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const int n = nbr[(size_t)v * D + d];
+        if (n < V) {
+            const float w = mode ? inv_deg[n] : 1.0f;
+            sx += w * xf[3 * n]; sy += w * xf[3 * n + 1]; sz += w * xf[3 * n + 2];
+        }
+    }
+    const float s = mode ? 1.0f : inv_deg[v];
+    float *o = out + ((size_t)f * V + v) * 3;
+    o[0] = s * sx - xf[3 * v]; o[1] = s * sy - xf[3 * v + 1]; o[2] = s * sz - xf[3 * v + 2];
+}
+
 }  // namespace
+
+extern "C" int fpcdr_laplacian_gather(const float *x, const int32_t *nbr, const float *inv_deg, float *out, int32_t F, int32_t V,
+                                      int32_t D, int32_t transpose, void *stream) {
+    FPCDR_REQUIRE(x && nbr && inv_deg && out, "null pointer");
+    FPCDR_REQUIRE(F > 0 && V > 0 && D > 0 && F <= 65535, "bad sizes");
+    hipLaunchKernelGGL(k_lap_gather, dim3(fpcdr_cdiv(V, 256), F), dim3(256), 0, (hipStream_t)stream, x, nbr, inv_deg, V, D,
+                       transpose ? 1 : 0, out);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
 
 extern "C" int fpcdr_transform_clip_fwd(const float *mvp, const float *verts, float *out, int32_t F, int32_t Nc, int32_t V,
                                         void *stream) {

@@ -223,29 +223,41 @@ class MeshTopology:
             nbr[a, fill[a]] = b; fill[a] += 1
             nbr[b, fill[b]] = a; fill[b] += 1
         self.nbr = torch.tensor(nbr, dtype=torch.long, device=device)
+        self.nbr32 = self.nbr.to(torch.int32).contiguous()
 
 
 class _uniform_laplacian(torch.autograd.Function):
     """L X with L = D^-1 A - I for a batch of vertex buffers [F,V,3].  Forward and backward are both GATHERS over the
-    static one-ring table (L^T = A D^-1 - I), so no scatter / index_put runs in the step."""
+    static one-ring table (L^T = A D^-1 - I), so no scatter / index_put runs in the step (fpcdr_laplacian_gather on
+    the GPU; the same arithmetic in torch elsewhere)."""
 
     @staticmethod
-    def forward(ctx, verts, nbr, inv_deg):
-        ctx.save_for_backward(nbr, inv_deg)
-        pad = torch.cat([verts, torch.zeros_like(verts[:, :1])], dim=1)
-        return pad[:, nbr].sum(dim=2) * inv_deg[None, :, None] - verts
+    def _apply(x, nbr, nbr32, inv_deg, transpose):
+        if x.is_cuda:
+            x = x.contiguous()
+            out = torch.empty_like(x)
+            _lib.call("fpcdr_laplacian_gather", _ptr(x), _ptr(nbr32), _ptr(inv_deg), _ptr(out), x.shape[0], x.shape[1],
+                      nbr32.shape[1], 1 if transpose else 0, _stream())
+            return out
+        xs = x * inv_deg[None, :, None] if transpose else x
+        pad = torch.cat([xs, torch.zeros_like(xs[:, :1])], dim=1)
+        s = pad[:, nbr].sum(dim=2)
+        return (s if transpose else s * inv_deg[None, :, None]) - x
+
+    @staticmethod
+    def forward(ctx, verts, nbr, nbr32, inv_deg):
+        ctx.save_for_backward(nbr, nbr32, inv_deg)
+        return _uniform_laplacian._apply(verts, nbr, nbr32, inv_deg, False)
 
     @staticmethod
     def backward(ctx, g):
-        nbr, inv_deg = ctx.saved_tensors
-        gs = g * inv_deg[None, :, None]
-        pad = torch.cat([gs, torch.zeros_like(gs[:, :1])], dim=1)
-        return pad[:, nbr].sum(dim=2) - g, None, None
+        nbr, nbr32, inv_deg = ctx.saved_tensors
+        return _uniform_laplacian._apply(g, nbr, nbr32, inv_deg, True), None, None, None
 
 
 def mesh_laplacian_smoothing(verts, topo):
     """Uniform Laplacian smoothing: mean_v || mean_{n in N(v)} x_n - x_v ||, averaged over meshes [F,V,3]."""
-    lap = _uniform_laplacian.apply(verts, topo.nbr, topo.inv_deg)
+    lap = _uniform_laplacian.apply(verts, topo.nbr, topo.nbr32, topo.inv_deg)
     return lap.norm(dim=2).mean()
 
 

@@ -282,6 +282,12 @@ int fpcdr_transform_clip_fwd(const float *mvp, const float *verts, float *out, i
 int fpcdr_transform_clip_bwd(const float *mvp, const float *verts, const float *grad_out, float *grad_verts, float *grad_mvp,
                              int32_t F, int32_t Nc, int32_t V, void *stream);
 
+/* uniform mesh Laplacian (reference fit.py:581, pytorch3d mesh_laplacian_smoothing 'uniform'), gather form:
+ *   transpose = 0: out = L x,  L = D^-1 A - I;   transpose = 1: out = L^T x (the backward of the former)
+ * x, out [F,V,3]; nbr [V,D] int32 one-ring table padded with indices >= V; inv_deg [V].                       */
+int fpcdr_laplacian_gather(const float *x, const int32_t *nbr, const float *inv_deg, float *out, int32_t F, int32_t V, int32_t D,
+                           int32_t transpose, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* blend -- V = v_base + Bmat . w     reference fit.py:115-122 (prior), :58-62 (free)            */
 /* ------------------------------------------------------------------------------------------ */
