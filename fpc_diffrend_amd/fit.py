@@ -300,6 +300,10 @@ class FitConfig:
     fused_render: bool = True       # rasterize + interpolate + texture as one kernel pair (non-mip); False = four separate ops
     fused_objective: bool = True    # with fused_render and fused_loss: the whole pixel term as three kernels (ops.pixel_objective)
     sparse_objective: bool = True   # the three kernels skip image regions far from any geometry (same result)
+    hip_graph: bool = False         # capture forward+backward and the Adam update as two HIP graphs (launch-bound
+                                    # small batches: cfg2 3.2 -> 1.8 ms / step; no gain once a step is GPU-bound)
+    shading: str = "texture"        # 'texture' = reference render(); 'vertex' = rasterize + interpolate of a per-vertex
+                                    # grey only (BASELINE.json configs[1]: "raster+interp only, no texture")
 
 
 def setup_dataset(blendshapes, n_frames, device):
@@ -343,6 +347,11 @@ class Fitter:
         self.uv = torch.tensor(sc.uv, dtype=torch.float32, device=dev)
         self.uv_idx = torch.tensor(sc.uv_idx, dtype=torch.int32, device=dev)
         self.topo = MeshTopology(sc.pos_idx, sc.n_vertices, dev)
+        if cfg.shading == 'vertex':
+            tex_np = np.asarray(sc.texture, dtype=np.float32)
+            iu = np.clip((sc.uv[:, 0] * tex_np.shape[1]).astype(int), 0, tex_np.shape[1] - 1)
+            iv = np.clip((sc.uv[:, 1] * tex_np.shape[0]).astype(int), 0, tex_np.shape[0] - 1)
+            self.vcol = torch.tensor(tex_np[iv, iu, :1], dtype=torch.float32, device=dev)      # [Vt,1]
         # ---- parameters (fit.py:433-480) ----
         gen = torch.Generator().manual_seed(cfg.seed)
         if cfg.init_texture == 'truth':
@@ -378,7 +387,14 @@ class Fitter:
                   {"params": self.maps_intermediate['local'], 'lr': cfg.lr_base}, {"params": self.t_opt, 'lr': cfg.lr_t},
                   {"params": self.q_opt, 'lr': cfg.lr_q}, {"params": self.per_frame_t, 'lr': cfg.lr_t},
                   {"params": self.per_frame_q, 'lr': cfg.lr_q}, {"params": self.tex_opt, 'lr': cfg.lr_base * cfg.lr_tex_coef}]
-        self.optimizer = torch.optim.Adam(groups, lr=cfg.lr_base)
+        self.use_graph = bool(cfg.hip_graph) and dev.type == 'cuda'
+        if self.use_graph:      # replayed updates read the learning rates from device memory
+            for g in groups:
+                g['lr'] = torch.tensor(float(g['lr']), dtype=torch.float32, device=dev)
+            self.optimizer = torch.optim.Adam(groups, lr=torch.tensor(cfg.lr_base, dtype=torch.float32, device=dev), capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=cfg.lr_base)
+        self._graphs, self._graph_key, self._frame_idx = None, None, None
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lr_lambda=lambda x: cfg.lr_ramp ** (float(x) / float(cfg.max_iter)))
         self.params = [g["params"][0] for g in self.optimizer.param_groups]
@@ -443,10 +459,21 @@ class Fitter:
             verts = blend_batched(self.v_base, self.datasets['local'], w_gt[ids]).reshape(len(ids), -1, 3)
             rigid = camera.rigid_grad(t_gt[ids], camera.unitquat_to_rotmat(q_gt[ids]))
             mvp = torch.matmul(self.proj[None], torch.matmul(rigid[:, None], self.t_mv[None])).reshape(-1, 4, 4)
-            img = render(ctx, mvp, verts, self.pos_idx, self.uv, self.uv_idx, tex, self.resolution, False, 0)
+            if self.cfg.shading == 'vertex':
+                img, rast_t = self.render_vertex(ctx, transform_clip_batched(mvp, verts))
+                img = torch.where(rast_t[..., 3:] > 0, img, torch.tensor(BACKGROUND, device=dev))
+            else:
+                img = render(ctx, mvp, verts, self.pos_idx, self.uv, self.uv_idx, tex, self.resolution, False, 0)
             img = torch.clamp(torch.round(img[..., 0] * 255.0), 0, 140).to(torch.uint8)
             out[lo - self.frame_lo: lo - self.frame_lo + len(ids)] = img.reshape(len(ids), Nc, H, W)
         return out
+
+    def render_vertex(self, glctx, pos_clip):
+        """rasterize + interpolate only (no texture, no antialias): per-vertex grey through the uv index buffer,
+        background composited like fit.py:161.  Returns (colour [B,H,W,1], rast)."""
+        rast, _ = dr.rasterize(glctx, pos_clip, self.pos_idx, resolution=self.resolution)
+        col, _ = dr.interpolate(self.vcol[None], rast, self.uv_idx)
+        return col, rast
 
     # ------------------------------------------------------------------------------------------
     def pick_frames(self):
@@ -454,8 +481,13 @@ class Fitter:
         k = self.cfg.frames_per_step or n_local
         if k >= n_local:
             return slice(self.frame_lo, self.frame_hi)     # the whole shard: views, no gathers
-        sel = np.sort(self.rng.choice(n_local, size=k, replace=False)) + self.frame_lo
-        return torch.tensor(sel, dtype=torch.long, device=self.device)
+        sel = torch.tensor(np.sort(self.rng.choice(n_local, size=k, replace=False)) + self.frame_lo, dtype=torch.long)
+        if not self.use_graph:
+            return sel.to(self.device)
+        if self._frame_idx is None:     # graphs read the minibatch's frame numbers from one fixed buffer
+            self._frame_idx = torch.empty(k, dtype=torch.long, device=self.device)
+        self._frame_idx.copy_(sel)
+        return self._frame_idx
 
     def loss_and_backward(self, frame_ids):
         """Forward + backward of fit.py:556-611 for a batch of frames x all cameras.  Returns the loss (tensor)."""
@@ -475,9 +507,13 @@ class Fitter:
         ref = self.targets[local].reshape(Fb * Nc, *self.resolution)
         C = self.tex_opt.shape[2]
         n_total = n_img_global * self.resolution[0] * self.resolution[1] * C
-        one_shot = cfg.fused_objective and cfg.fused_render and cfg.fused_loss and not cfg.enable_mip and C in (1, 3, 4)
+        one_shot = (cfg.fused_objective and cfg.fused_render and cfg.fused_loss and not cfg.enable_mip and C in (1, 3, 4)
+                    and cfg.shading == 'texture')
         pos_clip = transform_clip_batched(mvp, vtx_pos_split)        # camera.transform_clip (camera.py:11-23), batched
-        if not one_shot:
+        if cfg.shading == 'vertex':
+            colour, rast_out = self.render_vertex(self.glctx, pos_clip)
+            n_total = n_img_global * self.resolution[0] * self.resolution[1]
+        elif not one_shot:
             colour, rast_out = render_from_clip(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt,
                                                 self.resolution, cfg.enable_mip, cfg.max_mip_level, cfg.fused_render)
         # regularisers (fit.py:578-595): evaluated on this rank's meshes, averaged over all ranks
@@ -515,18 +551,58 @@ class Fitter:
         self.result[frame_ids] = vtx_pos.detach()
         return loss.detach()
 
-    def step(self):
-        """One Adam step (fit.py:524-618): forward, backward, gradient all-reduce, update, schedule, renormalise."""
-        frame_ids = self.pick_frames()
-        loss = self.loss_and_backward(frame_ids)
-        if self.reduce_fn is not None:
-            self.reduce_fn(self.params)
+    def _update(self):
         self.optimizer.step()
-        self.scheduler.step()
         with torch.no_grad():   # fit.py:616-618 (Q3: whole-tensor norm)
             self.q_opt /= torch.sum(self.q_opt ** 2) ** 0.5
             self.per_frame_q /= torch.sum(self.per_frame_q ** 2) ** 0.5
+
+    def step(self):
+        """One Adam step (fit.py:524-618): forward, backward, gradient all-reduce, update, schedule, renormalise."""
+        frame_ids = self.pick_frames()
+        if self.use_graph and self.iteration >= self.GRAPH_WARMUP:
+            loss = self._step_graphed(frame_ids)
+        else:
+            loss = self.loss_and_backward(frame_ids)
+            if self.reduce_fn is not None:
+                self.reduce_fn(self.params)
+            self._update()
+        self.scheduler.step()
         self.iteration += 1
+        return loss
+
+    GRAPH_WARMUP = 3    # eager steps before capture (allocator, Adam state, scratch and topology caches settle)
+
+    def _step_graphed(self, frame_ids):
+        """Replay (capturing first if needed) graph A = forward + backward into fixed gradient buffers and graph B =
+        Adam + quaternion renormalisation; the gradient all-reduce runs between them, outside any graph.  The set of
+        trainable tensors is part of the key: 'combined' mode switches the free-form basis on half way (fit.py:603-608)."""
+        switch = self.cfg.mode == 'combined' and self.iteration > self.cfg.max_iter / 2
+        key = (switch, tuple(p.requires_grad for p in self.params))
+        if self._graph_key != key:
+            # new set of trainable tensors: one eager step first, so that Adam creates their state outside a capture
+            self._graph_key, self._graphs = key, None
+            loss = self.loss_and_backward(frame_ids)
+            if self.reduce_fn is not None:
+                self.reduce_fn(self.params)
+            self._update()
+            return loss
+        if self._graphs is None:
+            if _lib.TIMER is not None:
+                raise RuntimeError("per-kernel timing (KernelTimer) cannot be recorded inside a HIP graph")
+            torch.cuda.synchronize()
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(ga):
+                loss = self.loss_and_backward(frame_ids)
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                self._update()
+            self._graphs = (ga, gb, loss)      # capture does not execute: fall through to the first replay
+        ga, gb, loss = self._graphs
+        ga.replay()
+        if self.reduce_fn is not None:
+            self.reduce_fn(self.params)
+        gb.replay()
         return loss
 
     @torch.no_grad()

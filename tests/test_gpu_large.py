@@ -93,3 +93,52 @@ def test_fit_modes_run_and_descend(mode, mip):
     assert min(losses[6:]) < losses[0], losses
     if mode != "prior":
         assert ft.m3.grad is not None and float(ft.m3.abs().max()) > 0     # the free-form basis is being learned
+
+
+def test_1080p_objective_sparse_equals_dense_and_chain(big):
+    """At BASELINE's full size the three-kernel objective gives the same loss and gradients whether or not it skips the
+    empty image regions, and both equal the chain of separate operators + pixel loss."""
+    dr, sc, pos, tri = big
+    from fpc_diffrend_amd import fit
+    dev = 'cuda'
+    ctx = dr.RasterizeGLContext(device=dev)
+    H, W = sc.resolution
+    trig = tri.to(dev)
+    uv = torch.tensor(sc.uv, device=dev)
+    uv_idx = torch.tensor(sc.uv_idx, device=dev)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    ref = torch.randint(0, 141, (pos.shape[0], H, W), generator=g, dtype=torch.uint8).to(dev)
+    res = {}
+    for name in ("sparse", "dense", "chain"):
+        p = pos.to(dev).clone().requires_grad_(True)
+        tex = torch.tensor(sc.texture, device=dev).clone().requires_grad_(True)
+        if name == "chain":
+            colour, rast = fit.render_from_clip(ctx, p, trig, uv, uv_idx, tex, sc.resolution, False, 0)
+            sum_sq, g_col = fit.pixel_loss_fused(colour, rast, ref)
+            torch.autograd.backward([colour], [g_col])
+            loss = float(sum_sq[0]) / colour.numel()
+        else:
+            out = dr.pixel_objective(ctx, p, trig, uv, uv_idx, tex, ref, sc.resolution, sparse=(name == "sparse"))
+            out.backward()
+            loss = float(out)
+        res[name] = (loss, p.grad.double().cpu(), tex.grad.double().cpu())
+    for name in ("sparse", "dense"):
+        assert abs(res[name][0] - res["chain"][0]) <= 1e-5 * abs(res["chain"][0]), (name, res[name][0], res["chain"][0])
+        assert rel_l2(res[name][1], res["chain"][1]) < 1e-4, name
+        assert rel_l2(res[name][2], res["chain"][2]) < 1e-4, name
+    assert rel_l2(res["sparse"][1], res["dense"][1]) < 2e-5 and rel_l2(res["sparse"][2], res["dense"][2]) < 2e-5
+
+
+def test_vertex_shading_fit_descends():
+    """BASELINE configs[1]'s chain ("raster + interp only, no texture"): rasterize -> interpolate of a per-vertex grey ->
+    pixel loss; the pose / weights gradients come through interpolate and rasterize backward only."""
+    from fpc_diffrend_amd import fit, scene
+    sc = scene.cfg('cfg1', n_frames=2)
+    sc.q_gt[:] = (0.0, 0.0, 0.0, 1.0)
+    cfg = fit.FitConfig(max_iter=20, cam_idxs=(0, 3), lr_base=5e-3, lr_t=5e-3, lr_q=1e-5, shading='vertex',
+                        optimize_texture=False, weight_laplacian=0.0)
+    ft = fit.Fitter(sc, cfg, device='cuda')
+    ft.init_near_truth(0.8)
+    losses = [float(ft.step()) for _ in range(20)]
+    assert np.isfinite(losses).all()
+    assert losses[-1] < losses[0], losses
