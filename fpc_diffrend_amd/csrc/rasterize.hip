@@ -72,6 +72,25 @@ static_assert(sizeof(EdgeRec) == 96, "EdgeRec layout");
 // bounding box touches, |P - anchor| <= 16384 + 2048 sub-pixel units and |A|,|B| <= 16384, so each edge
 // function fits in int32 and the products fit v_mad_i32_i24.  Same integers, fewer and full-rate instructions.
 constexpr int SMALL_EXTENT = 16384;
+// Triangles of the 32-bit class whose bounding box covers at most LANE_MAX pixels of the bin are rasterised by ONE LANE
+// each (a loop over the box, winners folded into the bin's LDS depth buffer with 64-bit atomic min); the others go
+// through the tile path in rounds of BIGB.  On the 30k-triangle rig a triangle's box holds ~50 pixels, a 16x16 tile
+// 256: one lane per triangle issues ~4x fewer instructions than one wave per (triangle, tile).
+#ifndef FPCDR_LANE_MAX
+#define FPCDR_LANE_MAX 256
+#endif
+constexpr int LANE_MAX = FPCDR_LANE_MAX;
+constexpr int BIGB = 64;         // triangles per round of the tile path
+constexpr int SCAN_K = 4;        // live chunks whose bounding boxes are tested per scan iteration
+
+// (depth, triangle) as one ordered 64-bit key: smaller depth first, ties to the smaller triangle index (R6).
+// d + 0.0f turns -0.0 into +0.0, so that the integer order of the keys is the float order of the depths.
+__device__ __forceinline__ unsigned long long zpack(float d, int id) {
+    unsigned int u = __float_as_uint(d + 0.0f);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned int)id;
+}
+constexpr unsigned long long Z_EMPTY = ~0ull;
 
 __device__ __forceinline__ long long floordiv256(long long a) { return a >> 8; }  // arithmetic shift = floor
 
@@ -182,7 +201,7 @@ template <bool SMALL>
 __device__ __forceinline__ void fine_tile(const unsigned long long *mrow, const EdgeRec *s_tri, int Px, int Py, float (&bd)[4],
                                           int (&bi)[4]) {
     constexpr int STEP = QUAD * SUBPIX;   // 2048 sub-pixel units between quadrants
-    for (int wd = 0; wd < BATCH / 64; ++wd) {
+    for (int wd = 0; wd < BIGB / 64; ++wd) {
         unsigned long long m = mrow[wd];
         const unsigned int mlo = __builtin_amdgcn_readfirstlane((unsigned int)m);
         const unsigned int mhi = __builtin_amdgcn_readfirstlane((unsigned int)(m >> 32));
@@ -208,7 +227,7 @@ __device__ __forceinline__ void fine_tile(const unsigned long long *mrow, const 
                     const int E2 = b2 + ((q & 1) ? A2 * STEP : 0) + ((q >> 1) ? B2 * STEP : 0);
                     if ((E0 | E1 | E2) >= 0) {
                         const float d = __fmaf_rn(zA, (float)(rx + (q & 1) * STEP), __fmaf_rn(zB, (float)(ry + (q >> 1) * STEP), z0));
-                        if (d >= -1.0f && d <= 1.0f && d < bd[q]) { bd[q] = d; bi[q] = id; }
+                        if (d >= -1.0f && d <= 1.0f && (d < bd[q] || (d == bd[q] && id < bi[q]))) { bd[q] = d; bi[q] = id; }
                     }
                 }
             } else {
@@ -223,7 +242,7 @@ __device__ __forceinline__ void fine_tile(const unsigned long long *mrow, const 
                     const long long E2 = b2 + ((q & 1) ? A2 * STEP : 0) + ((q >> 1) ? B2 * STEP : 0);
                     if ((E0 | E1 | E2) >= 0) {
                         const float d = __fmaf_rn(zA, (float)(rx + (q & 1) * STEP), __fmaf_rn(zB, (float)(ry + (q >> 1) * STEP), z0));
-                        if (d >= -1.0f && d <= 1.0f && d < bd[q]) { bd[q] = d; bi[q] = id; }
+                        if (d >= -1.0f && d <= 1.0f && (d < bd[q] || (d == bd[q] && id < bi[q]))) { bd[q] = d; bi[q] = id; }
                     }
                 }
             }
@@ -251,12 +270,14 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
                                               const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
                                               const ImgBox *__restrict__ ibox, float4 *__restrict__ rast,
                                               float4 *__restrict__ rast_db, ShadeArgs sh) {
-    __shared__ EdgeRec s_tri[BATCH];
+    __shared__ unsigned long long s_z[BIN * BIN];   // the bin's depth buffer: zpack(depth, triangle), Z_EMPTY = nothing yet
+    __shared__ EdgeRec s_tri[BIGB];     // tile path: edge equations of the current round
+    __shared__ int s_big[BATCH];        // tile path: triangles of the current batch waiting for a round
+    __shared__ int s_nbig;
     __shared__ int s_clist[256];        // live chunks of the current segment (ascending)
-    __shared__ unsigned long long s_mask[2][NTILES][BATCH / 64];   // [0] small triangles, [1] the rest
-    __shared__ int s_any_large;
-    __shared__ int s_list[2 * BATCH];   // pending triangle indices (ascending); first BATCH = current batch
-    __shared__ int s_wave_cnt[2][4];
+    __shared__ unsigned long long s_mask[2][2][NTILES][BIGB / 64];   // [round parity][0 = 32-bit class, 1 = the rest]
+    __shared__ int s_list[(SCAN_K + 1) * BATCH];   // pending triangle indices (any order), consumed from the top
+    __shared__ int s_pending, s_nlive;
 
     const int b = blockIdx.z;
     const int bin_x0 = blockIdx.x * BIN, bin_y0 = blockIdx.y * BIN;
@@ -271,6 +292,7 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
 #pragma unroll
         for (int q = 0; q < 4; ++q) { best_d[k][q] = 2.0f; best_id[k][q] = -1; }
 
+    int total_hits = 0;   // block-uniform: triangles whose bounding box touches this bin
     const ImgBox ib = ibox[b];
     const bool bin_live = !(ib.x1 < bin_x0 || ib.x0 > bin_x1 || ib.y1 < bin_y0 || ib.y0 > bin_y1);
     if (SHADE && sh.sparse_margin >= 0) {
@@ -282,64 +304,81 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
     }
 
     if (bin_live) {
-        for (int k = tid; k < 2 * NTILES * (BATCH / 64); k += 256) (&s_mask[0][0][0])[k] = 0ull;
-        if (tid == 0) s_any_large = 0;
+        for (int k = tid; k < BIN * BIN; k += 256) s_z[k] = Z_EMPTY;
+        for (int k = tid; k < 4 * NTILES * (BIGB / 64); k += 256) (&s_mask[0][0][0][0])[k] = 0ull;
+        if (tid == 0) { s_nbig = 0; s_pending = 0; s_nlive = 0; }
+        __syncthreads();
         const TriBox *bx = boxes + (size_t)b * T;
         const TriRec *rc = recs + (size_t)b * T;
         const int n_chunks = (T + 255) / 256;
         const TriBox *cbx = cboxes + (size_t)b * n_chunks;
-        int pending = 0;  // block-uniform: entries waiting in s_list
-        int it = 0;       // block-uniform: scan iterations done (parity selects the s_wave_cnt buffer)
-        for (int seg = 0; seg <= n_chunks; seg += 256) {
-          // ---- which of the next 256 chunks touch this bin?  (one box test per chunk) ----
-          int n_live = 0;
-          const bool flush_seg = (seg + 256 > n_chunks);   // last segment: flush what is pending at its end
-          {
-              const int c = seg + tid;
-              bool live = false;
-              if (c < n_chunks) {
-                  const TriBox q = cbx[c];
-                  live = (q.x0 <= q.x1) && !(q.x1 < bin_x0 || q.x0 > bin_x1 || q.y1 < bin_y0 || q.y0 > bin_y1);
-              }
-              const unsigned long long bal = __ballot(live);
-              int *cnt = s_wave_cnt[it & 1];
-              ++it;
-              if (lane == 0) cnt[wave] = __popcll(bal);
-              __syncthreads();
-              const int c0 = cnt[0], c1 = cnt[1], c2 = cnt[2], c3 = cnt[3];
-              const int base = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
-              if (live) s_clist[base + __popcll(bal & ((1ull << lane) - 1ull))] = c;
-              n_live = c0 + c1 + c2 + c3;
-              __syncthreads();
-          }
-          for (int ci = 0; ci <= n_live; ++ci) {
-            const bool last = flush_seg && (ci == n_live);
-            if (ci == n_live && !last) break;
-            // ---- scan the 256 bounding boxes of one live chunk, append hits in ascending order ----
-            if (!last) {
-                const int t = s_clist[ci] * 256 + tid;
-                bool hit = false;
-                if (t < T) {
-                    const TriBox q = bx[t];
-                    hit = (q.x0 <= q.x1) && !(q.x1 < bin_x0 || q.x0 > bin_x1 || q.y1 < bin_y0 || q.y0 > bin_y1);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int pending = 0;  // block-uniform copy of s_pending: entries waiting in s_list
+        int round_no = 0; // block-uniform: tile-path rounds done (parity selects the mask buffer)
+        // The winner of a pixel is the minimum of (depth, triangle index), which does not depend on the order in which
+        // triangles arrive: lists are filled with one LDS atomic per wave and consumed from the top, no ordered compaction.
+        auto process_batch = [&](const int n) {
+            // consumes entries [pending - n, pending) of s_list; a barrier has been passed since they were appended
+            // ---- lane path: thread `tid` rasterises triangle `tid` of the batch over its bounding box ----
+            if (tid < n) {
+                const int t = s_list[pending - n + tid];
+                const TriRec r = rc[t];
+                const TriBox q = bx[t];
+                const int ext_x = max(r.X0, max(r.X1, r.X2)) - min(r.X0, min(r.X1, r.X2));
+                const int ext_y = max(r.Y0, max(r.Y1, r.Y2)) - min(r.Y0, min(r.Y1, r.Y2));
+                const int x0 = max((int)q.x0, bin_x0), x1 = min((int)q.x1, bin_x1);
+                const int y0 = max((int)q.y0, bin_y0), y1 = min((int)q.y1, bin_y1);
+                const int bw = x1 - x0 + 1, area = bw * (y1 - y0 + 1);
+                if (ext_x <= SMALL_EXTENT && ext_y <= SMALL_EXTENT && area <= LANE_MAX) {
+                    // every sample lies inside the triangle's box: |P - anchor| <= 16384 + 128, |A|,|B| <= 16384, so the
+                    // edge functions fit int32 and their products v_mad_i32_i24 (same integers as the other paths)
+                    const int D = (r.X1 - r.X0) * (r.Y2 - r.Y0) - (r.Y1 - r.Y0) * (r.X2 - r.X0);
+                    const int sg = D > 0 ? 1 : -1;
+                    const int A0 = -(r.Y2 - r.Y1) * sg, B0 = (r.X2 - r.X1) * sg;
+                    const int A1 = -(r.Y0 - r.Y2) * sg, B1 = (r.X0 - r.X2) * sg;
+                    const int A2 = -(r.Y1 - r.Y0) * sg, B2 = (r.X1 - r.X0) * sg;
+                    // R5 tie rule, folded into the constants: E' = E - 1 for an edge that does not own E == 0
+                    const int n0 = ((-A0 > 0) || (A0 == 0 && B0 < 0)) ? 0 : 1;
+                    const int n1 = ((-A1 > 0) || (A1 == 0 && B1 < 0)) ? 0 : 1;
+                    const int n2 = ((-A2 > 0) || (A2 == 0 && B2 < 0)) ? 0 : 1;
+                    const int Px = x0 * SUBPIX + HALFPIX, Py = y0 * SUBPIX + HALFPIX;
+                    int R0 = __mul24(A0, Px - r.X1) + __mul24(B0, Py - r.Y1) - n0;   // edge functions at the row start
+                    int R1 = __mul24(A1, Px - r.X2) + __mul24(B1, Py - r.Y2) - n1;
+                    int R2 = __mul24(A2, Px - r.X0) + __mul24(B2, Py - r.Y0) - n2;
+                    const int rx0 = Px - r.X0;
+                    int E0 = R0, E1 = R1, E2 = R2, rx = rx0, ry = Py - r.Y0, cx = 0;
+                    int zi = (y0 - bin_y0) * BIN + (x0 - bin_x0);
+#ifdef FPCDR_ABL_NOLANE
+                    for (int i = 0; i < 0; ++i) {
+#else
+                    for (int i = 0; i < area; ++i) {
+#endif
+                        if ((E0 | E1 | E2) >= 0) {
+                            const float d = __fmaf_rn(r.zA, (float)rx, __fmaf_rn(r.zB, (float)ry, r.z0));
+                            if (d >= -1.0f && d <= 1.0f) atomicMin(&s_z[zi + cx], zpack(d, t));
+                        }
+                        ++cx;
+                        const bool wrap = cx == bw;
+                        R0 += wrap ? B0 * SUBPIX : 0; R1 += wrap ? B1 * SUBPIX : 0; R2 += wrap ? B2 * SUBPIX : 0;
+                        E0 = wrap ? R0 : E0 + A0 * SUBPIX; E1 = wrap ? R1 : E1 + A1 * SUBPIX; E2 = wrap ? R2 : E2 + A2 * SUBPIX;
+                        rx = wrap ? rx0 : rx + SUBPIX;
+                        ry += wrap ? SUBPIX : 0;
+                        zi += wrap ? BIN : 0;
+                        cx = wrap ? 0 : cx;
+                    }
+                } else {
+                    s_big[atomicAdd(&s_nbig, 1)] = t;
                 }
-                const unsigned long long bal = __ballot(hit);
-                int *cnt = s_wave_cnt[it & 1];
-                ++it;
-                if (lane == 0) cnt[wave] = __popcll(bal);
-                __syncthreads();
-                const int c0 = cnt[0], c1 = cnt[1], c2 = cnt[2], c3 = cnt[3];
-                const int base = pending + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
-                if (hit) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = t;
-                pending += c0 + c1 + c2 + c3;
             }
-            // ---- process a batch when full (or flush at the end) ----
-            while (pending >= BATCH || (last && pending > 0)) {
-                const int n = min(pending, BATCH);
-                __syncthreads();  // s_list entries and cleared masks are visible
-                // expand triangle `tid` of the batch into edge equations and mark its tiles
-                if (tid < n) {
-                    const int t = s_list[tid];
+            __syncthreads();
+            // ---- tile path, BIGB triangles per round (block-uniform loop; rare on the meshes this is built for) ----
+            const int nbig = s_nbig;
+            for (int base = 0; base < nbig; base += BIGB, ++round_no) {
+                const int m = min(BIGB, nbig - base);
+                unsigned long long (*mask)[NTILES][BIGB / 64] = s_mask[round_no & 1];
+                bool any_large = false;
+                if (tid < m) {
+                    const int t = s_big[base + tid];
                     const TriRec r = rc[t];
                     const TriBox q = bx[t];
                     EdgeRec e;
@@ -360,7 +399,7 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
                         nb = 8;
                         e.v.X1 = r.X1; e.v.Y1 = r.Y1; e.v.X2 = r.X2; e.v.Y2 = r.Y2; e.v.X0 = r.X0; e.v.Y0 = r.Y0;
                     } else {
-                        s_any_large = 1;
+                        any_large = true;
                         const long long X0 = r.X0, Y0 = r.Y0, X1 = r.X1, Y1 = r.Y1, X2 = r.X2, Y2 = r.Y2;
                         const long long D = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
                         const long long sg = D > 0 ? 1 : -1;
@@ -383,37 +422,111 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
                     const int ty0 = (max((int)q.y0, bin_y0) - bin_y0) >> 4, ty1 = (min((int)q.y1, bin_y1) - bin_y0) >> 4;
                     const unsigned long long bit = 1ull << (tid & 63);
                     for (int ty = ty0; ty <= ty1; ++ty)
-                        for (int tx = tx0; tx <= tx1; ++tx) atomicOr(&s_mask[small ? 0 : 1][ty * TILES_X + tx][tid >> 6], bit);
+                        for (int tx = tx0; tx <= tx1; ++tx) atomicOr(&mask[small ? 0 : 1][ty * TILES_X + tx][tid >> 6], bit);
                 }
-                __syncthreads();
-                // ---- fine raster: this wave's 4 tiles of 16x16, four pixels per lane ----
+                const int large_round = __syncthreads_or(any_large ? 1 : 0);
+                // fine raster: this wave's 16x16 tile, four pixels per lane, winners in registers
 #pragma unroll
                 for (int k = 0; k < TILES_PER_WAVE; ++k) {
                     const int tile = wave * TILES_PER_WAVE + k;
                     const int px = bin_x0 + (tile % TILES_X) * TILE + lx, py = bin_y0 + (tile / TILES_X) * TILE + ly;
-                    asm volatile("" ::: "memory");   // keep the 16 tiles' LDS mask loads from being hoisted together
-                    fine_tile<true>(s_mask[0][tile], s_tri, px * SUBPIX + HALFPIX, py * SUBPIX + HALFPIX, best_d[k], best_id[k]);
-                }
-                if (s_any_large) {   // block-uniform; large triangles are rare on the meshes this path is built for
-#pragma unroll
-                    for (int k = 0; k < TILES_PER_WAVE; ++k) {
-                        const int tile = wave * TILES_PER_WAVE + k;
-                        const int px = bin_x0 + (tile % TILES_X) * TILE + lx, py = bin_y0 + (tile / TILES_X) * TILE + ly;
-                        asm volatile("" ::: "memory");
-                        fine_tile<false>(s_mask[1][tile], s_tri, px * SUBPIX + HALFPIX, py * SUBPIX + HALFPIX, best_d[k], best_id[k]);
-                    }
+                    fine_tile<true>(mask[0][tile], s_tri, px * SUBPIX + HALFPIX, py * SUBPIX + HALFPIX, best_d[k], best_id[k]);
+                    if (large_round)
+                        fine_tile<false>(mask[1][tile], s_tri, px * SUBPIX + HALFPIX, py * SUBPIX + HALFPIX, best_d[k], best_id[k]);
                 }
                 __syncthreads();
-                // ---- retire the batch: shift the remaining pending entries down, clear masks ----
-                const int rest = pending - n;
-                int moved = (tid < rest) ? s_list[n + tid] : 0;
-                for (int k = tid; k < 2 * NTILES * (BATCH / 64); k += 256) (&s_mask[0][0][0])[k] = 0ull;
-                if (tid == 0) s_any_large = 0;
-                __syncthreads();
-                if (tid < rest) s_list[tid] = moved;
-                pending = rest;
+                // this parity's masks are next written two rounds from now, with a barrier in between
+                for (int k = tid; k < 2 * NTILES * (BIGB / 64); k += 256) (&mask[0][0][0])[k] = 0ull;
             }
-          }
+            if (tid == 0) { s_pending = pending - n; s_nbig = 0; }
+            pending -= n;
+            __syncthreads();
+        };
+        for (int seg = 0; seg < n_chunks; seg += 256) {
+            // ---- which of the next 256 chunks touch this bin?  (one box test per chunk) ----
+            {
+                const int c = seg + tid;
+                bool live = false;
+                if (c < n_chunks) {
+                    const TriBox q = cbx[c];
+                    live = (q.x0 <= q.x1) && !(q.x1 < bin_x0 || q.x0 > bin_x1 || q.y1 < bin_y0 || q.y0 > bin_y1);
+                }
+                const unsigned long long bal = __ballot(live);
+                int base = 0;
+                if (lane == 0 && bal) base = atomicAdd(&s_nlive, __popcll(bal));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (live) s_clist[base + __popcll(bal & below)] = c;
+            }
+            __syncthreads();
+            const int n_live = s_nlive;
+            // ---- scan the bounding boxes of SCAN_K live chunks per iteration (independent loads in flight) ----
+            for (int ci = 0; ci < n_live; ci += SCAN_K) {
+                bool hit[SCAN_K];
+                int tt[SCAN_K];
+#pragma unroll
+                for (int k = 0; k < SCAN_K; ++k) {
+                    hit[k] = false;
+                    tt[k] = (ci + k < n_live) ? s_clist[ci + k] * 256 + tid : T;
+                }
+                TriBox qk[SCAN_K];
+#pragma unroll
+                for (int k = 0; k < SCAN_K; ++k) qk[k] = bx[min(tt[k], T - 1)];
+                unsigned long long bal[SCAN_K];
+                int total = 0;
+#pragma unroll
+                for (int k = 0; k < SCAN_K; ++k) {
+                    const TriBox q = qk[k];
+                    hit[k] = tt[k] < T && (q.x0 <= q.x1) && !(q.x1 < bin_x0 || q.x0 > bin_x1 || q.y1 < bin_y0 || q.y0 > bin_y1);
+                    bal[k] = __ballot(hit[k]);
+                    total += __popcll(bal[k]);
+                }
+                int base = 0;
+                if (lane == 0 && total) base = atomicAdd(&s_pending, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int k = 0; k < SCAN_K; ++k) {
+                    if (hit[k]) s_list[base + __popcll(bal[k] & below)] = tt[k];
+                    base += __popcll(bal[k]);
+                }
+                __syncthreads();
+                const int before = pending;
+                pending = s_pending;
+                total_hits += pending - before;
+                while (pending >= BATCH) process_batch(BATCH);
+            }
+            if (seg + 256 < n_chunks) {   // another segment follows: recycle the chunk list
+                __syncthreads();
+                if (tid == 0) s_nlive = 0;
+                __syncthreads();
+            }
+        }
+        while (pending > 0) process_batch(min(pending, BATCH));
+    }
+
+#ifdef FPCDR_ABL_OCC
+    if (SHADE && sh.sparse_margin >= 0 && total_hits == 0) return;
+#endif
+    // ---- fold the tile path's register winners into the depth buffer, then read every pixel's winner ----
+    if (bin_live) {
+#pragma unroll
+        for (int k = 0; k < TILES_PER_WAVE; ++k) {
+            const int tile = wave * TILES_PER_WAVE + k;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int zx = (tile % TILES_X) * TILE + (q & 1) * QUAD + lx, zy = (tile / TILES_X) * TILE + (q >> 1) * QUAD + ly;
+                if (best_id[k][q] >= 0) atomicMin(&s_z[zy * BIN + zx], zpack(best_d[k][q], best_id[k][q]));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TILES_PER_WAVE; ++k) {
+            const int tile = wave * TILES_PER_WAVE + k;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int zx = (tile % TILES_X) * TILE + (q & 1) * QUAD + lx, zy = (tile / TILES_X) * TILE + (q >> 1) * QUAD + ly;
+                const unsigned long long z = s_z[zy * BIN + zx];
+                best_id[k][q] = z == Z_EMPTY ? -1 : (int)(unsigned int)z;
+            }
         }
     }
 
