@@ -13,6 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 MAX_ATTR = 32
 MAX_MIP = 16
 LOSS_SLOTS = 256
+OCC_BIN = 32         # FPCDR_OCC_BIN
 ABI_VERSION = 1
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
@@ -35,7 +36,7 @@ class RasterizeBwd(ctypes.Structure):
 class RenderFwd(ctypes.Structure):
     _fields_ = [("pos", _p), ("tri", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i), ("scratch", _p),
                 ("uv", _p), ("uv_tri", _p), ("Vt", _i), ("tex", _p), ("Ht", _i), ("Wt", _i), ("C", _i),
-                ("boundary_mode", _i), ("rast", _p), ("color", _p), ("tri_uv", _p), ("ibox", _p)]
+                ("boundary_mode", _i), ("rast", _p), ("color", _p), ("tri_uv", _p), ("occ", _p), ("empty_color", _p)]
 
 
 class RenderBwd(ctypes.Structure):
@@ -47,12 +48,14 @@ class RenderBwd(ctypes.Structure):
 class AaLossFwd(ctypes.Structure):
     _fields_ = [("color", _p), ("rast", _p), ("pos", _p), ("tri", _p), ("adj", _p), ("ref", _p), ("B", _i), ("H", _i),
                 ("W", _i), ("C", _i), ("V", _i), ("T", _i), ("bg", ctypes.c_float), ("color_scale", ctypes.c_float),
-                ("grad_scale", ctypes.c_float), ("sil", _p), ("flags", _p), ("grad_aa", _p), ("ibox", _p), ("loss_sum", _p)]
+                ("grad_scale", ctypes.c_float), ("sil", _p), ("flags", _p), ("grad_aa", _p), ("occ", _p), ("empty_color", _p),
+                ("loss_sum", _p)]
 
 
 class RenderAaBwd(ctypes.Structure):
     _fields_ = [("pos", _p), ("tri", _p), ("uv", _p), ("uv_tri", _p), ("tex", _p), ("rast", _p), ("color", _p),
-                ("grad_aa", _p), ("sil", _p), ("flags", _p), ("ibox", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i),
+                ("grad_aa", _p), ("sil", _p), ("flags", _p), ("occ", _p), ("empty_color", _p), ("B", _i), ("V", _i), ("T", _i),
+                ("H", _i), ("W", _i),
                 ("Vt", _i), ("Ht", _i), ("Wt", _i), ("C", _i), ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p),
                 ("tri_uv", _p)]
 
@@ -111,6 +114,7 @@ SYMBOLS = {
     "fpcdr_render_fwd": (_int, [ctypes.POINTER(RenderFwd), _p]),
     "fpcdr_render_bwd": (_int, [ctypes.POINTER(RenderBwd), _p]),
     "fpcdr_aa_loss_fwd": (_int, [ctypes.POINTER(AaLossFwd), _p]),
+    "fpcdr_ref_bg_sumsq": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, _p, _p]),
     "fpcdr_render_aa_bwd": (_int, [ctypes.POINTER(RenderAaBwd), _p]),
     "fpcdr_interpolate_fwd": (_int, [ctypes.POINTER(InterpolateFwd), _p]),
     "fpcdr_interpolate_bwd": (_int, [ctypes.POINTER(InterpolateBwd), _p]),

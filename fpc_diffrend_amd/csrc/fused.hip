@@ -10,6 +10,8 @@
 // functions); the separate operators remain the nvdiffrast-compatible API and the parity reference.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 #include "texsample.h"
@@ -17,88 +19,133 @@ namespace {
 #include "aa_pairs.h"
 
 // ------------------------------------------------------------------------------------------------
-// antialias forward (gather form, see antialias.hip) + background composite + squared error, one pixel per lane.
-// Writes d(sum of squares * grad_scale)/d(antialiased colour) and the two flag bit planes; reduces the loss.
-template <int CS>
+// Sparse mode: validity of pixels around a workgroup, from the occupancy map of fpcdr_render_fwd.  A pixel of an
+// unoccupied 32x32 bin was never written: it is EMPTY (rast = 0, colour = empty_color, no gradient).  The window holds
+// the 4 x 3 bins around (bin_x0, bin_y0): bit (dy + 1) * 4 + (dx + 1) for bin (bin_x0 + dx, bin_y0 + dy).
+struct OccWin {
+    unsigned int mask;
+    int bin_x0, bin_y0;
+    __device__ __forceinline__ bool bin(int dx, int dy) const { return (mask >> ((dy + 1) * 4 + dx + 1)) & 1u; }
+    __device__ __forceinline__ bool pixel(int x, int y) const {
+        return bin((x >> 5) - bin_x0, (y >> 5) - bin_y0);
+    }
+};
+__device__ __forceinline__ OccWin load_occ(const uint16_t *occ, int b, int H, int W, int bin_x0, int bin_y0) {
+    const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
+    OccWin w = {occ[((size_t)b * OY + bin_y0) * OX + bin_x0], bin_x0, bin_y0};   // one load, uniform over the workgroup
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// antialias forward (gather form, see antialias.hip) + background composite + squared error.  One workgroup per
+// 64 x 32 pixel block (two bins), one wave per 8 rows, one pixel per lane and row; the rows above / below travel in
+// registers from one row to the next.  Writes d(sum of squares * grad_scale)/d(antialiased colour) and the two flag bit
+// planes; reduces the loss.  SPARSE: blocks without an occupied bin (or an occupied right / upper neighbour, whose
+// pairs a block owns) leave at once, and the loss is accumulated as the difference to an all-background image.
+template <int CS, bool SPARSE>
 __global__ void __launch_bounds__(256) k_aa_loss(const float *__restrict__ color, const float4 *__restrict__ rast,
                                                  const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                  const uint8_t *__restrict__ sil, const uint8_t *__restrict__ ref, int B, int H,
                                                  int W, int V, int T, float bg, float color_scale, float grad_scale,
                                                  unsigned long long *__restrict__ flags, float *__restrict__ g_aa,
-                                                 const int4 *__restrict__ ibox, double *__restrict__ loss_sum) {
+                                                 const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
+                                                 double *__restrict__ loss_sum) {
     __shared__ float s_part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wave, b = blockIdx.z;
+    const int x = blockIdx.x * 64 + lane, b = blockIdx.z;
+    const int band = blockIdx.y;            // 32-row band = bin row
     const int Wq = FPCDR_AA_ROW_WORDS(W);
-    bool fx_flag = false, fy_flag = false;
-    float lsum = 0.0f;
-    bool far = false;   // sparse mode: this wave's 64x64 bin is farther than 64 px from the image's geometry
-    if (ibox) {
-        const int4 ib = ibox[b];
-        const int bx0 = blockIdx.x * 64, by0 = (y >> 6) << 6;
-        far = ib.z + 64 < bx0 || ib.x - 64 > bx0 + 63 || ib.w + 64 < by0 || ib.y - 64 > by0 + 63;
+    OccWin ow = {0xfffu, 2 * (int)blockIdx.x, band};
+    float ecol[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) ecol[c] = 0.0f;
+    if (SPARSE) {
+        ow = load_occ(occ, b, H, W, 2 * blockIdx.x, band);
+        // the block's two bins, their right neighbours (x pairs are owned by the left pixel) and upper neighbours (y pairs)
+        if (!(ow.bin(0, 0) || ow.bin(1, 0) || ow.bin(2, 0) || ow.bin(0, 1) || ow.bin(1, 1))) return;
+#pragma unroll
+        for (int c = 0; c < CS; ++c) ecol[c] = empty_color[c];
     }
-    if (far) {
-        // nothing but background here: (ref - 255 bg)^2, no gradient, no flags (the caller zero-filled them)
-        if (y < H && x < W) {
-            const float d = (float)ref[((size_t)b * H + y) * W + x] - bg * color_scale;
-            lsum = (float)CS * d * d;
-        }
-    } else if (y < H) {
+    const size_t img = (size_t)b * H * W;
+    const bool v_me = ow.bin(lane >> 5, 0);
+    auto load_row = [&](int yy) -> float2 {   // (z, id) of pixel (x, yy); empty outside the image / in an unwritten bin
+        if (x >= W || yy < 0 || yy >= H) return make_float2(0.f, 0.f);
+        if (SPARSE && !ow.pixel(x, yy)) return make_float2(0.f, 0.f);
+        return load_zid(rast, img + (size_t)yy * W + x);
+    };
+    const int ybase = band * 32 + wave * 8;
+    float lsum = 0.0f;
+    float2 dn = load_row(ybase - 1), cur = load_row(ybase);
+    for (int r = 0; r < 8; ++r) {
+        const int y = ybase + r;
+        if (y >= H) break;
+        const float2 up = load_row(y + 1);
+        const float2 me = cur;
+        bool fx_flag = false, fy_flag = false;
         // every lane of the wave (also beyond W) takes part in the neighbour exchange
-        float2 me_w = make_float2(0.f, 0.f);
-        if (x < W) me_w = load_zid(rast, ((size_t)b * H + y) * W + x);
-        const float zr = __shfl_down(me_w.x, 1, 64), ir = __shfl_down(me_w.y, 1, 64);
-        const float zl = __shfl_up(me_w.x, 1, 64), il = __shfl_up(me_w.y, 1, 64);
+        const float zr = __shfl_down(me.x, 1, 64), ir = __shfl_down(me.y, 1, 64);
+        const float zl = __shfl_up(me.x, 1, 64), il = __shfl_up(me.y, 1, 64);
         if (x < W) {
-            const size_t img = (size_t)b * H * W;
             const size_t off = img + (size_t)y * W + x;
-            const float2 me = me_w;
             const int id = (int)me.y;
             const bool hasR = x + 1 < W, hasL = x > 0, hasU = y + 1 < H, hasD = y > 0;
             // left / right neighbours come from the neighbouring lanes' registers; only the two ends of the wave's
-            // 64-pixel span and the rows above / below are loaded
-            const float2 nR = !hasR ? me : (lane < 63 ? make_float2(zr, ir) : load_zid(rast, off + 1));
-            const float2 nL = !hasL ? me : (lane > 0 ? make_float2(zl, il) : load_zid(rast, off - 1));
-            const float2 nU = hasU ? load_zid(rast, off + W) : me;
-            const float2 nD = hasD ? load_zid(rast, off - W) : me;
-            float acc[CS];
-            const float *cme = color + off * CS;
-#pragma unroll
-            for (int c = 0; c < CS; ++c) acc[c] = cme[c];
+            // 64-pixel span are loaded
+            float2 nR = me, nL = me;
+            if (hasR) nR = lane < 63 ? make_float2(zr, ir) : ((!SPARSE || ow.bin(2, 0)) ? load_zid(rast, off + 1) : make_float2(0.f, 0.f));
+            if (hasL) nL = lane > 0 ? make_float2(zl, il) : ((!SPARSE || ow.bin(-1, 0)) ? load_zid(rast, off - 1) : make_float2(0.f, 0.f));
+            const float2 nU = hasU ? up : me;
+            const float2 nD = hasD ? dn : me;
             const bool disc = ((int)nR.y != id) | ((int)nL.y != id) | ((int)nU.y != id) | ((int)nD.y != id);
-            if (disc) {
-                AAGeom g = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
-                auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own, bool &flag) {
-                    if ((int)p0.y == (int)p1.y) return;
-                    bool hit = for_active_edges(g, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
-                        [&](float t, int Px, int Py, int Qx, int Qy, int, int, const EdgeEval &, float) {
-                            const bool far = t >= 0.5f;
-                            const int rx = far ? Qx : Px, ry = far ? Qy : Py;
-                            if (rx != x || ry != y) return;
-                            const int ox = far ? Px : Qx, oy = far ? Py : Qy;
-                            const float amt = far ? t - 0.5f : 0.5f - t;
-                            const float *co = color + (img + (size_t)oy * W + ox) * CS;
-#pragma unroll
-                            for (int c = 0; c < CS; ++c) acc[c] += amt * (co[c] - cme[c]);
-                        });
-                    if (own && hit) flag = true;
-                };
-                bool dummy = false;
-                if (hasR) visit(x, y, 0, me, nR, true, fx_flag);
-                if (hasU) visit(x, y, 1, me, nU, true, fy_flag);
-                if (hasL) visit(x - 1, y, 0, nL, me, false, dummy);
-                if (hasD) visit(x, y - 1, 1, nD, me, false, dummy);
-            }
-            // background (fit.py:161) + squared error (fit.py:579) and its gradient
             const bool covered = id > 0;
-            const float r = (float)ref[off];
+            if (disc | covered) {
+                float acc[CS], cme[CS];
 #pragma unroll
-            for (int c = 0; c < CS; ++c) {
-                const float col = covered ? acc[c] : bg;
-                const float d = r - col * color_scale;
-                lsum += d * d;
-                g_aa[off * CS + c] = covered ? (-2.0f * color_scale * grad_scale) * d : 0.0f;
+                for (int c = 0; c < CS; ++c) { cme[c] = (!SPARSE || v_me) ? color[off * CS + c] : ecol[c]; acc[c] = cme[c]; }
+                if (disc) {
+                    AAGeom g = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
+                    auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own, bool &flag) {
+                        if ((int)p0.y == (int)p1.y) return;
+                        bool hit = for_active_edges(g, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
+                            [&](float t, int Px, int Py, int Qx, int Qy, int, int, const EdgeEval &, float) {
+                                const bool far = t >= 0.5f;
+                                const int rx = far ? Qx : Px, ry = far ? Qy : Py;
+                                if (rx != x || ry != y) return;
+                                const int ox = far ? Px : Qx, oy = far ? Py : Qy;
+                                const float amt = far ? t - 0.5f : 0.5f - t;
+                                const bool ovalid = !SPARSE || ow.pixel(ox, oy);
+                                const float *co = color + (img + (size_t)oy * W + ox) * CS;
+#pragma unroll
+                                for (int c = 0; c < CS; ++c) acc[c] += amt * ((ovalid ? co[c] : ecol[c]) - cme[c]);
+                            });
+                        if (own && hit) flag = true;
+                    };
+                    bool dummy = false;
+                    if (hasR) visit(x, y, 0, me, nR, true, fx_flag);
+                    if (hasU) visit(x, y, 1, me, nU, true, fy_flag);
+                    if (hasL) visit(x - 1, y, 0, nL, me, false, dummy);
+                    if (hasD) visit(x, y - 1, 1, nD, me, false, dummy);
+                }
+                if (covered) {   // background elsewhere (fit.py:161): no gradient, and in sparse mode no loss term either
+                    const float rf = (float)ref[off];
+                    const float d0 = rf - bg * color_scale;
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) {
+                        const float d = rf - acc[c] * color_scale;
+                        lsum += SPARSE ? (d * d - d0 * d0) : d * d;
+                        g_aa[off * CS + c] = (-2.0f * color_scale * grad_scale) * d;
+                    }
+                }
+            }
+            if (!covered) {
+                if (!SPARSE) {
+                    const float d0 = (float)ref[off] - bg * color_scale;
+                    lsum += (float)CS * d0 * d0;
+                }
+                if (!SPARSE || v_me) {
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) g_aa[off * CS + c] = 0.0f;
+                }
             }
         }
         const unsigned long long bx = __ballot(fx_flag), by = __ballot(fy_flag);
@@ -108,6 +155,8 @@ __global__ void __launch_bounds__(256) k_aa_loss(const float *__restrict__ color
             flags[wi] = bx;
             flags[plane + wi] = by;
         }
+        dn = cur;
+        cur = up;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
@@ -118,6 +167,37 @@ __global__ void __launch_bounds__(256) k_aa_loss(const float *__restrict__ color
         const unsigned int slot = (blockIdx.x + 31u * blockIdx.y + 977u * blockIdx.z) % FPCDR_LOSS_SLOTS;
         if (tot != 0.0) atomicAdd(loss_sum + slot, tot);
     }
+}
+
+// sum over one image of (ref - bg_scaled)^2: grid (chunks, images), 16 pixels per thread and trip
+__global__ void __launch_bounds__(256) k_ref_bg_sumsq(const uint8_t *__restrict__ ref, long long px, float bgs,
+                                                      double *__restrict__ out) {
+    __shared__ double s_part[4];
+    const uint8_t *r = ref + (size_t)blockIdx.y * px;
+    double acc = 0.0;
+    const long long nvec = ((size_t)r % 16 == 0) ? px / 16 : 0;   // 16-byte loads when the image base is aligned
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const uint4 v = ((const uint4 *)r)[i];
+        const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = (float)((w[k] >> (8 * j)) & 255u) - bgs;
+                s += d * d;
+            }
+        acc += (double)s;
+    }
+    for (long long i = nvec * 16 + (long long)blockIdx.x * 256 + threadIdx.x; i < px; i += (long long)gridDim.x * 256) {
+        const float d = (float)r[i] - bgs;
+        acc += (double)(d * d);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + blockIdx.y, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -145,7 +225,8 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
                                                        const float *__restrict__ color, const float *__restrict__ g_aa,
                                                        const uint8_t *__restrict__ sil,
                                                        const unsigned long long *__restrict__ flags,
-                                                       const int4 *__restrict__ ibox, int B, int V, int T, int H,
+                                                       const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
+                                                       int B, int V, int T, int H,
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex) {
     __shared__ int s_vkey[VSLOTS];
@@ -160,11 +241,21 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
     float go[CS];
     bool any = false;
     size_t off = 0;
-    if (ibox) {   // sparse mode: tiles farther than 64 px from the image's geometry carry no gradient (and no data)
-        const int4 ib = ibox[b];
-        const int bx0 = (blockIdx.x * 16) & ~63, by0 = (blockIdx.y * 16) & ~63;
-        if (ib.z + 64 < bx0 || ib.x - 64 > bx0 + 63 || ib.w + 64 < by0 || ib.y - 64 > by0 + 63) return;
+    OccWin ow = {0xfffu, (int)(blockIdx.x >> 1), (int)(blockIdx.y >> 1)};
+    float ecol[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) ecol[c] = 0.0f;
+    if (occ) {
+        // sparse mode: pixels of unoccupied bins were never written and are empty.  A tile works if its bin is occupied,
+        // or if it lies on an edge of its bin beyond which an occupied bin begins: it owns the pairs across the right / top
+        // edge, and its empty pixels receive colour gradient (for the texel at uv = (0,0)) from pairs across any edge.
+        ow = load_occ(occ, b, H, W, blockIdx.x >> 1, blockIdx.y >> 1);
+        const bool ex = blockIdx.x & 1, ey = blockIdx.y & 1;
+        if (!(ow.bin(0, 0) || (ex && ow.bin(1, 0)) || (ey && ow.bin(0, 1)) || (!ex && ow.bin(-1, 0)) || (!ey && ow.bin(0, -1)))) return;
+#pragma unroll
+        for (int c = 0; c < CS; ++c) ecol[c] = empty_color[c];
     }
+    const bool v_me = ow.bin(0, 0);
     if (x < W && y < H) {
         const int Wq = FPCDR_AA_ROW_WORDS(W);
         const size_t plane = (size_t)B * H * Wq;
@@ -177,17 +268,21 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
         const size_t img = (size_t)b * H * W;
         off = img + (size_t)y * W + x;
 #pragma unroll
-        for (int c = 0; c < CS; ++c) { go[c] = g_aa[off * CS + c]; any |= (go[c] != 0.0f); }
+        for (int c = 0; c < CS; ++c) { go[c] = v_me ? g_aa[off * CS + c] : 0.0f; any |= (go[c] != 0.0f); }
         if (own_x | own_y | left_x | down_y) {
             // antialias backward for this pixel (see k_aa_bwd_fix in antialias.hip); sparse: plain global atomics
             AAGeom geo = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
-            const float2 me = load_zid(rast, off);
+            const float2 me = v_me ? load_zid(rast, off) : make_float2(0.f, 0.f);
+            auto zid_at = [&](int xx, int yy) -> float2 {
+                return ow.pixel(xx, yy) ? load_zid(rast, img + (size_t)yy * W + xx) : make_float2(0.f, 0.f);
+            };
             auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own) {
                 for_active_edges(geo, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
                     [&](float t, int Px, int Py, int Qx, int Qy, int va, int vb, const EdgeEval &ev, float s) {
                         const bool far = t >= 0.5f;
                         const int rx = far ? Qx : Px, ry = far ? Qy : Py;
                         const float amt = far ? t - 0.5f : 0.5f - t;
+                        if (!ow.pixel(rx, ry)) return;   // the blended pixel is an unwritten, empty one: no gradient arrives
                         const float *gr = g_aa + (img + (size_t)ry * W + rx) * CS;
                         if (rx == x && ry == y) {
 #pragma unroll
@@ -197,11 +292,12 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
                             for (int c = 0; c < CS; ++c) go[c] += amt * gr[c];
                         }
                         if (!own) return;
+                        const bool vP = ow.pixel(Px, Py), vQ = ow.pixel(Qx, Qy);
                         const float *cP = color + (img + (size_t)Py * W + Px) * CS;
                         const float *cQ = color + (img + (size_t)Qy * W + Qx) * CS;
                         float G = 0.f;
 #pragma unroll
-                        for (int c = 0; c < CS; ++c) G += gr[c] * (cP[c] - cQ[c]);
+                        for (int c = 0; c < CS; ++c) G += gr[c] * ((vP ? cP[c] : ecol[c]) - (vQ ? cQ[c] : ecol[c]));
                         if (G == 0.0f) return;
                         const float Ld = d == 0 ? ev.Lx : ev.Ly;
                         const float gLz = -G / (s * Ld);
@@ -220,10 +316,10 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
                         atomicAdd(gp + 4 * (size_t)vb + 3, g_wb - fxp * g_qbx - fyp * g_qby);
                     });
             };
-            if (own_x) visit(x, y, 0, me, load_zid(rast, off + 1), true);
-            if (own_y) visit(x, y, 1, me, load_zid(rast, off + W), true);
-            if (left_x) visit(x - 1, y, 0, load_zid(rast, off - 1), me, false);
-            if (down_y) visit(x, y - 1, 1, load_zid(rast, off - W), me, false);
+            if (own_x) visit(x, y, 0, me, zid_at(x + 1, y), true);
+            if (own_y) visit(x, y, 1, me, zid_at(x, y + 1), true);
+            if (left_x) visit(x - 1, y, 0, zid_at(x - 1, y), me, false);
+            if (down_y) visit(x, y - 1, 1, zid_at(x, y - 1), me, false);
             any = false;
 #pragma unroll
             for (int c = 0; c < CS; ++c) any |= (go[c] != 0.0f);
@@ -240,7 +336,7 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
     int ux0 = 0x7fffffff, uy0 = 0x7fffffff;   // unwrapped texel coordinates of tap (0,0)
     Taps tp = {};
     if (any) {
-        r = rast[off];
+        if (v_me) r = rast[off];
         t = (int)r.w - 1;
         if (t >= T) t = -1;
         if (t >= 0) {
@@ -409,19 +505,37 @@ extern "C" int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream
                   "null pointer");
     FPCDR_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->C > 0 && p->V > 0 && p->T > 0, "sizes must be positive");
     FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
-    FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 4) <= 65535, "image batch / height too large for one launch");
+    FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 32) <= 65535, "image batch / height too large for one launch");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv((long long)p->B * p->T, 256)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil);
-    dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 4), p->B);
-#define LAUNCH(CS)                                                                                                         \
-    hipLaunchKernelGGL(k_aa_loss<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos,  \
-                       p->tri, p->sil, p->ref, p->B, p->H, p->W, p->V, p->T, p->bg, p->color_scale, p->grad_scale,         \
-                       (unsigned long long *)p->flags, p->grad_aa, (const int4 *)p->ibox, p->loss_sum)
-    if (p->C == 1) LAUNCH(1);
-    else if (p->C == 3) LAUNCH(3);
-    else LAUNCH(4);
+    dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 32), p->B);
+#define LAUNCH(CS, SP)                                                                                                         \
+    hipLaunchKernelGGL((k_aa_loss<CS, SP>), grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, \
+                       p->tri, p->sil, p->ref, p->B, p->H, p->W, p->V, p->T, p->bg, p->color_scale, p->grad_scale,             \
+                       (unsigned long long *)p->flags, p->grad_aa, p->occ, p->empty_color, p->loss_sum)
+    if (p->occ) {
+        FPCDR_REQUIRE(p->empty_color != nullptr, "sparse mode needs empty_color");
+        if (p->C == 1) LAUNCH(1, true);
+        else if (p->C == 3) LAUNCH(3, true);
+        else LAUNCH(4, true);
+    } else {
+        if (p->C == 1) LAUNCH(1, false);
+        else if (p->C == 3) LAUNCH(3, false);
+        else LAUNCH(4, false);
+    }
 #undef LAUNCH
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_ref_bg_sumsq(const uint8_t *ref, int64_t n_images, int64_t px_per_image, float bg_scaled, double *out,
+                                  void *stream) {
+    FPCDR_REQUIRE(ref && out, "null pointer");
+    FPCDR_REQUIRE(n_images > 0 && n_images <= 65535 && px_per_image > 0, "bad sizes");
+    const int chunks = (int)std::min<long long>(64, (px_per_image + 4095) / 4096);
+    hipLaunchKernelGGL(k_ref_bg_sumsq, dim3(chunks, (unsigned)n_images), dim3(256), 0, (hipStream_t)stream, ref,
+                       (long long)px_per_image, bg_scaled, out);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }
@@ -435,11 +549,12 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
                   "sizes must be positive");
     FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
     FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
+    FPCDR_REQUIRE(!p->occ || p->empty_color, "sparse mode needs empty_color");
     dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
 #define LAUNCH(CS)                                                                                                          \
     hipLaunchKernelGGL(k_render_aa_bwd<CS>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)p->pos, p->tri,        \
                        (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa, p->sil,     \
-                       (const unsigned long long *)p->flags, (const int4 *)p->ibox, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,   \
+                       (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,   \
                        p->boundary_mode,                                                                                        \
                        p->grad_pos, p->grad_tex)
     if (p->C == 1) LAUNCH(1);

@@ -81,7 +81,13 @@ constexpr int SMALL_EXTENT = 16384;
 #endif
 constexpr int LANE_MAX = FPCDR_LANE_MAX;
 constexpr int BIGB = 64;         // triangles per round of the tile path
-constexpr int SCAN_K = 4;        // live chunks whose bounding boxes are tested per scan iteration
+#ifndef FPCDR_BINS_WAVES
+#define FPCDR_BINS_WAVES 1
+#endif
+#ifndef FPCDR_SCAN_K
+#define FPCDR_SCAN_K 4
+#endif
+constexpr int SCAN_K = FPCDR_SCAN_K;        // live chunks whose bounding boxes are tested per scan iteration
 
 // (depth, triangle) as one ordered 64-bit key: smaller depth first, ties to the smaller triangle index (R6).
 // d + 0.0f turns -0.0 into +0.0, so that the integer order of the keys is the float order of the depths.
@@ -259,13 +265,15 @@ struct ShadeArgs {
     const float *tex;        // [Ht,Wt,C]
     float *color;            // out [B,H,W,C]
     int Ht, Wt, C, boundary;
-    int sparse_margin;       // >= 0: bins farther than this many pixels from the image's bounding box write nothing
-    int4 *ibox_out;          // sparse mode: per-image bounding box for the consumers (fused.hip), else null
+    uint8_t *occ;            // sparse mode (else null): out [B, gridDim.y, gridDim.x], 1 = some triangle's bounding box touches
+                             // the bin.  Bins with 0 are NOT written; the consumers (fused.hip) treat their pixels as empty.
+                             // (k_occ_window turns this byte map into the per-bin window masks the consumers read)
+    float *empty_out;        // sparse mode: out [4], the colour an empty pixel gets (texture at uv = (0,0))
     const float2 *tri_uv;    // optional [T,3]: uv[uv_tri] pre-gathered
 };
 
 template <bool WRITE_DB, bool SHADE>
-__global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+__global__ void __launch_bounds__(256, FPCDR_BINS_WAVES) k_bins(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               int V, int T, int H, int W, const TriRec *__restrict__ recs,
                                               const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
                                               const ImgBox *__restrict__ ibox, float4 *__restrict__ rast,
@@ -295,12 +303,14 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
     int total_hits = 0;   // block-uniform: triangles whose bounding box touches this bin
     const ImgBox ib = ibox[b];
     const bool bin_live = !(ib.x1 < bin_x0 || ib.x0 > bin_x1 || ib.y1 < bin_y0 || ib.y0 > bin_y1);
-    if (SHADE && sh.sparse_margin >= 0) {
-        // sparse mode of the fused objective: nothing of this image lies within `margin` pixels of the bin, and no
-        // consumer will look at it (they apply the same test with a smaller margin)
-        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) sh.ibox_out[b] = make_int4(ib.x0, ib.y0, ib.x1, ib.y1);
-        const int m = sh.sparse_margin;
-        if (ib.x1 + m < bin_x0 || ib.x0 - m > bin_x1 || ib.y1 + m < bin_y0 || ib.y0 - m > bin_y1) return;
+    const bool sparse = SHADE && sh.occ != nullptr;
+    if (sparse && b == 0 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        const Taps tp0 = make_taps(0.0f, 0.0f, sh.Ht, sh.Wt, sh.C, sh.boundary);
+        for (int c = 0; c < 4; ++c) sh.empty_out[c] = c < sh.C ? bilerp(sh.tex, tp0, c, sh.C) : 0.0f;
+    }
+    if (sparse && !bin_live) {   // nothing of this image near the bin: no pixel is written, the consumers skip it too
+        if (tid == 0) sh.occ[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 0;
+        return;
     }
 
     if (bin_live) {
@@ -503,9 +513,10 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
         while (pending > 0) process_batch(min(pending, BATCH));
     }
 
-#ifdef FPCDR_ABL_OCC
-    if (SHADE && sh.sparse_margin >= 0 && total_hits == 0) return;
-#endif
+    if (sparse) {
+        if (tid == 0) sh.occ[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total_hits > 0 ? 1 : 0;
+        if (total_hits == 0) return;
+    }
     // ---- fold the tile path's register winners into the depth buffer, then read every pixel's winner ----
     if (bin_live) {
 #pragma unroll
@@ -547,7 +558,12 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
             const int px = bin_x0 + (tile % TILES_X) * TILE + (q & 1) * QUAD + lx, py = bin_y0 + (tile / TILES_X) * TILE + (q >> 1) * QUAD + ly;
             if (px >= W || py >= H) continue;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef FPCDR_ABL_NOSHADE
+            const int t = -1;
+            if (best_id[k][q] >= 0) o.w = (float)(best_id[k][q] + 1);
+#else
             const int t = best_id[k][q];
+#endif
             if (t >= 0) {
                 const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
                 const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
@@ -577,6 +593,21 @@ __global__ void __launch_bounds__(256) k_bins(const float4 *__restrict__ pos, co
             }
         }
     }
+}
+
+// per-bin window masks of the occupancy map (include/fpcdr.h, fpcdr_render_fwd_params.occ)
+__global__ void __launch_bounds__(256) k_occ_window(const uint8_t *__restrict__ raw, int B, int OY, int OX, uint16_t *__restrict__ win) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * OY * OX) return;
+    const int x = (int)(i % OX), y = (int)((i / OX) % OY);
+    const uint8_t *img = raw + (i - (long long)y * OX - x);
+    unsigned int m = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 2; ++dx) {
+            const int cx = x + dx, cy = y + dy;
+            if (cx >= 0 && cx < OX && cy >= 0 && cy < OY && img[cy * OX + cx]) m |= 1u << ((dy + 1) * 4 + dx + 1);
+        }
+    win[i] = (uint16_t)m;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -795,9 +826,17 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
-                    p->ibox ? 160 : -1, (int4 *)p->ibox, (const float2 *)p->tri_uv};   // consumers look at most 64 + 64 + 1 px beyond the box
+                    nullptr, p->empty_color, (const float2 *)p->tri_uv};
+    const size_t nbins = (size_t)p->B * grid.y * grid.x;
+    if (p->occ) {
+        FPCDR_REQUIRE(p->empty_color != nullptr, "sparse mode needs empty_color");
+        sh.occ = (uint8_t *)(p->occ + nbins);   // raw byte map behind the window masks
+    }
     hipLaunchKernelGGL((k_bins<false, true>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
                        recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr, sh);
+    if (p->occ)
+        hipLaunchKernelGGL(k_occ_window, dim3(fpcdr_cdiv((long long)nbins, 256)), dim3(256), 0, st, sh.occ, p->B, (int)grid.y,
+                           (int)grid.x, p->occ);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }

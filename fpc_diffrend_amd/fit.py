@@ -413,6 +413,11 @@ class Fitter:
         self.iteration = 0
         # ---- reference images, resident in HBM as 8 bit [F_local, n_cam, H, W] (fit.py:529-533) ----
         self.targets = targets if targets is not None else self.render_targets()
+        # the pixel loss of an all-background image, per (frame, camera): depends on the targets only (sparse objective)
+        self.target_bg_sumsq = None
+        if dev.type == 'cuda':
+            t = self.targets
+            self.target_bg_sumsq = dr.reference_background_sumsq(t.reshape(-1, *self.resolution), BACKGROUND).reshape(t.shape[:2])
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -533,8 +538,9 @@ class Fitter:
         reg = reg / self.world
         self.optimizer.zero_grad(set_to_none=True)
         if one_shot:
+            bg_sum = self.target_bg_sumsq[local].sum() if (cfg.sparse_objective and self.target_bg_sumsq is not None) else None
             loss = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
-                                      n_total, BACKGROUND, sparse=cfg.sparse_objective) + reg
+                                      n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum) + reg
             loss.backward()
         elif cfg.fused_loss:
             sum_sq, g_colour = pixel_loss_fused(colour, rast_out, ref, n_total)

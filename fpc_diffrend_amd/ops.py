@@ -211,7 +211,7 @@ class _pixel_objective_func(torch.autograd.Function):
     """mean over n_total of (ref - 255 * where(covered, antialias(render(pos, tex)), bg))^2 as three kernels."""
 
     @staticmethod
-    def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, sparse):
+    def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, sparse, ref_bg_sumsq):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -220,12 +220,15 @@ class _pixel_objective_func(torch.autograd.Function):
         rast = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
         color = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
         scratch = torch.empty(lib.fpcdr_rasterize_scratch_bytes(B, T), dtype=torch.uint8, device=dev)
-        # sparse: image regions far from any geometry are neither written nor read by the three kernels
-        ibox = torch.empty(B, 4, dtype=torch.int32, device=dev) if sparse else None
+        # sparse: 32x32-pixel bins that no triangle's bounding box touches are neither written nor read by the three
+        # kernels; occ is the map of the others, ecol the colour of an empty pixel
+        occ = torch.empty(B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * 3, dtype=torch.uint8,
+                          device=dev) if sparse else None     # FPCDR_OCC_BYTES
+        ecol = torch.empty(4, dtype=torch.float32, device=dev) if sparse else None
         tri_uv = uv[uv_tri.long()].contiguous()      # [T,3,2], static per mesh: saves a dependent load per pixel
         p = _lib.RenderFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
                            uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C, boundary_mode=boundary,
-                           rast=_ptr(rast), color=_ptr(color), tri_uv=_ptr(tri_uv), ibox=_ptr(ibox))
+                           rast=_ptr(rast), color=_ptr(color), tri_uv=_ptr(tri_uv), occ=_ptr(occ), empty_color=_ptr(ecol))
         _lib.call("fpcdr_render_fwd", ctypes.byref(p), _stream())
         del scratch
         g_aa = torch.empty_like(color)
@@ -235,22 +238,28 @@ class _pixel_objective_func(torch.autograd.Function):
         acc = torch.zeros(_lib.LOSS_SLOTS, dtype=torch.float64, device=dev)
         q = _lib.AaLossFwd(color=_ptr(color), rast=_ptr(rast), pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), ref=_ptr(ref), B=B,
                            H=H, W=W, C=C, V=V, T=T, bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
-                           flags=_ptr(flags), grad_aa=_ptr(g_aa), ibox=_ptr(ibox), loss_sum=_ptr(acc))
+                           flags=_ptr(flags), grad_aa=_ptr(g_aa), occ=_ptr(occ), empty_color=_ptr(ecol), loss_sum=_ptr(acc))
         _lib.call("fpcdr_aa_loss_fwd", ctypes.byref(q), _stream())
-        ctx.save_for_backward(pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, ibox, tri_uv)
+        ctx.save_for_backward(pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, occ, ecol, tri_uv)
         ctx.boundary = boundary
-        return (acc.sum() / n_total).to(torch.float32)
+        total = acc.sum()
+        if sparse:
+            # the kernel summed only the difference to an all-background image; the rest depends on ref alone
+            if ref_bg_sumsq is None:
+                ref_bg_sumsq = reference_background_sumsq(ref, bg).sum()
+            total = total + C * ref_bg_sumsq
+        return (total / n_total).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
-        pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, ibox, tri_uv = ctx.saved_tensors
+        pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, occ, ecol, tri_uv = ctx.saved_tensors
         B, V, _ = pos.shape
         _, H, W, _ = rast.shape
         Ht, Wt, C = tex.shape
         g_pos = torch.zeros_like(pos)
         g_tex = torch.zeros_like(tex) if ctx.needs_input_grad[1] else None
         p = _lib.RenderAaBwd(pos=_ptr(pos), tri=_ptr(tri), uv=_ptr(uv), uv_tri=_ptr(uv_tri), tex=_ptr(tex), rast=_ptr(rast),
-                             color=_ptr(color), grad_aa=_ptr(g_aa), sil=_ptr(sil), flags=_ptr(flags), ibox=_ptr(ibox), B=B, V=V,
+                             color=_ptr(color), grad_aa=_ptr(g_aa), sil=_ptr(sil), flags=_ptr(flags), occ=_ptr(occ), empty_color=_ptr(ecol), B=B, V=V,
                              T=tri.shape[0],
                              H=H, W=W, Vt=uv.shape[0], Ht=Ht, Wt=Wt, C=C, boundary_mode=ctx.boundary, grad_pos=_ptr(g_pos),
                              grad_tex=_ptr(g_tex), tri_uv=_ptr(tri_uv))
@@ -258,17 +267,30 @@ class _pixel_objective_func(torch.autograd.Function):
         g_pos = g_pos * g if ctx.needs_input_grad[0] else None
         if g_tex is not None:
             g_tex = g_tex * g
-        return (g_pos, g_tex) + (None,) * 11
+        return (g_pos, g_tex) + (None,) * 12
+
+
+def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
+    """Per image sum over pixels of (ref - 255 * background)^2 (f64 [B]): the pixel loss (fit.py:579) of an image that
+    shows nothing but background.  It depends on the reference images only, so a fit loop computes it once and hands it
+    to pixel_objective(ref_bg_sumsq=...), which then reads reference pixels only where geometry is."""
+    _check_tensor('ref_u8', ref_u8, torch.uint8, 3)
+    ref_u8 = ref_u8.contiguous()
+    out = torch.zeros(ref_u8.shape[0], dtype=torch.float64, device=ref_u8.device)
+    _lib.call("fpcdr_ref_bg_sumsq", _ptr(ref_u8), ref_u8.shape[0], ref_u8.shape[1] * ref_u8.shape[2], float(background) * 255.0,
+              _ptr(out), _stream())
+    return out
 
 
 def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_total=None, background=45.0 / 255.0,
-                    boundary_mode='wrap', sparse=True):
+                    boundary_mode='wrap', sparse=True, ref_bg_sumsq=None):
     """The whole pixel term of the reference's loss (fit.py:151-161 + the first term of :579) for a minibatch,
     as three kernels:  mean((ref - 255 * where(rast.w > 0, antialias(texture(interpolate(rasterize(pos)))), bg))^2)
     over n_total elements (default: all of this call's).  pos [B,V,4], tex [Ht,Wt,C] (C in 1,3,4), ref_u8 [B,H,W] uint8.
     Differentiable w.r.t. pos and tex; equals the chain of separate operators + pixel loss.
-    sparse=True: 64x64-pixel regions farther than 64 / 128 px from an image's geometry are skipped by all three
-    kernels (they can only contribute (ref - 255 bg)^2 to the loss, which is still added); same result."""
+    sparse=True: 32x32-pixel bins that no triangle's bounding box touches are skipped by all three kernels (they can only
+    contribute (ref - 255 bg)^2 to the loss, which is added from ref_bg_sumsq: a scalar f64 tensor, the sum of
+    reference_background_sumsq(ref_u8, background) over this call's images; computed here when None); same result."""
     assert isinstance(glctx, RasterizeHipContext)
     _check_tensor('pos', pos, torch.float32, 3)
     _check_tensor('tri', tri, torch.int32, 2)
@@ -285,7 +307,7 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     adj = _cached_topology(tri)
     n_total = n_total or pos.shape[0] * H * W * tex.shape[2]
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
-                                       ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse))
+                                       ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq)
 
 
 # ----------------------------------------------------------------------------------------------

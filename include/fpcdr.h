@@ -88,10 +88,14 @@ typedef struct {
     float *rast;            /* out [B,H,W,4] */
     float *color;           /* out [B,H,W,C] */
     const float *tri_uv;    /* optional [T,3,2]: uv[uv_tri] gathered once per mesh (saves one dependent load per pixel); NULL = look up */
-    int32_t *ibox;          /* NULL = dense (every pixel of rast / color is written).  Otherwise out [B,4] = pixel bounding
-                               box (x0,y0,x1,y1) of each image's geometry, and SPARSE mode: 64x64-pixel bins farther than
-                               128 px from that box are not written at all -- only for consumers that apply the same test
-                               (fpcdr_aa_loss_fwd / fpcdr_render_aa_bwd with the same ibox) */
+    uint16_t *occ;          /* NULL = dense (every pixel of rast / color is written).  Otherwise SPARSE mode: out, a buffer of
+                               FPCDR_OCC_BYTES(B,H,W) bytes.  A 32x32-pixel bin is OCCUPIED if the bounding box of some
+                               triangle touches it; unoccupied bins hold no covered pixel and are NOT written at all -- only
+                               for consumers that read the map (fpcdr_aa_loss_fwd / fpcdr_render_aa_bwd) and take those
+                               pixels as empty: rast = 0, colour = empty_color.  The first B*OY*OX uint16 (OY, OX =
+                               FPCDR_OCC_DIM(H), (W)) are per-bin WINDOW masks: bit (dy+1)*4 + (dx+1) = bin (x+dx, y+dy) is
+                               occupied, dx in -1..2, dy in -1..1; the rest of the buffer is scratch. */
+    float *empty_color;     /* sparse mode: out [4], the colour of an empty pixel (the texture at uv = (0,0), fit.py:157-158) */
 } fpcdr_render_fwd_params;
 int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream);
 
@@ -112,6 +116,9 @@ typedef struct {
 int fpcdr_render_bwd(const fpcdr_render_bwd_params *p, void *stream);
 
 #define FPCDR_LOSS_SLOTS 256
+#define FPCDR_OCC_BIN 32
+#define FPCDR_OCC_DIM(n) (((n) + FPCDR_OCC_BIN - 1) / FPCDR_OCC_BIN)
+#define FPCDR_OCC_BYTES(B, H, W) ((size_t)(B) * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W) * 3)
 
 /* antialias + background + pixel loss in one pass (reference fit.py:160, 161, 579): reads colour, rast and the 8-bit
  * reference image, accumulates the sum of squares and writes d(grad_scale * sum)/d(antialiased colour); the
@@ -127,13 +134,22 @@ typedef struct {
     float bg, color_scale, grad_scale;
     uint8_t *sil;          /* scratch+saved [B,T] */
     uint64_t *flags;       /* saved, fpcdr_antialias_flags_bytes() */
-    float *grad_aa;        /* out [B,H,W,C] (sparse mode: only within 64 px of the image's box) */
-    const int32_t *ibox;   /* NULL = dense, else [B,4] from fpcdr_render_fwd (sparse mode); flags must then be zero-filled
-                              by the caller, spans farther than 64 px from the box only add (ref - 255 bg)^2 to the loss */
+    float *grad_aa;        /* out [B,H,W,C] (sparse mode: only the pixels of occupied bins) */
+    const uint16_t *occ;   /* NULL = dense, else the map written by fpcdr_render_fwd (sparse mode): flags must be zero-filled
+                              by the caller, and loss_sum receives only the DIFFERENCE to an all-background image,
+                              sum over covered pixels of (ref - s col)^2 - (ref - s bg)^2: the caller adds
+                              C * sum over all pixels of (ref - s bg)^2, which depends on the reference images alone
+                              (fpcdr_ref_bg_sumsq) */
+    const float *empty_color; /* sparse mode: [4] from fpcdr_render_fwd */
     double *loss_sum;      /* [FPCDR_LOSS_SLOTS] f64, accumulated: the loss is the sum of all slots (workgroups spread
                               their partial sums over the slots instead of hammering one address) */
 } fpcdr_aa_loss_fwd_params;
 int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream);
+
+/* out[i] += sum over the px_per_image pixels of image i of (ref - bg_scaled)^2, i < n_images; ref [n_images, px_per_image]
+ * uint8, out f64 (zero-filled by the caller).  The part of the pixel loss (fit.py:579) that a sparse fpcdr_aa_loss_fwd
+ * leaves to the caller: it depends on the reference images only, so a fit loop computes it once. */
+int fpcdr_ref_bg_sumsq(const uint8_t *ref, int64_t n_images, int64_t px_per_image, float bg_scaled, double *out, void *stream);
 
 /* Backward of antialias + texture + interpolate + rasterize in one pass: reads grad_aa (4C B/px), rast (16 B/px) and
  * the flag planes; scatters into grad_pos and grad_tex; writes nothing dense.                                 */
@@ -146,7 +162,8 @@ typedef struct {
     const float *rast, *color, *grad_aa;
     const uint8_t *sil;
     const uint64_t *flags;
-    const int32_t *ibox;   /* NULL = dense, else [B,4] (sparse mode, as in the forward calls) */
+    const uint16_t *occ;   /* NULL = dense, else the occupancy map of fpcdr_render_fwd (sparse mode, as in the forward calls) */
+    const float *empty_color; /* sparse mode: [4] from fpcdr_render_fwd */
     int32_t B, V, T, H, W, Vt, Ht, Wt, C, boundary_mode;
     float *grad_pos;       /* [B,V,4] accumulated */
     float *grad_tex;       /* [Ht,Wt,C] accumulated, or NULL */
