@@ -112,6 +112,41 @@ __device__ __forceinline__ void wave_group_reduce(int key, const float (&val)[N]
     if (is_leader) emit(key, out);
 }
 
+// Segmented sums over runs of equal `key` in LANE ORDER: consecutive lanes holding the same key (>= 0) form a segment, and
+// the last lane of every segment calls emit(key, sums) with the segment's totals; all of them at once, after a single
+// 6-step segmented scan (DPP row_shr 1,2,4,8 + row_bcast15/31) whose cost does not depend on the number of segments.
+// Lanes with key < 0 are skipped.  Convergent: every lane of the wave must call it.  Callers order their lanes so that
+// pixels of one triangle sit next to each other (rows of a tile, serpentine).
+template <int N, typename Emit>
+__device__ __forceinline__ void wave_segment_reduce(int key, const float (&val)[N], Emit &&emit) {
+    const int l = lane_id();
+    const int prev = __builtin_amdgcn_update_dpp(key, key, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps its own)
+    int f = (l == 0 || prev != key) ? 1 : 0;                                            // segment start
+    const int next = __builtin_amdgcn_update_dpp(key, key, 0x130, 0xF, 0xF, false);   // wave_shl:1 (lane 63 keeps its own)
+    const bool tail = (l == 63 || next != key);
+    float v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = val[i];
+    // row_shr:n = 0x110 + n; lanes without a source inside their row of 16 read `old` = 0
+#define FPCDR_SEG_STEP(CTRL, ROWMASK)                                                                                   \
+    {                                                                                                                    \
+        const int fp = __builtin_amdgcn_update_dpp(0, f, CTRL, ROWMASK, 0xF, false);                                     \
+        _Pragma("unroll") for (int i = 0; i < N; ++i) {                                                                  \
+            const float vp = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), CTRL, ROWMASK, 0xF, false)); \
+            v[i] += f ? 0.0f : vp;                                                                                       \
+        }                                                                                                                \
+        f |= fp;                                                                                                         \
+    }
+    FPCDR_SEG_STEP(0x111, 0xF)
+    FPCDR_SEG_STEP(0x112, 0xF)
+    FPCDR_SEG_STEP(0x114, 0xF)
+    FPCDR_SEG_STEP(0x118, 0xF)
+    FPCDR_SEG_STEP(0x142, 0xA)   // row_bcast15: lane 15 of rows 0, 2 into rows 1, 3
+    FPCDR_SEG_STEP(0x143, 0xC)   // row_bcast31: lane 31 into rows 2, 3
+#undef FPCDR_SEG_STEP
+    if (tail && key >= 0) emit(key, v);
+}
+
 // Full-wave integer min / max with DPP (same structure as wave_sum_dpp); result in every lane.
 __device__ __forceinline__ int wave_min_dpp(int v) {
     v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));

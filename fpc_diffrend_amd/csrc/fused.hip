@@ -201,22 +201,24 @@ __global__ void __launch_bounds__(256) k_ref_bg_sumsq(const uint8_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward of the whole pixel objective, one pixel per lane, one 16x16-pixel tile per workgroup:
+// Backward of the whole pixel objective, one workgroup per 32x32-pixel bin, four pixels per thread:
 //   g_c = g_aa + antialias corrections (gather form, only where a flag bit says a pair was blended)
 //   texture bwd -> grad_tex;  interpolate bwd;  rasterize bwd -> grad_pos;  + the antialias op's own d alpha / d pos.
 //
-// Measured at cfg3 (r1): the arithmetic + streaming of this kernel take 3.8 ms; scattering with global f32 atomics
-// took 6 ms more (51 ms without any pre-reduction): scattered atomics retire at only ~15-70 G lanes/s chip-wide, so
-// what matters is HOW MANY lanes reach memory.  Two levels of on-chip summation therefore precede every global atomic:
-//   vertices  the lanes of a wave that shade the same triangle reduce their nine components with DPP row operations;
-//             the group leaders add into a 256-slot LDS table keyed by vertex id; one flush per workgroup
-//             (a 16x16 tile touches a few dozen vertices: ~2300 per-pixel adds -> ~100 global atomics);
-//   texels    a TEXW x TEXH LDS window anchored at the tile's smallest tap absorbs the four taps of every covered
+// Scattered global f32 atomics retire at only ~15-70 G lanes/s chip-wide (r1: 51 ms for this kernel when every pixel
+// scattered), so everything is summed on chip first:
+//   vertices  lanes are ordered so that pixels of one triangle sit next to each other (two adjacent 32-pixel rows per
+//             wave, the second one reversed); ONE segmented DPP scan sums the nine components of every run of equal
+//             triangle in the wave (common.h wave_segment_reduce; the per-triangle loop it replaces took 1.1 ms of
+//             3.8), the run tails add into a 256-slot LDS table keyed by vertex, one flush per workgroup;
+//   texels    a TEXW x TEXH LDS window anchored at the bin's smallest tap absorbs the four taps of every covered
 //             pixel and is flushed row-contiguously; taps outside it (uv seams; empty pixels, which sample
 //             uv = (0,0)) go straight to global memory.
-// 85 % of the workgroups of the face rig see no gradient and leave at the first barrier.
+// (One lane per triangle walking its bounding box -- the scheme of the forward rasteriser -- was tried here and took
+// 6.9 ms: lanes reach their pixels at different trips, so the wave pays the full shading chain on almost every trip.)
 constexpr int VSLOTS = 256;
 constexpr int TEXW = 48, TEXH = 48;
+constexpr int BBIN = 32;
 
 template <int CS>
 __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
@@ -228,220 +230,247 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
                                                        const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
                                                        int B, int V, int T, int H,
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
-                                                       float *__restrict__ grad_tex) {
+                                                       float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv) {
     __shared__ int s_vkey[VSLOTS];
     __shared__ float s_vacc[VSLOTS][4];
     __shared__ float s_tex[TEXH * TEXW * CS];
-    __shared__ int s_org[2];   // smallest tap x, y of the tile (unwrapped texel coordinates)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const int b = blockIdx.z;
+    __shared__ int s_org[2];            // smallest tap x, y of the bin (unwrapped texel coordinates)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // pixel k of this thread: row 8 wave + 2 k + (lane >> 5) of the bin; the odd row runs right to left, so that lane 31
+    // and lane 32 are vertical neighbours and a triangle's run continues from one row into the next
+    const int col = (lane & 32) ? 63 - lane : lane;
+    const int rowk0 = 8 * wave + (lane >> 5);
+    const int bx0 = blockIdx.x * BBIN, by0 = blockIdx.y * BBIN, b = blockIdx.z;
+    const int x = bx0 + col;
     float *gp = grad_pos + (size_t)b * V * 4;
-    float go[CS];
-    bool any = false;
-    size_t off = 0;
-    OccWin ow = {0xfffu, (int)(blockIdx.x >> 1), (int)(blockIdx.y >> 1)};
+    OccWin ow = {0xfffu, (int)blockIdx.x, (int)blockIdx.y};
     float ecol[CS];
 #pragma unroll
     for (int c = 0; c < CS; ++c) ecol[c] = 0.0f;
     if (occ) {
-        // sparse mode: pixels of unoccupied bins were never written and are empty.  A tile works if its bin is occupied,
-        // or if it lies on an edge of its bin beyond which an occupied bin begins: it owns the pairs across the right / top
-        // edge, and its empty pixels receive colour gradient (for the texel at uv = (0,0)) from pairs across any edge.
-        ow = load_occ(occ, b, H, W, blockIdx.x >> 1, blockIdx.y >> 1);
-        const bool ex = blockIdx.x & 1, ey = blockIdx.y & 1;
-        if (!(ow.bin(0, 0) || (ex && ow.bin(1, 0)) || (ey && ow.bin(0, 1)) || (!ex && ow.bin(-1, 0)) || (!ey && ow.bin(0, -1)))) return;
+        // sparse mode: pixels of unoccupied bins were never written and are empty.  An unoccupied bin still works if a
+        // neighbour is occupied: it owns the pairs across its right / top edge, and its empty pixels receive colour
+        // gradient (for the texel at uv = (0,0)) from pairs across any edge.
+        ow = load_occ(occ, b, H, W, blockIdx.x, blockIdx.y);
+        if (!(ow.bin(0, 0) || ow.bin(1, 0) || ow.bin(0, 1) || ow.bin(-1, 0) || ow.bin(0, -1))) return;
 #pragma unroll
         for (int c = 0; c < CS; ++c) ecol[c] = empty_color[c];
     }
     const bool v_me = ow.bin(0, 0);
-    if (x < W && y < H) {
-        const int Wq = FPCDR_AA_ROW_WORDS(W);
-        const size_t plane = (size_t)B * H * Wq;
-        const size_t wi = ((size_t)b * H + y) * Wq + (x >> 6);
-        const int bit = x & 63;
-        const unsigned long long fxw = flags[wi], fyw = flags[plane + wi];
-        const bool own_x = (fxw >> bit) & 1ull, own_y = (fyw >> bit) & 1ull;
-        const bool left_x = bit > 0 ? ((fxw >> (bit - 1)) & 1ull) : (x > 0 ? ((flags[wi - 1] >> 63) & 1ull) : false);
-        const bool down_y = y > 0 ? ((flags[plane + wi - Wq] >> bit) & 1ull) : false;
-        const size_t img = (size_t)b * H * W;
-        off = img + (size_t)y * W + x;
-#pragma unroll
-        for (int c = 0; c < CS; ++c) { go[c] = v_me ? g_aa[off * CS + c] : 0.0f; any |= (go[c] != 0.0f); }
-        if (own_x | own_y | left_x | down_y) {
-            // antialias backward for this pixel (see k_aa_bwd_fix in antialias.hip); sparse: plain global atomics
-            AAGeom geo = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
-            const float2 me = v_me ? load_zid(rast, off) : make_float2(0.f, 0.f);
-            auto zid_at = [&](int xx, int yy) -> float2 {
-                return ow.pixel(xx, yy) ? load_zid(rast, img + (size_t)yy * W + xx) : make_float2(0.f, 0.f);
-            };
-            auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own) {
-                for_active_edges(geo, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
-                    [&](float t, int Px, int Py, int Qx, int Qy, int va, int vb, const EdgeEval &ev, float s) {
-                        const bool far = t >= 0.5f;
-                        const int rx = far ? Qx : Px, ry = far ? Qy : Py;
-                        const float amt = far ? t - 0.5f : 0.5f - t;
-                        if (!ow.pixel(rx, ry)) return;   // the blended pixel is an unwritten, empty one: no gradient arrives
-                        const float *gr = g_aa + (img + (size_t)ry * W + rx) * CS;
-                        if (rx == x && ry == y) {
-#pragma unroll
-                            for (int c = 0; c < CS; ++c) go[c] -= amt * gr[c];
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < CS; ++c) go[c] += amt * gr[c];
-                        }
-                        if (!own) return;
-                        const bool vP = ow.pixel(Px, Py), vQ = ow.pixel(Qx, Qy);
-                        const float *cP = color + (img + (size_t)Py * W + Px) * CS;
-                        const float *cQ = color + (img + (size_t)Qy * W + Qx) * CS;
-                        float G = 0.f;
-#pragma unroll
-                        for (int c = 0; c < CS; ++c) G += gr[c] * ((vP ? cP[c] : ecol[c]) - (vQ ? cQ[c] : ecol[c]));
-                        if (G == 0.0f) return;
-                        const float Ld = d == 0 ? ev.Lx : ev.Ly;
-                        const float gLz = -G / (s * Ld);
-                        const float gLd = -G * t / Ld;
-                        const float gLx = d == 0 ? gLd : 0.0f, gLy = d == 0 ? 0.0f : gLd;
-                        float g_qax = 0.f, g_qay = 0.f, g_wa = 0.f, g_qbx = 0.f, g_qby = 0.f, g_wb = 0.f;
-                        g_qay += gLx * ev.wb; g_wb += gLx * ev.qay; g_wa -= gLx * ev.qby; g_qby -= gLx * ev.wa;
-                        g_wa += gLy * ev.qbx; g_qbx += gLy * ev.wa; g_qax -= gLy * ev.wb; g_wb -= gLy * ev.qax;
-                        g_qax += gLz * ev.qby; g_qby += gLz * ev.qax; g_qay -= gLz * ev.qbx; g_qbx -= gLz * ev.qay;
-                        const float fxp = (float)Px + 0.5f - geo.hw, fyp = (float)Py + 0.5f - geo.hh;
-                        atomicAdd(gp + 4 * (size_t)va + 0, g_qax * geo.hw);
-                        atomicAdd(gp + 4 * (size_t)va + 1, g_qay * geo.hh);
-                        atomicAdd(gp + 4 * (size_t)va + 3, g_wa - fxp * g_qax - fyp * g_qay);
-                        atomicAdd(gp + 4 * (size_t)vb + 0, g_qbx * geo.hw);
-                        atomicAdd(gp + 4 * (size_t)vb + 1, g_qby * geo.hh);
-                        atomicAdd(gp + 4 * (size_t)vb + 3, g_wb - fxp * g_qbx - fyp * g_qby);
-                    });
-            };
-            if (own_x) visit(x, y, 0, me, zid_at(x + 1, y), true);
-            if (own_y) visit(x, y, 1, me, zid_at(x, y + 1), true);
-            if (left_x) visit(x - 1, y, 0, zid_at(x - 1, y), me, false);
-            if (down_y) visit(x, y - 1, 1, zid_at(x, y - 1), me, false);
-            any = false;
-#pragma unroll
-            for (int c = 0; c < CS; ++c) any |= (go[c] != 0.0f);
-        }
-    }
-    // most workgroups of an image see no gradient at all: leave before touching LDS
-    if (!__syncthreads_or(any ? 1 : 0)) return;
+    const size_t img = (size_t)b * H * W;
+    if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
 
-    // ---- texture coordinate + taps of this pixel ----
-    int t = -1;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    float2 q0 = make_float2(0.f, 0.f), q1 = q0, q2 = q0;
-    float tu = 0.0f, tv = 0.0f;
-    int ux0 = 0x7fffffff, uy0 = 0x7fffffff;   // unwrapped texel coordinates of tap (0,0)
-    Taps tp = {};
-    if (any) {
-        if (v_me) r = rast[off];
-        t = (int)r.w - 1;
-        if (t >= T) t = -1;
-        if (t >= 0) {
-            q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]];
-            const float w = 1.0f - r.x - r.y;
-            tu = r.x * q0.x + r.y * q1.x + w * q2.x;
-            tv = r.x * q0.y + r.y * q1.y + w * q2.y;
+    // ---- pixel phase A: gradient arriving at each pixel's colour (antialias backward folded in) ----
+    float go[4][CS];
+    bool any[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = by0 + rowk0 + 2 * k;
+        any[k] = false;
+#pragma unroll
+        for (int c = 0; c < CS; ++c) go[k][c] = 0.0f;
+        if (x < W && y < H) {
+            const int Wq = FPCDR_AA_ROW_WORDS(W);
+            const size_t plane = (size_t)B * H * Wq;
+            const size_t wi = ((size_t)b * H + y) * Wq + (x >> 6);
+            const int bit = x & 63;
+            const unsigned long long fxw = flags[wi], fyw = flags[plane + wi];
+            const bool own_x = (fxw >> bit) & 1ull, own_y = (fyw >> bit) & 1ull;
+            const bool left_x = bit > 0 ? ((fxw >> (bit - 1)) & 1ull) : (x > 0 ? ((flags[wi - 1] >> 63) & 1ull) : false);
+            const bool down_y = y > 0 ? ((flags[plane + wi - Wq] >> bit) & 1ull) : false;
+            const size_t off = img + (size_t)y * W + x;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) { go[k][c] = v_me ? g_aa[off * CS + c] : 0.0f; any[k] |= (go[k][c] != 0.0f); }
+            if (own_x | own_y | left_x | down_y) {
+                // antialias backward for this pixel (see k_aa_bwd_fix in antialias.hip); sparse: plain global atomics
+                AAGeom geo = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
+                const float2 me = v_me ? load_zid(rast, off) : make_float2(0.f, 0.f);
+                auto zid_at = [&](int xx, int yy) -> float2 {
+                    return ow.pixel(xx, yy) ? load_zid(rast, img + (size_t)yy * W + xx) : make_float2(0.f, 0.f);
+                };
+                auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own) {
+                    for_active_edges(geo, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
+                        [&](float t, int Px, int Py, int Qx, int Qy, int va, int vb, const EdgeEval &ev, float s) {
+                            const bool far = t >= 0.5f;
+                            const int rx = far ? Qx : Px, ry = far ? Qy : Py;
+                            const float amt = far ? t - 0.5f : 0.5f - t;
+                            if (!ow.pixel(rx, ry)) return;   // the blended pixel is an unwritten, empty one: no gradient arrives
+                            const float *gr = g_aa + (img + (size_t)ry * W + rx) * CS;
+                            if (rx == x && ry == y) {
+#pragma unroll
+                                for (int c = 0; c < CS; ++c) go[k][c] -= amt * gr[c];
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < CS; ++c) go[k][c] += amt * gr[c];
+                            }
+                            if (!own) return;
+                            const bool vP = ow.pixel(Px, Py), vQ = ow.pixel(Qx, Qy);
+                            const float *cP = color + (img + (size_t)Py * W + Px) * CS;
+                            const float *cQ = color + (img + (size_t)Qy * W + Qx) * CS;
+                            float G = 0.f;
+#pragma unroll
+                            for (int c = 0; c < CS; ++c) G += gr[c] * ((vP ? cP[c] : ecol[c]) - (vQ ? cQ[c] : ecol[c]));
+                            if (G == 0.0f) return;
+                            const float Ld = d == 0 ? ev.Lx : ev.Ly;
+                            const float gLz = -G / (s * Ld);
+                            const float gLd = -G * t / Ld;
+                            const float gLx = d == 0 ? gLd : 0.0f, gLy = d == 0 ? 0.0f : gLd;
+                            float g_qax = 0.f, g_qay = 0.f, g_wa = 0.f, g_qbx = 0.f, g_qby = 0.f, g_wb = 0.f;
+                            g_qay += gLx * ev.wb; g_wb += gLx * ev.qay; g_wa -= gLx * ev.qby; g_qby -= gLx * ev.wa;
+                            g_wa += gLy * ev.qbx; g_qbx += gLy * ev.wa; g_qax -= gLy * ev.wb; g_wb -= gLy * ev.qax;
+                            g_qax += gLz * ev.qby; g_qby += gLz * ev.qax; g_qay -= gLz * ev.qbx; g_qbx -= gLz * ev.qay;
+                            const float fxp = (float)Px + 0.5f - geo.hw, fyp = (float)Py + 0.5f - geo.hh;
+                            atomicAdd(gp + 4 * (size_t)va + 0, g_qax * geo.hw);
+                            atomicAdd(gp + 4 * (size_t)va + 1, g_qay * geo.hh);
+                            atomicAdd(gp + 4 * (size_t)va + 3, g_wa - fxp * g_qax - fyp * g_qay);
+                            atomicAdd(gp + 4 * (size_t)vb + 0, g_qbx * geo.hw);
+                            atomicAdd(gp + 4 * (size_t)vb + 1, g_qby * geo.hh);
+                            atomicAdd(gp + 4 * (size_t)vb + 3, g_wb - fxp * g_qbx - fyp * g_qby);
+                        });
+                };
+                if (own_x) visit(x, y, 0, me, zid_at(x + 1, y), true);
+                if (own_y) visit(x, y, 1, me, zid_at(x, y + 1), true);
+                if (left_x) visit(x - 1, y, 0, zid_at(x - 1, y), me, false);
+                if (down_y) visit(x, y - 1, 1, zid_at(x, y - 1), me, false);
+                any[k] = false;
+#pragma unroll
+                for (int c = 0; c < CS; ++c) any[k] |= (go[k][c] != 0.0f);
+            }
         }
-        tp = make_taps(tu, tv, Ht, Wt, CS, boundary);
     }
-    const bool windowed = any && t >= 0 && grad_tex != nullptr;   // empty pixels (uv = (0,0)) scatter directly
-    if (windowed) {
-        ux0 = (int)floorf(prep_coord(tu, boundary) * (float)Wt - 0.5f);
-        uy0 = (int)floorf(prep_coord(tv, boundary) * (float)Ht - 0.5f);
-    }
-    for (int k = threadIdx.x; k < VSLOTS; k += 256) {
+    // most bins of an image see no gradient at all: leave before touching the tables
+    if (!__syncthreads_or((any[0] | any[1] | any[2] | any[3]) ? 1 : 0)) return;
+
+    // ---- tables; texture coordinate of every pixel with a gradient; origin of the texel window ----
+    for (int k = tid; k < VSLOTS; k += 256) {
         s_vkey[k] = -1;
         s_vacc[k][0] = 0.f; s_vacc[k][1] = 0.f; s_vacc[k][2] = 0.f; s_vacc[k][3] = 0.f;
     }
-    for (int k = threadIdx.x; k < TEXH * TEXW * CS; k += 256) s_tex[k] = 0.0f;
-    if (threadIdx.x == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
-    __syncthreads();
+    for (int k = tid; k < TEXH * TEXW * CS; k += 256) s_tex[k] = 0.0f;
+    int pt[4];
+    float tu[4], tv[4], ru[4], rv[4];
     {
+        int ux0 = 0x7fffffff, uy0 = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pt[k] = -1; tu[k] = 0.f; tv[k] = 0.f; ru[k] = 0.f; rv[k] = 0.f;
+            if (any[k] && v_me) {
+                const float4 r = rast[img + (size_t)(by0 + rowk0 + 2 * k) * W + x];
+                int t = (int)r.w - 1;
+                if (t >= T) t = -1;
+                if (t >= 0) {
+                    float2 q0, q1, q2;
+                    if (tri_uv) { q0 = tri_uv[3 * t]; q1 = tri_uv[3 * t + 1]; q2 = tri_uv[3 * t + 2]; }
+                    else { q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]]; }
+                    const float w = 1.0f - r.x - r.y;
+                    tu[k] = r.x * q0.x + r.y * q1.x + w * q2.x;
+                    tv[k] = r.x * q0.y + r.y * q1.y + w * q2.y;
+                    ru[k] = r.x; rv[k] = r.y;
+                    pt[k] = t;
+                    if (grad_tex) {
+                        ux0 = min(ux0, (int)floorf(prep_coord(tu[k], boundary) * (float)Wt - 0.5f));
+                        uy0 = min(uy0, (int)floorf(prep_coord(tv[k], boundary) * (float)Ht - 0.5f));
+                    }
+                }
+            }
+        }
         const int mx = wave_min_dpp(ux0), my = wave_min_dpp(uy0);
         if (lane == 0 && mx != 0x7fffffff) { atomicMin(&s_org[0], mx); atomicMin(&s_org[1], my); }
     }
     __syncthreads();
     const int ox = s_org[0], oy = s_org[1];
 
-    int tkey = -1;
-    float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (any) {
-        const float w00 = (1.0f - tp.fx) * (1.0f - tp.fy), w10 = tp.fx * (1.0f - tp.fy);
-        const float w01 = (1.0f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
-        const int lx = ux0 - ox, ly = uy0 - oy;
-        const bool in_win = windowed && lx >= 0 && ly >= 0 && lx + 1 < TEXW && ly + 1 < TEXH;
-        float gfx = 0.f, gfy = 0.f;
+    // ---- pixel phase B: texture backward; (dL/du, dL/dv) of the barycentrics into LDS; triangle set ----
 #pragma unroll
-        for (int c = 0; c < CS; ++c) {
-            const float gc = go[c];
-            float t00, t10, t01, t11;
-            load_taps(tex, tp, c, CS, t00, t10, t01, t11);
-            gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
-            gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
-            if (grad_tex && gc != 0.0f) {
-                if (in_win) {
-                    float *w = s_tex + (ly * TEXW + lx) * CS + c;
-                    atomicAdd(w, gc * w00);
-                    atomicAdd(w + CS, gc * w10);
-                    atomicAdd(w + TEXW * CS, gc * w01);
-                    atomicAdd(w + TEXW * CS + CS, gc * w11);
-                } else {
-                    atomicAdd(grad_tex + tp.i00 + c, gc * w00);
-                    atomicAdd(grad_tex + tp.i10 + c, gc * w10);
-                    atomicAdd(grad_tex + tp.i01 + c, gc * w01);
-                    atomicAdd(grad_tex + tp.i11 + c, gc * w11);
+    for (int k = 0; k < 4; ++k) {
+        int tkey = -1;
+        float gu = 0.f, gvv = 0.f;
+        if (any[k]) {
+            const int t = pt[k];
+            const Taps tp = make_taps(tu[k], tv[k], Ht, Wt, CS, boundary);   // an empty pixel sampled uv = (0,0)
+            const float w00 = (1.0f - tp.fx) * (1.0f - tp.fy), w10 = tp.fx * (1.0f - tp.fy);
+            const float w01 = (1.0f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
+            bool in_win = false;
+            int lx = 0, ly = 0;
+            if (t >= 0 && grad_tex) {
+                lx = (int)floorf(prep_coord(tu[k], boundary) * (float)Wt - 0.5f) - ox;
+                ly = (int)floorf(prep_coord(tv[k], boundary) * (float)Ht - 0.5f) - oy;
+                in_win = lx >= 0 && ly >= 0 && lx + 1 < TEXW && ly + 1 < TEXH;
+            }
+            float gfx = 0.f, gfy = 0.f;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                const float gc = go[k][c];
+                float t00, t10, t01, t11;
+                load_taps(tex, tp, c, CS, t00, t10, t01, t11);
+                gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
+                gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
+                if (grad_tex && gc != 0.0f) {
+                    if (in_win) {
+                        float *w = s_tex + (ly * TEXW + lx) * CS + c;
+                        atomicAdd(w, gc * w00);
+                        atomicAdd(w + CS, gc * w10);
+                        atomicAdd(w + TEXW * CS, gc * w01);
+                        atomicAdd(w + TEXW * CS + CS, gc * w11);
+                    } else {
+                        atomicAdd(grad_tex + tp.i00 + c, gc * w00);
+                        atomicAdd(grad_tex + tp.i10 + c, gc * w10);
+                        atomicAdd(grad_tex + tp.i01 + c, gc * w01);
+                        atomicAdd(grad_tex + tp.i11 + c, gc * w11);
+                    }
                 }
             }
-        }
-        if (t >= 0) {
-            const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
-            const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv >= 0.0f && tv <= 1.0f)) ? 0.0f : 1.0f;
-            const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
-            const float gu = gtu * (q0.x - q2.x) + gtv * (q0.y - q2.y);
-            const float gvv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
-            if (gu != 0.0f || gvv != 0.0f) {
-                const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-                const float4 *p = pos + (size_t)b * V;
-                const float fx = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
-                const float fy = (2.0f * (float)y + 1.0f) / (float)H - 1.0f;
-                float g0[3], g1[3], g2[3];
-                shade_pixel_bwd<false>(p[i0], p[i1], p[i2], fx, fy, 2.0f / (float)W, 2.0f / (float)H,
-                                       make_float4(gu, gvv, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), g0, g1, g2);
-                gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
-                gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
-                gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
-                tkey = t;
+            if (t >= 0) {
+                float2 q0, q1, q2;
+                if (tri_uv) { q0 = tri_uv[3 * t]; q1 = tri_uv[3 * t + 1]; q2 = tri_uv[3 * t + 2]; }
+                else { q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]]; }
+                const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu[k] >= 0.0f && tu[k] <= 1.0f)) ? 0.0f : 1.0f;
+                const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv[k] >= 0.0f && tv[k] <= 1.0f)) ? 0.0f : 1.0f;
+                const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
+                gu = gtu * (q0.x - q2.x) + gtv * (q0.y - q2.y);
+                gvv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
+                if (gu != 0.0f || gvv != 0.0f) tkey = t;
             }
         }
+        // ---- vertices: chain through the barycentrics, sum per run of equal triangle, tails add into the LDS table ----
+        float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (tkey >= 0) {
+            const int i0 = tri[3 * tkey], i1 = tri[3 * tkey + 1], i2 = tri[3 * tkey + 2];
+            const float4 *p = pos + (size_t)b * V;
+            const float fx = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
+            const float fy = (2.0f * (float)(by0 + rowk0 + 2 * k) + 1.0f) / (float)H - 1.0f;
+            float g0[3], g1[3], g2[3];
+            shade_pixel_bwd<false>(p[i0], p[i1], p[i2], fx, fy, 2.0f / (float)W, 2.0f / (float)H,
+                                   make_float4(gu, gvv, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), g0, g1, g2);
+            gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
+            gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
+            gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
+        }
+        wave_segment_reduce<9>(tkey, gv9, [&](int tt, const float (&sm)[9]) {
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int key = tri[3 * tt + kk];
+                unsigned int slot = ((unsigned int)key * 2654435761u) >> 24;   // 8 bits = VSLOTS
+                bool done = false;
+                for (int probe = 0; probe < VSLOTS && !done; ++probe) {
+                    const int old = atomicCAS(&s_vkey[slot], -1, key);
+                    if (old == -1 || old == key) {
+                        atomicAdd(&s_vacc[slot][0], sm[3 * kk]); atomicAdd(&s_vacc[slot][1], sm[3 * kk + 1]);
+                        atomicAdd(&s_vacc[slot][3], sm[3 * kk + 2]);
+                        done = true;
+                    }
+                    slot = (slot + 1) & (VSLOTS - 1);
+                }
+                if (!done) {   // table full: straight to memory
+                    atomicAdd(gp + 4 * (size_t)key + 0, sm[3 * kk]); atomicAdd(gp + 4 * (size_t)key + 1, sm[3 * kk + 1]);
+                    atomicAdd(gp + 4 * (size_t)key + 3, sm[3 * kk + 2]);
+                }
+            }
+        });
     }
-    // ---- vertices: wave-level reduction per triangle, then the group leaders add into the LDS table ----
-    wave_group_reduce<9>(tkey, gv9, [&](int tt, const float (&sm)[9]) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int key = tri[3 * tt + k];
-            unsigned int slot = ((unsigned int)key * 2654435761u) >> 24;   // 8 bits = VSLOTS
-            bool done = false;
-            for (int probe = 0; probe < VSLOTS && !done; ++probe) {
-                const int old = atomicCAS(&s_vkey[slot], -1, key);
-                if (old == -1 || old == key) {
-                    atomicAdd(&s_vacc[slot][0], sm[3 * k]); atomicAdd(&s_vacc[slot][1], sm[3 * k + 1]);
-                    atomicAdd(&s_vacc[slot][3], sm[3 * k + 2]);
-                    done = true;
-                }
-                slot = (slot + 1) & (VSLOTS - 1);
-            }
-            if (!done) {   // table full: straight to memory
-                atomicAdd(gp + 4 * (size_t)key + 0, sm[3 * k]); atomicAdd(gp + 4 * (size_t)key + 1, sm[3 * k + 1]);
-                atomicAdd(gp + 4 * (size_t)key + 3, sm[3 * k + 2]);
-            }
-        }
-    });
     __syncthreads();
     // ---- flush: lane = (slot, component), so the four dwords of a vertex are one contiguous 16-byte access ----
-    for (int k = threadIdx.x; k < VSLOTS * 4; k += 256) {
+    for (int k = tid; k < VSLOTS * 4; k += 256) {
         const int slot = k >> 2, comp = k & 3;
         const int key = s_vkey[slot];
         if (key >= 0) {
@@ -450,12 +479,12 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
         }
     }
     if (grad_tex && ox != 0x7fffffff) {
-        for (int k = threadIdx.x; k < TEXH * TEXW * CS; k += 256) {
+        for (int k = tid; k < TEXH * TEXW * CS; k += 256) {
             const float v = s_tex[k];
             if (v != 0.0f) {
                 const int c = k % CS, cell = k / CS;
-                const int col = cell % TEXW, row = cell / TEXW;
-                const int gx = wrap_i(ox + col, Wt, boundary), gy = wrap_i(oy + row, Ht, boundary);
+                const int colx = cell % TEXW, row = cell / TEXW;
+                const int gx = wrap_i(ox + colx, Wt, boundary), gy = wrap_i(oy + row, Ht, boundary);
                 atomicAdd(grad_tex + ((size_t)gy * Wt + gx) * CS + c, v);
             }
         }
@@ -550,13 +579,13 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
     FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
     FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
     FPCDR_REQUIRE(!p->occ || p->empty_color, "sparse mode needs empty_color");
-    dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
+    dim3 grid(fpcdr_cdiv(p->W, BBIN), fpcdr_cdiv(p->H, BBIN), p->B);
 #define LAUNCH(CS)                                                                                                          \
     hipLaunchKernelGGL(k_render_aa_bwd<CS>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)p->pos, p->tri,        \
                        (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa, p->sil,     \
                        (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,   \
                        p->boundary_mode,                                                                                        \
-                       p->grad_pos, p->grad_tex)
+                       p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv)
     if (p->C == 1) LAUNCH(1);
     else if (p->C == 3) LAUNCH(3);
     else LAUNCH(4);
