@@ -129,6 +129,8 @@ SYMBOLS = {
     "fpcdr_antialias_bwd": (_int, [ctypes.POINTER(AntialiasBwd), _p]),
     "fpcdr_transform_clip_fwd": (_int, [_p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_transform_clip_bwd": (_int, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fpcdr_mvp_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "fpcdr_mvp_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "fpcdr_laplacian_gather": (_int, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fpcdr_blend_fwd": (_int, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_blend_bwd_w": (_int, [_p, _p, _p, _i, _i, _i, _p]),

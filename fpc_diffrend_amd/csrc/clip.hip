@@ -45,26 +45,38 @@ __global__ void __launch_bounds__(256) k_clip_bwd_verts(const float *__restrict_
 }
 
 // d/d mvp[b][i][j] = sum_v g[b][v][i] * (x,y,z,1)[j]: wave DPP sums, then 16 atomics per wave
+constexpr int MVP_VPB = 2048;   // vertices per workgroup of k_clip_bwd_mvp (8 per thread)
 __global__ void __launch_bounds__(256) k_clip_bwd_mvp(const float *__restrict__ verts, const float4 *__restrict__ g, int V, int Nc,
                                                       float *__restrict__ g_mvp) {
+    // grad_mvp[b] = sum_v grad_out[b][v] (x) (verts[v], 1): per-thread partial sums over 8 vertices, one DPP reduction per
+    // wave, LDS across the four waves, then 16 atomics per workgroup (same-address atomics are what this kernel waits for)
+    __shared__ float s_part[4][16];
     const int b = blockIdx.y, f = b / Nc;
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    float pw[4] = {0.f, 0.f, 0.f, 0.f};
-    if (v < V) {
-        q = g[(size_t)b * V + v];
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const int v_end = min((int)(blockIdx.x + 1) * MVP_VPB, V);
+    for (int v = blockIdx.x * MVP_VPB + threadIdx.x; v < v_end; v += 256) {
+        const float4 q = g[(size_t)b * V + v];
         const float *p = verts + ((size_t)f * V + v) * 3;
-        pw[0] = p[0]; pw[1] = p[1]; pw[2] = p[2]; pw[3] = 1.0f;
+        const float pw[4] = {p[0], p[1], p[2], 1.0f};
+        const float gi[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i * 4 + j] += gi[i] * pw[j];
     }
-    const float gi[4] = {q.x, q.y, q.z, q.w};
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float s = wave_sum_dpp(gi[i] * pw[j]);
-            if (lane == 0 && s != 0.0f) atomicAdd(g_mvp + (size_t)b * 16 + i * 4 + j, s);
-        }
+    for (int i = 0; i < 16; ++i) {
+        const float s = wave_sum_dpp(acc[i]);
+        if (lane == 0) s_part[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const float s = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+        if (s != 0.0f) atomicAdd(g_mvp + (size_t)b * 16 + threadIdx.x, s);
+    }
 }
 
 // Uniform-Laplacian gather over a static, padded one-ring table (reference regulariser, fit.py:581 via pytorch3d):
@@ -79,19 +91,151 @@ __global__ void __launch_bounds__(256) k_lap_gather(const float *__restrict__ x,
     if (v >= V) return;
     const float *xf = x + (size_t)f * V * 3;
     float sx = 0.f, sy = 0.f, sz = 0.f;
+    // slot-major table: consecutive threads read consecutive entries; a vertex's ring is stored front to back, so the
+    // first pad ends it (a UV sphere has two poles of degree ~100 among vertices of degree 6)
     for (int d = 0; d < D; ++d) {
-        const int n = nbr[(size_t)v * D + d];
-        if (n < V) {
-            const float w = mode ? inv_deg[n] : 1.0f;
-            sx += w * xf[3 * n]; sy += w * xf[3 * n + 1]; sz += w * xf[3 * n + 2];
-        }
+        const int n = nbr[(size_t)d * V + v];
+        if (n >= V) break;
+        const float w = mode ? inv_deg[n] : 1.0f;
+        sx += w * xf[3 * n]; sy += w * xf[3 * n + 1]; sz += w * xf[3 * n + 2];
     }
     const float s = mode ? 1.0f : inv_deg[v];
     float *o = out + ((size_t)f * V + v) * 3;
     o[0] = s * sx - xf[3 * v]; o[1] = s * sy - xf[3 * v + 1]; o[2] = s * sz - xf[3 * v + 2];
 }
 
+// ---------------------------------------------------------------------------------------------
+// mvp[f,c] = P_c . Rt(q_f, t_f) . (Rt(q_c, t_c) . MV_c)      reference fit.py:541-553, camera.py:117-132 and
+// roma.unitquat_to_rotmat (XYZW, applied WITHOUT normalisation, as the reference does after its whole-tensor
+// "renormalisation", fit.py:616-618).  One thread per (frame, camera); ~120 tiny torch launches otherwise.
+struct M4 { float m[4][4]; };
+__device__ __forceinline__ M4 m4_load(const float *p) {
+    M4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.m[i][j] = p[4 * i + j];
+    return r;
+}
+__device__ __forceinline__ M4 m4_mul(const M4 &a, const M4 &b) {
+    M4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += a.m[i][k] * b.m[k][j];
+            r.m[i][j] = s;
+        }
+    return r;
+}
+__device__ __forceinline__ M4 m4_mul_tn(const M4 &a, const M4 &b) {   // a^T b
+    M4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += a.m[k][i] * b.m[k][j];
+            r.m[i][j] = s;
+        }
+    return r;
+}
+__device__ __forceinline__ M4 m4_mul_nt(const M4 &a, const M4 &b) {   // a b^T
+    M4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += a.m[i][k] * b.m[j][k];
+            r.m[i][j] = s;
+        }
+    return r;
+}
+__device__ __forceinline__ M4 rigid(const float *q, const float *t) {
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w;
+    const float txx = tx * x, txy = ty * x, txz = tz * x;
+    const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    M4 r;
+    r.m[0][0] = 1.0f - (tyy + tzz); r.m[0][1] = txy - twz;          r.m[0][2] = txz + twy;          r.m[0][3] = t[0];
+    r.m[1][0] = txy + twz;          r.m[1][1] = 1.0f - (txx + tzz); r.m[1][2] = tyz - twx;          r.m[1][3] = t[1];
+    r.m[2][0] = txz - twy;          r.m[2][1] = tyz + twx;          r.m[2][2] = 1.0f - (txx + tyy); r.m[2][3] = t[2];
+    r.m[3][0] = 0.0f; r.m[3][1] = 0.0f; r.m[3][2] = 0.0f; r.m[3][3] = 1.0f;
+    return r;
+}
+// dL/d(q, t) from dL/d rigid(q, t): adds 7 values
+__device__ __forceinline__ void rigid_bwd(const float *q, const M4 &G, float *gq, float *gt) {
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float (*g)[4] = G.m;
+    const float gx = 2.0f * (y * (g[0][1] + g[1][0]) + z * (g[0][2] + g[2][0]) + w * (g[2][1] - g[1][2])) - 4.0f * x * (g[1][1] + g[2][2]);
+    const float gy = 2.0f * (x * (g[0][1] + g[1][0]) + z * (g[1][2] + g[2][1]) + w * (g[0][2] - g[2][0])) - 4.0f * y * (g[0][0] + g[2][2]);
+    const float gz = 2.0f * (x * (g[0][2] + g[2][0]) + y * (g[1][2] + g[2][1]) + w * (g[1][0] - g[0][1])) - 4.0f * z * (g[0][0] + g[1][1]);
+    const float gw = 2.0f * (z * (g[1][0] - g[0][1]) + y * (g[0][2] - g[2][0]) + x * (g[2][1] - g[1][2]));
+    atomicAdd(gq + 0, gx); atomicAdd(gq + 1, gy); atomicAdd(gq + 2, gz); atomicAdd(gq + 3, gw);
+    atomicAdd(gt + 0, g[0][3]); atomicAdd(gt + 1, g[1][3]); atomicAdd(gt + 2, g[2][3]);
+}
+
+__global__ void k_mvp_fwd(const float *__restrict__ proj, const float *__restrict__ t_mv, const float *__restrict__ q_cam,
+                          const float *__restrict__ t_cam, const float *__restrict__ q_frame, const float *__restrict__ t_frame,
+                          int Fb, int Nc, float *__restrict__ mvp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Fb * Nc) return;
+    const int f = i / Nc, c = i - f * Nc;
+    const M4 B = m4_mul(rigid(q_cam + 4 * c, t_cam + 3 * c), m4_load(t_mv + 16 * c));
+    const M4 X = m4_mul(rigid(q_frame + 4 * f, t_frame + 3 * f), B);
+    const M4 M = m4_mul(m4_load(proj + 16 * c), X);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mvp[(size_t)i * 16 + 4 * r + k] = M.m[r][k];
+}
+
+__global__ void k_mvp_bwd(const float *__restrict__ proj, const float *__restrict__ t_mv, const float *__restrict__ q_cam,
+                          const float *__restrict__ t_cam, const float *__restrict__ q_frame, const float *__restrict__ t_frame,
+                          const float *__restrict__ g_mvp, int Fb, int Nc, float *__restrict__ gq_cam, float *__restrict__ gt_cam,
+                          float *__restrict__ gq_frame, float *__restrict__ gt_frame) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Fb * Nc) return;
+    const int f = i / Nc, c = i - f * Nc;
+    const M4 MV = m4_load(t_mv + 16 * c);
+    const M4 B = m4_mul(rigid(q_cam + 4 * c, t_cam + 3 * c), MV);
+    const M4 A = rigid(q_frame + 4 * f, t_frame + 3 * f);
+    const M4 gX = m4_mul_tn(m4_load(proj + 16 * c), m4_load(g_mvp + (size_t)i * 16));   // P^T dL/dM
+    const M4 gA = m4_mul_nt(gX, B);                                                       // dL/dX B^T
+    const M4 gC = m4_mul_nt(m4_mul_tn(A, gX), MV);                                        // (A^T dL/dX) MV^T
+    rigid_bwd(q_frame + 4 * f, gA, gq_frame + 4 * f, gt_frame + 3 * f);
+    rigid_bwd(q_cam + 4 * c, gC, gq_cam + 4 * c, gt_cam + 3 * c);
+}
+
 }  // namespace
+
+extern "C" int fpcdr_mvp_fwd(const float *proj, const float *t_mv, const float *q_cam, const float *t_cam, const float *q_frame,
+                             const float *t_frame, float *mvp, int32_t Fb, int32_t Nc, void *stream) {
+    FPCDR_REQUIRE(proj && t_mv && q_cam && t_cam && q_frame && t_frame && mvp, "null pointer");
+    FPCDR_REQUIRE(Fb > 0 && Nc > 0, "bad sizes");
+    hipLaunchKernelGGL(k_mvp_fwd, dim3(fpcdr_cdiv((long long)Fb * Nc, 64)), dim3(64), 0, (hipStream_t)stream, proj, t_mv, q_cam,
+                       t_cam, q_frame, t_frame, Fb, Nc, mvp);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_mvp_bwd(const float *proj, const float *t_mv, const float *q_cam, const float *t_cam, const float *q_frame,
+                             const float *t_frame, const float *grad_mvp, float *gq_cam, float *gt_cam, float *gq_frame,
+                             float *gt_frame, int32_t Fb, int32_t Nc, void *stream) {
+    FPCDR_REQUIRE(proj && t_mv && q_cam && t_cam && q_frame && t_frame && grad_mvp && gq_cam && gt_cam && gq_frame && gt_frame,
+                  "null pointer");
+    FPCDR_REQUIRE(Fb > 0 && Nc > 0, "bad sizes");
+    hipLaunchKernelGGL(k_mvp_bwd, dim3(fpcdr_cdiv((long long)Fb * Nc, 64)), dim3(64), 0, (hipStream_t)stream, proj, t_mv, q_cam,
+                       t_cam, q_frame, t_frame, grad_mvp, Fb, Nc, gq_cam, gt_cam, gq_frame, gt_frame);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
 
 extern "C" int fpcdr_laplacian_gather(const float *x, const int32_t *nbr, const float *inv_deg, float *out, int32_t F, int32_t V,
                                       int32_t D, int32_t transpose, void *stream) {
@@ -122,7 +266,7 @@ extern "C" int fpcdr_transform_clip_bwd(const float *mvp, const float *verts, co
         hipLaunchKernelGGL(k_clip_bwd_verts, dim3(fpcdr_cdiv(V, 256), F), dim3(256), 0, st, mvp, (const float4 *)grad_out, V, Nc,
                            grad_verts);
     if (grad_mvp)
-        hipLaunchKernelGGL(k_clip_bwd_mvp, dim3(fpcdr_cdiv(V, 256), F * Nc), dim3(256), 0, st, verts, (const float4 *)grad_out, V,
+        hipLaunchKernelGGL(k_clip_bwd_mvp, dim3(fpcdr_cdiv(V, MVP_VPB), F * Nc), dim3(256), 0, st, verts, (const float4 *)grad_out, V,
                            Nc, grad_mvp);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;

@@ -338,6 +338,9 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
             }
         }
     }
+#ifdef FPCDR_ABL_EARLY
+    { float sink = 0.f; for (int k = 0; k < 4; ++k) for (int c = 0; c < CS; ++c) sink += go[k][c]; asm volatile("" :: "v"(sink)); return; }
+#endif
     // most bins of an image see no gradient at all: leave before touching the tables
     if (!__syncthreads_or((any[0] | any[1] | any[2] | any[3]) ? 1 : 0)) return;
 
@@ -405,7 +408,12 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
                 load_taps(tex, tp, c, CS, t00, t10, t01, t11);
                 gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
                 gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
+#ifdef FPCDR_ABL_NOTEX
+                asm volatile("" :: "v"(gc * w00), "v"(gc * w10), "v"(gc * w01), "v"(gc * w11), "v"(in_win));
+                if (false) {
+#else
                 if (grad_tex && gc != 0.0f) {
+#endif
                     if (in_win) {
                         float *w = s_tex + (ly * TEXW + lx) * CS + c;
                         atomicAdd(w, gc * w00);
@@ -446,6 +454,9 @@ __global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict_
             gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
             gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
         }
+#ifdef FPCDR_ABL_NOREDUCE
+        { float sink = 0.f; for (int q = 0; q < 9; ++q) sink += gv9[q]; asm volatile("" :: "v"(sink), "v"(tkey)); tkey = -1; }
+#endif
         wave_segment_reduce<9>(tkey, gv9, [&](int tt, const float (&sm)[9]) {
 #pragma unroll
             for (int kk = 0; kk < 3; ++kk) {

@@ -199,6 +199,31 @@ def pixel_loss_fused(colour, rast_out, ref_u8, n_total=None):
     return acc, grad
 
 
+class _mvp_func(torch.autograd.Function):
+    """Model-view-projection matrices of a minibatch in one kernel each way (fpcdr_mvp_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, q_cam, t_cam, q_frame, t_frame, proj, t_mv):
+        q_cam, t_cam, q_frame, t_frame = (a.contiguous() for a in (q_cam, t_cam, q_frame, t_frame))
+        Fb, Nc = q_frame.shape[0], q_cam.shape[0]
+        out = torch.empty(Fb * Nc, 4, 4, dtype=torch.float32, device=q_cam.device)
+        _lib.call("fpcdr_mvp_fwd", _ptr(proj), _ptr(t_mv), _ptr(q_cam), _ptr(t_cam), _ptr(q_frame), _ptr(t_frame), _ptr(out),
+                  Fb, Nc, _stream())
+        ctx.save_for_backward(q_cam, t_cam, q_frame, t_frame, proj, t_mv)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q_cam, t_cam, q_frame, t_frame, proj, t_mv = ctx.saved_tensors
+        Fb, Nc = q_frame.shape[0], q_cam.shape[0]
+        grads = torch.zeros(7 * (Fb + Nc), dtype=torch.float32, device=g.device)
+        gq_cam, gt_cam = grads[:4 * Nc].view(Nc, 4), grads[4 * Nc:7 * Nc].view(Nc, 3)
+        gq_frame, gt_frame = grads[7 * Nc:7 * Nc + 4 * Fb].view(Fb, 4), grads[7 * Nc + 4 * Fb:].view(Fb, 3)
+        _lib.call("fpcdr_mvp_bwd", _ptr(proj), _ptr(t_mv), _ptr(q_cam), _ptr(t_cam), _ptr(q_frame), _ptr(t_frame),
+                  _ptr(g.contiguous()), _ptr(gq_cam), _ptr(gt_cam), _ptr(gq_frame), _ptr(gt_frame), Fb, Nc, _stream())
+        return gq_cam, gt_cam, gq_frame, gt_frame, None, None
+
+
 # ----------------------------------------------------------------------------------------------
 # mesh regularisers (pytorch3d in the reference: fit.py:16-19, 578-582) -- torch restatement
 # ----------------------------------------------------------------------------------------------
@@ -223,7 +248,7 @@ class MeshTopology:
             nbr[a, fill[a]] = b; fill[a] += 1
             nbr[b, fill[b]] = a; fill[b] += 1
         self.nbr = torch.tensor(nbr, dtype=torch.long, device=device)
-        self.nbr32 = self.nbr.to(torch.int32).contiguous()
+        self.nbr32 = self.nbr.to(torch.int32).t().contiguous()      # [Dmax, V] slot-major for the gather kernel
 
 
 class _uniform_laplacian(torch.autograd.Function):
@@ -237,7 +262,7 @@ class _uniform_laplacian(torch.autograd.Function):
             x = x.contiguous()
             out = torch.empty_like(x)
             _lib.call("fpcdr_laplacian_gather", _ptr(x), _ptr(nbr32), _ptr(inv_deg), _ptr(out), x.shape[0], x.shape[1],
-                      nbr32.shape[1], 1 if transpose else 0, _stream())
+                      nbr32.shape[0], 1 if transpose else 0, _stream())
             return out
         xs = x * inv_deg[None, :, None] if transpose else x
         pad = torch.cat([xs, torch.zeros_like(xs[:, :1])], dim=1)
@@ -393,7 +418,7 @@ class Fitter:
                 g['lr'] = torch.tensor(float(g['lr']), dtype=torch.float32, device=dev)
             self.optimizer = torch.optim.Adam(groups, lr=torch.tensor(cfg.lr_base, dtype=torch.float32, device=dev), capturable=True)
         else:
-            self.optimizer = torch.optim.Adam(groups, lr=cfg.lr_base)
+            self.optimizer = torch.optim.Adam(groups, lr=cfg.lr_base, fused=(dev.type == 'cuda'))
         self._graphs, self._graph_key, self._frame_idx = None, None, None
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lr_lambda=lambda x: cfg.lr_ramp ** (float(x) / float(cfg.max_iter)))
@@ -426,6 +451,9 @@ class Fitter:
 
     def mvp(self, frame_ids):
         """mvp[f,c] = P_c . Rt(q_f,t_f) . Rt(q_c,t_c) . MV_c . T(0,170,0)   (fit.py:541-553), [Fb*Nc,4,4]."""
+        if self.device.type == 'cuda':
+            return _mvp_func.apply(self.q_opt[self.cam_sel], self.t_opt[self.cam_sel], self.per_frame_q[frame_ids],
+                                   self.per_frame_t[frame_ids], self.proj, self.t_mv)
         rigid_cam = camera.rigid_grad(self.t_opt[self.cam_sel], camera.unitquat_to_rotmat(self.q_opt[self.cam_sel]))
         rigid_frame = camera.rigid_grad(self.per_frame_t[frame_ids], camera.unitquat_to_rotmat(self.per_frame_q[frame_ids]))
         tr = torch.matmul(rigid_cam, self.t_mv)                       # [Nc,4,4]

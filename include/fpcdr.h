@@ -299,9 +299,20 @@ int fpcdr_transform_clip_fwd(const float *mvp, const float *verts, float *out, i
 int fpcdr_transform_clip_bwd(const float *mvp, const float *verts, const float *grad_out, float *grad_verts, float *grad_mvp,
                              int32_t F, int32_t Nc, int32_t V, void *stream);
 
+/* mvp[f*Nc + c] = proj[c] . Rt(q_frame[f], t_frame[f]) . Rt(q_cam[c], t_cam[c]) . t_mv[c]      reference fit.py:541-553
+ * (camera.rigid_grad, camera.py:128-132; roma.unitquat_to_rotmat on XYZW quaternions, NOT normalised, like the
+ * reference after fit.py:616-618).  proj, t_mv [Nc,4,4] row-major; q [.,4]; t [.,3]; mvp [Fb*Nc,4,4].
+ * bwd: the four gradient buffers are accumulated (zero them first).                                               */
+int fpcdr_mvp_fwd(const float *proj, const float *t_mv, const float *q_cam, const float *t_cam, const float *q_frame,
+                  const float *t_frame, float *mvp, int32_t Fb, int32_t Nc, void *stream);
+int fpcdr_mvp_bwd(const float *proj, const float *t_mv, const float *q_cam, const float *t_cam, const float *q_frame,
+                  const float *t_frame, const float *grad_mvp, float *gq_cam, float *gt_cam, float *gq_frame, float *gt_frame,
+                  int32_t Fb, int32_t Nc, void *stream);
+
 /* uniform mesh Laplacian (reference fit.py:581, pytorch3d mesh_laplacian_smoothing 'uniform'), gather form:
  *   transpose = 0: out = L x,  L = D^-1 A - I;   transpose = 1: out = L^T x (the backward of the former)
- * x, out [F,V,3]; nbr [V,D] int32 one-ring table padded with indices >= V; inv_deg [V].                       */
+ * x, out [F,V,3]; nbr [D,V] int32 one-ring table, slot-major: nbr[d][v] = d-th neighbour of v, rings stored front to
+ * back and padded with indices >= V; inv_deg [V].                                                              */
 int fpcdr_laplacian_gather(const float *x, const int32_t *nbr, const float *inv_deg, float *out, int32_t F, int32_t V, int32_t D,
                            int32_t transpose, void *stream);
 

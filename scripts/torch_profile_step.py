@@ -10,4 +10,4 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for _ in range(3): ft.step()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=60))

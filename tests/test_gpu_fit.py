@@ -231,3 +231,30 @@ def test_hip_graph_steps_equal_eager_steps(mode, fps, shading):
     assert np.isfinite(b).all()
     assert np.allclose(a, b, rtol=2e-3), (a, b)
     assert np.allclose(a[:5], b[:5], rtol=1e-5), (a, b)
+
+
+def test_mvp_kernel_matches_torch_chain():
+    """fpcdr_mvp_fwd / _bwd against the reference's chain of small torch ops (fit.py:541-553; camera.py:117-132)."""
+    from fpc_diffrend_amd import camera, fit
+    torch.manual_seed(3)
+    dev = 'cuda'
+    Fb, Nc = 5, 3
+    proj = torch.randn(Nc, 4, 4, device=dev)
+    t_mv = torch.randn(Nc, 4, 4, device=dev)
+    leaves = [torch.randn(Nc, 4, device=dev), torch.randn(Nc, 3, device=dev), torch.randn(Fb, 4, device=dev),
+              torch.randn(Fb, 3, device=dev)]          # quaternions deliberately not normalised (quirk Q3)
+    g = torch.randn(Fb * Nc, 4, 4, device=dev)
+    res = []
+    for fused in (True, False):
+        qc, tc, qf, tf = (a.clone().requires_grad_(True) for a in leaves)
+        if fused:
+            out = fit._mvp_func.apply(qc, tc, qf, tf, proj, t_mv)
+        else:
+            rigid_cam = camera.rigid_grad(tc, camera.unitquat_to_rotmat(qc))
+            rigid_frame = camera.rigid_grad(tf, camera.unitquat_to_rotmat(qf))
+            tr = torch.matmul(rigid_cam, t_mv)
+            out = torch.matmul(proj[None], torch.matmul(rigid_frame[:, None], tr[None])).reshape(-1, 4, 4)
+        out.backward(g)
+        res.append([out.detach()] + [a.grad for a in (qc, tc, qf, tf)])
+    for a, b in zip(*res):
+        assert rel_l2(a, b) < 1e-5
