@@ -42,8 +42,12 @@ __device__ __forceinline__ OccWin load_occ(const uint16_t *occ, int b, int H, in
 // registers from one row to the next.  Writes d(sum of squares * grad_scale)/d(antialiased colour) and the two flag bit
 // planes; reduces the loss.  SPARSE: blocks without an occupied bin (or an occupied right / upper neighbour, whose
 // pairs a block owns) leave at once, and the loss is accumulated as the difference to an all-background image.
+// latency-bound: 8 waves per SIMD (1.54 -> 1.34 ms)
+#ifndef FPCDR_AAL_WPE
+#define FPCDR_AAL_WPE __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
 template <int CS, bool SPARSE>
-__global__ void __launch_bounds__(256) k_aa_loss(const float *__restrict__ color, const float4 *__restrict__ rast,
+__global__ void __launch_bounds__(256) FPCDR_AAL_WPE k_aa_loss(const float *__restrict__ color, const float4 *__restrict__ rast,
                                                  const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                  const uint8_t *__restrict__ sil, const uint8_t *__restrict__ ref, int B, int H,
                                                  int W, int V, int T, float bg, float color_scale, float grad_scale,
@@ -220,8 +224,12 @@ constexpr int VSLOTS = 256;
 constexpr int TEXW = 48, TEXH = 48;
 constexpr int BBIN = 32;
 
+// latency-bound (dependent loads per bin): 8 waves per SIMD with a few spilled registers beat 5 without (3.26 -> 2.81 ms)
+#ifndef FPCDR_BWD_WPE
+#define FPCDR_BWD_WPE __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
 template <int CS>
-__global__ void __launch_bounds__(256) k_render_aa_bwd(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+__global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
                                                        const float *__restrict__ tex, const float4 *__restrict__ rast,
                                                        const float *__restrict__ color, const float *__restrict__ g_aa,

@@ -81,8 +81,8 @@ constexpr int SMALL_EXTENT = 16384;
 #endif
 constexpr int LANE_MAX = FPCDR_LANE_MAX;
 constexpr int BIGB = 64;         // triangles per round of the tile path
-#ifndef FPCDR_BINS_WAVES
-#define FPCDR_BINS_WAVES 1
+#ifndef FPCDR_BINS_WPE
+#define FPCDR_BINS_WPE
 #endif
 #ifndef FPCDR_SCAN_K
 #define FPCDR_SCAN_K 4
@@ -273,7 +273,7 @@ struct ShadeArgs {
 };
 
 template <bool WRITE_DB, bool SHADE>
-__global__ void __launch_bounds__(256, FPCDR_BINS_WAVES) k_bins(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+__global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               int V, int T, int H, int W, const TriRec *__restrict__ recs,
                                               const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
                                               const ImgBox *__restrict__ ibox, float4 *__restrict__ rast,
