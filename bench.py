@@ -50,6 +50,7 @@ def algorithmic_bytes_per_px(C, with_db):
         "fpcdr_render_fwd": 16 + 4 * C,                 # rast + colour written
         "fpcdr_aa_loss_fwd": 4 * C + 16 + 1 + 4 * C,    # colour + rast + 8-bit ref in, d loss / d aa out
         "fpcdr_render_aa_bwd": 4 * C + 16,              # d loss / d aa + rast in, scatter only
+        "fpcdr_render_loss_fwd": 16 + 4 * C + 1 + 4 * C,  # rast + colour + d loss / d aa written, 8-bit ref read
     }
 
 

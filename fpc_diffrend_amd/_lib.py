@@ -114,6 +114,7 @@ SYMBOLS = {
     "fpcdr_render_fwd": (_int, [ctypes.POINTER(RenderFwd), _p]),
     "fpcdr_render_bwd": (_int, [ctypes.POINTER(RenderBwd), _p]),
     "fpcdr_aa_loss_fwd": (_int, [ctypes.POINTER(AaLossFwd), _p]),
+    "fpcdr_render_loss_fwd": (_int, [ctypes.POINTER(RenderFwd), ctypes.POINTER(AaLossFwd), _p, _p]),
     "fpcdr_ref_bg_sumsq": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, _p, _p]),
     "fpcdr_render_aa_bwd": (_int, [ctypes.POINTER(RenderAaBwd), _p]),
     "fpcdr_interpolate_fwd": (_int, [ctypes.POINTER(InterpolateFwd), _p]),

@@ -37,6 +37,73 @@ __device__ __forceinline__ OccWin load_occ(const uint16_t *occ, int b, int H, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// One pixel of antialias (gather form, see antialias.hip) + background composite + squared error: evaluates the
+// pixel's four pairs (me-R, me-U owned; L-me, D-me not), writes d(sum of squares * grad_scale)/d(antialiased colour),
+// sets the two ownership flags and returns the pixel's loss term (SPARSE: the difference to a background pixel).
+template <int CS, bool SPARSE>
+__device__ __forceinline__ float aa_loss_pixel(const AAGeom &g, const OccWin &ow, const float *__restrict__ color, size_t img, int x,
+                                               int y, float2 me, float2 nR, float2 nL, float2 nU, float2 nD, bool hasR, bool hasL,
+                                               bool hasU, bool hasD, bool v_me, const float (&ecol)[CS],
+                                               const uint8_t *__restrict__ ref, float bg, float color_scale, float grad_scale,
+                                               float *__restrict__ g_aa, bool &fx_flag, bool &fy_flag) {
+    const int W = g.W;
+    const size_t off = img + (size_t)y * W + x;
+    const int id = (int)me.y;
+    float lsum = 0.0f;
+    const bool disc = ((int)nR.y != id) | ((int)nL.y != id) | ((int)nU.y != id) | ((int)nD.y != id);
+    const bool covered = id > 0;
+    if (disc | covered) {
+        float acc[CS], cme[CS];
+#pragma unroll
+        for (int c = 0; c < CS; ++c) { cme[c] = (!SPARSE || v_me) ? color[off * CS + c] : ecol[c]; acc[c] = cme[c]; }
+        if (disc) {
+            auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own, bool &flag) {
+                if ((int)p0.y == (int)p1.y) return;
+                bool hit = for_active_edges(g, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
+                    [&](float t, int Px, int Py, int Qx, int Qy, int, int, const EdgeEval &, float) {
+                        const bool far = t >= 0.5f;
+                        const int rx = far ? Qx : Px, ry = far ? Qy : Py;
+                        if (rx != x || ry != y) return;
+                        const int ox = far ? Px : Qx, oy = far ? Py : Qy;
+                        const float amt = far ? t - 0.5f : 0.5f - t;
+                        const bool ovalid = !SPARSE || ow.pixel(ox, oy);
+                        const float *co = color + (img + (size_t)oy * W + ox) * CS;
+#pragma unroll
+                        for (int c = 0; c < CS; ++c) acc[c] += amt * ((ovalid ? co[c] : ecol[c]) - cme[c]);
+                    });
+                if (own && hit) flag = true;
+            };
+            bool dummy = false;
+            if (hasR) visit(x, y, 0, me, nR, true, fx_flag);
+            if (hasU) visit(x, y, 1, me, nU, true, fy_flag);
+            if (hasL) visit(x - 1, y, 0, nL, me, false, dummy);
+            if (hasD) visit(x, y - 1, 1, nD, me, false, dummy);
+        }
+        if (covered) {   // background elsewhere (fit.py:161): no gradient, and in sparse mode no loss term either
+            const float rf = (float)ref[off];
+            const float d0 = rf - bg * color_scale;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                const float d = rf - acc[c] * color_scale;
+                lsum += SPARSE ? (d * d - d0 * d0) : d * d;
+                g_aa[off * CS + c] = (-2.0f * color_scale * grad_scale) * d;
+            }
+        }
+    }
+    if (!covered) {
+        if (!SPARSE) {
+            const float d0 = (float)ref[off] - bg * color_scale;
+            lsum += (float)CS * d0 * d0;
+        }
+        if (!SPARSE || v_me) {
+#pragma unroll
+            for (int c = 0; c < CS; ++c) g_aa[off * CS + c] = 0.0f;
+        }
+    }
+    return lsum;
+}
+
+// ------------------------------------------------------------------------------------------------
 // antialias forward (gather form, see antialias.hip) + background composite + squared error.  One workgroup per
 // 64 x 32 pixel block (two bins), one wave per 8 rows, one pixel per lane and row; the rows above / below travel in
 // registers from one row to the next.  Writes d(sum of squares * grad_scale)/d(antialiased colour) and the two flag bit
@@ -90,67 +157,18 @@ __global__ void __launch_bounds__(256) FPCDR_AAL_WPE k_aa_loss(const float *__re
         const float zr = __shfl_down(me.x, 1, 64), ir = __shfl_down(me.y, 1, 64);
         const float zl = __shfl_up(me.x, 1, 64), il = __shfl_up(me.y, 1, 64);
         if (x < W) {
-            const size_t off = img + (size_t)y * W + x;
-            const int id = (int)me.y;
             const bool hasR = x + 1 < W, hasL = x > 0, hasU = y + 1 < H, hasD = y > 0;
             // left / right neighbours come from the neighbouring lanes' registers; only the two ends of the wave's
             // 64-pixel span are loaded
+            const size_t off = img + (size_t)y * W + x;
             float2 nR = me, nL = me;
             if (hasR) nR = lane < 63 ? make_float2(zr, ir) : ((!SPARSE || ow.bin(2, 0)) ? load_zid(rast, off + 1) : make_float2(0.f, 0.f));
             if (hasL) nL = lane > 0 ? make_float2(zl, il) : ((!SPARSE || ow.bin(-1, 0)) ? load_zid(rast, off - 1) : make_float2(0.f, 0.f));
             const float2 nU = hasU ? up : me;
             const float2 nD = hasD ? dn : me;
-            const bool disc = ((int)nR.y != id) | ((int)nL.y != id) | ((int)nU.y != id) | ((int)nD.y != id);
-            const bool covered = id > 0;
-            if (disc | covered) {
-                float acc[CS], cme[CS];
-#pragma unroll
-                for (int c = 0; c < CS; ++c) { cme[c] = (!SPARSE || v_me) ? color[off * CS + c] : ecol[c]; acc[c] = cme[c]; }
-                if (disc) {
-                    AAGeom g = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
-                    auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own, bool &flag) {
-                        if ((int)p0.y == (int)p1.y) return;
-                        bool hit = for_active_edges(g, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
-                            [&](float t, int Px, int Py, int Qx, int Qy, int, int, const EdgeEval &, float) {
-                                const bool far = t >= 0.5f;
-                                const int rx = far ? Qx : Px, ry = far ? Qy : Py;
-                                if (rx != x || ry != y) return;
-                                const int ox = far ? Px : Qx, oy = far ? Py : Qy;
-                                const float amt = far ? t - 0.5f : 0.5f - t;
-                                const bool ovalid = !SPARSE || ow.pixel(ox, oy);
-                                const float *co = color + (img + (size_t)oy * W + ox) * CS;
-#pragma unroll
-                                for (int c = 0; c < CS; ++c) acc[c] += amt * ((ovalid ? co[c] : ecol[c]) - cme[c]);
-                            });
-                        if (own && hit) flag = true;
-                    };
-                    bool dummy = false;
-                    if (hasR) visit(x, y, 0, me, nR, true, fx_flag);
-                    if (hasU) visit(x, y, 1, me, nU, true, fy_flag);
-                    if (hasL) visit(x - 1, y, 0, nL, me, false, dummy);
-                    if (hasD) visit(x, y - 1, 1, nD, me, false, dummy);
-                }
-                if (covered) {   // background elsewhere (fit.py:161): no gradient, and in sparse mode no loss term either
-                    const float rf = (float)ref[off];
-                    const float d0 = rf - bg * color_scale;
-#pragma unroll
-                    for (int c = 0; c < CS; ++c) {
-                        const float d = rf - acc[c] * color_scale;
-                        lsum += SPARSE ? (d * d - d0 * d0) : d * d;
-                        g_aa[off * CS + c] = (-2.0f * color_scale * grad_scale) * d;
-                    }
-                }
-            }
-            if (!covered) {
-                if (!SPARSE) {
-                    const float d0 = (float)ref[off] - bg * color_scale;
-                    lsum += (float)CS * d0 * d0;
-                }
-                if (!SPARSE || v_me) {
-#pragma unroll
-                    for (int c = 0; c < CS; ++c) g_aa[off * CS + c] = 0.0f;
-                }
-            }
+            const AAGeom g = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
+            lsum += aa_loss_pixel<CS, SPARSE>(g, ow, color, img, x, y, me, nR, nL, nU, nD, hasR, hasL, hasU, hasD, v_me, ecol, ref, bg,
+                                              color_scale, grad_scale, g_aa, fx_flag, fy_flag);
         }
         const unsigned long long bx = __ballot(fx_flag), by = __ballot(fy_flag);
         if (lane == 0) {
@@ -510,6 +528,121 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second half of fpcdr_render_loss_fwd.  k_bins<LOSS> (rasterize.hip) gave every pixel the loss term and gradient of
+// its un-antialiased colour, marked the pixels with a silhouette pair INSIDE their bin and exported each bin's four
+// border lines.  One workgroup per 32x32 bin: 128 threads classify the pairs ACROSS the bin's border from its own and
+// its neighbours' lines (2 KB, contiguous), the candidates are gathered into an LDS list, and each gets the full
+// antialias + loss pixel, which overwrites its gradient and CORRECTS the loss; flag bits are OR-ed into the
+// (zero-filled) planes.  An unoccupied bin was never rasterised (its pixels are empty) but still owns the pairs
+// across its right / top border.
+template <int CS>
+__global__ void __launch_bounds__(256) k_aa_fix(const float *__restrict__ color, const float4 *__restrict__ rast,
+                                                const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                const uint8_t *__restrict__ sil, const uint8_t *__restrict__ ref, int B, int H,
+                                                int W, int V, int T, float bg, float color_scale, float grad_scale,
+                                                unsigned long long *__restrict__ flags, float *__restrict__ g_aa,
+                                                const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
+                                                const uint32_t *__restrict__ cmask, const unsigned long long *__restrict__ edges,
+                                                double *__restrict__ loss_sum) {
+    __shared__ unsigned int s_mask[BBIN];
+    __shared__ int s_list[BBIN * BBIN];
+    __shared__ int s_n;
+    __shared__ float s_part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, bx0 = blockIdx.x * BBIN, by0 = blockIdx.y * BBIN;
+    const OccWin ow = load_occ(occ, b, H, W, blockIdx.x, blockIdx.y);
+    const bool v_me = ow.bin(0, 0);
+    if (!(v_me || ow.bin(1, 0) || ow.bin(0, 1))) return;
+    const size_t bin_id = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid < BBIN) s_mask[tid] = v_me ? cmask[bin_id * BBIN + tid] : 0u;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const uint8_t *silb = sil + (size_t)b * T;
+    if (tid < 4 * BBIN) {
+        // pair across the border: side 0 left column, 1 right column, 2 bottom row, 3 top row; the neighbour's facing line
+        const int side = tid >> 5, i = tid & 31;
+        const int dx = side == 0 ? -1 : (side == 1 ? 1 : 0), dy = side == 2 ? -1 : (side == 3 ? 1 : 0);
+        const int zx = side == 0 ? 0 : (side == 1 ? BBIN - 1 : i), zy = side == 2 ? 0 : (side == 3 ? BBIN - 1 : i);
+        const int x = bx0 + zx, y = by0 + zy;
+        const int nx = x + dx, ny = y + dy;
+        // (an empty, never-written pixel matters only as the OWNER of a pair: right / top side)
+        if (x < W && y < H && nx >= 0 && nx < W && ny >= 0 && ny < H && (v_me || (side & 1))) {
+            const unsigned long long me = v_me ? edges[bin_id * (4 * BBIN) + side * BBIN + i] : 0ull;
+            unsigned long long nb = 0ull;
+            if (ow.bin(dx, dy)) {
+                const size_t nbin = ((size_t)b * gridDim.y + (blockIdx.y + dy)) * gridDim.x + (blockIdx.x + dx);
+                nb = edges[nbin * (4 * BBIN) + (side ^ 1) * BBIN + i];
+            }
+            const int id = (int)(unsigned int)me, nid = (int)(unsigned int)nb;
+            if (id != nid) {
+                const float z = __uint_as_float((unsigned int)(me >> 32)), nz = __uint_as_float((unsigned int)(nb >> 32));
+                const bool me_first = (side & 1);   // right / upper pairs are (me, n), left / lower pairs (n, me)
+                const PairSel ps = me_first ? pair_select(id, z, nid, nz, T) : pair_select(nid, nz, id, z, T);
+                if (ps.tau >= 0 && silb[ps.tau] != 0) atomicOr(&s_mask[zy], 1u << zx);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BBIN * BBIN / 256; ++k) {
+        const int pix = k * 256 + tid;
+        const bool c = (s_mask[pix >> 5] >> (pix & 31)) & 1u;
+        const unsigned long long bal = __ballot(c);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (c) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = pix;
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n == 0) return;
+    float ecol[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) ecol[c] = empty_color[c];
+    const size_t img = (size_t)b * H * W;
+    const int Wq = FPCDR_AA_ROW_WORDS(W);
+    const size_t plane = (size_t)B * H * Wq;
+    const AAGeom g = {pos + (size_t)b * V, tri, silb, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
+    float lsum = 0.0f;
+    for (int i = tid; i < n; i += 256) {
+        const int pix = s_list[i];
+        const int x = bx0 + (pix & 31), y = by0 + (pix >> 5);
+        if (x >= W || y >= H) continue;
+        auto zid_at = [&](int xx, int yy) -> float2 {
+            return ow.pixel(xx, yy) ? load_zid(rast, img + (size_t)yy * W + xx) : make_float2(0.f, 0.f);
+        };
+        const bool hasR = x + 1 < W, hasL = x > 0, hasU = y + 1 < H, hasD = y > 0;
+        const float2 me = zid_at(x, y);
+        const float2 nR = hasR ? zid_at(x + 1, y) : me, nL = hasL ? zid_at(x - 1, y) : me;
+        const float2 nU = hasU ? zid_at(x, y + 1) : me, nD = hasD ? zid_at(x, y - 1) : me;
+        bool fx_flag = false, fy_flag = false;
+        lsum += aa_loss_pixel<CS, true>(g, ow, color, img, x, y, me, nR, nL, nU, nD, hasR, hasL, hasU, hasD, v_me, ecol, ref, bg,
+                                        color_scale, grad_scale, g_aa, fx_flag, fy_flag);
+        if (v_me && (int)me.y > 0) {   // take back what k_bins added for the un-antialiased colour
+            const size_t off = img + (size_t)y * W + x;
+            const float rf = (float)ref[off];
+            const float d0 = rf - bg * color_scale;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                const float dd = rf - color[off * CS + c] * color_scale;
+                lsum -= dd * dd - d0 * d0;
+            }
+        }
+        const size_t wi = ((size_t)b * H + y) * Wq + (x >> 6);
+        if (fx_flag) atomicOr(flags + wi, 1ull << (x & 63));
+        if (fy_flag) atomicOr(flags + plane + wi, 1ull << (x & 63));
+    }
+    lsum = wave_sum_dpp(lsum);
+    if (lane == 0) s_part[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+        const double tot = (double)s_part[0] + (double)s_part[1] + (double)s_part[2] + (double)s_part[3];
+        const unsigned int slot = (blockIdx.x + 31u * blockIdx.y + 977u * blockIdx.z + 128u) % FPCDR_LOSS_SLOTS;
+        if (tot != 0.0) atomicAdd(loss_sum + slot, tot);
+    }
+}
+
 // per-image silhouette classification (same arithmetic as k_sil in antialias.hip)
 __global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               const int32_t *__restrict__ adj, int B, int V, int T, float hw, float hh,
@@ -546,6 +679,30 @@ __global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, co
 }
 
 }  // namespace
+
+// ---- pieces of fpcdr_render_loss_fwd (rasterize.hip) that live in this file; not part of the C ABI ----
+int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, int B, int V, int T, int H, int W, uint8_t *sil,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv((long long)B * T, 256)), dim3(256), 0, st, (const float4 *)pos, tri, adj, B, V, T,
+                       0.5f * (float)W, 0.5f * (float)H, sil);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask, hipStream_t st) {
+    dim3 grid(fpcdr_cdiv(p->W, BBIN), fpcdr_cdiv(p->H, BBIN), p->B);
+#define LAUNCH(CS)                                                                                                            \
+    hipLaunchKernelGGL(k_aa_fix<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, p->tri, \
+                       p->sil, p->ref, p->B, p->H, p->W, p->V, p->T, p->bg, p->color_scale, p->grad_scale,                      \
+                       (unsigned long long *)p->flags, p->grad_aa, p->occ, p->empty_color, cmask,                \
+                       (const unsigned long long *)(cmask + (size_t)grid.x * grid.y * grid.z * BBIN), p->loss_sum)
+    if (p->C == 1) LAUNCH(1);
+    else if (p->C == 3) LAUNCH(3);
+    else LAUNCH(4);
+#undef LAUNCH
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
 
 extern "C" int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream) {
     FPCDR_REQUIRE(p != nullptr, "null params");

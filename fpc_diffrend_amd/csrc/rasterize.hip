@@ -28,6 +28,7 @@ namespace {
 
 #include "texsample.h"
 #include "raster_math.h"
+#include "aa_pairs.h"
 
 constexpr int SUBPIX = 256;
 constexpr int HALFPIX = 128;
@@ -81,8 +82,9 @@ constexpr int SMALL_EXTENT = 16384;
 #endif
 constexpr int LANE_MAX = FPCDR_LANE_MAX;
 constexpr int BIGB = 64;         // triangles per round of the tile path
+// latency-bound: never fewer than 6 waves per SIMD (the LOSS variant otherwise lands on 81 VGPRs = 5 waves: +0.3 ms)
 #ifndef FPCDR_BINS_WPE
-#define FPCDR_BINS_WPE
+#define FPCDR_BINS_WPE __attribute__((amdgpu_waves_per_eu(6, 8)))
 #endif
 #ifndef FPCDR_SCAN_K
 #define FPCDR_SCAN_K 4
@@ -270,9 +272,17 @@ struct ShadeArgs {
                              // (k_occ_window turns this byte map into the per-bin window masks the consumers read)
     float *empty_out;        // sparse mode: out [4], the colour an empty pixel gets (texture at uv = (0,0))
     const float2 *tri_uv;    // optional [T,3]: uv[uv_tri] pre-gathered
+    // LOSS (fpcdr_render_loss_fwd): background + squared error of every pixel that antialiasing cannot touch
+    const uint8_t *sil;      // [B,T] silhouette bits (k_sil2)
+    const uint8_t *ref;      // [B,H,W]
+    float *g_aa;             // out [B,H,W,C]
+    uint32_t *cmask;         // out [B*bins][32]: row masks of the bin's CANDIDATE pixels, left to k_aa_fix
+    unsigned long long *edges;   // out [B*bins][4][32]: (z/w bits << 32 | id) of the bin's four border lines
+    double *loss_sum;        // [FPCDR_LOSS_SLOTS]
+    float bg, color_scale, grad_scale;
 };
 
-template <bool WRITE_DB, bool SHADE>
+template <bool WRITE_DB, bool SHADE, bool LOSS = false>
 __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               int V, int T, int H, int W, const TriRec *__restrict__ recs,
                                               const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
@@ -542,6 +552,11 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
     }
 
     // ---- shade + write (every pixel of the bin is written exactly once) ----
+    float col0[TILES_PER_WAVE][4];   // LOSS: channel 0 of this thread's pixels (re-reading a just-written line stalls)
+#pragma unroll
+    for (int k = 0; k < TILES_PER_WAVE; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) col0[k][q] = 0.0f;
     const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
     const float4 *p = pos + (size_t)b * V;
     Taps empty_tp = {};
@@ -575,6 +590,10 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
             const size_t off = ((size_t)b * H + py) * W + px;
             rast[off] = o;
             if (WRITE_DB) rast_db[off] = d;
+            if (LOSS) {   // (z/w, id) of the bin's pixels for the neighbour tests below; this thread owns the entry
+                const int zx = (tile % TILES_X) * TILE + (q & 1) * QUAD + lx, zy = (tile / TILES_X) * TILE + (q >> 1) * QUAD + ly;
+                s_z[zy * BIN + zx] = ((unsigned long long)__float_as_uint(o.z) << 32) | (unsigned int)(t + 1);
+            }
             if (SHADE) {
                 // interpolate (reference fit.py:157) + texture 'linear' (fit.py:158), same arithmetic as the stand-alone
                 // kernels; an empty pixel samples uv = (0,0) exactly as they do (one tap set, hoisted out of the loops)
@@ -586,11 +605,85 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
                     const float tu = o.x * q0.x + o.y * q1.x + w * q2.x;
                     const float tv = o.x * q0.y + o.y * q1.y + w * q2.y;
                     const Taps tp = make_taps(tu, tv, sh.Ht, sh.Wt, sh.C, sh.boundary);
-                    for (int c = 0; c < sh.C; ++c) sh.color[off * sh.C + c] = bilerp(sh.tex, tp, c, sh.C);
+                    for (int c = 0; c < sh.C; ++c) {
+                        const float v = bilerp(sh.tex, tp, c, sh.C);
+                        sh.color[off * sh.C + c] = v;
+                        if (LOSS && c == 0) col0[k][q] = v;
+                    }
                 } else {
                     for (int c = 0; c < sh.C; ++c) sh.color[off * sh.C + c] = c < 4 ? empty_col[c] : bilerp(sh.tex, empty_tp, c, sh.C);
                 }
             }
+        }
+    }
+    if (LOSS) {
+        // ---- every pixel gets the loss term and gradient of its UN-antialiased colour; CANDIDATES are marked ----
+        // A pixel's antialiased colour differs from its colour only if one of its four pixel pairs has different ids AND
+        // the nearer triangle of the pair has a silhouette edge (the early-outs of for_active_edges, aa_pairs.h).  The
+        // pairs inside the bin are classified here from the ids in LDS; for the pairs across the bin's border the four
+        // border lines (z/w, id) go to a compact edge buffer.  k_aa_fix (fused.hip) classifies those, runs the full
+        // antialias on the candidates only and corrects their loss / gradient: no dense antialias pass over the image.
+        __shared__ unsigned int s_cmask[BIN];
+        __shared__ float s_lpart[4];
+        if (tid < BIN) s_cmask[tid] = 0u;
+        __syncthreads();   // (z/w, id) entries and the cleared masks are visible
+        const uint8_t *silb = sh.sil + (size_t)b * T;
+        const size_t bin_id = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        unsigned long long *edge = sh.edges + bin_id * (4 * BIN);   // [left col | right col | bottom row | top row][32]
+        float lsum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < TILES_PER_WAVE; ++k) {
+            const int tile = wave * TILES_PER_WAVE + k;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int zx = (tile % TILES_X) * TILE + (q & 1) * QUAD + lx, zy = (tile / TILES_X) * TILE + (q >> 1) * QUAD + ly;
+                const int px = bin_x0 + zx, py = bin_y0 + zy;
+                const bool inimg = px < W && py < H;
+                const int idx = zy * BIN + zx;
+                const unsigned long long me = inimg ? s_z[idx] : 0ull;
+                if (zx == 0) edge[zy] = me;
+                if (zx == BIN - 1) edge[BIN + zy] = me;
+                if (zy == 0) edge[2 * BIN + zx] = me;
+                if (zy == BIN - 1) edge[3 * BIN + zx] = me;
+                if (!inimg) continue;
+                const int id = (int)(unsigned int)me;
+                const float z = __uint_as_float((unsigned int)(me >> 32));
+                // pair_select keeps the FIRST pixel's triangle on a depth tie: right / upper pairs are (me, n), left / lower
+                // pairs (n, me), as for_active_edges is called
+                auto pair = [&](int nidx, bool me_first) {
+                    const unsigned long long n = s_z[nidx];
+                    const int nid = (int)(unsigned int)n;
+                    if (nid == id) return false;
+                    const float nz = __uint_as_float((unsigned int)(n >> 32));
+                    const PairSel ps = me_first ? pair_select(id, z, nid, nz, T) : pair_select(nid, nz, id, z, T);
+                    return ps.tau >= 0 && silb[ps.tau] != 0;
+                };
+                const bool cand = (zx < BIN - 1 && px + 1 < W && pair(idx + 1, true)) || (zy < BIN - 1 && py + 1 < H && pair(idx + BIN, true)) ||
+                                  (zx > 0 && pair(idx - 1, false)) || (zy > 0 && pair(idx - BIN, false));
+                if (cand) atomicOr(&s_cmask[zy], 1u << zx);
+                const size_t off = ((size_t)b * H + py) * W + px;
+                if (id > 0) {
+                    const float rf = (float)sh.ref[off];
+                    const float d0 = rf - sh.bg * sh.color_scale;
+                    for (int c = 0; c < sh.C; ++c) {
+                        const float cv = c == 0 ? col0[k][q] : sh.color[off * sh.C + c];   // this thread wrote it above
+                        const float dd = rf - cv * sh.color_scale;
+                        lsum += dd * dd - d0 * d0;
+                        sh.g_aa[off * sh.C + c] = (-2.0f * sh.color_scale * sh.grad_scale) * dd;
+                    }
+                } else {
+                    for (int c = 0; c < sh.C; ++c) sh.g_aa[off * sh.C + c] = 0.0f;
+                }
+            }
+        }
+        lsum = wave_sum_dpp(lsum);
+        if (lane == 0) s_lpart[wave] = lsum;
+        __syncthreads();
+        if (tid < BIN) sh.cmask[bin_id * BIN + tid] = s_cmask[tid];
+        if (tid == 0) {
+            const double tot = (double)s_lpart[0] + (double)s_lpart[1] + (double)s_lpart[2] + (double)s_lpart[3];
+            const unsigned int slot = (blockIdx.x + 31u * blockIdx.y + 977u * blockIdx.z) % FPCDR_LOSS_SLOTS;
+            if (tot != 0.0) atomicAdd(sh.loss_sum + slot, tot);
         }
     }
 }
@@ -854,4 +947,47 @@ extern "C" int fpcdr_render_bwd(const fpcdr_render_bwd_params *p, void *stream) 
                        p->Wt, p->C, p->boundary_mode, p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
+}
+
+extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpcdr_aa_loss_fwd_params *l, uint32_t *cmask,
+                                     void *stream) {
+    FPCDR_REQUIRE(p != nullptr && l != nullptr && cmask != nullptr, "null params");
+    FPCDR_REQUIRE(p->pos && p->tri && p->scratch && p->uv && p->uv_tri && p->tex && p->rast && p->color, "null pointer");
+    FPCDR_REQUIRE(p->occ && p->empty_color, "fpcdr_render_loss_fwd works in sparse mode only (occ, empty_color)");
+    FPCDR_REQUIRE(l->adj && l->ref && l->sil && l->flags && l->grad_aa && l->loss_sum, "null pointer");
+    FPCDR_REQUIRE(l->color == p->color && l->rast == p->rast && l->pos == p->pos && l->tri == p->tri && l->occ == p->occ &&
+                      l->empty_color == p->empty_color && l->B == p->B && l->H == p->H && l->W == p->W && l->C == p->C &&
+                      l->V == p->V && l->T == p->T,
+                  "the two parameter blocks describe different batches");
+    FPCDR_REQUIRE(p->B > 0 && p->V > 0 && p->T > 0 && p->H > 0 && p->W > 0 && p->Vt > 0 && p->Ht > 0 && p->Wt > 0 && p->C > 0,
+                  "sizes must be positive");
+    FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
+    FPCDR_REQUIRE(p->H <= 32767 && p->W <= 32767 && p->B <= 65535, "resolution / batch too large");
+    FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
+    FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C <= 0x7fffffffLL, "texture too large");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = fpcdr_launch_sil(p->pos, p->tri, l->adj, p->B, p->V, p->T, p->H, p->W, l->sil, st);
+    if (rc) return rc;
+    size_t n = (size_t)p->B * p->T;
+    char *s = (char *)p->scratch;
+    TriRec *recs = (TriRec *)s;
+    TriBox *boxes = (TriBox *)(s + align_up(n * sizeof(TriRec), 256));
+    TriBox *cboxes = (TriBox *)((char *)boxes + align_up(n * sizeof(TriBox), 256));
+    const size_t nc = (size_t)p->B * (size_t)fpcdr_cdiv(p->T, 256);
+    ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
+    hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
+    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
+    dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
+    const size_t nbins = (size_t)p->B * grid.y * grid.x;
+    ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
+                    (uint8_t *)(p->occ + nbins), p->empty_color, (const float2 *)p->tri_uv,
+                    l->sil, l->ref, l->grad_aa, cmask, (unsigned long long *)(cmask + nbins * BIN), l->loss_sum, l->bg, l->color_scale,
+                    l->grad_scale};
+    hipLaunchKernelGGL((k_bins<false, true, true>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H,
+                       p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr, sh);
+    hipLaunchKernelGGL(k_occ_window, dim3(fpcdr_cdiv((long long)nbins, 256)), dim3(256), 0, st, sh.occ, p->B, (int)grid.y,
+                       (int)grid.x, p->occ);
+    FPCDR_CHECK_LAUNCH();
+    return fpcdr_launch_aa_fix(l, cmask, st);
 }

@@ -229,8 +229,6 @@ class _pixel_objective_func(torch.autograd.Function):
         p = _lib.RenderFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
                            uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C, boundary_mode=boundary,
                            rast=_ptr(rast), color=_ptr(color), tri_uv=_ptr(tri_uv), occ=_ptr(occ), empty_color=_ptr(ecol))
-        _lib.call("fpcdr_render_fwd", ctypes.byref(p), _stream())
-        del scratch
         g_aa = torch.empty_like(color)
         sil = torch.empty(B, T, dtype=torch.uint8, device=dev)
         nflag = lib.fpcdr_antialias_flags_bytes(B, H, W) // 8
@@ -239,7 +237,14 @@ class _pixel_objective_func(torch.autograd.Function):
         q = _lib.AaLossFwd(color=_ptr(color), rast=_ptr(rast), pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), ref=_ptr(ref), B=B,
                            H=H, W=W, C=C, V=V, T=T, bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
                            flags=_ptr(flags), grad_aa=_ptr(g_aa), occ=_ptr(occ), empty_color=_ptr(ecol), loss_sum=_ptr(acc))
-        _lib.call("fpcdr_aa_loss_fwd", ctypes.byref(q), _stream())
+        if sparse:
+            # one call: the rasteriser settles every pixel antialiasing cannot touch, a second kernel the candidates it marks
+            cmask = torch.empty(occ.numel() // 3 * (32 + 256), dtype=torch.int32, device=dev)     # FPCDR_CMASK_BYTES
+            _lib.call("fpcdr_render_loss_fwd", ctypes.byref(p), ctypes.byref(q), _ptr(cmask), _stream())
+        else:
+            _lib.call("fpcdr_render_fwd", ctypes.byref(p), _stream())
+            _lib.call("fpcdr_aa_loss_fwd", ctypes.byref(q), _stream())
+        del scratch
         ctx.save_for_backward(pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, occ, ecol, tri_uv)
         ctx.boundary = boundary
         total = acc.sum()

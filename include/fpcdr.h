@@ -119,6 +119,7 @@ int fpcdr_render_bwd(const fpcdr_render_bwd_params *p, void *stream);
 #define FPCDR_OCC_BIN 32
 #define FPCDR_OCC_DIM(n) (((n) + FPCDR_OCC_BIN - 1) / FPCDR_OCC_BIN)
 #define FPCDR_OCC_BYTES(B, H, W) ((size_t)(B) * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W) * 3)
+#define FPCDR_CMASK_BYTES(B, H, W) ((size_t)(B) * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W) * (32 * 4 + 4 * 32 * 8))
 
 /* antialias + background + pixel loss in one pass (reference fit.py:160, 161, 579): reads colour, rast and the 8-bit
  * reference image, accumulates the sum of squares and writes d(grad_scale * sum)/d(antialiased colour); the
@@ -145,6 +146,15 @@ typedef struct {
                               their partial sums over the slots instead of hammering one address) */
 } fpcdr_aa_loss_fwd_params;
 int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream);
+
+/* fpcdr_render_fwd (sparse mode) + fpcdr_aa_loss_fwd in one call, without the dense antialias pass: the rasteriser's
+ * workgroup, which still holds its bin's ids, gives every pixel that antialiasing cannot touch (no pixel pair with
+ * different ids at a silhouette edge) its loss term and gradient straight away and leaves a bit mask of the others
+ * (bin-border pixels included); a second kernel runs antialias + loss on those candidates only.  Same outputs as the
+ * two calls.  r->occ, r->empty_color must be set (sparse mode only); l->color / rast / pos / tri / occ / empty_color
+ * must equal r's; flags zero-filled by the caller; cmask: scratch of FPCDR_CMASK_BYTES(B,H,W) bytes (per bin 32 row
+ * masks of candidate pixels and the bin's four border lines).                                                   */
+int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *r, const fpcdr_aa_loss_fwd_params *l, uint32_t *cmask, void *stream);
 
 /* out[i] += sum over the px_per_image pixels of image i of (ref - bg_scaled)^2, i < n_images; ref [n_images, px_per_image]
  * uint8, out f64 (zero-filled by the caller).  The part of the pixel loss (fit.py:579) that a sparse fpcdr_aa_loss_fwd
