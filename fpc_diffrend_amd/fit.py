@@ -247,6 +247,19 @@ class MeshTopology:
         for a, b in e:
             nbr[a, fill[a]] = b; fill[a] += 1
             nbr[b, fill[b]] = a; fill[b] += 1
+        # interior edges (exactly two incident faces) with those faces, for the normal-consistency term
+        self.faces = torch.tensor(f, dtype=torch.long, device=device)
+        fe = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], axis=0), axis=1)
+        fid = np.tile(np.arange(f.shape[0]), 3)
+        key = fe[:, 0] * (n_vertices + 1) + fe[:, 1]
+        order = np.argsort(key, kind='stable')
+        ks, fs = key[order], fid[order]
+        first = np.concatenate([[True], ks[1:] != ks[:-1]])
+        starts = np.nonzero(first)[0]
+        counts = np.diff(np.concatenate([starts, [len(ks)]]))
+        two = starts[counts == 2]
+        self.edge_faces = (torch.tensor(fs[two], dtype=torch.long, device=device),
+                           torch.tensor(fs[two + 1], dtype=torch.long, device=device))
         self.nbr = torch.tensor(nbr, dtype=torch.long, device=device)
         self.nbr32 = self.nbr.to(torch.int32).t().contiguous()      # [Dmax, V] slot-major for the gather kernel
 
@@ -284,6 +297,25 @@ def mesh_laplacian_smoothing(verts, topo):
     """Uniform Laplacian smoothing: mean_v || mean_{n in N(v)} x_n - x_v ||, averaged over meshes [F,V,3]."""
     lap = _uniform_laplacian.apply(verts, topo.nbr, topo.nbr32, topo.inv_deg)
     return lap.norm(dim=2).mean()
+
+
+def mesh_normal_consistency(verts, topo):
+    """pytorch3d.loss.mesh_normal_consistency restated (reference fit.py:582; weight 0 in main.py:40): for every edge
+    shared by exactly two faces, 1 - cos of the angle between the two face normals (oriented by the faces' own vertex
+    order, as pytorch3d does through the edge's two opposite vertices); mean over those edges and over the batch.
+    verts [F,V,3]."""
+    f0, f1 = topo.edge_faces
+    if f0.numel() == 0:
+        return verts.sum() * 0.0
+    tri = topo.faces
+
+    def normals(fid):
+        a, b, c = verts[:, tri[fid, 0]], verts[:, tri[fid, 1]], verts[:, tri[fid, 2]]
+        return torch.cross(b - a, c - a, dim=-1)
+
+    n0, n1 = normals(f0), normals(f1)
+    cos = torch.nn.functional.cosine_similarity(n0, n1, dim=-1, eps=1e-8)
+    return (1.0 - cos).mean()
 
 
 def mesh_edge_loss(verts, topo, target_length=0.0):
@@ -556,7 +588,7 @@ class Fitter:
         if cfg.weight_laplacian:
             reg = reg + cfg.weight_laplacian * mesh_laplacian_smoothing(vtx_pos_split, self.topo) ** 2
         if cfg.weight_normalconsistency:
-            raise NotImplementedError("mesh_normal_consistency (weight 0 in the reference's main.py:40)")
+            reg = reg + cfg.weight_normalconsistency * mesh_normal_consistency(vtx_pos_split, self.topo)
         if cfg.regularize_correctives and cfg.mode == 'combined' and i > cfg.max_iter / 2:
             basis = torch.matmul(self.m2, self.m1[:, frame_ids])
             reg = reg + torch.mean(torch.matmul(self.m3, basis) ** 2)
@@ -655,6 +687,45 @@ class Fitter:
         """Current blendshape activations [F,K] (prior mode): (M2 M1)^T."""
         with torch.no_grad():
             return torch.matmul(self.maps_intermediate['local'], self.maps['local']).t()
+
+    # ------------------------------------------------------------------------------------------
+    def state_dict(self):
+        """Everything a resumed run needs to continue bit-identically (the reference has no checkpointing, SURVEY.md
+        section 5): parameters, Adam moments, schedule position, iteration, minibatch RNG and the result buffer."""
+        names = ("m1", "m2", "m3", "maps_local", "maps_intermediate_local", "t_opt", "q_opt", "per_frame_t", "per_frame_q", "tex_opt")
+        return {"params": {n: p.detach().clone() for n, p in zip(names, self.params)},
+                "requires_grad": [bool(p.requires_grad) for p in self.params],
+                "optimizer": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict(),
+                "iteration": self.iteration, "rng": self.rng.bit_generator.state, "result": self.result.clone(),
+                "config": dict(self.cfg.__dict__)}
+
+    def load_state_dict(self, state):
+        with torch.no_grad():
+            for p, (_, v) in zip(self.params, state["params"].items()):
+                p.copy_(v.to(p.device))
+        for p, rg in zip(self.params, state["requires_grad"]):
+            p.requires_grad = rg
+        self.optimizer.load_state_dict(state["optimizer"])
+        self.scheduler.load_state_dict(state["scheduler"])
+        self.iteration = int(state["iteration"])
+        self.rng.bit_generator.state = state["rng"]
+        self.result.copy_(state["result"].to(self.result.device))
+        self._graphs, self._graph_key = None, None
+
+    def save_checkpoint(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load_checkpoint(self, path):
+        self.load_state_dict(torch.load(path, map_location=self.device, weights_only=False))
+
+    def save_config(self, directory, extra=None):
+        """config.txt in the reference's format (fit.py:651-657): one "key: 'value'" line per setting."""
+        os.makedirs(directory, exist_ok=True)
+        args = dict(self.cfg.__dict__)
+        args.update(extra or {})
+        with open(os.path.join(directory, "config.txt"), "w") as f:
+            for k, v in args.items():
+                f.write(f"{k}: '{v}'\n")
 
     def save(self, directory):
         """Result files in the reference's layout (fit.py:235-286): result/{i}.obj, texture.png, pose.json."""
