@@ -107,14 +107,36 @@ def cpu_baseline(sc, seconds_budget=30.0):
     threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
-    dt, n_img, used = ofit.timed_steps(sc, cams=[3], frame_ids=[0], steps=1, threads=threads)
+    dt, n_img, used, first = ofit.timed_steps(sc, cams=[3], frame_ids=[0], steps=1, threads=threads, keep_first=True)
     steps = 1
+    # the same 1080p image through the HIP operators, from the oracle's own clip-space positions: the "L2 pixel err vs
+    # ref" half of BASELINE.json's metric, with the oracle as the checker (integer buffer must match exactly)
+    parity = None
+    try:
+        import fpc_diffrend_amd.ops as dr
+        from fpc_diffrend_amd import fit as gfit
+        dev = torch.device("cuda", torch.cuda.current_device())
+        st = first["state"]
+        ctx = dr.RasterizeGLContext(device=dev)
+        pos = first["pos_clip"].to(dev).contiguous()
+        tri = st.pos_idx.to(dev).to(torch.int32).contiguous()
+        rast, _ = dr.rasterize(ctx, pos, tri, sc.resolution)
+        texc, _ = dr.interpolate(st.uv.to(dev)[None].contiguous(), rast, st.uv_idx.to(dev).to(torch.int32).contiguous())
+        col = dr.antialias(dr.texture(first["tex"].to(dev)[None].contiguous(), texc, filter_mode='linear'), rast, pos, tri)
+        img = torch.where(rast[..., 3:] > 0, col, torch.tensor(gfit.BACKGROUND, device=dev)).cpu()
+        mism = int((rast[..., 3].cpu() != first["ids"]).sum())
+        err = float((img.double() - first["image"].double()).norm() / first["image"].double().norm())
+        parity = {"id_mismatches": mism, "image_rel_l2": err, "pixels": int(first["ids"].numel()),
+                  "covered_pixels": int((first["ids"] > 0).sum()),
+                  "what": "rasterize / interpolate / texture / antialias / background on the oracle's clip positions vs the oracle image"}
+    except Exception as e:   # never take the measurement down
+        parity = {"error": repr(e)}
     if dt < seconds_budget / 3:
         k = max(1, int(seconds_budget / 3 / dt))
         dt, n_img, used = ofit.timed_steps(sc, cams=[3], frame_ids=[0], steps=k, threads=threads)
         steps = k
     n_views = 9
-    return {"value": (n_img / n_views) / dt, "unit": "frames/s", "cores": used, "kind": "port",
+    return {"value": (n_img / n_views) / dt, "unit": "frames/s", "cores": used, "kind": "port", "parity_1080p": parity,
             "sample": f"{steps} full fit step(s) (forward + backward + Adam) of 1 frame x 1 view at "
                       f"{sc.resolution[1]}x{sc.resolution[0]} on the same mesh/rig, {dt:.2f} s per image, scaled linearly to "
                       f"{n_views} views per frame; wall {time.perf_counter() - t0:.1f} s"}

@@ -181,7 +181,7 @@ def smoke_upstream(sc, grad_pos_clip, cams=(0, 4), dtype=torch.float64):
     return _grads(st)
 
 
-def timed_steps(sc, cams, frame_ids, steps=1, threads=None):
+def timed_steps(sc, cams, frame_ids, steps=1, threads=None, keep_first=False):
     """CPU baseline: full optimisation steps (forward, backward, Adam) on the host cores.
     Returns (seconds per step, images per step, threads used)."""
     if threads:
@@ -191,11 +191,18 @@ def timed_steps(sc, cams, frame_ids, steps=1, threads=None):
     targets = torch.full((len(frame_ids), len(cams), H, W), 90, dtype=torch.uint8)
     opt = torch.optim.Adam(st.params(), lr=1e-3)
     fid = torch.tensor(list(frame_ids))
+    first = None
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
         opt.zero_grad()
-        loss, _, _ = forward(st, fid, targets)
+        pos_clip, _ = clip_positions(st, fid)
+        loss, image, rast = forward_from_clip(st, pos_clip, targets)
+        if i == 0 and keep_first:    # what the first forward pass saw and produced, for a parity check of the same image
+            first = {"pos_clip": pos_clip.detach().clone(), "image": image.detach().clone(), "ids": rast[..., 3].detach().clone(),
+                     "tex": st.tex.detach().clone(), "state": st}
         loss.backward()
         opt.step()
     dt = (time.perf_counter() - t0) / steps
+    if keep_first:
+        return dt, len(frame_ids) * len(cams), torch.get_num_threads(), first
     return dt, len(frame_ids) * len(cams), torch.get_num_threads()
