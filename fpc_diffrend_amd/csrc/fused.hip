@@ -574,12 +574,14 @@ __global__ void __launch_bounds__(256) k_aa_fix(const float *__restrict__ color,
                 const size_t nbin = ((size_t)b * gridDim.y + (blockIdx.y + dy)) * gridDim.x + (blockIdx.x + dx);
                 nb = edges[nbin * (4 * BBIN) + (side ^ 1) * BBIN + i];
             }
-            const int id = (int)(unsigned int)me, nid = (int)(unsigned int)nb;
+            // entries: z/w bits << 32 | silhouette bits << 24 | id + 1
+            const int id = (int)((unsigned int)me & 0xffffffu), nid = (int)((unsigned int)nb & 0xffffffu);
             if (id != nid) {
                 const float z = __uint_as_float((unsigned int)(me >> 32)), nz = __uint_as_float((unsigned int)(nb >> 32));
                 const bool me_first = (side & 1);   // right / upper pairs are (me, n), left / lower pairs (n, me)
                 const PairSel ps = me_first ? pair_select(id, z, nid, nz, T) : pair_select(nid, nz, id, z, T);
-                if (ps.tau >= 0 && silb[ps.tau] != 0) atomicOr(&s_mask[zy], 1u << zx);
+                const bool takes_n = me_first ? ps.use1 : !ps.use1;
+                if (ps.tau >= 0 && (((unsigned int)(takes_n ? nb : me) >> 24) & 0xffu) != 0) atomicOr(&s_mask[zy], 1u << zx);
             }
         }
     }

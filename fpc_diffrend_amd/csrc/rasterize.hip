@@ -277,7 +277,7 @@ struct ShadeArgs {
     const uint8_t *ref;      // [B,H,W]
     float *g_aa;             // out [B,H,W,C]
     uint32_t *cmask;         // out [B*bins][32]: row masks of the bin's CANDIDATE pixels, left to k_aa_fix
-    unsigned long long *edges;   // out [B*bins][4][32]: (z/w bits << 32 | id) of the bin's four border lines
+    unsigned long long *edges;   // out [B*bins][4][32]: (z/w bits << 32 | silhouette bits << 24 | id + 1) of the four border lines
     double *loss_sum;        // [FPCDR_LOSS_SLOTS]
     float bg, color_scale, grad_scale;
 };
@@ -592,7 +592,9 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
             if (WRITE_DB) rast_db[off] = d;
             if (LOSS) {   // (z/w, id) of the bin's pixels for the neighbour tests below; this thread owns the entry
                 const int zx = (tile % TILES_X) * TILE + (q & 1) * QUAD + lx, zy = (tile / TILES_X) * TILE + (q >> 1) * QUAD + ly;
-                s_z[zy * BIN + zx] = ((unsigned long long)__float_as_uint(o.z) << 32) | (unsigned int)(t + 1);
+                // id + 1 in 24 bits (ids are exact in rast's float anyway), the triangle's silhouette bits above them
+                const unsigned int sb = t >= 0 ? (unsigned int)sh.sil[(size_t)b * T + t] : 0u;
+                s_z[zy * BIN + zx] = ((unsigned long long)__float_as_uint(o.z) << 32) | (sb << 24) | (unsigned int)(t + 1);
             }
             if (SHADE) {
                 // interpolate (reference fit.py:157) + texture 'linear' (fit.py:158), same arithmetic as the stand-alone
@@ -627,7 +629,6 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
         __shared__ float s_lpart[4];
         if (tid < BIN) s_cmask[tid] = 0u;
         __syncthreads();   // (z/w, id) entries and the cleared masks are visible
-        const uint8_t *silb = sh.sil + (size_t)b * T;
         const size_t bin_id = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         unsigned long long *edge = sh.edges + bin_id * (4 * BIN);   // [left col | right col | bottom row | top row][32]
         float lsum = 0.0f;
@@ -646,17 +647,18 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
                 if (zy == 0) edge[2 * BIN + zx] = me;
                 if (zy == BIN - 1) edge[3 * BIN + zx] = me;
                 if (!inimg) continue;
-                const int id = (int)(unsigned int)me;
+                const int id = (int)((unsigned int)me & 0xffffffu);
                 const float z = __uint_as_float((unsigned int)(me >> 32));
                 // pair_select keeps the FIRST pixel's triangle on a depth tie: right / upper pairs are (me, n), left / lower
-                // pairs (n, me), as for_active_edges is called
+                // pairs (n, me), as for_active_edges is called; the chosen triangle's silhouette bits ride in the entries
                 auto pair = [&](int nidx, bool me_first) {
                     const unsigned long long n = s_z[nidx];
-                    const int nid = (int)(unsigned int)n;
+                    const int nid = (int)((unsigned int)n & 0xffffffu);
                     if (nid == id) return false;
                     const float nz = __uint_as_float((unsigned int)(n >> 32));
                     const PairSel ps = me_first ? pair_select(id, z, nid, nz, T) : pair_select(nid, nz, id, z, T);
-                    return ps.tau >= 0 && silb[ps.tau] != 0;
+                    const bool takes_n = me_first ? ps.use1 : !ps.use1;
+                    return ps.tau >= 0 && (((unsigned int)(takes_n ? n : me) >> 24) & 0xffu) != 0;
                 };
                 const bool cand = (zx < BIN - 1 && px + 1 < W && pair(idx + 1, true)) || (zy < BIN - 1 && py + 1 < H && pair(idx + BIN, true)) ||
                                   (zx > 0 && pair(idx - 1, false)) || (zy > 0 && pair(idx - BIN, false));
@@ -963,6 +965,7 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
                   "sizes must be positive");
     FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
     FPCDR_REQUIRE(p->H <= 32767 && p->W <= 32767 && p->B <= 65535, "resolution / batch too large");
+    FPCDR_REQUIRE(p->T < (1 << 24), "more than 2^24 triangles");
     FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C <= 0x7fffffffLL, "texture too large");
     hipStream_t st = (hipStream_t)stream;
