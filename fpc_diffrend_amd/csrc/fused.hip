@@ -683,6 +683,14 @@ __global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, co
 }  // namespace
 
 // ---- pieces of fpcdr_render_loss_fwd (rasterize.hip) that live in this file; not part of the C ABI ----
+int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, int B, int V, int T, int H, int W, uint8_t *sil,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv((long long)B * T, 256)), dim3(256), 0, st, (const float4 *)pos, tri, adj, B, V, T,
+                       0.5f * (float)W, 0.5f * (float)H, sil);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
 int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask, hipStream_t st) {
     dim3 grid(fpcdr_cdiv(p->W, BBIN), fpcdr_cdiv(p->H, BBIN), p->B);
 #define LAUNCH(CS)                                                                                                            \

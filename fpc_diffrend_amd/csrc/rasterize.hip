@@ -103,12 +103,10 @@ constexpr unsigned long long Z_EMPTY = ~0ull;
 __device__ __forceinline__ long long floordiv256(long long a) { return a >> 8; }  // arithmetic shift = floor
 
 // ---------------------------------------------------------------------------------------------
-template <bool SIL = false>
 __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                 int B, int V, int T, int H, int W, TriRec *__restrict__ recs,
                                                 TriBox *__restrict__ boxes, TriBox *__restrict__ cboxes,
-                                                ImgBox *__restrict__ ibox, const int32_t *__restrict__ adj = nullptr,
-                                                uint8_t *__restrict__ sil = nullptr) {
+                                                ImgBox *__restrict__ ibox) {
     // grid: x over 256-triangle chunks, y = image.  A block never straddles two images, so the union of
     // its triangles' bounding boxes can be reduced in the block: it is stored as the CHUNK box (meshes
     // keep neighbouring triangles at neighbouring indices, so a bin later skips most chunks with one
@@ -124,35 +122,6 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
         bool ok = !(i0 < 0 || i0 >= V || i1 < 0 || i1 >= V || i2 < 0 || i2 >= V);
         long long X[3], Y[3];
         double zw[3];
-        if (SIL) {
-            // silhouette bits of the antialias op for this (image, triangle), same arithmetic as k_sil (antialias.hip):
-            // the vertices are in registers here anyway (fpcdr_render_loss_fwd)
-            unsigned int bits = 0;
-            if (ok) {
-                const float4 *p = pos + (size_t)b * V;
-                const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
-                const int vi[3] = {i0, i1, i2};
-                float qx[3], qy[3], qw[3];
-                for (int k = 0; k < 3; ++k) {
-                    const float4 c = p[vi[k]];
-                    qx[k] = c.x * hw; qy[k] = c.y * hh; qw[k] = c.w;
-                }
-                for (int e = 0; e < 3; ++e) {
-                    const int ad = adj[3 * t + e];
-                    if (ad == -1) { bits |= 1u << e; continue; }
-                    if (ad < 0 || ad >= V) continue;
-                    const int a = (e + 1) % 3, bb = (e + 2) % 3;
-                    const float Lx = qy[a] * qw[bb] - qw[a] * qy[bb];
-                    const float Ly = qw[a] * qx[bb] - qx[a] * qw[bb];
-                    const float Lz = qx[a] * qy[bb] - qy[a] * qx[bb];
-                    const float so = Lx * qx[e] + Ly * qy[e] + Lz * qw[e];
-                    const float4 c = p[ad];
-                    const float sp = Lx * (c.x * hw) + Ly * (c.y * hh) + Lz * c.w;
-                    if ((so > 0.0f && sp > 0.0f) || (so < 0.0f && sp < 0.0f)) bits |= 1u << e;
-                }
-            }
-            sil[gid] = (uint8_t)bits;
-        }
         if (ok) {
             const float4 *p = pos + (size_t)b * V;
             float4 v[3] = {p[i0], p[i1], p[i2]};
@@ -901,7 +870,7 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
     const size_t nc = (size_t)p->B * (size_t)fpcdr_cdiv(p->T, 256);
     ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
-    hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     if (p->rast_db)
@@ -948,7 +917,7 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
     const size_t nc = (size_t)p->B * (size_t)fpcdr_cdiv(p->T, 256);
     ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
-    hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
@@ -1000,6 +969,8 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C <= 0x7fffffffLL, "texture too large");
     hipStream_t st = (hipStream_t)stream;
+    int rc = fpcdr_launch_sil(p->pos, p->tri, l->adj, p->B, p->V, p->T, p->H, p->W, l->sil, st);
+    if (rc) return rc;
     size_t n = (size_t)p->B * p->T;
     char *s = (char *)p->scratch;
     TriRec *recs = (TriRec *)s;
@@ -1008,8 +979,8 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     const size_t nc = (size_t)p->B * (size_t)fpcdr_cdiv(p->T, 256);
     ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
-    hipLaunchKernelGGL(k_setup<true>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, l->adj, l->sil);
+    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     const size_t nbins = (size_t)p->B * grid.y * grid.x;
     ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
