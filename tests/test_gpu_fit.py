@@ -316,3 +316,41 @@ def test_rerender_of_saved_result_matches_the_fit_images(tmp_path):
     diff, _ = rerender.mean_abs_diff(grids[0][..., 0], want[..., 0], rows=(0, 3 * H), cols=(0, 3 * W))
     assert diff < 0.05, diff       # OBJ text round trip of the vertices moves a few silhouette pixels at most
     assert (grids[0] > 50).mean() > 0.02   # something other than background was drawn
+
+
+@pytest.mark.parametrize("C,res,boundary", [(1, (150, 200), 'wrap'), (3, (97, 131), 'clamp'), (4, (64, 320), 'wrap')])
+def test_objective_sparse_dense_chain_agree_at_odd_sizes(C, res, boundary):
+    """pixel_objective (candidate-based sparse forward, dense forward) == the operator chain + pixel loss when neither
+    image side is a multiple of the 32-pixel bin or the 64-pixel flag word, for every channel count it supports."""
+    import fpc_diffrend_amd.ops as dr
+    from fpc_diffrend_amd import fit, scene
+    from helpers import clip_positions
+    sc = scene.cfg('cfg1', n_frames=2)
+    sc.resolution = res
+    pos, _ = clip_positions(sc, [0, 3, 7], frames=[0, 1])
+    dev = 'cuda'
+    tri = torch.tensor(sc.pos_idx, device=dev)
+    uv = torch.tensor(sc.uv, device=dev) * 1.2 - 0.05
+    uv_idx = torch.tensor(sc.uv_idx, device=dev)
+    g = torch.Generator().manual_seed(1)
+    tex0 = torch.rand(48, 64, C, generator=g) * 0.5
+    ref = torch.randint(0, 141, (pos.shape[0], res[0], res[1]), generator=g, dtype=torch.uint8).to(dev)
+    ctx = dr.RasterizeGLContext(device=dev)
+    out = {}
+    for name in ("sparse", "dense", "chain"):
+        p = pos.to(dev).clone().requires_grad_(True)
+        t = tex0.to(dev).clone().requires_grad_(True)
+        if name == "chain":
+            rast, _ = dr.rasterize(ctx, p, tri, res)
+            texc, _ = dr.interpolate(uv[None], rast, uv_idx)
+            col = dr.antialias(dr.texture(t[None], texc, filter_mode='linear', boundary_mode=boundary), rast, p, tri)
+            img = torch.where(rast[..., 3:] > 0, col, torch.tensor(fit.BACKGROUND, device=dev))
+            loss = torch.mean((ref[..., None].float() - img * 255) ** 2)
+        else:
+            loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, res, boundary_mode=boundary, sparse=(name == "sparse"))
+        loss.backward()
+        out[name] = (float(loss), p.grad.double().cpu(), t.grad.double().cpu())
+    for name in ("sparse", "dense"):
+        assert abs(out[name][0] - out["chain"][0]) <= 2e-6 * abs(out["chain"][0]), (name, out[name][0], out["chain"][0])
+        assert rel_l2(out[name][1], out["chain"][1]) < 1e-4, name
+        assert rel_l2(out[name][2], out["chain"][2]) < 1e-4, name
