@@ -365,26 +365,30 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
                     int R0 = __mul24(A0, Px - r.X1) + __mul24(B0, Py - r.Y1) - n0;   // edge functions at the row start
                     int R1 = __mul24(A1, Px - r.X2) + __mul24(B1, Py - r.Y2) - n1;
                     int R2 = __mul24(A2, Px - r.X0) + __mul24(B2, Py - r.Y0) - n2;
+                    const int A0s = A0 * SUBPIX, A1s = A1 * SUBPIX, A2s = A2 * SUBPIX;
                     const int rx0 = Px - r.X0;
-                    int E0 = R0, E1 = R1, E2 = R2, rx = rx0, ry = Py - r.Y0, cx = 0;
-                    int zi = (y0 - bin_y0) * BIN + (x0 - bin_x0);
+                    int ry = Py - r.Y0;
+                    unsigned long long *zrow = &s_z[(y0 - bin_y0) * BIN + (x0 - bin_x0)];
 #ifdef FPCDR_ABL_NOLANE
-                    for (int i = 0; i < 0; ++i) {
+                    const int bh = 0;
 #else
-                    for (int i = 0; i < area; ++i) {
+                    const int bh = y1 - y0 + 1;
 #endif
-                        if ((E0 | E1 | E2) >= 0) {
-                            const float d = __fmaf_rn(r.zA, (float)rx, __fmaf_rn(r.zB, (float)ry, r.z0));
-                            if (d >= -1.0f && d <= 1.0f) atomicMin(&s_z[zi + cx], zpack(d, t));
+                    // rows outside, columns inside: the inner trip is three additions and one test (the flattened loop that
+                    // this replaces spent two thirds of its instructions on wrap-around selects)
+                    for (int rr = 0; rr < bh; ++rr) {
+                        int E0 = R0, E1 = R1, E2 = R2, rx = rx0;
+                        const float dzr = __fmaf_rn(r.zB, (float)ry, r.z0);
+                        for (int c = 0; c < bw; ++c) {
+                            if ((E0 | E1 | E2) >= 0) {
+                                const float d = __fmaf_rn(r.zA, (float)rx, dzr);
+                                if (d >= -1.0f && d <= 1.0f) atomicMin(&zrow[c], zpack(d, t));
+                            }
+                            E0 += A0s; E1 += A1s; E2 += A2s; rx += SUBPIX;
                         }
-                        ++cx;
-                        const bool wrap = cx == bw;
-                        R0 += wrap ? B0 * SUBPIX : 0; R1 += wrap ? B1 * SUBPIX : 0; R2 += wrap ? B2 * SUBPIX : 0;
-                        E0 = wrap ? R0 : E0 + A0 * SUBPIX; E1 = wrap ? R1 : E1 + A1 * SUBPIX; E2 = wrap ? R2 : E2 + A2 * SUBPIX;
-                        rx = wrap ? rx0 : rx + SUBPIX;
-                        ry += wrap ? SUBPIX : 0;
-                        zi += wrap ? BIN : 0;
-                        cx = wrap ? 0 : cx;
+                        R0 += B0 * SUBPIX; R1 += B1 * SUBPIX; R2 += B2 * SUBPIX;
+                        ry += SUBPIX;
+                        zrow += BIN;
                     }
                 } else {
                     s_big[atomicAdd(&s_nbig, 1)] = t;
