@@ -10,6 +10,17 @@ __device__ __forceinline__ int wrap_i(int i, int n, int mode) {
     return min(max(i, 0), n - 1);
 }
 
+// wrap_i without the integer division (~35 instructions each, four per sample) for the usual case of an index in
+// [-n, 2n): the taps of a coordinate in [0, 1] have x0 in [-1, n - 1] and x0 + 1 in [0, n].  Anything else (a NaN
+// coordinate converts to INT_MIN) takes the general path, so the result is always a valid index.
+__device__ __forceinline__ int wrap_near(int i, int n, int mode) {
+    if (mode == FPCDR_BOUNDARY_WRAP) {
+        if (__builtin_expect(i >= -n && i < 2 * n, 1)) return i < 0 ? i + n : (i >= n ? i - n : i);
+        return wrap_i(i, n, mode);
+    }
+    return min(max(i, 0), n - 1);
+}
+
 __device__ __forceinline__ float prep_coord(float u, int mode) {
     if (mode == FPCDR_BOUNDARY_WRAP) return u - floorf(u);
     return fminf(fmaxf(u, 0.0f), 1.0f);
@@ -28,8 +39,8 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int Ht, int Wt, int 
     t.fx = x - x0f;
     t.fy = y - y0f;
     const int x0 = (int)x0f, y0 = (int)y0f;
-    const int ix0 = wrap_i(x0, Wt, mode), ix1 = wrap_i(x0 + 1, Wt, mode);
-    const int iy0 = wrap_i(y0, Ht, mode), iy1 = wrap_i(y0 + 1, Ht, mode);
+    const int ix0 = wrap_near(x0, Wt, mode), ix1 = wrap_near(x0 + 1, Wt, mode);
+    const int iy0 = wrap_near(y0, Ht, mode), iy1 = wrap_near(y0 + 1, Ht, mode);
     t.i00 = (iy0 * Wt + ix0) * C; t.i10 = (iy0 * Wt + ix1) * C;
     t.i01 = (iy1 * Wt + ix0) * C; t.i11 = (iy1 * Wt + ix1) * C;
     return t;
