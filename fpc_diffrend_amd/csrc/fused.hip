@@ -468,37 +468,41 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
         }
         // ---- vertices: chain through the barycentrics, sum per run of equal triangle, tails add into the LDS table ----
         float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int vk[3] = {0, 0, 0};   // the triangle's vertex ids: the run's last lane emits with them
         if (tkey >= 0) {
-            const int i0 = tri[3 * tkey], i1 = tri[3 * tkey + 1], i2 = tri[3 * tkey + 2];
+            vk[0] = tri[3 * tkey]; vk[1] = tri[3 * tkey + 1]; vk[2] = tri[3 * tkey + 2];
             const float4 *p = pos + (size_t)b * V;
             const float fx = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
             const float fy = (2.0f * (float)(by0 + rowk0 + 2 * k) + 1.0f) / (float)H - 1.0f;
             float g0[3], g1[3], g2[3];
-            shade_pixel_bwd<false>(p[i0], p[i1], p[i2], fx, fy, 2.0f / (float)W, 2.0f / (float)H,
+            shade_pixel_bwd<false>(p[vk[0]], p[vk[1]], p[vk[2]], fx, fy, 2.0f / (float)W, 2.0f / (float)H,
                                    make_float4(gu, gvv, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), g0, g1, g2);
             gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
             gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
             gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
         }
-#ifdef FPCDR_ABL_NOREDUCE
-        { float sink = 0.f; for (int q = 0; q < 9; ++q) sink += gv9[q]; asm volatile("" :: "v"(sink), "v"(tkey)); tkey = -1; }
-#endif
-        wave_segment_reduce<9>(tkey, gv9, [&](int tt, const float (&sm)[9]) {
+        wave_segment_reduce<9>(tkey, gv9, [&](int, const float (&sm)[9]) {
+            // the three slots are claimed with three INDEPENDENT compare-and-swaps in flight (one LDS round trip instead of
+            // three); only a vertex whose home slot is taken by another walks on
+            unsigned int slot[3];
+            int old[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) slot[kk] = ((unsigned int)vk[kk] * 2654435761u) >> 24;   // 8 bits = VSLOTS
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) old[kk] = atomicCAS(&s_vkey[slot[kk]], -1, vk[kk]);
 #pragma unroll
             for (int kk = 0; kk < 3; ++kk) {
-                const int key = tri[3 * tt + kk];
-                unsigned int slot = ((unsigned int)key * 2654435761u) >> 24;   // 8 bits = VSLOTS
-                bool done = false;
-                for (int probe = 0; probe < VSLOTS && !done; ++probe) {
-                    const int old = atomicCAS(&s_vkey[slot], -1, key);
-                    if (old == -1 || old == key) {
-                        atomicAdd(&s_vacc[slot][0], sm[3 * kk]); atomicAdd(&s_vacc[slot][1], sm[3 * kk + 1]);
-                        atomicAdd(&s_vacc[slot][3], sm[3 * kk + 2]);
-                        done = true;
-                    }
-                    slot = (slot + 1) & (VSLOTS - 1);
+                const int key = vk[kk];
+                bool done = (old[kk] == -1 || old[kk] == key);
+                for (int probe = 1; probe < VSLOTS && !done; ++probe) {
+                    slot[kk] = (slot[kk] + 1) & (VSLOTS - 1);
+                    const int o = atomicCAS(&s_vkey[slot[kk]], -1, key);
+                    done = (o == -1 || o == key);
                 }
-                if (!done) {   // table full: straight to memory
+                if (done) {
+                    atomicAdd(&s_vacc[slot[kk]][0], sm[3 * kk]); atomicAdd(&s_vacc[slot[kk]][1], sm[3 * kk + 1]);
+                    atomicAdd(&s_vacc[slot[kk]][3], sm[3 * kk + 2]);
+                } else {   // table full: straight to memory
                     atomicAdd(gp + 4 * (size_t)key + 0, sm[3 * kk]); atomicAdd(gp + 4 * (size_t)key + 1, sm[3 * kk + 1]);
                     atomicAdd(gp + 4 * (size_t)key + 3, sm[3 * kk + 2]);
                 }
