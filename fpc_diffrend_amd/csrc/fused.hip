@@ -256,7 +256,8 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
                                                        const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
                                                        int B, int V, int T, int H,
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
-                                                       float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv) {
+                                                       float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
+                                                       const float *__restrict__ upstream) {
     __shared__ int s_vkey[VSLOTS];
     __shared__ float s_vacc[VSLOTS][4];
     __shared__ float s_tex[TEXH * TEXW * CS];
@@ -284,6 +285,7 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
     }
     const bool v_me = ow.bin(0, 0);
     const size_t img = (size_t)b * H * W;
+    const float up = upstream ? upstream[0] : 1.0f;   // d(final loss)/d(this objective), a device scalar
     if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
 
     // ---- pixel phase A: gradient arriving at each pixel's colour (antialias backward folded in) ----
@@ -306,7 +308,7 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
             const bool down_y = y > 0 ? ((flags[plane + wi - Wq] >> bit) & 1ull) : false;
             const size_t off = img + (size_t)y * W + x;
 #pragma unroll
-            for (int c = 0; c < CS; ++c) { go[k][c] = v_me ? g_aa[off * CS + c] : 0.0f; any[k] |= (go[k][c] != 0.0f); }
+            for (int c = 0; c < CS; ++c) { go[k][c] = v_me ? g_aa[off * CS + c] * up : 0.0f; any[k] |= (go[k][c] != 0.0f); }
             if (own_x | own_y | left_x | down_y) {
                 // antialias backward for this pixel (see k_aa_bwd_fix in antialias.hip); sparse: plain global atomics
                 AAGeom geo = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
@@ -321,7 +323,9 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
                             const int rx = far ? Qx : Px, ry = far ? Qy : Py;
                             const float amt = far ? t - 0.5f : 0.5f - t;
                             if (!ow.pixel(rx, ry)) return;   // the blended pixel is an unwritten, empty one: no gradient arrives
-                            const float *gr = g_aa + (img + (size_t)ry * W + rx) * CS;
+                            float gr[CS];
+#pragma unroll
+                            for (int c = 0; c < CS; ++c) gr[c] = g_aa[(img + (size_t)ry * W + rx) * CS + c] * up;
                             if (rx == x && ry == y) {
 #pragma unroll
                                 for (int c = 0; c < CS; ++c) go[k][c] -= amt * gr[c];
@@ -767,7 +771,7 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
                        (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa, p->sil,     \
                        (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,   \
                        p->boundary_mode,                                                                                        \
-                       p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv)
+                       p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream)
     if (p->C == 1) LAUNCH(1);
     else if (p->C == 3) LAUNCH(3);
     else LAUNCH(4);

@@ -263,15 +263,15 @@ class _pixel_objective_func(torch.autograd.Function):
         Ht, Wt, C = tex.shape
         g_pos = torch.zeros_like(pos)
         g_tex = torch.zeros_like(tex) if ctx.needs_input_grad[1] else None
+        g = g.to(torch.float32).contiguous()
         p = _lib.RenderAaBwd(pos=_ptr(pos), tri=_ptr(tri), uv=_ptr(uv), uv_tri=_ptr(uv_tri), tex=_ptr(tex), rast=_ptr(rast),
                              color=_ptr(color), grad_aa=_ptr(g_aa), sil=_ptr(sil), flags=_ptr(flags), occ=_ptr(occ), empty_color=_ptr(ecol), B=B, V=V,
                              T=tri.shape[0],
                              H=H, W=W, Vt=uv.shape[0], Ht=Ht, Wt=Wt, C=C, boundary_mode=ctx.boundary, grad_pos=_ptr(g_pos),
-                             grad_tex=_ptr(g_tex), tri_uv=_ptr(tri_uv))
+                             grad_tex=_ptr(g_tex), tri_uv=_ptr(tri_uv), upstream=_ptr(g))   # g: applied inside the kernel
         _lib.call("fpcdr_render_aa_bwd", ctypes.byref(p), _stream())
-        g_pos = g_pos * g if ctx.needs_input_grad[0] else None
-        if g_tex is not None:
-            g_tex = g_tex * g
+        if not ctx.needs_input_grad[0]:
+            g_pos = None
         return (g_pos, g_tex) + (None,) * 12
 
 

@@ -178,6 +178,7 @@ typedef struct {
     float *grad_pos;       /* [B,V,4] accumulated */
     float *grad_tex;       /* [Ht,Wt,C] accumulated, or NULL */
     const float *tri_uv;   /* optional [T,3,2], as in fpcdr_render_fwd */
+    const float *upstream; /* optional device scalar: d(final loss)/d(objective), multiplied into both gradients (NULL = 1) */
 } fpcdr_render_aa_bwd_params;
 int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *stream);
 

@@ -354,3 +354,24 @@ def test_objective_sparse_dense_chain_agree_at_odd_sizes(C, res, boundary):
         assert abs(out[name][0] - out["chain"][0]) <= 2e-6 * abs(out["chain"][0]), (name, out[name][0], out["chain"][0])
         assert rel_l2(out[name][1], out["chain"][1]) < 1e-4, name
         assert rel_l2(out[name][2], out["chain"][2]) < 1e-4, name
+
+
+def test_objective_backward_applies_the_upstream_scalar():
+    """d(3.5 * objective) = 3.5 * d(objective): the upstream scalar is multiplied inside the backward kernel."""
+    import fpc_diffrend_amd.ops as dr
+    from fpc_diffrend_amd import scene
+    from helpers import clip_positions
+    sc = scene.cfg('cfg1', n_frames=1)
+    pos, _ = clip_positions(sc, [0, 5], frames=[0])
+    dev = 'cuda'
+    tri = torch.tensor(sc.pos_idx, device=dev)
+    uv, uv_idx = torch.tensor(sc.uv, device=dev), torch.tensor(sc.uv_idx, device=dev)
+    ref = torch.full((pos.shape[0],) + tuple(sc.resolution), 90, dtype=torch.uint8, device=dev)
+    ctx = dr.RasterizeGLContext(device=dev)
+    grads = []
+    for scale in (1.0, 3.5):
+        p = pos.to(dev).clone().requires_grad_(True)
+        t = torch.tensor(sc.texture, device=dev).clone().requires_grad_(True)
+        (dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, sc.resolution) * scale).backward()
+        grads.append((p.grad.double(), t.grad.double()))
+    assert rel_l2(grads[1][0], 3.5 * grads[0][0]) < 1e-5 and rel_l2(grads[1][1], 3.5 * grads[0][1]) < 1e-5
