@@ -92,12 +92,29 @@ __global__ void __launch_bounds__(256) k_lap_gather(const float *__restrict__ x,
     const float *xf = x + (size_t)f * V * 3;
     float sx = 0.f, sy = 0.f, sz = 0.f;
     // slot-major table: consecutive threads read consecutive entries; a vertex's ring is stored front to back, so the
-    // first pad ends it (a UV sphere has two poles of degree ~100 among vertices of degree 6)
-    for (int d = 0; d < D; ++d) {
-        const int n = nbr[(size_t)d * V + v];
-        if (n >= V) break;
-        const float w = mode ? inv_deg[n] : 1.0f;
-        sx += w * xf[3 * n]; sy += w * xf[3 * n + 1]; sz += w * xf[3 * n + 2];
+    // first pad ends it (a UV sphere has two poles of degree ~100 among vertices of degree 6).  The first eight slots
+    // are fetched together and their neighbours gathered together: the kernel is a chain of dependent loads otherwise.
+    constexpr int U = 8;
+    int nb[U];
+#pragma unroll
+    for (int d = 0; d < U; ++d) nb[d] = d < D ? nbr[(size_t)d * V + v] : V;
+    float wgt[U], gx[U], gy[U], gz[U];
+#pragma unroll
+    for (int d = 0; d < U; ++d) {
+        const bool ok = nb[d] < V;
+        const int n = ok ? nb[d] : v;
+        wgt[d] = ok ? (mode ? inv_deg[n] : 1.0f) : 0.0f;
+        gx[d] = xf[3 * n]; gy[d] = xf[3 * n + 1]; gz[d] = xf[3 * n + 2];
+    }
+#pragma unroll
+    for (int d = 0; d < U; ++d) { sx += wgt[d] * gx[d]; sy += wgt[d] * gy[d]; sz += wgt[d] * gz[d]; }
+    if (D > U && nb[U - 1] < V) {
+        for (int d = U; d < D; ++d) {
+            const int n = nbr[(size_t)d * V + v];
+            if (n >= V) break;
+            const float w = mode ? inv_deg[n] : 1.0f;
+            sx += w * xf[3 * n]; sy += w * xf[3 * n + 1]; sz += w * xf[3 * n + 2];
+        }
     }
     const float s = mode ? 1.0f : inv_deg[v];
     float *o = out + ((size_t)f * V + v) * 3;

@@ -225,7 +225,7 @@ class _pixel_objective_func(torch.autograd.Function):
         occ = torch.empty(B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * 3, dtype=torch.uint8,
                           device=dev) if sparse else None     # FPCDR_OCC_BYTES
         ecol = torch.empty(4, dtype=torch.float32, device=dev) if sparse else None
-        tri_uv = uv[uv_tri.long()].contiguous()      # [T,3,2], static per mesh: saves a dependent load per pixel
+        tri_uv = _cached_tri_uv(uv, uv_tri)          # [T,3,2], static per mesh: saves a dependent load per pixel
         p = _lib.RenderFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
                            uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C, boundary_mode=boundary,
                            rast=_ptr(rast), color=_ptr(color), tri_uv=_ptr(tri_uv), occ=_ptr(occ), empty_color=_ptr(ecol))
@@ -564,6 +564,23 @@ def antialias_construct_topology_hash(tri):
     adj = torch.empty(T, 3, dtype=torch.int32, device=tri.device)
     _lib.call("fpcdr_topology_build", _ptr(tri), T, _ptr(scratch), _ptr(adj), _stream())
     return adj
+
+
+_tri_uv_cache = OrderedDict()
+
+
+def _cached_tri_uv(uv, uv_tri):
+    """uv[uv_tri] as [T,3,2], gathered once per (uv, uv_tri) pair: static per mesh, saves a dependent load per pixel."""
+    key = (uv.data_ptr(), uv._version, uv_tri.data_ptr(), uv_tri._version, tuple(uv.shape), tuple(uv_tri.shape), str(uv.device))
+    hit = _tri_uv_cache.get(key)
+    if hit is not None:
+        _tri_uv_cache.move_to_end(key)
+        return hit[2]
+    out = uv.detach()[uv_tri.long()].contiguous()
+    _tri_uv_cache[key] = (uv, uv_tri, out)     # holding the tensors keeps their storage (and so the key) alive
+    while len(_tri_uv_cache) > _TOPOLOGY_CACHE_SIZE:
+        _tri_uv_cache.popitem(last=False)
+    return out
 
 
 def _cached_topology(tri):
