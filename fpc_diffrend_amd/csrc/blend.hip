@@ -39,15 +39,32 @@ __global__ void __launch_bounds__(256) k_blend_fwd(const float *__restrict__ v_b
         const int fr = min(f0 + col, F - 1);
         const float *wrow = w + (size_t)fr * K;
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int kc = 0; kc < K; kc += 2 * KC) {
-            const int kb = kc + h * KC;
+        if ((K & 1) == 0) {
+            // even K: rows are 8-byte aligned, two k per load (the lanes of a wave walk 64 different rows, so the number
+            // of load instructions, not bytes, is what this loop waits for)
+            for (int kc = 0; kc < K; kc += 2 * KC) {
+                const int kb = kc + h * KC;
 #pragma unroll 8
-            for (int s = 0; s < KC; ++s) {
-                const int k = kb + s;
-                const bool ok = k < K;
-                const float a = ok ? wrow[k] : 0.0f;   // A[i = frame][k]
-                const float b = ok ? brow[k] : 0.0f;   // B[k][j = coord]
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                for (int s = 0; s < KC; s += 2) {
+                    const int k = kb + s;
+                    const bool ok = k < K;
+                    const float2 a = ok ? *reinterpret_cast<const float2 *>(wrow + k) : make_float2(0.f, 0.f);
+                    const float2 b = ok ? *reinterpret_cast<const float2 *>(brow + k) : make_float2(0.f, 0.f);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                }
+            }
+        } else {
+            for (int kc = 0; kc < K; kc += 2 * KC) {
+                const int kb = kc + h * KC;
+#pragma unroll 8
+                for (int s = 0; s < KC; ++s) {
+                    const int k = kb + s;
+                    const bool ok = k < K;
+                    const float a = ok ? wrow[k] : 0.0f;   // A[i = frame][k]
+                    const float b = ok ? brow[k] : 0.0f;   // B[k][j = coord]
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                }
             }
         }
         const int i = i0 + col;
@@ -76,13 +93,27 @@ __global__ void __launch_bounds__(256) k_blend_bwd_w(const float *__restrict__ B
     const int base = blockIdx.y * SLAB + wave * rows_per_wave + h * rows_per_half;
     const float *grow = gout + (size_t)fr * M;
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if ((M & 1) == 0) {
+        // even M: the frame's gradient row is 8-byte aligned at every even i -- two i per (uncoalesced) load of A
 #pragma unroll 8
-    for (int s = 0; s < rows_per_half; ++s) {
-        const int i = base + s;
-        const bool ok = i < M;
-        const float a = ok ? grow[i] : 0.0f;                                  // A[frame][i]
-        const float b = (ok && kk < K) ? Bmat[(size_t)i * K + kk] : 0.0f;     // B[i][k]
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int s = 0; s < rows_per_half; s += 2) {
+            const int i = base + s;
+            const bool ok = i < M;      // i even, M even: i + 1 < M as well
+            const float2 a = ok ? *reinterpret_cast<const float2 *>(grow + i) : make_float2(0.f, 0.f);   // A[frame][i], [i + 1]
+            const float b0 = (ok && kk < K) ? Bmat[(size_t)i * K + kk] : 0.0f;                           // B[i][k]
+            const float b1 = (ok && kk < K) ? Bmat[(size_t)(i + 1) * K + kk] : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
+        }
+    } else {
+#pragma unroll 8
+        for (int s = 0; s < rows_per_half; ++s) {
+            const int i = base + s;
+            const bool ok = i < M;
+            const float a = ok ? grow[i] : 0.0f;                                  // A[frame][i]
+            const float b = (ok && kk < K) ? Bmat[(size_t)i * K + kk] : 0.0f;     // B[i][k]
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
     }
     if (kk < K) {
 #pragma unroll
