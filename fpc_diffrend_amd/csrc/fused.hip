@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
             if (v != 0.0f) {
                 const int c = k % CS, cell = k / CS;
                 const int colx = cell % TEXW, row = cell / TEXW;
-                const int gx = wrap_i(ox + colx, Wt, boundary), gy = wrap_i(oy + row, Ht, boundary);
+                const int gx = wrap_near(ox + colx, Wt, boundary), gy = wrap_near(oy + row, Ht, boundary);   // no division
                 atomicAdd(grad_tex + ((size_t)gy * Wt + gx) * CS + c, v);
             }
         }
@@ -593,7 +593,8 @@ __global__ void __launch_bounds__(256) k_aa_fix(const float *__restrict__ color,
             }
         }
     }
-    __syncthreads();
+    // most occupied bins lie inside the mesh and have no candidate at all: they leave here
+    if (!__syncthreads_or((tid < BBIN && s_mask[tid] != 0u) ? 1 : 0)) return;
 #pragma unroll
     for (int k = 0; k < BBIN * BBIN / 256; ++k) {
         const int pix = k * 256 + tid;
