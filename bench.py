@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--mip", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--time-all-calls", action="store_true", help="HIP-event timing of every C-ABI call, not only the pixel kernels")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay each step as two HIP graphs (FitConfig.hip_graph); default: on for cfg2 (launch-bound), off otherwise")
     args = ap.parse_args()
@@ -191,7 +192,10 @@ def main():
 
     timer = None
     if not args.no_kernel_timer:
-        timer = _lib.KernelTimer()
+        # inside the timed region only the entry points with per-pixel traffic are bracketed by HIP events (an event pair
+        # costs the stream ~15 us; eleven calls per step would add 3 % to the step being measured); the small calls'
+        # durations are in the rocprofv3 summaries under profiles/
+        timer = _lib.KernelTimer(names=None if args.time_all_calls else algorithmic_bytes_per_px(1, False).keys())
     timer_steps = args.steps
     if use_graph:
         # HIP events cannot be read back from inside a graph: the per-kernel durations come from an eager pass of the

@@ -182,8 +182,9 @@ class KernelTimer:
     """Per-entry-point device time, measured with HIP events recorded on the launch stream (torch's current
     stream, the one every fpcdr_* launch goes to).  Used by bench.py for the roofline figures."""
 
-    def __init__(self):
+    def __init__(self, names=None):
         self.records = {}
+        self.names = set(names) if names is not None else None   # None = every entry point; else only these
 
     def add(self, name, e0, e1):
         self.records.setdefault(name, []).append((e0, e1))
@@ -202,7 +203,7 @@ def call(name, *args):
     """Invoke one C-ABI entry point, raise on a non-zero return code."""
     fn = getattr(load(), name)
     t = TIMER
-    if t is not None:
+    if t is not None and (t.names is None or name in t.names):
         import torch
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
