@@ -484,8 +484,9 @@ class Fitter:
     def mvp(self, frame_ids):
         """mvp[f,c] = P_c . Rt(q_f,t_f) . Rt(q_c,t_c) . MV_c . T(0,170,0)   (fit.py:541-553), [Fb*Nc,4,4]."""
         if self.device.type == 'cuda':
-            return _mvp_func.apply(self.q_opt[self.cam_sel], self.t_opt[self.cam_sel], self.per_frame_q[frame_ids],
-                                   self.per_frame_t[frame_ids], self.proj, self.t_mv)
+            all_cams = self.cam_idxs == list(range(self.q_opt.shape[0]))    # no gather (and no sort in its backward) then
+            q_c, t_c = (self.q_opt, self.t_opt) if all_cams else (self.q_opt[self.cam_sel], self.t_opt[self.cam_sel])
+            return _mvp_func.apply(q_c, t_c, self.per_frame_q[frame_ids], self.per_frame_t[frame_ids], self.proj, self.t_mv)
         rigid_cam = camera.rigid_grad(self.t_opt[self.cam_sel], camera.unitquat_to_rotmat(self.q_opt[self.cam_sel]))
         rigid_frame = camera.rigid_grad(self.per_frame_t[frame_ids], camera.unitquat_to_rotmat(self.per_frame_q[frame_ids]))
         tr = torch.matmul(rigid_cam, self.t_mv)                       # [Nc,4,4]

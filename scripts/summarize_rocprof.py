@@ -18,7 +18,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.DictReader(open(f)))
         print(f"-- kernel stats ({os.path.basename(f)}): name, calls, total_ms, avg_us, pct")
-        for r in rows[:48]:
+        for r in rows[:90]:
             print(f"{short(r['Name']):72s} {int(r['Calls']):6d} {float(r['TotalDurationNs']) / 1e6:10.3f} "
                   f"{float(r['AverageNs']) / 1e3:10.1f} {float(r['Percentage']):6.2f}")
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
