@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FPCDR_ABI_VERSION 1
+#define FPCDR_ABI_VERSION 2
 
 enum {
     FPCDR_OK = 0,
