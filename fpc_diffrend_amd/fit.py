@@ -266,21 +266,17 @@ class MeshTopology:
 
 class _uniform_laplacian(torch.autograd.Function):
     """L X with L = D^-1 A - I for a batch of vertex buffers [F,V,3].  Forward and backward are both GATHERS over the
-    static one-ring table (L^T = A D^-1 - I), so no scatter / index_put runs in the step (fpcdr_laplacian_gather on
-    the GPU; the same arithmetic in torch elsewhere)."""
+    static one-ring table (L^T = A D^-1 - I), so no scatter / index_put runs in the step (fpcdr_laplacian_gather)."""
 
     @staticmethod
     def _apply(x, nbr, nbr32, inv_deg, transpose):
-        if x.is_cuda:
-            x = x.contiguous()
-            out = torch.empty_like(x)
-            _lib.call("fpcdr_laplacian_gather", _ptr(x), _ptr(nbr32), _ptr(inv_deg), _ptr(out), x.shape[0], x.shape[1],
-                      nbr32.shape[0], 1 if transpose else 0, _stream())
-            return out
-        xs = x * inv_deg[None, :, None] if transpose else x
-        pad = torch.cat([xs, torch.zeros_like(xs[:, :1])], dim=1)
-        s = pad[:, nbr].sum(dim=2)
-        return (s if transpose else s * inv_deg[None, :, None]) - x
+        if not x.is_cuda:
+            raise RuntimeError("the mesh regularisers run on the GPU only (fpcdr_laplacian_gather); there is no CPU fallback")
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        _lib.call("fpcdr_laplacian_gather", _ptr(x), _ptr(nbr32), _ptr(inv_deg), _ptr(out), x.shape[0], x.shape[1],
+                  nbr32.shape[0], 1 if transpose else 0, _stream())
+        return out
 
     @staticmethod
     def forward(ctx, verts, nbr, nbr32, inv_deg):
@@ -390,6 +386,8 @@ class Fitter:
     def __init__(self, sc, cfg: FitConfig, device='cuda', rank=0, world=1, targets=None, reduce_fn=None):
         assert cfg.mode in ('prior', 'free', 'combined'), f"No valid mode ('{cfg.mode}')"
         self.sc, self.cfg, self.device = sc, cfg, torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError("Fitter runs on an MI355X (device='cuda'): the HIP path has no CPU fallback")
         self.rank, self.world, self.reduce_fn = rank, world, reduce_fn
         dev = self.device
         F = sc.weights_gt.shape[0]
@@ -444,13 +442,13 @@ class Fitter:
                   {"params": self.maps_intermediate['local'], 'lr': cfg.lr_base}, {"params": self.t_opt, 'lr': cfg.lr_t},
                   {"params": self.q_opt, 'lr': cfg.lr_q}, {"params": self.per_frame_t, 'lr': cfg.lr_t},
                   {"params": self.per_frame_q, 'lr': cfg.lr_q}, {"params": self.tex_opt, 'lr': cfg.lr_base * cfg.lr_tex_coef}]
-        self.use_graph = bool(cfg.hip_graph) and dev.type == 'cuda'
+        self.use_graph = bool(cfg.hip_graph)
         if self.use_graph:      # replayed updates read the learning rates from device memory
             for g in groups:
                 g['lr'] = torch.tensor(float(g['lr']), dtype=torch.float32, device=dev)
             self.optimizer = torch.optim.Adam(groups, lr=torch.tensor(cfg.lr_base, dtype=torch.float32, device=dev), capturable=True)
         else:
-            self.optimizer = torch.optim.Adam(groups, lr=cfg.lr_base, fused=(dev.type == 'cuda'))
+            self.optimizer = torch.optim.Adam(groups, lr=cfg.lr_base, fused=True)
         self._graphs, self._graph_key, self._frame_idx = None, None, None
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lr_lambda=lambda x: cfg.lr_ramp ** (float(x) / float(cfg.max_iter)))
@@ -471,10 +469,8 @@ class Fitter:
         # ---- reference images, resident in HBM as 8 bit [F_local, n_cam, H, W] (fit.py:529-533) ----
         self.targets = targets if targets is not None else self.render_targets()
         # the pixel loss of an all-background image, per (frame, camera): depends on the targets only (sparse objective)
-        self.target_bg_sumsq = None
-        if dev.type == 'cuda':
-            t = self.targets
-            self.target_bg_sumsq = dr.reference_background_sumsq(t.reshape(-1, *self.resolution), BACKGROUND).reshape(t.shape[:2])
+        t = self.targets
+        self.target_bg_sumsq = dr.reference_background_sumsq(t.reshape(-1, *self.resolution), BACKGROUND).reshape(t.shape[:2])
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -483,15 +479,9 @@ class Fitter:
 
     def mvp(self, frame_ids):
         """mvp[f,c] = P_c . Rt(q_f,t_f) . Rt(q_c,t_c) . MV_c . T(0,170,0)   (fit.py:541-553), [Fb*Nc,4,4]."""
-        if self.device.type == 'cuda':
-            all_cams = self.cam_idxs == list(range(self.q_opt.shape[0]))    # no gather (and no sort in its backward) then
-            q_c, t_c = (self.q_opt, self.t_opt) if all_cams else (self.q_opt[self.cam_sel], self.t_opt[self.cam_sel])
-            return _mvp_func.apply(q_c, t_c, self.per_frame_q[frame_ids], self.per_frame_t[frame_ids], self.proj, self.t_mv)
-        rigid_cam = camera.rigid_grad(self.t_opt[self.cam_sel], camera.unitquat_to_rotmat(self.q_opt[self.cam_sel]))
-        rigid_frame = camera.rigid_grad(self.per_frame_t[frame_ids], camera.unitquat_to_rotmat(self.per_frame_q[frame_ids]))
-        tr = torch.matmul(rigid_cam, self.t_mv)                       # [Nc,4,4]
-        tr_pose = torch.matmul(rigid_frame[:, None], tr[None])        # [Fb,Nc,4,4]
-        return torch.matmul(self.proj[None], tr_pose).reshape(-1, 4, 4)
+        all_cams = self.cam_idxs == list(range(self.q_opt.shape[0]))    # no gather (and no sort in its backward) then
+        q_c, t_c = (self.q_opt, self.t_opt) if all_cams else (self.q_opt[self.cam_sel], self.t_opt[self.cam_sel])
+        return _mvp_func.apply(q_c, t_c, self.per_frame_q[frame_ids], self.per_frame_t[frame_ids], self.proj, self.t_mv)
 
     def vertices(self, frame_ids, iteration=None):
         """Blended vertex buffers [Fb,3V] for a batch of frames (fit.py:555-562).  The reference multiplies by a
@@ -599,7 +589,7 @@ class Fitter:
         reg = reg / self.world
         self.optimizer.zero_grad(set_to_none=True)
         if one_shot:
-            bg_sum = self.target_bg_sumsq[local].sum() if (cfg.sparse_objective and self.target_bg_sumsq is not None) else None
+            bg_sum = self.target_bg_sumsq[local].sum() if cfg.sparse_objective else None
             loss = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
                                       n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum) + reg
             loss.backward()
