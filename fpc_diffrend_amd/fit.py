@@ -353,6 +353,7 @@ class FitConfig:
     fused_render: bool = True       # rasterize + interpolate + texture as one kernel pair (non-mip); False = four separate ops
     fused_objective: bool = True    # with fused_render and fused_loss: the whole pixel term as three kernels (ops.pixel_objective)
     sparse_objective: bool = True   # the three kernels skip image regions far from any geometry (same result)
+    overlap_regularisers: bool = True   # fused path: mesh regularisers on a second stream beside the pixel objective
     hip_graph: bool = False         # capture forward+backward and the Adam update as two HIP graphs (launch-bound
                                     # small batches: cfg2 3.2 -> 1.8 ms / step; no gain once a step is GPU-bound)
     shading: str = "texture"        # 'texture' = reference render(); 'vertex' = rasterize + interpolate of a per-vertex
@@ -450,6 +451,7 @@ class Fitter:
         else:
             self.optimizer = torch.optim.Adam(groups, lr=cfg.lr_base, fused=True)
         self._graphs, self._graph_key, self._frame_idx = None, None, None
+        self._side_stream = torch.cuda.Stream(device=dev)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lr_lambda=lambda x: cfg.lr_ramp ** (float(x) / float(cfg.max_iter)))
         self.params = [g["params"][0] for g in self.optimizer.param_groups]
@@ -572,7 +574,14 @@ class Fitter:
         elif not one_shot:
             colour, rast_out = render_from_clip(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt,
                                                 self.resolution, cfg.enable_mip, cfg.max_mip_level, cfg.fused_render)
-        # regularisers (fit.py:578-595): evaluated on this rank's meshes, averaged over all ranks
+        # regularisers (fit.py:578-595): evaluated on this rank's meshes, averaged over all ranks.  They depend on the
+        # vertices only, so in the fused path they run on a second stream beside the pixel objective (forward here; autograd
+        # replays each backward on the stream of its forward): their ~25 small launches hide behind the raster kernels.
+        main_stream = torch.cuda.current_stream()
+        side = self._side_stream if (one_shot and cfg.overlap_regularisers and not self.use_graph) else None
+        if side is not None:
+            side.wait_stream(main_stream)
+            torch.cuda.set_stream(side)
         reg = torch.zeros((), dtype=torch.float32, device=self.device)
         if cfg.weight_meshedge:
             reg = reg + cfg.weight_meshedge * mesh_edge_loss(vtx_pos_split, self.topo, 0.1)
@@ -587,12 +596,21 @@ class Fitter:
             mi = torch.matmul(self.maps_intermediate['local'], self.maps['local'][:, frame_ids])
             reg = reg + torch.mean(mi ** 2)
         reg = reg / self.world
+        if side is not None:
+            torch.cuda.set_stream(main_stream)
+            vtx_pos_split.record_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
         if one_shot:
             bg_sum = self.target_bg_sumsq[local].sum() if cfg.sparse_objective else None
-            loss = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
-                                      n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum) + reg
+            pix = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
+                                     n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum)
+            if side is not None:
+                main_stream.wait_stream(side)
+                reg.record_stream(main_stream)
+            loss = pix + reg
             loss.backward()
+            if side is not None:
+                main_stream.wait_stream(side)    # the regularisers' backward ran on the side stream
         elif cfg.fused_loss:
             sum_sq, g_colour = pixel_loss_fused(colour, rast_out, ref, n_total)
             roots, seeds = [colour], [g_colour]
