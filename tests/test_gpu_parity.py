@@ -205,3 +205,34 @@ def test_topology_matches_oracle(dr, oracle_ops):
     cnt, oth = oracle_ops.edge_table(tri)
     expect = torch.where(cnt == 1, torch.full_like(oth, -1), torch.where(cnt == 2, oth, torch.full_like(oth, -2)))
     assert torch.equal(adj, expect)
+
+
+@pytest.mark.parametrize("res,T,size,seed", [((256, 256), 20000, 0.03, 5), ((192, 320), 8000, 0.08, 6)])
+def test_rasterize_small_triangle_soup_ids_bit_exact(dr, ctx, oracle_ops, res, T, size, seed):
+    """Thousands of small overlapping triangles: the one-lane-per-triangle path with its LDS depth buffer (heavy overdraw,
+    bins with several batches) against the oracle's plain loops."""
+    pos, tri = random_soup(2, T, seed, size=size)
+    rast, _ = dr.rasterize(ctx, pos.cuda(), tri.cuda(), res)
+    assert torch.equal(_ids(rast), oracle_ops.rasterize_ids(pos, tri, res))
+
+
+def test_rasterize_depth_ties_go_to_the_smaller_index(dr, ctx, oracle_ops):
+    """Every triangle twice (identical vertices, so identical depth planes): rule R6 gives the pixel to the smaller index
+    although triangles reach a bin in no particular order; plus triangles with w <= 0 and NaN vertices, which are dropped."""
+    pos, tri = random_soup(1, 600, 7, size=0.2)
+    T = tri.shape[0]
+    perm = torch.randperm(2 * T, generator=torch.Generator().manual_seed(0))
+    tri2 = torch.cat([tri, tri], dim=0)[perm].contiguous()          # duplicates scattered over the index range
+    pos = pos.clone()
+    pos[0, 30, 3] = -0.5            # w <= 0
+    pos[0, 91, 0] = float('nan')    # NaN x
+    rast, _ = dr.rasterize(ctx, pos.cuda(), tri2.cuda(), (160, 160))
+    ids = _ids(rast)
+    assert torch.equal(ids, oracle_ops.rasterize_ids(pos, tri2, (160, 160)))
+    # direct statement of the rule: a covered pixel's winner is the smaller of the two copies' indices
+    first = torch.full((T,), 2 * T, dtype=torch.long)
+    src = perm % T                                                  # original triangle of each entry of tri2
+    for j in range(2 * T):
+        first[src[j]] = min(first[src[j]], j)
+    win = ids[ids > 0].long() - 1
+    assert torch.equal(first[src[win]], win)
