@@ -785,7 +785,13 @@ def smoke_step(sc, device='cuda:0', cams=(0, 4), mode='prior'):
     loss = sum_sq[0].to(torch.float32) / colour.numel()
     with torch.no_grad():
         image = torch.where(rast[..., 3:] > 0, colour, torch.tensor(BACKGROUND, device=ft.device))
+    # the same clip positions through the fused objective, the form the fit loop runs (two C-ABI calls)
+    pc = pos_clip.detach().clone().requires_grad_(True)
+    tex_f = ft.tex_opt.detach().clone().requires_grad_(True)
+    loss_f = dr.pixel_objective(ft.glctx, pc, ft.pos_idx, ft.uv, ft.uv_idx, tex_f, ref, ft.resolution)
+    loss_f.backward()
     return {'loss': loss.detach(), 'ids': rast[..., 3].to(torch.int32), 'image': image.detach(),
+            'loss_fused': loss_f.detach(), 'grad_pos_clip_fused': pc.grad.clone(), 'grad_tex_fused': tex_f.grad.clone(),
             'pos_clip': pos_clip.detach(), 'grad_pos_clip': pos_clip.grad.clone(),
             'grad_w': ft.maps_intermediate['local'].grad.clone(), 'grad_tex': ft.tex_opt.grad.clone(),
             'grad_pose': torch.cat([ft.per_frame_t.grad.reshape(-1), ft.per_frame_q.grad.reshape(-1),
