@@ -290,6 +290,28 @@ def main():
                                                      "note": "stand-alone dr.antialias backward at the same batch, outside the timed region"}
             except Exception as e:   # the sweep must never take the measurement down
                 out["kernels_standalone_ops"] = {"error": repr(e)}
+            if world == 1:
+                # the same step through the DROP-IN surface only: the reference's render() on the four nvdiffrast-style
+                # operators and its torch loss (no fused objective) -- what a user gets by switching the import alone
+                try:
+                    _lib.TIMER = None
+                    cfg_d = fit.FitConfig(max_iter=80000, frames_per_step=0, init_texture="random", fused_objective=False,
+                                          fused_render=False, fused_loss=False)
+                    ft_d = fit.Fitter(sc, cfg_d, device=device, targets=fitter.targets)
+                    for _ in range(2):
+                        ft_d.step()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        ft_d.step()
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / 3
+                    out["drop_in_path"] = {"ms_per_step": 1e3 * dt, "frames_per_s": fpg / dt,
+                                           "what": "rasterize / interpolate / texture / antialias as four separate operators + "
+                                                   "the reference's torch.where / mean loss, same batch, outside the timed region"}
+                    del ft_d
+                except Exception as e:
+                    out["drop_in_path"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(sc)
