@@ -23,9 +23,8 @@ Reference quirks are reproduced and flagged where they 
 """
 import ctypes
 import json
-import math
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional, Sequence
 
 import numpy as np
