@@ -531,6 +531,30 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
         if (tid == 0) sh.occ[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total_hits > 0 ? 1 : 0;
         if (total_hits == 0) return;
     }
+    if (total_hits == 0) {
+        // ---- nothing touches this bin (most bins of a dense call): stream the empty result, two full 512-byte rows of
+        // rast per wave instruction instead of the shading loop's 8x8 quadrant pattern ----
+        float ecol[4] = {0.f, 0.f, 0.f, 0.f};
+        if (SHADE) {
+            const Taps tp0 = make_taps(0.0f, 0.0f, sh.Ht, sh.Wt, sh.C, sh.boundary);
+            for (int c = 0; c < min(sh.C, 4); ++c) ecol[c] = bilerp(sh.tex, tp0, c, sh.C);
+        }
+        for (int i = tid; i < BIN * BIN; i += 256) {
+            const int px = bin_x0 + (i % BIN), py = bin_y0 + (i / BIN);
+            if (px >= W || py >= H) continue;
+            const size_t off = ((size_t)b * H + py) * W + px;
+            rast[off] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (WRITE_DB) rast_db[off] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (SHADE) {
+                if (sh.C <= 4) { for (int c = 0; c < sh.C; ++c) sh.color[off * sh.C + c] = ecol[c]; }
+                else {
+                    const Taps tp0 = make_taps(0.0f, 0.0f, sh.Ht, sh.Wt, sh.C, sh.boundary);
+                    for (int c = 0; c < sh.C; ++c) sh.color[off * sh.C + c] = bilerp(sh.tex, tp0, c, sh.C);
+                }
+            }
+        }
+        return;
+    }
     // ---- fold the tile path's register winners into the depth buffer, then read every pixel's winner ----
     if (bin_live) {
 #pragma unroll
