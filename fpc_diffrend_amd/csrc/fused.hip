@@ -238,8 +238,14 @@ __global__ void __launch_bounds__(256) k_ref_bg_sumsq(const uint8_t *__restrict_
 //             uv = (0,0)) go straight to global memory.
 // (One lane per triangle walking its bounding box -- the scheme of the forward rasteriser -- was tried here and took
 // 6.9 ms: lanes reach their pixels at different trips, so the wave pays the full shading chain on almost every trip.)
+// Window capacity: measured at cfg3 (~1 texel per pixel, a 32x32 bin spans ~36 texels): 64 -> 3.18 ms, 56 -> 2.72, 48 -> 2.67,
+// 40 -> 2.59, 36 -> 2.55, 32 -> 2.49, 28 -> 2.62, 24 -> 2.98, 16 -> 3.80 (taps outside go straight to memory).  40 keeps
+// headroom for denser textures; override with -DFPCDR_TEXWIN=n.
+#ifndef FPCDR_TEXWIN
+#define FPCDR_TEXWIN 40
+#endif
 constexpr int VSLOTS = 256;
-constexpr int TEXW = 48, TEXH = 48;
+constexpr int TEXW = FPCDR_TEXWIN, TEXH = FPCDR_TEXWIN;
 constexpr int BBIN = 32;
 
 // latency-bound (dependent loads per bin): 8 waves per SIMD with a few spilled registers beat 5 without (3.26 -> 2.81 ms)
