@@ -244,7 +244,10 @@ __global__ void __launch_bounds__(256) k_ref_bg_sumsq(const uint8_t *__restrict_
 #ifndef FPCDR_TEXWIN
 #define FPCDR_TEXWIN 40
 #endif
-constexpr int VSLOTS = 256;
+#ifndef FPCDR_VSLOTS
+#define FPCDR_VSLOTS 256
+#endif
+constexpr int VSLOTS = FPCDR_VSLOTS;
 constexpr int TEXW = FPCDR_TEXWIN, TEXH = FPCDR_TEXWIN;
 constexpr int BBIN = 32;
 
@@ -508,7 +511,7 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
             unsigned int slot[3];
             int old[3];
 #pragma unroll
-            for (int kk = 0; kk < 3; ++kk) slot[kk] = ((unsigned int)vk[kk] * 2654435761u) >> 24;   // 8 bits = VSLOTS
+            for (int kk = 0; kk < 3; ++kk) slot[kk] = (((unsigned int)vk[kk] * 2654435761u) >> 16) & (VSLOTS - 1);
 #pragma unroll
             for (int kk = 0; kk < 3; ++kk) old[kk] = atomicCAS(&s_vkey[slot[kk]], -1, vk[kk]);
 #pragma unroll
