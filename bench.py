@@ -244,6 +244,7 @@ def main():
                    "blendshapes": int(sc.blendshapes.shape[1]), "texture": list(sc.texture.shape),
                    "parallelism": f"dp{world} (frames sharded, one RCCL all-reduce of {bucket.nbytes / 1e6:.1f} MB per step)"},
         "final_loss": float(loss) if loss is not None else None,
+        "hbm_allocated_peak_GB": torch.cuda.max_memory_allocated(device) / 1e9,
     }
     if rank == 0 and timer is not None:
         bpp = algorithmic_bytes_per_px(C, args.mip)
