@@ -147,7 +147,8 @@ typedef struct {
 } fpcdr_aa_loss_fwd_params;
 int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream);
 
-/* fpcdr_render_fwd (sparse mode) + fpcdr_aa_loss_fwd in one call, without the dense antialias pass: the rasteriser's
+/* fpcdr_render_fwd (sparse mode) + fpcdr_aa_loss_fwd in one call -- reference fit.py:151-161 (render: rasterize, interpolate,
+ * texture, antialias, background) and the pixel term of fit.py:579 -- without the dense antialias pass: the rasteriser's
  * workgroup, which still holds its bin's ids, gives every pixel that antialiasing cannot touch (no pixel pair with
  * different ids at a silhouette edge) its loss term and gradient straight away and leaves a bit mask of the others
  * (bin-border pixels included); a second kernel runs antialias + loss on those candidates only.  Same outputs as the
