@@ -279,7 +279,7 @@ def main():
                                        "HIP-event time of the C-ABI call inside the timed region; traffic = HBM bytes the "
                                        "call really moved (PMC): the sparse objective touches 17 % of the pixels, and its "
                                        "kernels are bound by vector-ALU issue and LDS atomics, not by HBM (DESIGN.md 4.5)"}
-        if not args.mip and args.workload in ("cfg1", "cfg3"):
+        if not args.mip and args.workload in ("cfg1", "cfg3") and world == 1:   # (scaling runs: all ranks leave together)
             try:
                 st = table_of(standalone_op_sweep(fitter))
                 out["kernels_standalone_ops"] = st
