@@ -255,8 +255,14 @@ constexpr int BBIN = 32;
 #ifndef FPCDR_BWD_WPE
 #define FPCDR_BWD_WPE __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
+#ifndef FPCDR_BWD_NT
+#define FPCDR_BWD_NT 256
+#endif
+constexpr int BWD_NT = FPCDR_BWD_NT;          // threads per bin workgroup (measured: 128 -> 3.08 ms, 256 -> 2.61, 512 -> 3.28)
+constexpr int BWD_NPX = BBIN * BBIN / BWD_NT;  // pixels per thread
+
 template <int CS>
-__global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+__global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
                                                        const float *__restrict__ tex, const float4 *__restrict__ rast,
                                                        const float *__restrict__ color, const float *__restrict__ g_aa,
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
     // pixel k of this thread: row 8 wave + 2 k + (lane >> 5) of the bin; the odd row runs right to left, so that lane 31
     // and lane 32 are vertical neighbours and a triangle's run continues from one row into the next
     const int col = (lane & 32) ? 63 - lane : lane;
-    const int rowk0 = 8 * wave + (lane >> 5);
+    const int rowk0 = 2 * BWD_NPX * wave + (lane >> 5);
     const int bx0 = blockIdx.x * BBIN, by0 = blockIdx.y * BBIN, b = blockIdx.z;
     const int x = bx0 + col;
     float *gp = grad_pos + (size_t)b * V * 4;
@@ -300,10 +306,10 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
     if (tid < CS) s_esum[tid] = 0.0f;
 
     // ---- pixel phase A: gradient arriving at each pixel's colour (antialias backward folded in) ----
-    float go[4][CS];
-    bool any[4];
+    float go[BWD_NPX][CS];
+    bool any[BWD_NPX];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < BWD_NPX; ++k) {
         const int y = by0 + rowk0 + 2 * k;
         any[k] = false;
 #pragma unroll
@@ -380,23 +386,26 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
         }
     }
 #ifdef FPCDR_ABL_EARLY
-    { float sink = 0.f; for (int k = 0; k < 4; ++k) for (int c = 0; c < CS; ++c) sink += go[k][c]; asm volatile("" :: "v"(sink)); return; }
+    { float sink = 0.f; for (int k = 0; k < BWD_NPX; ++k) for (int c = 0; c < CS; ++c) sink += go[k][c]; asm volatile("" :: "v"(sink)); return; }
 #endif
     // most bins of an image see no gradient at all: leave before touching the tables
-    if (!__syncthreads_or((any[0] | any[1] | any[2] | any[3]) ? 1 : 0)) return;
+    bool any_px = false;
+#pragma unroll
+    for (int k = 0; k < BWD_NPX; ++k) any_px |= any[k];
+    if (!__syncthreads_or(any_px ? 1 : 0)) return;
 
     // ---- tables; texture coordinate of every pixel with a gradient; origin of the texel window ----
-    for (int k = tid; k < VSLOTS; k += 256) {
+    for (int k = tid; k < VSLOTS; k += BWD_NT) {
         s_vkey[k] = -1;
         s_vacc[k][0] = 0.f; s_vacc[k][1] = 0.f; s_vacc[k][2] = 0.f; s_vacc[k][3] = 0.f;
     }
-    for (int k = tid; k < TEXH * TEXW * CS; k += 256) s_tex[k] = 0.0f;
-    int pt[4];
-    float tu[4], tv[4], ru[4], rv[4];
+    for (int k = tid; k < TEXH * TEXW * CS; k += BWD_NT) s_tex[k] = 0.0f;
+    int pt[BWD_NPX];
+    float tu[BWD_NPX], tv[BWD_NPX], ru[BWD_NPX], rv[BWD_NPX];
     {
         int ux0 = 0x7fffffff, uy0 = 0x7fffffff;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < BWD_NPX; ++k) {
             pt[k] = -1; tu[k] = 0.f; tv[k] = 0.f; ru[k] = 0.f; rv[k] = 0.f;
             if (any[k] && v_me) {
                 const float4 r = rast[img + (size_t)(by0 + rowk0 + 2 * k) * W + x];
@@ -429,7 +438,7 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
 #pragma unroll
     for (int c = 0; c < CS; ++c) esum[c] = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < BWD_NPX; ++k) {
         int tkey = -1;
         float gu = 0.f, gvv = 0.f;
         if (any[k] && pt[k] < 0) {
@@ -548,7 +557,7 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
         atomicAdd(grad_tex + tp0.i11 + tid, e * (tp0.fx * tp0.fy));
     }
     // ---- flush: lane = (slot, component), so the four dwords of a vertex are one contiguous 16-byte access ----
-    for (int k = tid; k < VSLOTS * 4; k += 256) {
+    for (int k = tid; k < VSLOTS * 4; k += BWD_NT) {
         const int slot = k >> 2, comp = k & 3;
         const int key = s_vkey[slot];
         if (key >= 0) {
@@ -557,7 +566,7 @@ __global__ void __launch_bounds__(256) FPCDR_BWD_WPE k_render_aa_bwd(const float
         }
     }
     if (grad_tex && ox != 0x7fffffff) {
-        for (int k = tid; k < TEXH * TEXW * CS; k += 256) {
+        for (int k = tid; k < TEXH * TEXW * CS; k += BWD_NT) {
             const float v = s_tex[k];
             if (v != 0.0f) {
                 const int c = k % CS, cell = k / CS;
@@ -800,7 +809,7 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
     FPCDR_REQUIRE(!p->occ || p->empty_color, "sparse mode needs empty_color");
     dim3 grid(fpcdr_cdiv(p->W, BBIN), fpcdr_cdiv(p->H, BBIN), p->B);
 #define LAUNCH(CS)                                                                                                          \
-    hipLaunchKernelGGL(k_render_aa_bwd<CS>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)p->pos, p->tri,        \
+    hipLaunchKernelGGL(k_render_aa_bwd<CS>, grid, dim3(BWD_NT), 0, (hipStream_t)stream, (const float4 *)p->pos, p->tri,        \
                        (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa, p->sil,     \
                        (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,   \
                        p->boundary_mode,                                                                                        \
