@@ -296,6 +296,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
     __shared__ unsigned long long s_mask[2][2][NTILES][BIGB / 64];   // [round parity][0 = 32-bit class, 1 = the rest]
     __shared__ int s_list[(SCAN_K + 1) * BATCH];   // pending triangle indices (any order), consumed from the top
     __shared__ int s_pending, s_nlive;
+    __shared__ int s_wtot[2][4];        // hits each wave appended in a scan iteration (double-buffered by iteration parity)
 
     const int b = blockIdx.z;
     const int bin_x0 = blockIdx.x * BIN, bin_y0 = blockIdx.y * BIN;
@@ -484,7 +485,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
             __syncthreads();
             const int n_live = s_nlive;
             // ---- scan the bounding boxes of SCAN_K live chunks per iteration (independent loads in flight) ----
-            for (int ci = 0; ci < n_live; ci += SCAN_K) {
+            for (int ci = 0, it = 0; ci < n_live; ci += SCAN_K, ++it) {
                 bool hit[SCAN_K];
                 int tt[SCAN_K];
 #pragma unroll
@@ -506,6 +507,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
                 }
                 int base = 0;
                 if (lane == 0 && total) base = atomicAdd(&s_pending, total);
+                if (lane == 0) s_wtot[it & 1][wave] = total;
                 base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
                 for (int k = 0; k < SCAN_K; ++k) {
@@ -513,9 +515,11 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
                     base += __popcll(bal[k]);
                 }
                 __syncthreads();
-                const int before = pending;
-                pending = s_pending;
-                total_hits += pending - before;
+                // block-uniform by construction: the four waves' counts of THIS iteration (a fast wave may already be
+                // adding the next iteration's hits to s_pending, so that counter must not be re-read here)
+                const int added = s_wtot[it & 1][0] + s_wtot[it & 1][1] + s_wtot[it & 1][2] + s_wtot[it & 1][3];
+                pending += added;
+                total_hits += added;
                 while (pending >= BATCH) process_batch(BATCH);
             }
             if (seg + 256 < n_chunks) {   // another segment follows: recycle the chunk list

@@ -24,6 +24,7 @@ Reference quirks are reproduced and flagged where they 
 import ctypes
 import json
 import os
+import time
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -288,10 +289,13 @@ class _uniform_laplacian(torch.autograd.Function):
         return _uniform_laplacian._apply(g, nbr, nbr32, inv_deg, True), None, None, None
 
 
-def mesh_laplacian_smoothing(verts, topo):
-    """Uniform Laplacian smoothing: mean_v || mean_{n in N(v)} x_n - x_v ||, averaged over meshes [F,V,3]."""
+def mesh_laplacian_smoothing(verts, topo, per_mesh=False):
+    """Uniform Laplacian smoothing (pytorch3d mesh_laplacian_smoothing(method='uniform'), reference fit.py:581):
+    mean_v || mean_{n in N(v)} x_n - x_v || of every mesh of verts [F,V,3]; per_mesh=True returns the [F] values, else
+    their mean."""
     lap = _uniform_laplacian.apply(verts, topo.nbr, topo.nbr32, topo.inv_deg)
-    return lap.norm(dim=2).mean()
+    per = lap.norm(dim=2).mean(dim=1)
+    return per if per_mesh else per.mean()
 
 
 def mesh_normal_consistency(verts, topo):
@@ -357,6 +361,9 @@ class FitConfig:
                                     # small batches: cfg2 3.2 -> 1.8 ms / step; no gain once a step is GPU-bound)
     shading: str = "texture"        # 'texture' = reference render(); 'vertex' = rasterize + interpolate of a per-vertex
                                     # grey only (BASELINE.json configs[1]: "raster+interp only, no texture")
+    log_interval: int = 0           # every n steps one JSON line {it, loss, lr, frames_per_s} (reference print, fit.py:621-623)
+    reg_log_interval: int = 500     # every n steps the regulariser breakdown MEL / LAP / MNC (reference fit.py:597-601)
+    log_path: Optional[str] = None  # JSON-lines file (appended); None with log_interval > 0 = stdout
 
 
 def setup_dataset(blendshapes, n_frames, device):
@@ -377,7 +384,8 @@ def setup_dataset_free(n_frames, n_vertices_x3, device):
 
 
 class Fitter:
-    """State + one optimisation step of the fit loop for a (synthetic) take.
+    """State + one optimisation step of the fit loop for a take: a synthetic Scene (scene.cfg: targets are rendered from
+    its hidden ground truth) or one read from disk (scene.from_take: targets are its reference images).
 
     rank / world: this process optimises frames [rank * F / world, (rank + 1) * F / world); parameters are
     replicated; `reduce_fn(flat_grad)` (dist.GradBucket) sums gradients over ranks before Adam.
@@ -390,8 +398,8 @@ class Fitter:
             raise RuntimeError("Fitter runs on an MI355X (device='cuda'): the HIP path has no CPU fallback")
         self.rank, self.world, self.reduce_fn = rank, world, reduce_fn
         dev = self.device
-        F = sc.weights_gt.shape[0]
-        assert F % world == 0, "frames must divide evenly over ranks"
+        F = sc.n_frames
+        assert F > 0 and F % world == 0, "frames must divide evenly over ranks"
         self.n_frames = F
         self.frame_lo, self.frame_hi = rank * F // world, (rank + 1) * F // world
         self.resolution = tuple(cfg.resolution or sc.resolution)
@@ -465,10 +473,19 @@ class Fitter:
         self.t_mv = torch.tensor(np.stack(TMV), dtype=torch.float32, device=dev)
         self.cam_sel = torch.tensor(self.cam_idxs, dtype=torch.long, device=dev)
         self.rng = np.random.default_rng(cfg.seed + 1000 * rank)
-        self.result = torch.empty(F, self.v_base.shape[0], dtype=torch.float32, device=dev)
+        # final shapes (fit.py:457); every rank fills the rows of its own frames, gather_result() joins the shards
+        self.result = torch.zeros(F, self.v_base.shape[0], dtype=torch.float32, device=dev)
         self.iteration = 0
+        self._log_file, self._log_t, self._log_it = None, None, 0
         # ---- reference images, resident in HBM as 8 bit [F_local, n_cam, H, W] (fit.py:529-533) ----
-        self.targets = targets if targets is not None else self.render_targets()
+        if targets is not None:
+            self.targets = targets
+        elif sc.images is not None:      # a take from disk: this rank's frames x the selected cameras
+            assert tuple(sc.images.shape[2:]) == self.resolution, "FitConfig.resolution differs from the take's images"
+            self.targets = torch.from_numpy(np.ascontiguousarray(sc.images[self.frame_lo:self.frame_hi][:, self.cam_idxs])).to(dev)
+        else:
+            assert sc.weights_gt is not None, "a Scene needs reference images (scene.from_take) or a synthetic ground truth"
+            self.targets = self.render_targets()
         # the pixel loss of an all-background image, per (frame, camera): depends on the targets only (sparse objective)
         t = self.targets
         self.target_bg_sumsq = dr.reference_background_sumsq(t.reshape(-1, *self.resolution), BACKGROUND).reshape(t.shape[:2])
@@ -550,7 +567,9 @@ class Fitter:
         """Forward + backward of fit.py:556-611 for a batch of frames x all cameras.  Returns the loss (tensor)."""
         cfg = self.cfg
         i = self.iteration
-        if cfg.mode == 'combined' and i > cfg.max_iter / 2:   # fit.py:603-608
+        # fit.py:603-608 switches the learned basis on AFTER the forward pass of the first iteration i > max_iter / 2, so
+        # it receives its first gradient in the iteration after that one
+        if cfg.mode == 'combined' and (i - 1) > cfg.max_iter / 2:
             for m in (self.m1, self.m2, self.m3):
                 m.requires_grad = True
         Fb, Nc = self._n(frame_ids), len(self.cam_idxs)
@@ -585,7 +604,8 @@ class Fitter:
         if cfg.weight_meshedge:
             reg = reg + cfg.weight_meshedge * mesh_edge_loss(vtx_pos_split, self.topo, 0.1)
         if cfg.weight_laplacian:
-            reg = reg + cfg.weight_laplacian * mesh_laplacian_smoothing(vtx_pos_split, self.topo) ** 2
+            # the reference squares the value of ONE mesh per step (fit.py:581): a batch is the mean of the squares
+            reg = reg + cfg.weight_laplacian * (mesh_laplacian_smoothing(vtx_pos_split, self.topo, per_mesh=True) ** 2).mean()
         if cfg.weight_normalconsistency:
             reg = reg + cfg.weight_normalconsistency * mesh_normal_consistency(vtx_pos_split, self.topo)
         if cfg.regularize_correctives and cfg.mode == 'combined' and i > cfg.max_iter / 2:
@@ -642,8 +662,44 @@ class Fitter:
                 self.reduce_fn(self.params)
             self._update()
         self.scheduler.step()
+        if self.cfg.log_interval:
+            self._log_step(frame_ids, loss)
         self.iteration += 1
         return loss
+
+    # ------------------------------------------------------------------------------------------
+    def _log_step(self, frame_ids, loss):
+        """JSON-lines step log on rank 0: the reference prints loss and learning rates every log_interval iterations
+        (fit.py:621-623; reading the loss is its one host sync) and the regulariser breakdown every 500 (fit.py:597-601)."""
+        cfg, i = self.cfg, self.iteration
+        if self.rank != 0:
+            return
+        rec = None
+        if i % cfg.log_interval == 0:
+            now = time.perf_counter()
+            rec = {"it": i, "frames": self._n(frame_ids) * self.world, "loss": float(loss),
+                   "lr": [float(x) for x in self.scheduler.get_last_lr()]}
+            if self._log_t is not None and i > self._log_it:
+                rec["frames_per_s"] = self._n(frame_ids) * self.world * (i - self._log_it) / (now - self._log_t)
+            self._log_t, self._log_it = time.perf_counter(), i
+        if cfg.reg_log_interval and i % cfg.reg_log_interval == 0:
+            with torch.no_grad():
+                v = self.vertices(frame_ids).reshape(self._n(frame_ids), -1, 3)
+                rec = rec or {"it": i}
+                rec["MEL"] = float(cfg.weight_meshedge * mesh_edge_loss(v, self.topo, 0.1))
+                rec["LAP"] = float(cfg.weight_laplacian * (mesh_laplacian_smoothing(v, self.topo, per_mesh=True) ** 2).mean())
+                rec["MNC"] = float(cfg.weight_normalconsistency * mesh_normal_consistency(v, self.topo))
+        if rec is None:
+            return
+        line = json.dumps(rec)
+        if cfg.log_path:
+            if self._log_file is None:
+                os.makedirs(os.path.dirname(os.path.abspath(cfg.log_path)), exist_ok=True)
+                self._log_file = open(cfg.log_path, "a")
+            self._log_file.write(line + "\n")
+            self._log_file.flush()
+        else:
+            print(line, flush=True)
 
     GRAPH_WARMUP = 3    # eager steps before capture (allocator, Adam state, scratch and topology caches settle)
 
@@ -651,7 +707,7 @@ class Fitter:
         """Replay (capturing first if needed) graph A = forward + backward into fixed gradient buffers and graph B =
         Adam + quaternion renormalisation; the gradient all-reduce runs between them, outside any graph.  The set of
         trainable tensors is part of the key: 'combined' mode switches the free-form basis on half way (fit.py:603-608)."""
-        switch = self.cfg.mode == 'combined' and self.iteration > self.cfg.max_iter / 2
+        switch = self.cfg.mode == 'combined' and (self.iteration - 1) > self.cfg.max_iter / 2
         key = (switch, tuple(p.requires_grad for p in self.params))
         if self._graph_key != key:
             # new set of trainable tensors: one eager step first, so that Adam creates their state outside a capture
@@ -704,7 +760,9 @@ class Fitter:
         return {"params": {n: p.detach().clone() for n, p in zip(names, self.params)},
                 "requires_grad": [bool(p.requires_grad) for p in self.params],
                 "optimizer": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict(),
-                "iteration": self.iteration, "rng": self.rng.bit_generator.state, "result": self.result.clone(),
+                "iteration": self.iteration, "rng": self.rng.bit_generator.state,
+                "result": self.result.clone(),      # this rank's rows (others zero): checkpoints are per rank
+                "frame_range": (self.frame_lo, self.frame_hi),
                 "config": dict(self.cfg.__dict__)}
 
     def load_state_dict(self, state):
@@ -735,15 +793,30 @@ class Fitter:
             for k, v in args.items():
                 f.write(f"{k}: '{v}'\n")
 
+    def gather_result(self):
+        """The per-frame final meshes [F,3V] of ALL ranks (every rank holds only its own frames' rows of self.result):
+        one all-gather of the contiguous shards.  Collective: every rank must call it."""
+        if self.world == 1:
+            return self.result
+        import torch.distributed as tdist
+        assert tdist.is_initialized(), "world > 1 needs an initialised process group (dist.init)"
+        shards = [torch.empty_like(self.result[self.frame_lo:self.frame_hi]) for _ in range(self.world)]
+        tdist.all_gather(shards, self.result[self.frame_lo:self.frame_hi].contiguous())
+        return torch.cat(shards, dim=0)       # contiguous, equal shards in rank order = frame order
+
     def save(self, directory):
-        """Result files in the reference's layout (fit.py:235-286): result/{i}.obj, texture.png, pose.json."""
+        """Result files in the reference's layout (fit.py:235-286): result/{i}.obj, texture.png, pose.json.
+        With several ranks the shards are gathered first (collective) and rank 0 writes."""
         from PIL import Image
+        result = self.gather_result()
+        if self.rank != 0:
+            return
         directory = os.path.join(directory, "result")
         os.makedirs(directory, exist_ok=True)
         uv = self.uv.cpu().numpy()
         faces = ["f " + " ".join(f"{int(v) + 1}/{int(t) + 1}" for v, t in zip(fv, ft)) + "\n"
                  for fv, ft in zip(self.sc.pos_idx, self.sc.uv_idx)]
-        for i, mesh in enumerate(self.result.cpu().numpy()):
+        for i, mesh in enumerate(result.cpu().numpy()):
             with open(os.path.join(directory, f"{i}.obj"), "w") as f:
                 for v in mesh.reshape(-1, 3):
                     f.write(f"v {v[0]} {v[1]} {v[2]}\n")
@@ -751,7 +824,9 @@ class Fitter:
                     f.write(f"vt {u[0]} {u[1]}\n")
                 f.writelines(faces)
         tex = self.tex_opt.detach().cpu().numpy()
-        img = (np.flip(tex, 0) * 255).clip(0, 255).astype(np.uint8)
+        # the reference casts (flip(tex) * 255) straight to uint8 (fit.py:268), which WRAPS values outside [0,255]
+        # (an unconstrained Adam texture can leave the range): reproduced via int64 so the wrap is defined behaviour
+        img = (np.flip(tex, 0) * 255).astype(np.int64).astype(np.uint8)
         Image.fromarray(img[..., 0] if img.shape[2] == 1 else img).save(os.path.join(directory, "texture.png"))
         with open(os.path.join(directory, "pose.json"), "w", encoding="utf-8") as f:
             json.dump({'translation': self.per_frame_t.detach().cpu().tolist(),
@@ -760,9 +835,10 @@ class Fitter:
 
 
 # ----------------------------------------------------------------------------------------------
-def smoke_step(sc, device='cuda:0', cams=(0, 4), mode='prior'):
+def smoke_step(sc, device='cuda:0', cams=(0, 4), mode='prior', m3_init=None):
     """One small forward + backward of the whole hot path (used by __graft_entry__.smoke and the tests).
-    Starts from a perturbed state so that every gradient is non-trivial."""
+    Starts from a perturbed state so that every gradient is non-trivial; `m3_init` [3V,F] fills the learned basis of the
+    'free' / 'combined' modes (zero in the reference's start state, which would leave m1 / m2 without gradient)."""
     cfg = FitConfig(max_iter=100, cam_idxs=tuple(cams), mode=mode, weight_laplacian=0.0, fused_loss=True)
     targets = smoke_targets(sc, cams)
     ft = Fitter(sc, cfg, device=device, targets=targets.to(device))
@@ -771,6 +847,11 @@ def smoke_step(sc, device='cuda:0', cams=(0, 4), mode='prior'):
         ft.maps['local'].copy_(torch.eye(F, device=ft.device))
         ft.maps_intermediate['local'].copy_(0.5 * torch.tensor(sc.weights_gt, device=ft.device).t())
         ft.per_frame_t.copy_(0.5 * torch.tensor(sc.t_gt, device=ft.device))
+        if m3_init is not None:
+            ft.m3.copy_(m3_init.to(ft.device))
+    if mode == 'combined':      # as after the switch of fit.py:603-608
+        for m in (ft.m1, ft.m2, ft.m3):
+            m.requires_grad = True
     frame_ids = torch.arange(0, F, device=ft.device)
     Nc = len(ft.cam_idxs)
     verts = ft.vertices(frame_ids).reshape(F, -1, 3)
@@ -789,10 +870,15 @@ def smoke_step(sc, device='cuda:0', cams=(0, 4), mode='prior'):
     tex_f = ft.tex_opt.detach().clone().requires_grad_(True)
     loss_f = dr.pixel_objective(ft.glctx, pc, ft.pos_idx, ft.uv, ft.uv_idx, tex_f, ref, ft.resolution)
     loss_f.backward()
+
+    def g(t):
+        return t.grad.clone() if t.grad is not None else None
+
     return {'loss': loss.detach(), 'ids': rast[..., 3].to(torch.int32), 'image': image.detach(),
             'loss_fused': loss_f.detach(), 'grad_pos_clip_fused': pc.grad.clone(), 'grad_tex_fused': tex_f.grad.clone(),
             'pos_clip': pos_clip.detach(), 'grad_pos_clip': pos_clip.grad.clone(),
-            'grad_w': ft.maps_intermediate['local'].grad.clone(), 'grad_tex': ft.tex_opt.grad.clone(),
+            'grad_w': g(ft.maps_intermediate['local']), 'grad_M1': g(ft.maps['local']), 'grad_m1': g(ft.m1), 'grad_m2': g(ft.m2),
+            'grad_m3': g(ft.m3), 'grad_tex': ft.tex_opt.grad.clone(),
             'grad_pose': torch.cat([ft.per_frame_t.grad.reshape(-1), ft.per_frame_q.grad.reshape(-1),
                                     ft.t_opt.grad.reshape(-1), ft.q_opt.grad.reshape(-1)])}
 
@@ -801,7 +887,7 @@ def smoke_targets(sc, cams):
     """Deterministic stand-in reference images for smoke_step: a smooth 8-bit pattern (no renderer involved,
     so the HIP path and the oracle are compared on identical targets)."""
     H, W = sc.resolution
-    F = sc.weights_gt.shape[0]
+    F = sc.n_frames
     yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
     imgs = np.zeros((F, len(cams), H, W), dtype=np.uint8)
     for f in range(F):

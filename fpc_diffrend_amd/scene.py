@@ -12,11 +12,13 @@ generated here with numpy.random.default_rng(seed):
               with a centred principal point (reference camera.py:38-39 assumes one)
   weights     per-frame ground-truth activations, sparse and temporally smooth; small per-frame pose
 """
+import os
 from dataclasses import dataclass
+from typing import Optional
 
 import numpy as np
 
-from . import camera
+from . import camera, data
 
 # BASELINE.json configs -> (n_lon, n_rings): T = 2 n_lon + (n_rings - 1) 2 n_lon, V = n_rings n_lon + 2
 MESH_1K = (32, 16)      # T = 1024,  V = 514
@@ -33,13 +35,22 @@ class Scene:
     texture: np.ndarray     # [Ht,Wt,C] float32 in [0,1]
     cams: list              # calib_lookup entries (fit.py:514-521) with rebuilt 'intr'
     resolution: tuple       # (H, W)
-    weights_gt: np.ndarray  # [F,K]
-    t_gt: np.ndarray        # [F,3]
-    q_gt: np.ndarray        # [F,4] XYZW
+    weights_gt: Optional[np.ndarray] = None  # [F,K]    hidden ground truth of a synthetic take (None for a take
+    t_gt: Optional[np.ndarray] = None        # [F,3]    read from disk: its reference images are in `images`)
+    q_gt: Optional[np.ndarray] = None        # [F,4] XYZW
+    images: Optional[np.ndarray] = None      # [F,Ncam,H,W] uint8: reference images as the reference's loader leaves them
+                                             # (fit.py:529-533: clipped to [0,140], row 0 = bottom)
+    frames: int = 0                          # number of frames when there is no ground truth to count
 
     @property
     def n_vertices(self):
         return self.v_base.shape[0] // 3
+
+    @property
+    def n_frames(self):
+        if self.weights_gt is not None:
+            return self.weights_gt.shape[0]
+        return self.images.shape[0] if self.images is not None else self.frames
 
 
 def make_mesh(n_lon, n_rings, radii=(8.0, 11.0, 9.0)):
@@ -173,6 +184,88 @@ def make_scene(mesh=MESH_1K, K=10, n_frames=4, resolution=(256, 256), texshape=(
     w, t, q = make_motion(n_frames, K, rng)
     return Scene(v_base=verts.reshape(-1).copy(), pos_idx=tris, uv=uv, uv_idx=tuvs, blendshapes=B, texture=tex,
                  cams=cams, resolution=tuple(resolution), weights_gt=w, t_gt=t, q_gt=q)
+
+
+def from_take(basemeshpath, localblpath, calibpath, imdir, texpath="", texshape=(1024, 1024, 1), seed=0):
+    """A take on disk in the reference's layout -> Scene (reference fit.py:415-439, 461, 514-533):
+
+      basemeshpath  base mesh .obj (v / vt / f v/vt triangles)                       fit.py:424-432, data.py:7-39
+      localblpath   directory of blendshape .obj files (same vertex order)           fit.py:199-220
+      calibpath     calibration.json keyed by camera name                            fit.py:419-420, 514-521
+      imdir         one directory per camera, named <x>_<camera name>..., holding
+                    <dir>_<frame:0{digits}d>.tif, the same number in every directory fit.py:415-416, 29-43, 528-530
+      texpath       optional start texture (8-bit image); else uniform noise         fit.py:433-438
+
+    The reference decodes ONE image from disk per iteration; here every frame of every camera is read once (clipped to
+    [0,140] and flipped like fit.py:531-532) so that the fit loop finds them resident in HBM as 8-bit.  Camera
+    directories are taken in sorted order (the reference uses os.listdir order, which is file-system dependent)."""
+    cams = sorted(os.listdir(imdir))
+    n_frames, digits = data.assert_num_frames(cams, imdir)
+    base = data.MeshData(basemeshpath)
+    lookup = data.load_calibration(calibpath, cams)
+    first = data.load_reference_image(os.path.join(imdir, cams[0], f"{cams[0]}_{0:0{digits}d}.tif"))
+    H, W = first.shape[:2]
+    images = np.empty((n_frames, len(cams), H, W), dtype=np.uint8)
+    for c, cam in enumerate(cams):
+        for f in range(n_frames):
+            img = data.load_reference_image(os.path.join(imdir, cam, f"{cam}_{f:0{digits}d}.tif"))
+            assert img.shape[:2] == (H, W), f"{cam} frame {f}: {img.shape[:2]} differs from {(H, W)}"
+            images[f, c] = img if img.ndim == 2 else img[..., 0]
+    if texpath:
+        from PIL import Image
+        tex = np.array(Image.open(texpath)) / 255.0                      # fit.py:434-436
+        tex = np.flip(tex[..., np.newaxis] if tex.ndim == 2 else tex, 0)
+    else:
+        tex = np.random.default_rng(seed).uniform(low=0.0, high=1.0, size=texshape)   # fit.py:438 (seeded here)
+    blend = data.load_blendshape_deltas(localblpath, base.vertices)
+    return Scene(v_base=base.vertices, pos_idx=base.faces, uv=base.uv, uv_idx=base.fuv, blendshapes=blend,
+                 texture=np.ascontiguousarray(tex, dtype=np.float32), cams=lookup, resolution=(H, W), images=images)
+
+
+def write_take(sc, directory, images, cam_idxs=None, blendshape_scale=1.0):
+    """Write a Scene + reference images [F,Nc,H,W] uint8 (row 0 = bottom) to `directory` in the layout `from_take`
+    reads (the reference's, fit.py:415-432, 514-533): basemesh.obj, blendshapes/*.obj, calibration.json,
+    images/cam_<name>/cam_<name>_<frame>.tif.  Returns the four paths.  (Test / example helper: the reference ships
+    no data.)"""
+    import json
+    from PIL import Image
+    cam_idxs = list(range(len(sc.cams))) if cam_idxs is None else list(cam_idxs)
+    os.makedirs(directory, exist_ok=True)
+    V = sc.n_vertices
+
+    def write_obj(path, verts):
+        with open(path, "w") as f:
+            for v in np.asarray(verts, dtype=np.float32).reshape(-1, 3):
+                f.write(f"v {float(v[0])!r} {float(v[1])!r} {float(v[2])!r}\n")
+            for u in sc.uv:
+                f.write(f"vt {float(u[0])!r} {float(u[1])!r}\n")
+            for fv, ft in zip(sc.pos_idx, sc.uv_idx):
+                f.write("f " + " ".join(f"{int(a) + 1}/{int(b) + 1}" for a, b in zip(fv, ft)) + "\n")
+
+    base = os.path.join(directory, "basemesh.obj")
+    write_obj(base, sc.v_base)
+    bldir = os.path.join(directory, "blendshapes")
+    os.makedirs(bldir, exist_ok=True)
+    for k in range(sc.blendshapes.shape[1]):
+        write_obj(os.path.join(bldir, f"shape_{k:04d}.obj"), sc.v_base + blendshape_scale * sc.blendshapes[:, k])
+    calib = {}
+    for c in cam_idxs:
+        cam = sc.cams[c]
+        calib[cam['cam']] = {'intrinsic': np.asarray(cam['intr'], dtype=np.float64).tolist(), 'distortion': np.zeros((5, 1)).tolist(),
+                             'rotation': np.asarray(cam['rot'], dtype=np.float64).tolist(),
+                             'translation': np.asarray(cam['trans_calib'], dtype=np.float64).reshape(3, 1).tolist()}
+    calibpath = os.path.join(directory, "calibration.json")
+    with open(calibpath, "w") as f:
+        json.dump(calib, f)
+    imdir = os.path.join(directory, "images")
+    F = images.shape[0]
+    digits = 2 if F < 100 else 3
+    for j, c in enumerate(cam_idxs):
+        name = f"cam_{sc.cams[c]['cam']}"
+        os.makedirs(os.path.join(imdir, name), exist_ok=True)
+        for fr in range(F):
+            Image.fromarray(np.flip(np.asarray(images[fr, j]), 0)).save(os.path.join(imdir, name, f"{name}_{fr:0{digits}d}.tif"))
+    return base, bldir, calibpath, imdir
 
 
 def cfg(name, n_frames=None, seed=0):

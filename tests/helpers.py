@@ -59,3 +59,13 @@ def random_soup(B, T, seed, spread=1.2, size=0.5, wmin=0.5, wmax=3.0):
     pos = torch.cat([xy * w, z * w, w], dim=-1).reshape(B, T * 3, 4).contiguous()
     tri = torch.arange(T * 3, dtype=torch.int32).reshape(T, 3)
     return pos, tri
+
+
+def decode_aa_flags(flags, B, H, W):
+    """The antialias flag planes of include/fpcdr.h (uint64 words [2][B][H][ceil(W/64)], bit x % 64 of word x // 64; plane 0:
+    pair (p, p+x) blended, plane 1: pair (p, p+y)) -> [B,H,W] uint8 with bit 0 / bit 1, the oracle's form."""
+    Wq = (W + 63) // 64
+    words = flags.detach().cpu().reshape(2, B, H, Wq)
+    shifts = torch.arange(64, dtype=torch.int64)
+    bits = ((words[..., None] >> shifts) & 1).reshape(2, B, H, Wq * 64)[..., :W].to(torch.uint8)
+    return bits[0] | (bits[1] << 1)

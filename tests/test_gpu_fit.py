@@ -69,29 +69,60 @@ def test_pixel_loss_fused_equals_reference_chain():
 def test_smoke_step_matches_oracle(oracle_ops):
     from fpc_diffrend_amd import fit, scene
     from oracle import fit as ofit
+    cams = (0, 4)
     sc = scene.cfg('cfg1', n_frames=2)
-    res = fit.smoke_step(sc, device='cuda:0')
+    targets = fit.smoke_targets(sc, cams)
+    res = fit.smoke_step(sc, device='cuda:0', cams=cams)
     pos_clip = res['pos_clip'].cpu()
-    # (1) the four ops + loss on bit-identical input (the clip positions the GPU chain produced)
-    ref = ofit.smoke_from_clip(sc, pos_clip)
+    # (1) the four ops + loss on bit-identical input (the clip positions the GPU chain produced), against the float32
+    # oracle: integer buffer bit-exact, image / loss / both gradients within 1e-4 relative L2 -- for the operator chain and
+    # for the fused objective (the form Fitter.step runs)
+    ref = ofit.smoke_from_clip(sc, pos_clip, targets, cams)
     assert torch.equal(res['ids'].cpu(), ref['ids'])
     assert rel_l2(res['image'], ref['image']) < TOL
     assert abs(float(res['loss']) - float(ref['loss'])) < 1e-4 * float(ref['loss'])
-    # Gradients of this chain are ill-conditioned in float32 (clip coordinates ~170 with sub-pixel differences):
-    # the float32 ORACLE itself sits well above 1e-4 from a float64 evaluation.  Bar: within 1e-4 of the float64
-    # truth, or no worse than 2x the float32 oracle's own distance from it.  (Per-op gradients on well-conditioned
-    # inputs meet 1e-4: test_gpu_parity.)
-    ref64 = ofit.smoke_from_clip(sc, pos_clip, dtype=torch.float64, ids=ref['ids'])
+    assert abs(float(res['loss_fused']) - float(ref['loss'])) < 1e-4 * float(ref['loss'])
+    ref64 = ofit.smoke_from_clip(sc, pos_clip, targets, cams, dtype=torch.float64, ids=ref['ids'])
     for k in ('grad_pos_clip', 'grad_tex'):
-        floor = rel_l2(ref[k], ref64[k])
-        assert rel_l2(res[k], ref64[k]) < max(TOL, 2.0 * floor), (k, rel_l2(res[k], ref64[k]), floor)
+        e_ops, e_fused = rel_l2(res[k], ref[k]), rel_l2(res[k + '_fused'], ref[k])
+        print(f"{k}: operators vs f32 oracle {e_ops:.2e}, fused vs f32 oracle {e_fused:.2e}; (information) operators vs f64 "
+              f"{rel_l2(res[k], ref64[k]):.2e}, f32 oracle vs f64 {rel_l2(ref[k], ref64[k]):.2e}")
+        assert e_ops < TOL, (k, e_ops)
+        assert e_fused < TOL, (k, e_fused)
     # (2) upstream of the ops (transform_clip, MVP chain, MFMA blend): chain the GPU's d loss / d pos_clip through
     # the CPU restatement in float64 and compare the parameter gradients
-    up = ofit.smoke_upstream(sc, res['grad_pos_clip'].cpu())
+    up = ofit.smoke_upstream(sc, res['grad_pos_clip'].cpu(), cams)
     for k in ('grad_w', 'grad_pose'):
         assert rel_l2(res[k], up[k]) < TOL, (k, rel_l2(res[k], up[k]))
     # (3) the end-to-end oracle (its own CPU matmul for the positions) agrees up to depth near-ties at folds
-    e2e = ofit.smoke_step(sc)
+    e2e = ofit.smoke_step(sc, targets, cams)
+    assert int((res['ids'].cpu() != e2e['ids']).sum()) <= 1e-4 * e2e['ids'].numel()
+    assert abs(float(res['loss']) - float(e2e['loss'])) < 1e-3 * float(e2e['loss'])
+
+
+@pytest.mark.parametrize("mode", ["free", "combined"])
+def test_free_form_modes_gradients_match_oracle(mode, oracle_ops):
+    """BASELINE configs[4]'s "per-vertex free-form offsets" (reference fit.py:47-62, 66-99): the gradients of the learned
+    basis m1 / m2 / m3 (and, combined, of the rig prior M1 / M2) through fpcdr_blend_bwd_basis / _bwd_w equal the float64
+    restatement chained from the same d loss / d pos_clip; the raster ops are compared on the same positions as above."""
+    from fpc_diffrend_amd import fit, scene
+    from oracle import fit as ofit
+    cams = (0, 4)
+    sc = scene.cfg('cfg1', n_frames=2)
+    targets = fit.smoke_targets(sc, cams)
+    m3 = ofit.free_form_pattern(sc.v_base.shape[0], 2)
+    res = fit.smoke_step(sc, device='cuda:0', cams=cams, mode=mode, m3_init=m3)
+    ref = ofit.smoke_from_clip(sc, res['pos_clip'].cpu(), targets, cams)
+    assert torch.equal(res['ids'].cpu(), ref['ids'])
+    for k in ('grad_pos_clip', 'grad_tex'):
+        assert rel_l2(res[k], ref[k]) < TOL, (k, rel_l2(res[k], ref[k]))
+    up = ofit.smoke_upstream(sc, res['grad_pos_clip'].cpu(), cams, mode=mode)
+    keys = ['grad_m1', 'grad_m2', 'grad_m3', 'grad_pose'] + (['grad_w', 'grad_M1'] if mode == 'combined' else [])
+    for k in keys:
+        assert res[k] is not None and float(up[k].abs().max()) > 0, k
+        assert rel_l2(res[k], up[k]) < TOL, (k, rel_l2(res[k], up[k]))
+    # the oracle's own end-to-end evaluation of the mode (its CPU blend) sees the same image up to fold near-ties
+    e2e = ofit.smoke_step(sc, targets, cams, mode=mode)
     assert int((res['ids'].cpu() != e2e['ids']).sum()) <= 1e-4 * e2e['ids'].numel()
     assert abs(float(res['loss']) - float(e2e['loss'])) < 1e-3 * float(e2e['loss'])
 
@@ -375,3 +406,84 @@ def test_objective_backward_applies_the_upstream_scalar():
         (dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, sc.resolution) * scale).backward()
         grads.append((p.grad.double(), t.grad.double()))
     assert rel_l2(grads[1][0], 3.5 * grads[0][0]) < 1e-5 and rel_l2(grads[1][1], 3.5 * grads[0][1]) < 1e-5
+
+
+@pytest.mark.parametrize("mode,steps,max_iter", [("prior", 4, 100), ("combined", 6, 2)])
+def test_optimiser_steps_match_oracle(mode, steps, max_iter, oracle_ops):
+    """ten Adam groups, lr * ramp^(i/max_iter), whole-tensor quaternion division (Q3) and -- combined mode --
+    the learned basis switching on half way (reference fit.py:493-505, 603-618).
+
+    (A) update rules: after every Fitter.step() the oracle's Trainer takes the SAME iteration from the gradients the GPU
+        step left on its parameters (which must exist exactly for the tensors the reference would have trained in that
+        iteration); all ten parameter tensors must agree after every step.
+    (B) end to end: a second Trainer runs its own forward / backward (oracle raster ops, per-mesh squared Laplacian, edge and
+        normal-consistency terms, fit.py:578-582) from the same start; its losses follow the GPU's.  (Parameters are not
+        compared there: a handful of depth near-ties at the rim decide differently for positions that differ in the last
+        bit -- GPU vs CPU matmul -- and the grazing-angle pixels they belong to carry ~10 % of this chain's gradient.)"""
+    from fpc_diffrend_amd import fit, scene
+    from oracle import fit as ofit
+    cams = (0, 4)
+    sc = scene.cfg('cfg1', n_frames=2)
+    targets = fit.smoke_targets(sc, cams)
+    hp = dict(max_iter=max_iter, lr_base=2e-3, lr_tex_coef=0.5, lr_ramp=0.005, lr_t=1e-3, lr_q=1e-4, weight_laplacian=300.0,
+              weight_meshedge=0.5, weight_normalconsistency=0.2)
+    st, F = ofit.perturbed_state(sc, cams, mode=mode)
+    st_e2e, _ = ofit.perturbed_state(sc, cams, mode=mode)
+    start = [p.detach().clone() for p in st.params()]
+    ft = fit.Fitter(sc, fit.FitConfig(cam_idxs=cams, mode=mode, **hp), device='cuda', targets=targets.cuda())
+    with torch.no_grad():
+        for p, v in zip(ft.params, start):
+            p.copy_(v.cuda())
+    tr, tr_e2e = ofit.Trainer(st, **hp), ofit.Trainer(st_e2e, **hp)
+    lg, lo = [], []
+    for i in range(steps):
+        for p in ft.params:
+            p.grad = None
+        lg.append(float(ft.step()))
+        tr.step_with_gradients([p.grad.cpu() if p.grad is not None else None for p in ft.params])
+        for name, p, q in zip(ofit.State.NAMES, ft.params, st.params()):
+            assert rel_l2(p, q) < 2e-6, (i, name, rel_l2(p, q))
+        assert abs(float(ft.scheduler.get_last_lr()[3]) - tr.scheduler.get_last_lr()[3]) < 1e-12
+        lo.append(tr_e2e.step(torch.arange(F), targets))
+    assert np.allclose(lg, lo, rtol=2e-3), (lg, lo)
+    moved = [float((q.detach() - p0).abs().max()) > 0 for q, p0 in zip(st.params(), start)]
+    assert moved == ([False, False, False] + [True] * 7 if mode == "prior" else [True] * 10), moved
+
+
+def test_fit_from_a_take_on_disk_equals_the_in_memory_run(tmp_path):
+    """base mesh OBJ + blendshape OBJ directory + calibration.json + per-camera TIFF directories (the
+    reference's take layout, fit.py:415-432, 461, 514-533) -> scene.from_take -> Fitter, without any synthetic ground
+    truth; ten steps from disk equal ten steps of the in-memory Scene the files were written from."""
+    from fpc_diffrend_amd import fit, scene
+    cams = (0, 3, 6)
+    sc = scene.cfg('cfg1', n_frames=4)
+    sc.q_gt[:] = (0.0, 0.0, 0.0, 1.0)
+    cfg = dict(max_iter=40, lr_base=5e-3, lr_t=5e-3, lr_q=1e-5, weight_laplacian=20.0, init_texture='truth',
+               log_interval=2, reg_log_interval=4)
+    a = fit.Fitter(sc, fit.FitConfig(cam_idxs=cams, log_path=str(tmp_path / "a.jsonl"), **cfg), device='cuda')
+    images = a.targets.cpu().numpy()                                    # [F,3,H,W] uint8, rendered from the ground truth
+    from PIL import Image
+    Image.fromarray((np.flip(sc.texture[..., 0], 0) * 255 + 0.5).astype(np.uint8)).save(tmp_path / "tex.png")
+    base, bldir, calib, imdir = scene.write_take(sc, str(tmp_path / "take"), images, cam_idxs=cams)
+    take = scene.from_take(base, bldir, calib, imdir, texpath=str(tmp_path / "tex.png"))
+    assert take.weights_gt is None and take.n_frames == 4 and take.images.shape == images.shape
+    assert np.array_equal(take.images, images) and np.array_equal(take.pos_idx, sc.pos_idx) and np.array_equal(take.uv_idx, sc.uv_idx)
+    assert np.allclose(take.v_base, sc.v_base) and [c['cam'] for c in take.cams] == ['cam_' + sc.cams[c]['cam'] for c in cams]
+    # blendshape files come back in os.listdir order (as in the reference): same set of columns
+    assert np.allclose(np.sort(np.abs(take.blendshapes).sum(0)), np.sort(np.abs(sc.blendshapes).sum(0)), rtol=1e-4)
+    b = fit.Fitter(take, fit.FitConfig(cam_idxs=(0, 1, 2), log_path=str(tmp_path / "b.jsonl"), **cfg), device='cuda')
+    with torch.no_grad():       # same texture start (the PNG is 8 bit) and same column order of the basis
+        a.tex_opt.copy_(b.tex_opt)
+        b.datasets['local'].copy_(a.datasets['local'])
+    la = [float(a.step()) for _ in range(10)]
+    lb = [float(b.step()) for _ in range(10)]
+    assert np.isfinite(lb).all() and lb[-1] < lb[0]
+    assert np.allclose(la, lb, rtol=1e-4), (la, lb)
+    # the step log (reference fit.py:597-601, 621-623) as JSON lines
+    import json
+    recs = [json.loads(l) for l in open(tmp_path / "b.jsonl")]
+    assert [r["it"] for r in recs] == [0, 2, 4, 6, 8]
+    assert all(len(r["lr"]) == 10 and r["frames"] == 4 for r in recs) and abs(recs[0]["loss"] - lb[0]) < 1e-6 * lb[0]
+    assert "LAP" in recs[0] and "LAP" in recs[2] and "LAP" not in recs[1] and recs[2]["frames_per_s"] > 0
+    b.save(str(tmp_path / "out"))
+    assert sorted(os.listdir(tmp_path / "out" / "result"))[:4] == ["0.obj", "1.obj", "2.obj", "3.obj"]

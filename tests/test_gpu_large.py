@@ -142,3 +142,125 @@ def test_vertex_shading_fit_descends():
     losses = [float(ft.step()) for _ in range(20)]
     assert np.isfinite(losses).all()
     assert losses[-1] < losses[0], losses
+
+
+def _one_image_against_oracle(dr, sc, pos1, tri, cam, seed):
+    """ONE image at full size: the four operators + pixel loss and the fused objective, forward and backward, against the
+    float32 oracle on the same clip positions: ids and antialias pair flags bit-exact, loss / image / gradients to 1e-4."""
+    from fpc_diffrend_amd import fit
+    from oracle import fit as ofit
+    from helpers import decode_aa_flags
+    dev = 'cuda'
+    H, W = sc.resolution
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    targets = (70 + 60 * torch.sin(0.011 * xx + 0.3) * torch.cos(0.017 * yy)).clamp(0, 140).to(torch.uint8).reshape(1, 1, H, W)
+    ref = ofit.smoke_from_clip(sc, pos1, targets, cams=(cam,))
+    assert int((ref['aa_flags'] > 0).sum()) > 100 and int((ref['ids'] > 0).sum()) > 0.05 * H * W
+    ctx = dr.RasterizeGLContext(device=dev)
+    trig, uv, uv_idx = tri.to(dev), torch.tensor(sc.uv, device=dev), torch.tensor(sc.uv_idx, device=dev)
+    tg = targets.reshape(1, H, W).to(dev)
+    out = {}
+    for name in ("operators", "objective"):
+        p = pos1.to(dev).clone().requires_grad_(True)
+        tex = torch.tensor(sc.texture, device=dev).clone().requires_grad_(True)
+        if name == "operators":
+            rast, _ = dr.rasterize(ctx, p, trig, sc.resolution)
+            texc, _ = dr.interpolate(uv[None], rast, uv_idx)
+            aa = dr.antialias(dr.texture(tex[None], texc, filter_mode='linear'), rast, p, trig)
+            flags = aa.grad_fn.saved_tensors[6]
+            sum_sq, g_col = fit.pixel_loss_fused(aa, rast, tg)
+            torch.autograd.backward([aa], [g_col])
+            loss = float(sum_sq[0]) / aa.numel()
+            assert torch.equal(rast[..., 3].to(torch.int32).cpu(), ref['ids'])
+            assert rel_l2(rast, ref['rast']) < 1e-4
+            img = torch.where(rast[..., 3:] > 0, aa, torch.tensor(fit.BACKGROUND, device=dev))
+            assert rel_l2(img, ref['image']) < 1e-4
+        else:
+            obj = dr.pixel_objective(ctx, p, trig, uv, uv_idx, tex, tg, sc.resolution)
+            flags = obj.grad_fn.saved_tensors[9]
+            obj.backward()
+            loss = float(obj)
+        assert torch.equal(decode_aa_flags(flags, 1, H, W), ref['aa_flags']), f"{name}: antialias pair set differs"
+        assert abs(loss - float(ref['loss'])) < 1e-4 * float(ref['loss']), (name, loss, float(ref['loss']))
+        out[name] = (rel_l2(p.grad, ref['grad_pos_clip']), rel_l2(tex.grad, ref['grad_tex']))
+    print("rel-L2 vs f32 oracle (grad_pos_clip, grad_tex):", out)
+    for name, (ep, et) in out.items():
+        assert ep < 1e-4 and et < 1e-4, (name, ep, et)
+
+
+def test_1080p_one_image_gradients_and_flags_match_oracle(big, oracle_ops):
+    dr, sc, pos, tri = big
+    _one_image_against_oracle(dr, sc, pos[13:14], tri, cam=4, seed=3)
+
+
+@pytest.fixture(scope="module")
+def big4k():
+    import fpc_diffrend_amd.ops as dr
+    from fpc_diffrend_amd import scene
+    sc = scene.cfg('cfg5', n_frames=2)
+    pos, _ = clip_positions(sc, [0, 4, 8], frames=[1])
+    return dr, sc, pos, torch.tensor(sc.pos_idx)
+
+
+def test_4k_ids_bit_exact_and_one_image_matches_oracle(big4k, oracle_ops):
+    """BASELINE configs[4]'s raster size (3840 x 2160): visibility of three views bit-exact against the C oracle, and one
+    whole image (operators and fused objective, forward + backward) against the float32 oracle."""
+    dr, sc, pos, tri = big4k
+    assert tuple(sc.resolution) == (2160, 3840)
+    ctx = dr.RasterizeGLContext(device='cuda')
+    rast, _ = dr.rasterize(ctx, pos.cuda(), tri.cuda(), sc.resolution)
+    for b in range(3):
+        assert torch.equal(rast[b:b + 1, ..., 3].to(torch.int32).cpu(), oracle_ops.rasterize_ids(pos[b:b + 1], tri, sc.resolution)), b
+    del rast
+    _one_image_against_oracle(dr, sc, pos[1:2], tri, cam=4, seed=4)
+
+
+def test_4k_combined_mode_step_gradients_match_upstream_oracle(oracle_ops):
+    """cfg5 as the bench runs it: 9 views of 3840 x 2160, rig prior + per-vertex free-form offsets (mode 'combined' after
+    its switch).  The gradients Fitter.loss_and_backward leaves on M1 / M2 / m1 / m2 / m3 and the poses equal the float64
+    restatement of blend + MVP chain + transform_clip (reference fit.py:66-99, 541-564) fed with the same d loss / d pos_clip
+    (the raster kernels' share is checked against the oracle image by image above)."""
+    from fpc_diffrend_amd import fit, scene
+    from oracle import fit as ofit
+    sc = scene.cfg('cfg5', n_frames=2)
+    cams = tuple(range(9))
+    cfg = fit.FitConfig(max_iter=2, mode='combined', weight_laplacian=0.0, init_texture='truth')
+    ft = fit.Fitter(sc, cfg, device='cuda')
+    st, F = ofit.perturbed_state(sc, cams, dtype=torch.float64, mode='combined')
+    with torch.no_grad():
+        for p, q in zip(ft.params, st.params()):
+            p.copy_(q.to(torch.float32).cuda())
+    for m in (ft.m1, ft.m2, ft.m3):
+        m.requires_grad = True
+    ids = torch.arange(0, F, device='cuda')
+    # capture d loss / d pos_clip of the fused objective as the fit loop runs it
+    grabbed = {}
+    orig = fit.transform_clip_batched
+
+    def spy(mvp, verts):
+        out = orig(mvp, verts)
+        out.register_hook(lambda g: grabbed.__setitem__('g', g.detach().clone()))
+        grabbed['pos'] = out.detach()
+        return out
+
+    fit.transform_clip_batched = spy
+    try:
+        ft.iteration = 5            # past the switch (fit.py:603-608)
+        loss = ft.loss_and_backward(ids)
+    finally:
+        fit.transform_clip_batched = orig
+    assert np.isfinite(float(loss)) and grabbed['g'].abs().max() > 0
+    # the positions themselves: MFMA blend + fused MVP + clip kernels vs the float64 chain
+    for m in (st.m1, st.m2, st.m3):
+        m.requires_grad = True
+    pos_ref, _ = ofit.clip_positions(st, torch.arange(F))
+    assert rel_l2(grabbed['pos'], pos_ref) < 1e-6
+    pos_ref.backward(grabbed['g'].cpu().double())
+    pairs = [("m1", ft.m1, st.m1), ("m2", ft.m2, st.m2), ("m3", ft.m3, st.m3), ("M1", ft.maps['local'], st.M1),
+             ("M2", ft.maps_intermediate['local'], st.M2), ("t_opt", ft.t_opt, st.t_opt), ("q_opt", ft.q_opt, st.q_opt),
+             ("per_frame_t", ft.per_frame_t, st.per_frame_t), ("per_frame_q", ft.per_frame_q, st.per_frame_q)]
+    for name, a, b in pairs:
+        assert a.grad is not None and float(b.grad.abs().max()) > 0, name
+        e = rel_l2(a.grad, b.grad)
+        assert e < 1e-4, (name, e)
