@@ -14,7 +14,7 @@ MAX_ATTR = 32
 MAX_MIP = 16
 LOSS_SLOTS = 256
 OCC_BIN = 32         # FPCDR_OCC_BIN
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
 BOUNDARY = {'wrap': 0, 'clamp': 1}
@@ -49,7 +49,7 @@ class AaLossFwd(ctypes.Structure):
     _fields_ = [("color", _p), ("rast", _p), ("pos", _p), ("tri", _p), ("adj", _p), ("ref", _p), ("B", _i), ("H", _i),
                 ("W", _i), ("C", _i), ("V", _i), ("T", _i), ("bg", ctypes.c_float), ("color_scale", ctypes.c_float),
                 ("grad_scale", ctypes.c_float), ("sil", _p), ("flags", _p), ("grad_aa", _p), ("occ", _p), ("empty_color", _p),
-                ("loss_sum", _p)]
+                ("loss_sum", _p), ("cap_bins", _i), ("cap_fix", _i)]
 
 
 class RenderAaBwd(ctypes.Structure):
@@ -57,7 +57,7 @@ class RenderAaBwd(ctypes.Structure):
                 ("grad_aa", _p), ("sil", _p), ("flags", _p), ("occ", _p), ("empty_color", _p), ("B", _i), ("V", _i), ("T", _i),
                 ("H", _i), ("W", _i),
                 ("Vt", _i), ("Ht", _i), ("Wt", _i), ("C", _i), ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p),
-                ("tri_uv", _p), ("upstream", _p)]
+                ("tri_uv", _p), ("upstream", _p), ("queued", _i), ("cap_bwd", _i)]
 
 
 class InterpolateFwd(ctypes.Structure):
@@ -115,6 +115,8 @@ SYMBOLS = {
     "fpcdr_render_bwd": (_int, [ctypes.POINTER(RenderBwd), _p]),
     "fpcdr_aa_loss_fwd": (_int, [ctypes.POINTER(AaLossFwd), _p]),
     "fpcdr_render_loss_fwd": (_int, [ctypes.POINTER(RenderFwd), ctypes.POINTER(AaLossFwd), _p, _p]),
+    "fpcdr_occ_bytes": (_sz, [_i, _i, _i]),
+    "fpcdr_cmask_bytes": (_sz, [_i, _i, _i]),
     "fpcdr_ref_bg_sumsq": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, _p, _p]),
     "fpcdr_render_aa_bwd": (_int, [ctypes.POINTER(RenderAaBwd), _p]),
     "fpcdr_interpolate_fwd": (_int, [ctypes.POINTER(InterpolateFwd), _p]),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/fpcdr.h"
 
@@ -32,7 +33,51 @@ static inline int fpcdr_cdiv(long long a, long long b) { return (int)((a + b - 1
 // internal cross-file launchers (fused.hip), used by fpcdr_render_loss_fwd (rasterize.hip)
 int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, int B, int V, int T, int H, int W, uint8_t *sil,
                      hipStream_t st);
-int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask, hipStream_t st);
+int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask, const unsigned long long *edges,
+                        const int32_t *fix_list, const int32_t *fix_count, int nbins, hipStream_t st);
+
+// workgroups of the strided sweep behind a hinted single-shot launch (normally they find nothing to do)
+#define FPCDR_SWEEP_WGS 256
+
+// Byte offsets inside the two buffers of the sparse objective (include/fpcdr.h: fpcdr_occ_bytes / fpcdr_cmask_bytes).
+//   occ   (saved for the backward call): window masks u16[nb] | raw occupancy u8[nb] | header i32[16] | backward bin list i32[nb]
+//   cmask (forward scratch): candidate row masks u32[nb*32] | border lines u64[nb*128] | header i32[16] | live bin list i32[nb] |
+//         antialias-fix bin list i32[nb] | live map u8[nb] | per-block counts i32[2][ceil(nb / 256)]
+struct fpcdr_queue_layout {
+    size_t occ_raw, occ_hdr, occ_bwd_list, occ_bytes;
+    size_t cm_edges, cm_hdr, cm_bin_list, cm_fix_list, cm_live, cm_blk, cm_bytes;
+};
+static inline fpcdr_queue_layout fpcdr_queue_layout_of(int B, int H, int W) {
+    const size_t nb = (size_t)B * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W);
+    const size_t nb4 = (nb + 3) / 4 * 4;
+    fpcdr_queue_layout q;
+    q.occ_raw = 2 * nb;
+    q.occ_hdr = (3 * nb + 3) / 4 * 4;
+    q.occ_bwd_list = q.occ_hdr + 64;
+    q.occ_bytes = q.occ_bwd_list + 4 * nb;
+    q.cm_edges = nb * 128;
+    q.cm_hdr = q.cm_edges + nb * 1024;
+    q.cm_bin_list = q.cm_hdr + 64;
+    q.cm_fix_list = q.cm_bin_list + 4 * nb;
+    q.cm_live = q.cm_fix_list + 4 * nb;
+    q.cm_blk = q.cm_live + nb4;
+    q.cm_bytes = q.cm_blk + 2 * 4 * ((nb + 255) / 256);
+    return q;
+}
+
+// tuning override for the number of resident workgroups per CU of a work-queue kernel (experiments; default = dflt)
+static inline int fpcdr_env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// compute units of the current device (work-queue kernels launch a fixed number of resident workgroups per CU)
+static inline int fpcdr_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 256;   // MI355X
+    return n;
+}
 
 // ---- wave-level helpers ---------------------------------------------------------------------
 

@@ -11,6 +11,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -32,7 +33,9 @@ struct OccWin {
 };
 __device__ __forceinline__ OccWin load_occ(const uint16_t *occ, int b, int H, int W, int bin_x0, int bin_y0) {
     const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
-    OccWin w = {occ[((size_t)b * OY + bin_y0) * OX + bin_x0], bin_x0, bin_y0};   // one load, uniform over the workgroup
+    // one load, uniform over the workgroup -- and readfirstlane makes that visible to the compiler: every early exit that
+    // depends on the window is then a scalar branch (the work-queue kernels rely on it, see k_aa_fix_queue)
+    OccWin w = {(unsigned int)__builtin_amdgcn_readfirstlane((int)occ[((size_t)b * OY + bin_y0) * OX + bin_x0]), bin_x0, bin_y0};
     return w;
 }
 
@@ -262,7 +265,8 @@ constexpr int BWD_NT = FPCDR_BWD_NT;          // threads per bin workgroup (meas
 constexpr int BWD_NPX = BBIN * BBIN / BWD_NT;  // pixels per thread
 
 template <int CS>
-__global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+__device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, const int byi,
+                                                       const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
                                                        const float *__restrict__ tex, const float4 *__restrict__ rast,
                                                        const float *__restrict__ color, const float *__restrict__ g_aa,
@@ -283,10 +287,10 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
     // and lane 32 are vertical neighbours and a triangle's run continues from one row into the next
     const int col = (lane & 32) ? 63 - lane : lane;
     const int rowk0 = 2 * BWD_NPX * wave + (lane >> 5);
-    const int bx0 = blockIdx.x * BBIN, by0 = blockIdx.y * BBIN, b = blockIdx.z;
+    const int bx0 = bxi * BBIN, by0 = byi * BBIN;
     const int x = bx0 + col;
     float *gp = grad_pos + (size_t)b * V * 4;
-    OccWin ow = {0xfffu, (int)blockIdx.x, (int)blockIdx.y};
+    OccWin ow = {0xfffu, bxi, byi};
     float ecol[CS];
 #pragma unroll
     for (int c = 0; c < CS; ++c) ecol[c] = 0.0f;
@@ -294,7 +298,7 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
         // sparse mode: pixels of unoccupied bins were never written and are empty.  An unoccupied bin still works if a
         // neighbour is occupied: it owns the pairs across its right / top edge, and its empty pixels receive colour
         // gradient (for the texel at uv = (0,0)) from pairs across any edge.
-        ow = load_occ(occ, b, H, W, blockIdx.x, blockIdx.y);
+        ow = load_occ(occ, b, H, W, bxi, byi);
         if (!(ow.bin(0, 0) || ow.bin(1, 0) || ow.bin(0, 1) || ow.bin(-1, 0) || ow.bin(0, -1))) return;
 #pragma unroll
         for (int c = 0; c < CS; ++c) ecol[c] = empty_color[c];
@@ -304,6 +308,8 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
     const float up = upstream ? upstream[0] : 1.0f;   // d(final loss)/d(this objective), a device scalar
     if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
     if (tid < CS) s_esum[tid] = 0.0f;
+    // (both are read only behind the barriers below; in the work-queue form the pop's barriers separate one bin's reads from
+    // the next bin's initialisation)
 
     // ---- pixel phase A: gradient arriving at each pixel's colour (antialias backward folded in) ----
     float go[BWD_NPX][CS];
@@ -392,7 +398,7 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
     bool any_px = false;
 #pragma unroll
     for (int k = 0; k < BWD_NPX; ++k) any_px |= any[k];
-    if (!__syncthreads_or(any_px ? 1 : 0)) return;
+    if (!__builtin_amdgcn_readfirstlane(__syncthreads_or(any_px ? 1 : 0))) return;
 
     // ---- tables; texture coordinate of every pixel with a gradient; origin of the texel window ----
     for (int k = tid; k < VSLOTS; k += BWD_NT) {
@@ -578,6 +584,73 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
     }
 }
 
+// grid form (dense mode, and sparse mode after the two-call forward): one workgroup per bin, grid (OX, OY, B)
+template <int CS>
+__global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                       const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
+                                                       const float *__restrict__ tex, const float4 *__restrict__ rast,
+                                                       const float *__restrict__ color, const float *__restrict__ g_aa,
+                                                       const uint8_t *__restrict__ sil,
+                                                       const unsigned long long *__restrict__ flags,
+                                                       const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
+                                                       int B, int V, int T, int H,
+                                                       int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
+                                                       float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
+                                                       const float *__restrict__ upstream) {
+    render_aa_bwd_body<CS>(blockIdx.z, blockIdx.x, blockIdx.y, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ, empty_color,
+                           B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream);
+}
+
+// list form (after fpcdr_render_loss_fwd): one workgroup per entry of the list k_occ_window built (own or a 4-neighbour bin
+// occupied); the launch is sized by the caller's hint, the strided form sweeps up the rest (see k_bins_list, rasterize.hip)
+template <int CS>
+__global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
+                                                       const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                       const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
+                                                       const float *__restrict__ tex, const float4 *__restrict__ rast,
+                                                       const float *__restrict__ color, const float *__restrict__ g_aa,
+                                                       const uint8_t *__restrict__ sil,
+                                                       const unsigned long long *__restrict__ flags,
+                                                       const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
+                                                       int B, int V, int T, int H,
+                                                       int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
+                                                       float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
+                                                       const float *__restrict__ upstream) {
+    const int item = blockIdx.x;
+    if (item >= *count) return;
+    const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
+    const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+    render_aa_bwd_body<CS>(lin / (OX * OY), lin % OX, (lin / OX) % OY, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ,
+                           empty_color, B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream);
+}
+
+#ifndef FPCDR_BWDQ_WPE
+#define FPCDR_BWDQ_WPE
+#endif
+template <int CS>
+__global__ void __launch_bounds__(BWD_NT) FPCDR_BWDQ_WPE k_render_aa_bwd_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
+                                                       int first,
+                                                       const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                       const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
+                                                       const float *__restrict__ tex, const float4 *__restrict__ rast,
+                                                       const float *__restrict__ color, const float *__restrict__ g_aa,
+                                                       const uint8_t *__restrict__ sil,
+                                                       const unsigned long long *__restrict__ flags,
+                                                       const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
+                                                       int B, int V, int T, int H,
+                                                       int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
+                                                       float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
+                                                       const float *__restrict__ upstream) {
+    const int n = *count;
+    const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
+    for (int item = first + blockIdx.x; item < n; item += gridDim.x) {      // scalar loop variable: uniform for the compiler
+        const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+        render_aa_bwd_body<CS>(lin / (OX * OY), lin % OX, (lin / OX) % OY, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ,
+                               empty_color, B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream);
+        __syncthreads();     // the next bin's first LDS writes must not overtake this bin's last LDS reads
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Second half of fpcdr_render_loss_fwd.  k_bins<LOSS> (rasterize.hip) gave every pixel the loss term and gradient of
 // its un-antialiased colour, marked the pixels with a silhouette pair INSIDE their bin and exported each bin's four
@@ -587,24 +660,25 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
 // (zero-filled) planes.  An unoccupied bin was never rasterised (its pixels are empty) but still owns the pairs
 // across its right / top border.
 template <int CS>
-__global__ void __launch_bounds__(256) k_aa_fix(const float *__restrict__ color, const float4 *__restrict__ rast,
-                                                const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
-                                                const uint8_t *__restrict__ sil, const uint8_t *__restrict__ ref, int B, int H,
-                                                int W, int V, int T, float bg, float color_scale, float grad_scale,
-                                                unsigned long long *__restrict__ flags, float *__restrict__ g_aa,
-                                                const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
-                                                const uint32_t *__restrict__ cmask, const unsigned long long *__restrict__ edges,
-                                                double *__restrict__ loss_sum) {
+__device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const int byi, const int OX, const int OY,
+                                            const float *__restrict__ color, const float4 *__restrict__ rast,
+                                            const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                            const uint8_t *__restrict__ sil, const uint8_t *__restrict__ ref, int B, int H,
+                                            int W, int V, int T, float bg, float color_scale, float grad_scale,
+                                            unsigned long long *__restrict__ flags, float *__restrict__ g_aa,
+                                            const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
+                                            const uint32_t *__restrict__ cmask, const unsigned long long *__restrict__ edges,
+                                            double *__restrict__ loss_sum) {
     __shared__ unsigned int s_mask[BBIN];
     __shared__ int s_list[BBIN * BBIN];
     __shared__ int s_n;
     __shared__ float s_part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, bx0 = blockIdx.x * BBIN, by0 = blockIdx.y * BBIN;
-    const OccWin ow = load_occ(occ, b, H, W, blockIdx.x, blockIdx.y);
+    const int bx0 = bxi * BBIN, by0 = byi * BBIN;
+    const OccWin ow = load_occ(occ, b, H, W, bxi, byi);
     const bool v_me = ow.bin(0, 0);
     if (!(v_me || ow.bin(1, 0) || ow.bin(0, 1))) return;
-    const size_t bin_id = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const size_t bin_id = ((size_t)b * OY + byi) * OX + bxi;
     if (tid < BBIN) s_mask[tid] = v_me ? cmask[bin_id * BBIN + tid] : 0u;
     if (tid == 0) s_n = 0;
     __syncthreads();
@@ -621,7 +695,7 @@ __global__ void __launch_bounds__(256) k_aa_fix(const float *__restrict__ color,
             const unsigned long long me = v_me ? edges[bin_id * (4 * BBIN) + side * BBIN + i] : 0ull;
             unsigned long long nb = 0ull;
             if (ow.bin(dx, dy)) {
-                const size_t nbin = ((size_t)b * gridDim.y + (blockIdx.y + dy)) * gridDim.x + (blockIdx.x + dx);
+                const size_t nbin = ((size_t)b * OY + (byi + dy)) * OX + (bxi + dx);
                 nb = edges[nbin * (4 * BBIN) + (side ^ 1) * BBIN + i];
             }
             // entries: z/w bits << 32 | silhouette bits << 24 | id + 1
@@ -647,7 +721,7 @@ __global__ void __launch_bounds__(256) k_aa_fix(const float *__restrict__ color,
         if (c) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = pix;
     }
     __syncthreads();
-    const int n = s_n;
+    const int n = __builtin_amdgcn_readfirstlane(s_n);
     if (n == 0) return;
     float ecol[CS];
 #pragma unroll
@@ -690,8 +764,37 @@ __global__ void __launch_bounds__(256) k_aa_fix(const float *__restrict__ color,
     __syncthreads();
     if (tid == 0) {
         const double tot = (double)s_part[0] + (double)s_part[1] + (double)s_part[2] + (double)s_part[3];
-        const unsigned int slot = (blockIdx.x + 31u * blockIdx.y + 977u * blockIdx.z + 128u) % FPCDR_LOSS_SLOTS;
+        const unsigned int slot = ((unsigned int)bxi + 31u * (unsigned int)byi + 977u * (unsigned int)b + 128u) % FPCDR_LOSS_SLOTS;
         if (tot != 0.0) atomicAdd(loss_sum + slot, tot);
+    }
+}
+
+// list form: one workgroup per entry of the list k_occ_window built (own, right or upper bin occupied), + strided sweep
+#define FPCDR_AA_FIX_ARGS                                                                                                       \
+    const float *__restrict__ color, const float4 *__restrict__ rast, const float4 *__restrict__ pos, const int32_t *__restrict__ tri, \
+    const uint8_t *__restrict__ sil, const uint8_t *__restrict__ ref, int B, int H, int W, int V, int T, float bg, float color_scale,  \
+    float grad_scale, unsigned long long *__restrict__ flags, float *__restrict__ g_aa, const uint16_t *__restrict__ occ,              \
+    const float *__restrict__ empty_color, const uint32_t *__restrict__ cmask, const unsigned long long *__restrict__ edges,           \
+    double *__restrict__ loss_sum
+#define FPCDR_AA_FIX_PASS                                                                                                       \
+    color, rast, pos, tri, sil, ref, B, H, W, V, T, bg, color_scale, grad_scale, flags, g_aa, occ, empty_color, cmask, edges, loss_sum
+template <int CS>
+__global__ void __launch_bounds__(256) k_aa_fix_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, FPCDR_AA_FIX_ARGS) {
+    const int item = blockIdx.x;
+    if (item >= *count) return;
+    const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
+    const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+    aa_fix_body<CS>(lin / (OX * OY), lin % OX, (lin / OX) % OY, OX, OY, FPCDR_AA_FIX_PASS);
+}
+template <int CS>
+__global__ void __launch_bounds__(256) k_aa_fix_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int first,
+                                                      FPCDR_AA_FIX_ARGS) {
+    const int n = *count;
+    const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
+    for (int item = first + blockIdx.x; item < n; item += gridDim.x) {
+        const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+        aa_fix_body<CS>(lin / (OX * OY), lin % OX, (lin / OX) % OY, OX, OY, FPCDR_AA_FIX_PASS);
+        __syncthreads();
     }
 }
 
@@ -741,17 +844,22 @@ int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, i
     return FPCDR_OK;
 }
 
-int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask, hipStream_t st) {
-    dim3 grid(fpcdr_cdiv(p->W, BBIN), fpcdr_cdiv(p->H, BBIN), p->B);
-#define LAUNCH(CS)                                                                                                            \
-    hipLaunchKernelGGL(k_aa_fix<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, p->tri, \
-                       p->sil, p->ref, p->B, p->H, p->W, p->V, p->T, p->bg, p->color_scale, p->grad_scale,                      \
-                       (unsigned long long *)p->flags, p->grad_aa, p->occ, p->empty_color, cmask,                \
-                       (const unsigned long long *)(cmask + (size_t)grid.x * grid.y * grid.z * BBIN), p->loss_sum)
+int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask, const unsigned long long *edges,
+                        const int32_t *fix_list, const int32_t *fix_count, int nbins, hipStream_t st) {
+    const int cap = (p->cap_fix > 0 && p->cap_fix < nbins) ? p->cap_fix : nbins;
+#define ARGS                                                                                                                   \
+    p->color, (const float4 *)p->rast, (const float4 *)p->pos, p->tri, p->sil, p->ref, p->B, p->H, p->W, p->V, p->T, p->bg,   \
+    p->color_scale, p->grad_scale, (unsigned long long *)p->flags, p->grad_aa, p->occ, p->empty_color, cmask, edges, p->loss_sum
+#define LAUNCH(CS)                                                                                                             \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL(k_aa_fix_list<CS>, dim3(cap), dim3(256), 0, st, fix_list, fix_count, ARGS);                        \
+        if (cap < nbins) hipLaunchKernelGGL(k_aa_fix_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(256), 0, st, fix_list, fix_count, cap, ARGS); \
+    } while (0)
     if (p->C == 1) LAUNCH(1);
     else if (p->C == 3) LAUNCH(3);
     else LAUNCH(4);
 #undef LAUNCH
+#undef ARGS
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }
@@ -807,9 +915,35 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
     FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
     FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
     FPCDR_REQUIRE(!p->occ || p->empty_color, "sparse mode needs empty_color");
+    hipStream_t st = (hipStream_t)stream;
+    if (p->queued) {
+        FPCDR_REQUIRE(p->occ != nullptr, "queued = 1 needs the occupancy buffer of fpcdr_render_loss_fwd");
+        const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W);
+        const int32_t *hdr = (const int32_t *)((const char *)p->occ + q.occ_hdr);      // [0] = number of listed bins
+        const int32_t *list = (const int32_t *)((const char *)p->occ + q.occ_bwd_list);
+        const long long nbins = (long long)p->B * FPCDR_OCC_DIM(p->H) * FPCDR_OCC_DIM(p->W);
+        const int cap = (p->cap_bwd > 0 && p->cap_bwd < nbins) ? p->cap_bwd : (int)nbins;
+#define ARGSQ                                                                                                               \
+        (const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa,  \
+        p->sil, (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,        \
+        p->boundary_mode, p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream
+#define LAUNCHQ(CS)                                                                                                         \
+        do {                                                                                                                \
+            hipLaunchKernelGGL(k_render_aa_bwd_list<CS>, dim3(cap), dim3(BWD_NT), 0, st, list, hdr, ARGSQ);                  \
+            if (cap < nbins)                                                                                                \
+                hipLaunchKernelGGL(k_render_aa_bwd_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(BWD_NT), 0, st, list, hdr, cap, ARGSQ); \
+        } while (0)
+        if (p->C == 1) LAUNCHQ(1);
+        else if (p->C == 3) LAUNCHQ(3);
+        else LAUNCHQ(4);
+#undef LAUNCHQ
+#undef ARGSQ
+        FPCDR_CHECK_LAUNCH();
+        return FPCDR_OK;
+    }
     dim3 grid(fpcdr_cdiv(p->W, BBIN), fpcdr_cdiv(p->H, BBIN), p->B);
 #define LAUNCH(CS)                                                                                                          \
-    hipLaunchKernelGGL(k_render_aa_bwd<CS>, grid, dim3(BWD_NT), 0, (hipStream_t)stream, (const float4 *)p->pos, p->tri,        \
+    hipLaunchKernelGGL(k_render_aa_bwd<CS>, grid, dim3(BWD_NT), 0, st, (const float4 *)p->pos, p->tri,        \
                        (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa, p->sil,     \
                        (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,   \
                        p->boundary_mode,                                                                                        \

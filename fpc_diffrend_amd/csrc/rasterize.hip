@@ -24,6 +24,8 @@
 // explicit fmaf, and is compiled with -ffp-contract=off, so it agrees bit for bit with oracle/raster_ref.c.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 #include "texsample.h"
@@ -106,7 +108,7 @@ __device__ __forceinline__ long long floordiv256(long long a) { return a >> 8; }
 __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                 int B, int V, int T, int H, int W, TriRec *__restrict__ recs,
                                                 TriBox *__restrict__ boxes, TriBox *__restrict__ cboxes,
-                                                ImgBox *__restrict__ ibox) {
+                                                ImgBox *__restrict__ ibox, uint8_t *__restrict__ live) {
     // grid: x over 256-triangle chunks, y = image.  A block never straddles two images, so the union of
     // its triangles' bounding boxes can be reduced in the block: it is stored as the CHUNK box (meshes
     // keep neighbouring triangles at neighbouring indices, so a bin later skips most chunks with one
@@ -191,6 +193,19 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
             atomicMax(&ibox[b].x1, bx1); atomicMax(&ibox[b].y1, by1);
         }
         cboxes[(size_t)b * gridDim.x + blockIdx.x] = cb;
+        if (live) { s_box[0][0] = bx0; s_box[0][1] = by0; s_box[0][2] = bx1; s_box[0][3] = by1; }
+    }
+    if (live) {
+        // work-queue mode: every bin the chunk box touches becomes a work item of k_bins_queue (a superset of the bins
+        // some triangle's box touches; all writers store 1)
+        __syncthreads();
+        const int cx0 = s_box[0][0], cy0 = s_box[0][1], cx1 = s_box[0][2], cy1 = s_box[0][3];
+        if (cx1 >= 0) {
+            const int OX = (W + BIN - 1) / BIN, OY = (H + BIN - 1) / BIN;
+            const int gx0 = cx0 / BIN, gy0 = cy0 / BIN, nx = cx1 / BIN - gx0 + 1, ny = cy1 / BIN - gy0 + 1;
+            for (int k = threadIdx.x; k < nx * ny; k += blockDim.x)
+                live[((size_t)b * OY + gy0 + k / nx) * OX + gx0 + k % nx] = 1;
+        }
     }
 }
 
@@ -199,6 +214,133 @@ __global__ void k_init_ibox(ImgBox *ibox, int B) {
     if (i < B) ibox[i] = {0x7fffffff, 0x7fffffff, -1, -1};
 }
 
+// work-queue mode: image boxes + zeroed live map, raw occupancy map and queue header (grid-stride)
+__global__ void __launch_bounds__(256) k_init_queue(ImgBox *ibox, int B, uint32_t *__restrict__ live_words, long long n_live_words,
+                                                    uint32_t *__restrict__ occ_words, long long n_occ_words, int32_t *__restrict__ hdr,
+                                                    int32_t *__restrict__ hdr_bwd) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    if (i0 < B) ibox[i0] = {0x7fffffff, 0x7fffffff, -1, -1};
+    if (i0 < 16) { hdr[i0] = 0; hdr_bwd[i0] = 0; }
+    for (long long i = i0; i < n_live_words; i += stride) live_words[i] = 0u;
+    for (long long i = i0; i < n_occ_words; i += stride) occ_words[i] = 0u;
+}
+
+// ---- ordered compaction of per-bin flags into lists (ascending bin index: neighbouring bins, which share vertices and
+// texels, stay neighbours in launch order; appending with atomics scrambles them at wave granularity and cost the
+// backward pass 10 %) -- three tiny kernels: per-block counts, one-workgroup scan, ordered write ----
+constexpr int NLISTS = 2;   // lists built per round (round A: live bins; round B: antialias-fix bins, backward bins)
+
+// flags of bin i for round A (live map) / round B (window mask m of the raw occupancy map)
+__device__ __forceinline__ unsigned int window_mask(const uint8_t *__restrict__ raw, long long i, int OY, int OX) {
+    const int x = (int)(i % OX), y = (int)((i / OX) % OY);
+    const uint8_t *img = raw + (i - (long long)y * OX - x);
+    unsigned int m = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 2; ++dx) {
+            const int cx = x + dx, cy = y + dy;
+            if (cx >= 0 && cx < OX && cy >= 0 && cy < OY && img[cy * OX + cx]) m |= 1u << ((dy + 1) * 4 + dx + 1);
+        }
+    return m;
+}
+__device__ __forceinline__ bool wbit(unsigned int m, int dx, int dy) { return (m >> ((dy + 1) * 4 + dx + 1)) & 1u; }
+
+template <bool ROUND_B>
+__device__ __forceinline__ void bin_flags(const uint8_t *__restrict__ map, long long i, long long nbins, int OY, int OX, bool (&f)[NLISTS],
+                                          unsigned int &m) {
+    f[0] = false; f[1] = false; m = 0;
+    if (i >= nbins) return;
+    if (!ROUND_B) { f[0] = map[i] != 0; return; }
+    m = window_mask(map, i, OY, OX);
+    f[0] = wbit(m, 0, 0) || wbit(m, 1, 0) || wbit(m, 0, 1);                                        // k_aa_fix
+    f[1] = f[0] || wbit(m, -1, 0) || wbit(m, 0, -1);                                              // k_render_aa_bwd
+}
+
+template <bool ROUND_B>
+__global__ void __launch_bounds__(256) k_list_count(const uint8_t *__restrict__ map, long long nbins, int OY, int OX,
+                                                    int32_t *__restrict__ blk_counts, uint16_t *__restrict__ win,
+                                                    const float *__restrict__ tex, int Ht, int Wt, int C, int boundary,
+                                                    float *__restrict__ empty_out) {
+    __shared__ int s_c[NLISTS][4];
+    if (!ROUND_B && blockIdx.x == 0 && threadIdx.x == 0) {   // the colour of an empty pixel: the texture at uv = (0,0)
+        const Taps tp0 = make_taps(0.0f, 0.0f, Ht, Wt, C, boundary);
+        for (int c = 0; c < 4; ++c) empty_out[c] = c < C ? bilerp(tex, tp0, c, C) : 0.0f;
+    }
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    bool f[NLISTS];
+    unsigned int m;
+    bin_flags<ROUND_B>(map, i, nbins, OY, OX, f, m);
+    if (ROUND_B && i < nbins) win[i] = (uint16_t)m;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NLISTS; ++k) {
+        const int c = __popcll(__ballot(f[k]));
+        if (lane == 0) s_c[k][wave] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < NLISTS)
+        blk_counts[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_c[threadIdx.x][0] + s_c[threadIdx.x][1] + s_c[threadIdx.x][2] + s_c[threadIdx.x][3];
+}
+
+// one workgroup: exclusive scan of the per-block counts of each list, in place; totals to count[k]
+__global__ void __launch_bounds__(1024) k_list_scan(int32_t *__restrict__ blk_counts, int nblk, int32_t *__restrict__ count0,
+                                                    int32_t *__restrict__ count1) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = 0; k < NLISTS; ++k) {
+        int32_t *c = blk_counts + (size_t)k * nblk;
+        if (tid == 0) s_carry = 0;
+        __syncthreads();
+        for (int base = 0; base < nblk; base += 1024) {
+            const int i = base + tid;
+            const int v = i < nblk ? c[i] : 0;
+            int incl = v;      // inclusive scan inside the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) s_w[wave] = incl;
+            __syncthreads();
+            int woff = 0;
+            for (int w = 0; w < wave; ++w) woff += s_w[w];
+            const int carry = s_carry;
+            if (i < nblk) c[i] = carry + woff + incl - v;
+            __syncthreads();
+            if (tid == 1023) s_carry = carry + woff + incl;
+            __syncthreads();
+        }
+        if (tid == 0) { int32_t *dst = k == 0 ? count0 : count1; if (dst) *dst = s_carry; }
+        __syncthreads();
+    }
+}
+
+template <bool ROUND_B>
+__global__ void __launch_bounds__(256) k_list_write(const uint8_t *__restrict__ map, long long nbins, int OY, int OX,
+                                                    const int32_t *__restrict__ blk_offsets, int32_t *__restrict__ list0,
+                                                    int32_t *__restrict__ list1) {
+    __shared__ int s_c[NLISTS][4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    bool f[NLISTS];
+    unsigned int m;
+    bin_flags<ROUND_B>(map, i, nbins, OY, OX, f, m);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long bal[NLISTS];
+#pragma unroll
+    for (int k = 0; k < NLISTS; ++k) {
+        bal[k] = __ballot(f[k]);
+        if (lane == 0) s_c[k][wave] = __popcll(bal[k]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NLISTS; ++k) {
+        int32_t *list = k == 0 ? list0 : list1;
+        if (!list || !f[k]) continue;
+        int off = blk_offsets[(size_t)k * gridDim.x + blockIdx.x];
+        for (int w = 0; w < wave; ++w) off += s_c[k][w];
+        list[off + __popcll(bal[k] & ((1ull << lane) - 1ull))] = (int32_t)i;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Fine raster of one 16x16 tile against the triangles of the current batch whose bit is set in `mrow`.  Each lane
@@ -282,12 +424,14 @@ struct ShadeArgs {
     float bg, color_scale, grad_scale;
 };
 
-template <bool WRITE_DB, bool SHADE, bool LOSS = false>
-__global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
-                                              int V, int T, int H, int W, const TriRec *__restrict__ recs,
-                                              const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
-                                              const ImgBox *__restrict__ ibox, float4 *__restrict__ rast,
-                                              float4 *__restrict__ rast_db, ShadeArgs sh) {
+// One 32x32 bin (bxi, byi) of image b; OX x OY bins per image.  Every branch that leaves is uniform over the workgroup.
+template <bool WRITE_DB, bool SHADE, bool LOSS, bool QUEUE>
+__device__ __forceinline__ void bins_body(const int b, const int bxi, const int byi, const int OX, const int OY,
+                                          const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                          int V, int T, int H, int W, const TriRec *__restrict__ recs,
+                                          const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
+                                          const ImgBox *__restrict__ ibox, float4 *__restrict__ rast,
+                                          float4 *__restrict__ rast_db, const ShadeArgs &sh) {
     __shared__ unsigned long long s_z[BIN * BIN];   // the bin's depth buffer: zpack(depth, triangle), Z_EMPTY = nothing yet
     __shared__ EdgeRec s_tri[BIGB];     // tile path: edge equations of the current round
     __shared__ int s_big[BATCH];        // tile path: triangles of the current batch waiting for a round
@@ -298,11 +442,11 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
     __shared__ int s_pending, s_nlive;
     __shared__ int s_wtot[2][4];        // hits each wave appended in a scan iteration (double-buffered by iteration parity)
 
-    const int b = blockIdx.z;
-    const int bin_x0 = blockIdx.x * BIN, bin_y0 = blockIdx.y * BIN;
+    const int bin_x0 = bxi * BIN, bin_y0 = byi * BIN;
     const int bin_x1 = min(bin_x0 + BIN, W) - 1, bin_y1 = min(bin_y0 + BIN, H) - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lx = lane & 7, ly = lane >> 3;
+    const size_t bin_lin = ((size_t)b * OY + byi) * OX + bxi;
 
     float best_d[TILES_PER_WAVE][4];
     int best_id[TILES_PER_WAVE][4];
@@ -315,12 +459,15 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
     const ImgBox ib = ibox[b];
     const bool bin_live = !(ib.x1 < bin_x0 || ib.x0 > bin_x1 || ib.y1 < bin_y0 || ib.y0 > bin_y1);
     const bool sparse = SHADE && sh.occ != nullptr;
-    if (sparse && b == 0 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    if (sparse && !QUEUE && b == 0 && bxi == 0 && byi == 0 && tid == 0) {   // (queue form: k_worklist writes it)
         const Taps tp0 = make_taps(0.0f, 0.0f, sh.Ht, sh.Wt, sh.C, sh.boundary);
         for (int c = 0; c < 4; ++c) sh.empty_out[c] = c < sh.C ? bilerp(sh.tex, tp0, c, sh.C) : 0.0f;
     }
+#ifdef FPCDR_ABL_EXIT0
+    if (sparse) { if (tid == 0) sh.occ[bin_lin] = 0; return; }
+#endif
     if (sparse && !bin_live) {   // nothing of this image near the bin: no pixel is written, the consumers skip it too
-        if (tid == 0) sh.occ[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 0;
+        if (tid == 0) sh.occ[bin_lin] = 0;
         return;
     }
 
@@ -397,7 +544,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
             }
             __syncthreads();
             // ---- tile path, BIGB triangles per round (block-uniform loop; rare on the meshes this is built for) ----
-            const int nbig = s_nbig;
+            const int nbig = __builtin_amdgcn_readfirstlane(s_nbig);
             for (int base = 0; base < nbig; base += BIGB, ++round_no) {
                 const int m = min(BIGB, nbig - base);
                 unsigned long long (*mask)[NTILES][BIGB / 64] = s_mask[round_no & 1];
@@ -449,7 +596,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
                     for (int ty = ty0; ty <= ty1; ++ty)
                         for (int tx = tx0; tx <= tx1; ++tx) atomicOr(&mask[small ? 0 : 1][ty * TILES_X + tx][tid >> 6], bit);
                 }
-                const int large_round = __syncthreads_or(any_large ? 1 : 0);
+                const int large_round = __builtin_amdgcn_readfirstlane(__syncthreads_or(any_large ? 1 : 0));
                 // fine raster: this wave's 16x16 tile, four pixels per lane, winners in registers
 #pragma unroll
                 for (int k = 0; k < TILES_PER_WAVE; ++k) {
@@ -483,7 +630,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
                 if (live) s_clist[base + __popcll(bal & below)] = c;
             }
             __syncthreads();
-            const int n_live = s_nlive;
+            const int n_live = __builtin_amdgcn_readfirstlane(s_nlive);
             // ---- scan the bounding boxes of SCAN_K live chunks per iteration (independent loads in flight) ----
             for (int ci = 0, it = 0; ci < n_live; ci += SCAN_K, ++it) {
                 bool hit[SCAN_K];
@@ -517,7 +664,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
                 __syncthreads();
                 // block-uniform by construction: the four waves' counts of THIS iteration (a fast wave may already be
                 // adding the next iteration's hits to s_pending, so that counter must not be re-read here)
-                const int added = s_wtot[it & 1][0] + s_wtot[it & 1][1] + s_wtot[it & 1][2] + s_wtot[it & 1][3];
+                const int added = __builtin_amdgcn_readfirstlane(s_wtot[it & 1][0] + s_wtot[it & 1][1] + s_wtot[it & 1][2] + s_wtot[it & 1][3]);
                 pending += added;
                 total_hits += added;
                 while (pending >= BATCH) process_batch(BATCH);
@@ -531,8 +678,11 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
         while (pending > 0) process_batch(min(pending, BATCH));
     }
 
+#ifdef FPCDR_ABL_SCANONLY
+    if (sparse) { if (tid == 0) sh.occ[bin_lin] = 0; return; }
+#endif
     if (sparse) {
-        if (tid == 0) sh.occ[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total_hits > 0 ? 1 : 0;
+        if (tid == 0) sh.occ[bin_lin] = total_hits > 0 ? 1 : 0;
         if (total_hits == 0) return;
     }
     if (total_hits == 0) {
@@ -650,6 +800,13 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
             }
         }
     }
+#ifdef FPCDR_ABL_NOLOSSPASS
+    if (LOSS) {
+        const size_t bin_id0 = bin_lin;
+        if (tid < BIN) sh.cmask[bin_id0 * BIN + tid] = 0u;
+        return;
+    }
+#endif
     if (LOSS) {
         // ---- every pixel gets the loss term and gradient of its UN-antialiased colour; CANDIDATES are marked ----
         // A pixel's antialiased colour differs from its colour only if one of its four pixel pairs has different ids AND
@@ -661,7 +818,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
         __shared__ float s_lpart[4];
         if (tid < BIN) s_cmask[tid] = 0u;
         __syncthreads();   // (z/w, id) entries and the cleared masks are visible
-        const size_t bin_id = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const size_t bin_id = bin_lin;
         unsigned long long *edge = sh.edges + bin_id * (4 * BIN);   // [left col | right col | bottom row | top row][32]
         float lsum = 0.0f;
 #pragma unroll
@@ -716,9 +873,64 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
         if (tid < BIN) sh.cmask[bin_id * BIN + tid] = s_cmask[tid];
         if (tid == 0) {
             const double tot = (double)s_lpart[0] + (double)s_lpart[1] + (double)s_lpart[2] + (double)s_lpart[3];
-            const unsigned int slot = (blockIdx.x + 31u * blockIdx.y + 977u * blockIdx.z) % FPCDR_LOSS_SLOTS;
+            const unsigned int slot = ((unsigned int)bxi + 31u * (unsigned int)byi + 977u * (unsigned int)b) % FPCDR_LOSS_SLOTS;
             if (tot != 0.0) atomicAdd(sh.loss_sum + slot, tot);
         }
+    }
+}
+
+// grid form: one workgroup per bin, grid (OX, OY, B)
+template <bool WRITE_DB, bool SHADE, bool LOSS = false>
+__global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                              int V, int T, int H, int W, const TriRec *__restrict__ recs,
+                                              const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
+                                              const ImgBox *__restrict__ ibox, float4 *__restrict__ rast,
+                                              float4 *__restrict__ rast_db, ShadeArgs sh) {
+    bins_body<WRITE_DB, SHADE, LOSS, false>(blockIdx.z, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, pos, tri, V, T, H, W, recs, boxes, cboxes,
+                                     ibox, rast, rast_db, sh);
+}
+
+// list form (sparse objective): one workgroup per entry of the list k_worklist built (the bins some chunk box touches,
+// ~20 % of a face-rig frame).  Dispatching one workgroup per bin of the whole batch costs 0.21 ms for 588 k workgroups
+// that mostly leave at once; the caller sizes this launch from the count of an EARLIER call (`cap`), and whatever lies
+// beyond it is swept up by the strided form below, so the result never depends on the hint.
+#ifndef FPCDR_BINSQ_WPE
+#define FPCDR_BINSQ_WPE
+#endif
+template <bool WRITE_DB, bool SHADE, bool LOSS>
+__global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
+                                              int OX, int OY,
+                                              const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                              int V, int T, int H, int W, const TriRec *__restrict__ recs,
+                                              const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
+                                              const ImgBox *__restrict__ ibox, float4 *__restrict__ rast,
+                                              float4 *__restrict__ rast_db, ShadeArgs sh) {
+    const int item = blockIdx.x;
+    if (item >= *count) return;
+    const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+    bins_body<WRITE_DB, SHADE, LOSS, true>(lin / (OX * OY), lin % OX, (lin / OX) % OY, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox,
+                                           rast, rast_db, sh);
+}
+
+// strided form: entries first, first + gridDim.x, ... of the list.  The loop variable is scalar by construction, so the loop
+// and the body's barriers stay uniform for the compiler.  (A dynamic pop -- thread 0's atomic handed round through LDS
+// between two barriers -- made LLVM's structurizer wrap the barrier pair in a second loop level, and waves repeated
+// barriers out of step; and the body inlined into a loop runs ~25 % slower than stand-alone -- 150 spilled SGPRs --, which
+// is why this form only sweeps up what the hinted launch above did not reach.)
+template <bool WRITE_DB, bool SHADE, bool LOSS>
+__global__ void __launch_bounds__(256) FPCDR_BINSQ_WPE k_bins_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
+                                              int first, int OX, int OY,
+                                              const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                              int V, int T, int H, int W, const TriRec *__restrict__ recs,
+                                              const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
+                                              const ImgBox *__restrict__ ibox, float4 *__restrict__ rast,
+                                              float4 *__restrict__ rast_db, ShadeArgs sh) {
+    const int n = *count;
+    for (int item = first + blockIdx.x; item < n; item += gridDim.x) {
+        const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+        const int bxi = lin % OX, byi = (lin / OX) % OY, b = lin / (OX * OY);
+        bins_body<WRITE_DB, SHADE, LOSS, true>(b, bxi, byi, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox, rast, rast_db, sh);
+        __syncthreads();     // the next bin's first LDS writes must not overtake this bin's last LDS reads
     }
 }
 
@@ -726,15 +938,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
 __global__ void __launch_bounds__(256) k_occ_window(const uint8_t *__restrict__ raw, int B, int OY, int OX, uint16_t *__restrict__ win) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)B * OY * OX) return;
-    const int x = (int)(i % OX), y = (int)((i / OX) % OY);
-    const uint8_t *img = raw + (i - (long long)y * OX - x);
-    unsigned int m = 0;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 2; ++dx) {
-            const int cx = x + dx, cy = y + dy;
-            if (cx >= 0 && cx < OX && cy >= 0 && cy < OY && img[cy * OX + cx]) m |= 1u << ((dy + 1) * 4 + dx + 1);
-        }
-    win[i] = (uint16_t)m;
+    win[i] = (uint16_t)window_mask(raw, i, OY, OX);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -903,7 +1107,7 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
     ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     if (p->rast_db)
         hipLaunchKernelGGL((k_bins<true, false>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
@@ -950,14 +1154,14 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
     ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
                     nullptr, p->empty_color, (const float2 *)p->tri_uv};
     const size_t nbins = (size_t)p->B * grid.y * grid.x;
     if (p->occ) {
         FPCDR_REQUIRE(p->empty_color != nullptr, "sparse mode needs empty_color");
-        sh.occ = (uint8_t *)(p->occ + nbins);   // raw byte map behind the window masks
+        sh.occ = (uint8_t *)p->occ + fpcdr_queue_layout_of(p->B, p->H, p->W).occ_raw;   // raw byte map behind the window masks
     }
     hipLaunchKernelGGL((k_bins<false, true>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
                        recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr, sh);
@@ -988,6 +1192,7 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     FPCDR_REQUIRE(p != nullptr && l != nullptr && cmask != nullptr, "null params");
     FPCDR_REQUIRE(p->pos && p->tri && p->scratch && p->uv && p->uv_tri && p->tex && p->rast && p->color, "null pointer");
     FPCDR_REQUIRE(p->occ && p->empty_color, "fpcdr_render_loss_fwd works in sparse mode only (occ, empty_color)");
+    FPCDR_REQUIRE(((size_t)p->occ & 3) == 0 && ((size_t)cmask & 7) == 0, "occ must be 4-byte and cmask 8-byte aligned");
     FPCDR_REQUIRE(l->adj && l->ref && l->sil && l->flags && l->grad_aa && l->loss_sum, "null pointer");
     FPCDR_REQUIRE(l->color == p->color && l->rast == p->rast && l->pos == p->pos && l->tri == p->tri && l->occ == p->occ &&
                       l->empty_color == p->empty_color && l->B == p->B && l->H == p->H && l->W == p->W && l->C == p->C &&
@@ -1010,19 +1215,54 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     TriBox *cboxes = (TriBox *)((char *)boxes + align_up(n * sizeof(TriBox), 256));
     const size_t nc = (size_t)p->B * (size_t)fpcdr_cdiv(p->T, 256);
     ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
-    hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
+    const int OX = fpcdr_cdiv(p->W, BIN), OY = fpcdr_cdiv(p->H, BIN);
+    const size_t nbins = (size_t)p->B * OY * OX;
+    FPCDR_REQUIRE(nbins < 0x7fffffffULL, "too many bins for one call");
+    const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W);
+    char *cm = (char *)cmask, *oc = (char *)p->occ;
+    int32_t *hdr = (int32_t *)(cm + q.cm_hdr), *bin_list = (int32_t *)(cm + q.cm_bin_list), *fix_list = (int32_t *)(cm + q.cm_fix_list);
+    uint8_t *live = (uint8_t *)(cm + q.cm_live);
+    int32_t *hdr_bwd = (int32_t *)(oc + q.occ_hdr), *bwd_list = (int32_t *)(oc + q.occ_bwd_list);
+    uint8_t *occ_raw = (uint8_t *)(oc + q.occ_raw);
+    // header in occ (survives the call; include/fpcdr.h FPCDR_OCC_COUNTS): [0] backward bins, [2] live bins, [3] antialias-fix bins
+    hipLaunchKernelGGL(k_init_queue, dim3(256), dim3(256), 0, st, ibox, p->B, (uint32_t *)live, (long long)(align_up(nbins, 4) / 4),
+                       (uint32_t *)oc, (long long)(q.occ_hdr / 4), hdr, hdr_bwd);
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox);
-    dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
-    const size_t nbins = (size_t)p->B * grid.y * grid.x;
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, live);
+    int32_t *n_bins = hdr_bwd + 2, *n_fix = hdr_bwd + 3;     // all three counts live in the occ header, where the caller finds them
+    const int nblk = fpcdr_cdiv((long long)nbins, 256);
+    int32_t *blk = (int32_t *)(cm + q.cm_blk);          // [2][nblk] per-block counts, then offsets
+    hipLaunchKernelGGL(k_list_count<false>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, (uint16_t *)nullptr,
+                       p->tex, p->Ht, p->Wt, p->C, p->boundary_mode, p->empty_color);
+    hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, n_bins, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_list_write<false>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, bin_list, (int32_t *)nullptr);
     ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
-                    (uint8_t *)(p->occ + nbins), p->empty_color, (const float2 *)p->tri_uv,
-                    l->sil, l->ref, l->grad_aa, cmask, (unsigned long long *)(cmask + nbins * BIN), l->loss_sum, l->bg, l->color_scale,
+                    occ_raw, p->empty_color, (const float2 *)p->tri_uv,
+                    l->sil, l->ref, l->grad_aa, cmask, (unsigned long long *)(cm + q.cm_edges), l->loss_sum, l->bg, l->color_scale,
                     l->grad_scale};
-    hipLaunchKernelGGL((k_bins<false, true, true>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H,
-                       p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr, sh);
-    hipLaunchKernelGGL(k_occ_window, dim3(fpcdr_cdiv((long long)nbins, 256)), dim3(256), 0, st, sh.occ, p->B, (int)grid.y,
-                       (int)grid.x, p->occ);
+    // hinted single-shot launch + strided sweep of the rest (l->cap_bins <= 0: no hint, one workgroup per possible entry)
+    const int cap_bins = (l->cap_bins > 0 && (size_t)l->cap_bins < nbins) ? l->cap_bins : (int)nbins;
+    hipLaunchKernelGGL((k_bins_list<false, true, true>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY,
+                       (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
+                       (float4 *)nullptr, sh);
+    if ((size_t)cap_bins < nbins)
+        hipLaunchKernelGGL((k_bins_queue<false, true, true>), dim3(FPCDR_SWEEP_WGS), dim3(256), 0, st, bin_list, n_bins, cap_bins, OX, OY,
+                           (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
+                           (float4 *)nullptr, sh);
+    hipLaunchKernelGGL(k_list_count<true>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, p->occ,
+                       (const float *)nullptr, 0, 0, 0, 0, (float *)nullptr);
+    hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, n_fix, hdr_bwd);
+    hipLaunchKernelGGL(k_list_write<true>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, fix_list, bwd_list);
     FPCDR_CHECK_LAUNCH();
-    return fpcdr_launch_aa_fix(l, cmask, st);
+    return fpcdr_launch_aa_fix(l, cmask, (const unsigned long long *)(cm + q.cm_edges), fix_list, n_fix, (int)nbins, st);
+}
+
+extern "C" size_t fpcdr_occ_bytes(int32_t B, int32_t H, int32_t W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return fpcdr_queue_layout_of(B, H, W).occ_bytes;
+}
+
+extern "C" size_t fpcdr_cmask_bytes(int32_t B, int32_t H, int32_t W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return fpcdr_queue_layout_of(B, H, W).cm_bytes;
 }

@@ -207,11 +207,42 @@ def render_textured(glctx, pos, tri, uv, uv_tri, tex, resolution, boundary_mode=
                                        tex.contiguous(), H, W, _lib.BOUNDARY[boundary_mode])
 
 
+class _ListHints:
+    """Launch-size hints for the list kernels of the sparse objective (include/fpcdr.h: cap_bins / cap_fix / cap_bwd).
+    Every forward call leaves the number of bins each of its three list kernels visited in the occupancy buffer; they are
+    copied to pinned host memory asynchronously and the NEXT call on a batch of the same shape sizes its launches from them
+    (+ 12 % margin) -- never waiting: a copy that has not landed yet simply means "no hint".  Results do not depend on the
+    hints (entries beyond one are swept up on the device)."""
+
+    def __init__(self):
+        self.host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.event = None
+        self.caps = (0, 0, 0)       # bins, fix, bwd
+
+    def poll(self):
+        if self.event is not None and self.event.query():
+            n_bwd, _, n_bins, n_fix = (int(v) for v in self.host.tolist())
+            self.caps = tuple(n + max(256, n // 8) if n > 0 else 0 for n in (n_bins, n_fix, n_bwd))
+            self.event = None
+        return self.caps
+
+    def update(self, counts_dev):
+        if self.event is not None or torch.cuda.is_current_stream_capturing():
+            return                  # a copy is still in flight / no host read-back from inside a HIP graph
+        self.host.copy_(counts_dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+
+_list_hints = {}
+
+
 class _pixel_objective_func(torch.autograd.Function):
     """mean over n_total of (ref - 255 * where(covered, antialias(render(pos, tex)), bg))^2 as three kernels."""
 
     @staticmethod
-    def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, sparse, ref_bg_sumsq):
+    def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, sparse, ref_bg_sumsq, use_hints,
+                queued_backward):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -222,8 +253,7 @@ class _pixel_objective_func(torch.autograd.Function):
         scratch = torch.empty(lib.fpcdr_rasterize_scratch_bytes(B, T), dtype=torch.uint8, device=dev)
         # sparse: 32x32-pixel bins that no triangle's bounding box touches are neither written nor read by the three
         # kernels; occ is the map of the others, ecol the colour of an empty pixel
-        occ = torch.empty(B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * 3, dtype=torch.uint8,
-                          device=dev) if sparse else None     # FPCDR_OCC_BYTES
+        occ = torch.empty(lib.fpcdr_occ_bytes(B, H, W), dtype=torch.uint8, device=dev) if sparse else None
         ecol = torch.empty(4, dtype=torch.float32, device=dev) if sparse else None
         tri_uv = _cached_tri_uv(uv, uv_tri)          # [T,3,2], static per mesh: saves a dependent load per pixel
         p = _lib.RenderFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
@@ -237,16 +267,28 @@ class _pixel_objective_func(torch.autograd.Function):
         q = _lib.AaLossFwd(color=_ptr(color), rast=_ptr(rast), pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), ref=_ptr(ref), B=B,
                            H=H, W=W, C=C, V=V, T=T, bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
                            flags=_ptr(flags), grad_aa=_ptr(g_aa), occ=_ptr(occ), empty_color=_ptr(ecol), loss_sum=_ptr(acc))
+        ctx.cap_bwd = 0
         if sparse:
             # one call: the rasteriser settles every pixel antialiasing cannot touch, a second kernel the candidates it marks
-            cmask = torch.empty(occ.numel() // 3 * (32 + 256), dtype=torch.int32, device=dev)     # FPCDR_CMASK_BYTES
+            cmask = torch.empty(lib.fpcdr_cmask_bytes(B, H, W), dtype=torch.uint8, device=dev)
+            hints = _list_hints.setdefault((dev.index, B, V, T, H, W), _ListHints()) if use_hints else None
+            if hints is not None:
+                q.cap_bins, q.cap_fix, ctx.cap_bwd = hints.poll()
             _lib.call("fpcdr_render_loss_fwd", ctypes.byref(p), ctypes.byref(q), _ptr(cmask), _stream())
+            if hints is not None:
+                nb = B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN)
+                off = (3 * nb + 3) // 4 * 4                       # FPCDR_OCC_COUNTS_OFFSET
+                hints.update(occ[off:off + 16].view(torch.int32))
         else:
             _lib.call("fpcdr_render_fwd", ctypes.byref(p), _stream())
             _lib.call("fpcdr_aa_loss_fwd", ctypes.byref(q), _stream())
         del scratch
         ctx.save_for_backward(pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, occ, ecol, tri_uv)
         ctx.boundary = boundary
+        # the one-call sparse forward leaves the list of bins the backward visits in `occ`; measured at cfg3 the backward gains
+        # nothing from it (2.69 vs 2.64 ms: its dead workgroups' dispatch hides behind the live ones' work), so the grid form is
+        # the default and the list form stays selectable
+        ctx.queued = 1 if (sparse and queued_backward) else 0
         total = acc.sum()
         if sparse:
             # the kernel summed only the difference to an all-background image; the rest depends on ref alone
@@ -268,11 +310,12 @@ class _pixel_objective_func(torch.autograd.Function):
                              color=_ptr(color), grad_aa=_ptr(g_aa), sil=_ptr(sil), flags=_ptr(flags), occ=_ptr(occ), empty_color=_ptr(ecol), B=B, V=V,
                              T=tri.shape[0],
                              H=H, W=W, Vt=uv.shape[0], Ht=Ht, Wt=Wt, C=C, boundary_mode=ctx.boundary, grad_pos=_ptr(g_pos),
-                             grad_tex=_ptr(g_tex), tri_uv=_ptr(tri_uv), upstream=_ptr(g))   # g: applied inside the kernel
+                             grad_tex=_ptr(g_tex), tri_uv=_ptr(tri_uv), upstream=_ptr(g),    # g: applied inside the kernel
+                             queued=ctx.queued, cap_bwd=ctx.cap_bwd)
         _lib.call("fpcdr_render_aa_bwd", ctypes.byref(p), _stream())
         if not ctx.needs_input_grad[0]:
             g_pos = None
-        return (g_pos, g_tex) + (None,) * 12
+        return (g_pos, g_tex) + (None,) * 14
 
 
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
@@ -288,14 +331,17 @@ def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
 
 
 def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_total=None, background=45.0 / 255.0,
-                    boundary_mode='wrap', sparse=True, ref_bg_sumsq=None):
+                    boundary_mode='wrap', sparse=True, ref_bg_sumsq=None, launch_hints=True, queued_backward=False):
     """The whole pixel term of the reference's loss (fit.py:151-161 + the first term of :579) for a minibatch,
     as three kernels:  mean((ref - 255 * where(rast.w > 0, antialias(texture(interpolate(rasterize(pos)))), bg))^2)
     over n_total elements (default: all of this call's).  pos [B,V,4], tex [Ht,Wt,C] (C in 1,3,4), ref_u8 [B,H,W] uint8.
     Differentiable w.r.t. pos and tex; equals the chain of separate operators + pixel loss.
     sparse=True: 32x32-pixel bins that no triangle's bounding box touches are skipped by all three kernels (they can only
     contribute (ref - 255 bg)^2 to the loss, which is added from ref_bg_sumsq: a scalar f64 tensor, the sum of
-    reference_background_sumsq(ref_u8, background) over this call's images; computed here when None); same result."""
+    reference_background_sumsq(ref_u8, background) over this call's images; computed here when None); same result.
+    launch_hints: size the sparse kernels' launches from the bin counts of the previous call on the same batch shape
+    (read back asynchronously, never waited for; the result does not depend on them).  queued_backward: the backward
+    kernel also runs over the compact list of occupied bins instead of one workgroup per bin (same result)."""
     assert isinstance(glctx, RasterizeHipContext)
     _check_tensor('pos', pos, torch.float32, 3)
     _check_tensor('tri', tri, torch.int32, 2)
@@ -312,7 +358,8 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     adj = _cached_topology(tri)
     n_total = n_total or pos.shape[0] * H * W * tex.shape[2]
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
-                                       ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq)
+                                       ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq,
+                                       bool(launch_hints), bool(queued_backward))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FPCDR_ABI_VERSION 2
+#define FPCDR_ABI_VERSION 3
 
 enum {
     FPCDR_OK = 0,
@@ -89,12 +89,13 @@ typedef struct {
     float *color;           /* out [B,H,W,C] */
     const float *tri_uv;    /* optional [T,3,2]: uv[uv_tri] gathered once per mesh (saves one dependent load per pixel); NULL = look up */
     uint16_t *occ;          /* NULL = dense (every pixel of rast / color is written).  Otherwise SPARSE mode: out, a buffer of
-                               FPCDR_OCC_BYTES(B,H,W) bytes.  A 32x32-pixel bin is OCCUPIED if the bounding box of some
+                               fpcdr_occ_bytes(B,H,W) bytes (4-byte aligned).  A 32x32-pixel bin is OCCUPIED if the bounding box of some
                                triangle touches it; unoccupied bins hold no covered pixel and are NOT written at all -- only
                                for consumers that read the map (fpcdr_aa_loss_fwd / fpcdr_render_aa_bwd) and take those
                                pixels as empty: rast = 0, colour = empty_color.  The first B*OY*OX uint16 (OY, OX =
                                FPCDR_OCC_DIM(H), (W)) are per-bin WINDOW masks: bit (dy+1)*4 + (dx+1) = bin (x+dx, y+dy) is
-                               occupied, dx in -1..2, dy in -1..1; the rest of the buffer is scratch. */
+                               occupied, dx in -1..2, dy in -1..1; the rest of the buffer belongs to the library (raw map, and the
+                               list of bins the backward call visits with its work cursor). */
     float *empty_color;     /* sparse mode: out [4], the colour of an empty pixel (the texture at uv = (0,0), fit.py:157-158) */
 } fpcdr_render_fwd_params;
 int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream);
@@ -118,8 +119,13 @@ int fpcdr_render_bwd(const fpcdr_render_bwd_params *p, void *stream);
 #define FPCDR_LOSS_SLOTS 256
 #define FPCDR_OCC_BIN 32
 #define FPCDR_OCC_DIM(n) (((n) + FPCDR_OCC_BIN - 1) / FPCDR_OCC_BIN)
-#define FPCDR_OCC_BYTES(B, H, W) ((size_t)(B) * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W) * 3)
-#define FPCDR_CMASK_BYTES(B, H, W) ((size_t)(B) * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W) * (32 * 4 + 4 * 32 * 8))
+/* bytes of the occupancy buffer (fpcdr_render_fwd_params.occ) and of the forward scratch of fpcdr_render_loss_fwd */
+/* After fpcdr_render_loss_fwd, int32 counts[4] at byte offset FPCDR_OCC_COUNTS_OFFSET(B,H,W) of occ hold: [0] bins the backward
+ * call visits, [2] live bins of the rasteriser, [3] bins of the antialias pass -- what a caller feeds back (with a margin) as
+ * cap_bwd / cap_bins / cap_fix of its NEXT calls. */
+#define FPCDR_OCC_COUNTS_OFFSET(B, H, W) ((((size_t)(B) * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W) * 3) + 3) / 4 * 4)
+size_t fpcdr_occ_bytes(int32_t B, int32_t H, int32_t W);
+size_t fpcdr_cmask_bytes(int32_t B, int32_t H, int32_t W);
 
 /* antialias + background + pixel loss in one pass (reference fit.py:160, 161, 579): reads colour, rast and the 8-bit
  * reference image, accumulates the sum of squares and writes d(grad_scale * sum)/d(antialiased colour); the
@@ -144,6 +150,11 @@ typedef struct {
     const float *empty_color; /* sparse mode: [4] from fpcdr_render_fwd */
     double *loss_sum;      /* [FPCDR_LOSS_SLOTS] f64, accumulated: the loss is the sum of all slots (workgroups spread
                               their partial sums over the slots instead of hammering one address) */
+    int32_t cap_bins, cap_fix; /* fpcdr_render_loss_fwd only: launch-size HINTS for its two list kernels (0 = none): at least
+                              the number of live / antialias-fix bins an earlier call on a similar batch reported (see
+                              FPCDR_OCC_COUNTS), plus a margin.  Results never depend on them: entries beyond a hint are
+                              swept up by a second, strided launch; without a hint one workgroup per bin of the batch is
+                              dispatched (0.15-0.2 ms per kernel at 288 x 1080p). */
 } fpcdr_aa_loss_fwd_params;
 int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream);
 
@@ -153,8 +164,9 @@ int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream);
  * different ids at a silhouette edge) its loss term and gradient straight away and leaves a bit mask of the others
  * (bin-border pixels included); a second kernel runs antialias + loss on those candidates only.  Same outputs as the
  * two calls.  r->occ, r->empty_color must be set (sparse mode only); l->color / rast / pos / tri / occ / empty_color
- * must equal r's; flags zero-filled by the caller; cmask: scratch of FPCDR_CMASK_BYTES(B,H,W) bytes (per bin 32 row
- * masks of candidate pixels and the bin's four border lines).                                                   */
+ * must equal r's; flags zero-filled by the caller; cmask: scratch of fpcdr_cmask_bytes(B,H,W) bytes, 8-byte aligned
+ * (per bin 32 row masks of candidate pixels and the bin's four border lines; the work lists of the call's kernels).
+ * The rasteriser and the antialias pass run over compact LISTS of the occupied bins (l->cap_bins, l->cap_fix).      */
 int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *r, const fpcdr_aa_loss_fwd_params *l, uint32_t *cmask, void *stream);
 
 /* out[i] += sum over the px_per_image pixels of image i of (ref - bg_scaled)^2, i < n_images; ref [n_images, px_per_image]
@@ -173,13 +185,17 @@ typedef struct {
     const float *rast, *color, *grad_aa;
     const uint8_t *sil;
     const uint64_t *flags;
-    const uint16_t *occ;   /* NULL = dense, else the occupancy map of fpcdr_render_fwd (sparse mode, as in the forward calls) */
+    uint16_t *occ;         /* NULL = dense, else the occupancy buffer of the forward call (sparse mode).  After
+                              fpcdr_render_loss_fwd it also holds the list of bins to visit; the call resets its work cursor */
     const float *empty_color; /* sparse mode: [4] from fpcdr_render_fwd */
     int32_t B, V, T, H, W, Vt, Ht, Wt, C, boundary_mode;
     float *grad_pos;       /* [B,V,4] accumulated */
     float *grad_tex;       /* [Ht,Wt,C] accumulated, or NULL */
     const float *tri_uv;   /* optional [T,3,2], as in fpcdr_render_fwd */
     const float *upstream; /* optional device scalar: d(final loss)/d(objective), multiplied into both gradients (NULL = 1) */
+    int32_t queued;        /* 1: occ was filled by fpcdr_render_loss_fwd -- visit only the bins on its list;
+                              0: one workgroup per bin of the batch (dense mode, or occ from fpcdr_render_fwd) */
+    int32_t cap_bwd;       /* queued = 1: launch-size hint for the list kernel, as cap_bins above (0 = none) */
 } fpcdr_render_aa_bwd_params;
 int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *stream);
 

@@ -349,20 +349,30 @@ def test_rerender_of_saved_result_matches_the_fit_images(tmp_path):
     assert (grids[0] > 50).mean() > 0.02   # something other than background was drawn
 
 
-@pytest.mark.parametrize("C,res,boundary", [(1, (150, 200), 'wrap'), (3, (97, 131), 'clamp'), (4, (64, 320), 'wrap')])
-def test_objective_sparse_dense_chain_agree_at_odd_sizes(C, res, boundary):
+@pytest.mark.parametrize("C,res,boundary,geom", [(1, (150, 200), 'wrap', 'mesh'), (3, (97, 131), 'clamp', 'mesh'), (4, (64, 320), 'wrap', 'mesh'),
+                                                 (1, (97, 131), 'wrap', 'few'), (3, (33, 65), 'wrap', 'few')])
+def test_objective_sparse_dense_chain_agree_at_odd_sizes(C, res, boundary, geom):
     """pixel_objective (candidate-based sparse forward, dense forward) == the operator chain + pixel loss when neither
-    image side is a multiple of the 32-pixel bin or the 64-pixel flag word, for every channel count it supports."""
+    image side is a multiple of the 32-pixel bin or the 64-pixel flag word, for every channel count it supports.
+    geom 'few': a handful of large open triangles, so that most bins hold no or one or two antialias candidates and some
+    are entirely covered -- the k_aa_fix case whose barrier predicate once raced (commit 675621d)."""
     import fpc_diffrend_amd.ops as dr
     from fpc_diffrend_amd import fit, scene
-    from helpers import clip_positions
+    from helpers import clip_positions, random_soup
     sc = scene.cfg('cfg1', n_frames=2)
     sc.resolution = res
-    pos, _ = clip_positions(sc, [0, 3, 7], frames=[0, 1])
     dev = 'cuda'
-    tri = torch.tensor(sc.pos_idx, device=dev)
-    uv = torch.tensor(sc.uv, device=dev) * 1.2 - 0.05
-    uv_idx = torch.tensor(sc.uv_idx, device=dev)
+    if geom == 'mesh':
+        pos, _ = clip_positions(sc, [0, 3, 7], frames=[0, 1])
+        tri = torch.tensor(sc.pos_idx, device=dev)
+        uv = torch.tensor(sc.uv, device=dev) * 1.2 - 0.05
+        uv_idx = torch.tensor(sc.uv_idx, device=dev)
+    else:
+        pos, tri = random_soup(4, 5, seed=21, spread=0.7, size=0.9)
+        tri = tri.to(dev)
+        g0 = torch.Generator().manual_seed(8)
+        uv = (torch.rand(15, 2, generator=g0) * 1.2 - 0.1).to(dev)
+        uv_idx = tri.clone()
     g = torch.Generator().manual_seed(1)
     tex0 = torch.rand(48, 64, C, generator=g) * 0.5
     ref = torch.randint(0, 141, (pos.shape[0], res[0], res[1]), generator=g, dtype=torch.uint8).to(dev)
@@ -487,3 +497,45 @@ def test_fit_from_a_take_on_disk_equals_the_in_memory_run(tmp_path):
     assert "LAP" in recs[0] and "LAP" in recs[2] and "LAP" not in recs[1] and recs[2]["frames_per_s"] > 0
     b.save(str(tmp_path / "out"))
     assert sorted(os.listdir(tmp_path / "out" / "result"))[:4] == ["0.obj", "1.obj", "2.obj", "3.obj"]
+
+
+def test_objective_launch_hints_do_not_change_the_result():
+    """The sparse objective sizes its list kernels from the bin counts of the previous call (ops._ListHints).  Whatever the
+    hint -- none, right, or far too small (the strided sweep kernels then do nearly all the work) -- loss and gradients are the
+    same."""
+    import fpc_diffrend_amd.ops as dr
+    from fpc_diffrend_amd import scene
+    from helpers import clip_positions
+    sc = scene.cfg('cfg1', n_frames=2)
+    pos, _ = clip_positions(sc, [0, 3, 7], frames=[0, 1])
+    dev = 'cuda'
+    tri = torch.tensor(sc.pos_idx, device=dev)
+    uv, uv_idx = torch.tensor(sc.uv, device=dev), torch.tensor(sc.uv_idx, device=dev)
+    g = torch.Generator().manual_seed(3)
+    ref = torch.randint(0, 141, (pos.shape[0],) + tuple(sc.resolution), generator=g, dtype=torch.uint8).to(dev)
+    ctx = dr.RasterizeGLContext(device=dev)
+
+    def run(**kw):
+        p = pos.to(dev).clone().requires_grad_(True)
+        t = torch.tensor(sc.texture, device=dev).clone().requires_grad_(True)
+        loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, sc.resolution, **kw)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), p.grad.double().cpu(), t.grad.double().cpu()
+
+    base = run(launch_hints=False)
+    dr._list_hints.clear()
+    first = run(queued_backward=True)   # no hint yet; leaves its counts behind
+    key = next(iter(dr._list_hints))
+    hints = dr._list_hints[key]
+    assert hints.poll() != (0, 0, 0) and all(c >= 256 for c in hints.caps)
+    second = run(queued_backward=True)  # hinted launches
+    hints.event = None
+    hints.caps = (3, 2, 5)              # absurdly small hints: almost every bin goes through the strided sweep
+    hints.update = lambda counts: None
+    third = run(queued_backward=True)
+    fourth = run()                      # default: list forward, grid backward
+    for r in (first, second, third, fourth):
+        assert abs(r[0] - base[0]) <= 1e-6 * abs(base[0])
+        assert rel_l2(r[1], base[1]) < 1e-5 and rel_l2(r[2], base[2]) < 1e-5
+    dr._list_hints.clear()
