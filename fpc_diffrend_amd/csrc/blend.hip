@@ -79,6 +79,120 @@ __global__ void __launch_bounds__(256) k_blend_fwd(const float *__restrict__ v_b
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-staged forward (K <= LDS_KMAX): one workgroup per 32-coordinate tile.  The tile's rows are CONTIGUOUS in Bmat
+// (32 K floats), so the workgroup streams them with aligned 16-byte loads -- every 128-byte line once, whole -- instead of
+// 64 lanes walking 64 different rows 8 bytes at a time (52 us for the 27 MB of the 30k rig; this form: 32 us by HIP events, of
+// which 20 us remain with the global loads compiled out: LDS scatter, barriers and 75 MFMAs of 64 cycles per tile).  Rows go to LDS with
+// a stride of KQ + 4 floats (== 4 mod 32: 16-byte reads of 8 consecutive rows cover all 32 banks); the four waves split the
+// k range, each lane half walks its own contiguous run with ds_read_b128 feeding four MFMA k-steps, and the four partial
+// 32 x 32 tiles are summed through LDS.
+constexpr int LDS_KMAX = 224;
+constexpr int TM = 32;
+
+__global__ void __launch_bounds__(256) k_blend_fwd_lds(const float *__restrict__ v_base, const float *__restrict__ Bmat,
+                                                       const float *__restrict__ w, float *__restrict__ out, int M, int K, int F,
+                                                       int KQ) {
+    extern __shared__ float smem[];
+    const int KP = KQ + 4;
+    float *s_b = smem;                    // [32][KP] Bmat tile, zero beyond K
+    float *s_w = smem + TM * KP;          // [32][KP] weights of the current 32 frames
+    float *s_red = s_w;                   // [3][16][64] partial accumulators of waves 1..3 (aliases s_w once it is consumed)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.x * TM;
+    // (row, k) of a flat element index advance by a fixed step per trip: two divisions per thread instead of one per element
+    const int step4_r = 1024 / K, step4_k = 1024 - step4_r * K;     // +1024 elements (256 float4)
+    // zero the pad columns [K, KP) of both tiles (the copies below never touch them)
+    {
+        const int np = KP - K;
+        for (int e = tid; e < 32 * np; e += 256) {
+            const int r = e / np, k = K + e - r * np;
+            s_b[r * KP + k] = 0.0f;
+            s_w[r * KP + k] = 0.0f;
+        }
+    }
+    // Both tiles are contiguous runs of 32 K floats, 16-byte aligned (tile bytes = 128 K).  ALL of a thread's loads are issued
+    // before the first one is consumed (NQ4 = 7 >= 32 K / 4 / 256 for K <= 224): one memory latency per tile, not one per trip
+    // (a load -> LDS-store loop of 19 trips made this kernel latency-bound at 35 us).
+    constexpr int NQ4 = (LDS_KMAX * TM / 4 + 255) / 256;
+    const int n4 = (TM * K) / 4;          // 32 K is a multiple of 4
+    auto load_tile = [&](const float *__restrict__ src, long long avail, float4 (&v)[NQ4]) {
+        // src: tile start; avail: floats that may be read from src (the rest of the tile is zero)
+#pragma unroll
+        for (int j = 0; j < NQ4; ++j) {
+            const int q = tid + 256 * j;
+            const long long e0 = 4ll * q;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < n4) {
+                if (e0 + 3 < avail) v[j] = *reinterpret_cast<const float4 *>(src + e0);
+                else {
+                    if (e0 < avail) v[j].x = src[e0];
+                    if (e0 + 1 < avail) v[j].y = src[e0 + 1];
+                    if (e0 + 2 < avail) v[j].z = src[e0 + 2];
+                }
+            }
+        }
+    };
+    auto store_tile = [&](float *__restrict__ dst, const float4 (&v)[NQ4]) {
+        int r = (4 * tid) / K, k = 4 * tid - r * K;
+#pragma unroll
+        for (int j = 0; j < NQ4; ++j) {
+            if (tid + 256 * j < n4) {
+                const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                int rr = r, kk = k;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    dst[rr * KP + kk] = vv[c];
+                    if (++kk == K) { kk = 0; ++rr; }
+                }
+            }
+            r += step4_r; k += step4_k;
+            if (k >= K) { k -= K; ++r; }
+        }
+    };
+    float4 vb4[NQ4], vw4[NQ4];
+    load_tile(Bmat + (size_t)i0 * K, (long long)(M - i0) * K, vb4);
+    load_tile(w, (long long)F * K, vw4);
+    store_tile(s_b, vb4);
+    const int kw = KQ / 4, kh = KQ / 8;               // k per wave, per lane half (a multiple of 4)
+    const int kbase = wave * kw + h * kh;
+    for (int f0 = 0; f0 < F; f0 += 32) {
+        if (f0 > 0) {
+            __syncthreads();                          // previous frame tile (and its s_red) consumed
+            load_tile(w + (size_t)f0 * K, (long long)(F - f0) * K, vw4);
+        }
+        store_tile(s_w, vw4);
+        __syncthreads();
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const float *pa = s_w + col * KP + kbase, *pb = s_b + col * KP + kbase;
+        for (int s = 0; s < kh; s += 4) {
+            const float4 a = *reinterpret_cast<const float4 *>(pa + s);
+            const float4 b = *reinterpret_cast<const float4 *>(pb + s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+        __syncthreads();                              // every wave has read its part of s_w: s_red may overwrite it
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int i = i0 + col;
+            const float vb = (v_base && i < M) ? v_base[i] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[r] + s_red[r * 64 + lane] + s_red[(16 + r) * 64 + lane] + s_red[(32 + r) * 64 + lane];
+                const int f = f0 + acc_row(r, lane);
+                if (f < F && i < M) out[(size_t)f * M + i] = v + vb;
+            }
+        }
+    }
+}
+
 // grad_w[f][k] += sum_i gout[f][i] Bmat[i][k];  D[i = frame][j = k]; the long i reduction is split over
 // blockIdx.y slabs of SLAB rows and finished with f32 atomics (few adders per address).
 constexpr int SLAB = 512;
@@ -157,6 +271,15 @@ extern "C" int fpcdr_blend_fwd(const float *v_base, const float *Bmat, const flo
                                int32_t F, void *stream) {
     FPCDR_REQUIRE(Bmat && w && out, "null pointer");
     FPCDR_REQUIRE(M > 0 && K > 0 && F > 0, "sizes must be positive");
+    if (K <= LDS_KMAX && ((size_t)Bmat & 15) == 0 && ((size_t)w & 15) == 0) {
+        const int KQ = (K + 31) / 32 * 32;
+        const size_t tile = (size_t)32 * (KQ + 4);
+        const size_t lds = (tile + (tile > 3 * 16 * 64 ? tile : (size_t)3 * 16 * 64)) * sizeof(float);   // s_b + max(s_w, s_red): <= 58 KB
+        hipLaunchKernelGGL(k_blend_fwd_lds, dim3(fpcdr_cdiv(M, TM)), dim3(256), lds, (hipStream_t)stream, v_base, Bmat, w, out, M, K,
+                           F, KQ);
+        FPCDR_CHECK_LAUNCH();
+        return FPCDR_OK;
+    }
     hipLaunchKernelGGL(k_blend_fwd, dim3(fpcdr_cdiv(fpcdr_cdiv(M, 32), 4)), dim3(256), 0, (hipStream_t)stream, v_base, Bmat, w,
                        out, M, K, F);
     FPCDR_CHECK_LAUNCH();
