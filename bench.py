@@ -54,16 +54,49 @@ def algorithmic_bytes_per_px(C, with_db):
     }
 
 
-def measured_traffic(name, workload, n_images, C):
-    """HBM bytes per launch of one entry point from the committed rocprofv3 PMC passes (profiles/r01_traffic.json),
-    or None when no pass exists for this configuration."""
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_counters_cfg3.json")
+# kernels behind each C-ABI entry point (the PMC passes are per kernel)
+ENTRY_KERNELS = {
+    "fpcdr_render_loss_fwd": ["k_sil2", "k_init_queue", "k_setup", "void k_list_count<false>", "k_list_scan", "void k_list_write<false>",
+                              "void k_bins_list<false, true, true>", "void k_bins_queue<false, true, true>", "void k_list_count<true>",
+                              "void k_list_write<true>", "void k_aa_fix_list<1>", "void k_aa_fix_queue<1>"],
+    "fpcdr_render_aa_bwd": ["void k_render_aa_bwd<1>"],
+    "fpcdr_antialias_bwd": ["k_copy_f4_chunk", "void k_aa_bwd_fix<1>"],
+    "fpcdr_blend_fwd": ["k_blend_fwd_lds"],
+}
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X dense f32 matrix peak (MI355X_MICROARCH.md)
+
+
+def measured_counters(name, workload, n_images, C):
+    """Per-launch PMC figures of one entry point from the committed rocprofv3 passes (profiles/r02_counters_cfg3.json: separate
+    --pmc passes of scripts/prof_objective.py, scripts/measure_round.sh), or None when no pass exists for this configuration.
+    HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE: on gfx950 FETCH_SIZE reports exactly half the bytes of a coalesced stream of ANY
+    width per lane (1, 2, 4, 8, 16 B: profiles/r02_fetch_calibration.txt); the kernels' gathers (vertices, texels) hit L2 and do
+    not reach the counter."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(COUNTERS_FILE) as f:
             t = json.load(f)
         if t["workload"] != workload or t["images"] != n_images or t["channels"] != C:
             return None
-        k = t["kernels"][name]
-        return (k["fetch_kb"] * k["fetch_factor"] + k["write_kb"]) * 1024.0
+        tot = {"fetch_kb": 0.0, "write_kb": 0.0, "valu_insts": 0.0, "gui_active": 0.0, "mfma_busy": 0.0, "lds_conflict": 0.0, "lds_active": 0.0}
+        for k in ENTRY_KERNELS[name]:
+            c = t["kernels"].get(k, {}).get("counters")
+            if not c:
+                continue
+            tot["fetch_kb"] += c.get("FETCH_SIZE", 0.0)
+            tot["write_kb"] += c.get("WRITE_SIZE", 0.0)
+            tot["valu_insts"] += c.get("SQ_INSTS_VALU", 0.0)
+            tot["gui_active"] += c.get("GRBM_GUI_ACTIVE", 0.0)
+            tot["mfma_busy"] += c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+            tot["lds_conflict"] += c.get("SQ_LDS_BANK_CONFLICT", 0.0)
+            tot["lds_active"] += c.get("SQ_LDS_IDX_ACTIVE", 0.0)
+        tot["hbm_bytes"] = (2.0 * tot["fetch_kb"] + tot["write_kb"]) * 1024.0
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles of the launches = / 8; a VALU wave-instruction occupies its SIMD 4 cycles
+        cyc = tot["gui_active"] / 8.0
+        tot["valu_issue_frac"] = (tot["valu_insts"] * 4.0 / (N_SIMD * cyc)) if cyc else None
+        tot["mfma_busy_frac"] = (tot["mfma_busy"] / (N_SIMD * cyc)) if cyc else None
+        return tot
     except Exception:
         return None
 
@@ -104,9 +137,19 @@ def cpu_baseline(sc, seconds_budget=30.0):
     from oracle import fit as ofit
     from oracle import ops as oops
     oops.build()
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
     t0 = time.perf_counter()
+    # torch's CPU kernels stop scaling long before the box's core count (r1: one step took 65 s on 256 threads, 1.7 s on 8):
+    # time one step at a few thread counts and keep the fastest -- `cores` reports the threads actually used
+    ncpu = os.cpu_count() or 1
+    best = None
+    for threads in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
+        dt_t, _, used_t = ofit.timed_steps(sc, cams=[3], frame_ids=[0], steps=1, threads=threads)
+        if best is None or dt_t < best[0]:
+            best = (dt_t, threads)
+        if dt_t > 2.0 * best[0]:
+            break
+    threads = best[1]
+    torch.set_num_threads(threads)
     dt, n_img, used, first = ofit.timed_steps(sc, cams=[3], frame_ids=[0], steps=1, threads=threads, keep_first=True)
     steps = 1
     # the same 1080p image through the HIP operators, from the oracle's own clip-space positions: the "L2 pixel err vs
@@ -139,7 +182,8 @@ def cpu_baseline(sc, seconds_budget=30.0):
     return {"value": (n_img / n_views) / dt, "unit": "frames/s", "cores": used, "kind": "port", "parity_1080p": parity,
             "sample": f"{steps} full fit step(s) (forward + backward + Adam) of 1 frame x 1 view at "
                       f"{sc.resolution[1]}x{sc.resolution[0]} on the same mesh/rig, {dt:.2f} s per image, scaled linearly to "
-                      f"{n_views} views per frame; wall {time.perf_counter() - t0:.1f} s"}
+                      f"{n_views} views per frame ({used} of the box's {ncpu} hardware threads: the fastest of 8 / 16 / 32 / 64); "
+                      f"wall {time.perf_counter() - t0:.1f} s"}
 
 
 def main():
@@ -154,6 +198,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--time-all-calls", action="store_true", help="HIP-event timing of every C-ABI call, not only the pixel kernels")
+    ap.add_argument("--fill", type=float, default=0.0,
+                    help="head height as a fraction of the image height (default: the scene generator's 0.6 = 11.5 %% of a 1080p frame covered)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay each step as two HIP graphs (FitConfig.hip_graph); default: on for cfg2 (launch-bound), off otherwise")
     args = ap.parse_args()
@@ -170,6 +216,8 @@ def main():
     fpg = args.frames_per_gpu or {"cfg1": 4, "cfg2": 1, "cfg3": 32, "cfg5": 4}[args.workload]
     n_frames = fpg * world
     sc = scene.cfg(args.workload, n_frames=n_frames)
+    if args.fill:
+        sc.cams = scene.make_cameras(sc.resolution, fill=args.fill)
     if args.channels != 1:
         import numpy as np
         sc.texture = np.repeat(sc.texture, args.channels, axis=2)[:, :, :args.channels].copy()
@@ -189,6 +237,13 @@ def main():
     H, W = fitter.resolution
     n_cam = len(fitter.cam_idxs)
     C = sc.texture.shape[2]
+    with torch.no_grad():       # covered share of the frame at the starting pose (the sparse objective's speed depends on it)
+        import fpc_diffrend_amd.ops as _dr
+        ids0 = slice(fitter.frame_lo, fitter.frame_lo + 1)
+        pos0 = fit.transform_clip_batched(fitter.mvp(ids0), fitter.vertices(ids0).reshape(1, -1, 3))
+        rast0, _ = _dr.rasterize(_dr.RasterizeGLContext(output_db=False, device=device), pos0, fitter.pos_idx, fitter.resolution)
+        coverage = float((rast0[..., 3] > 0).float().mean())
+        del rast0, pos0
 
     timer = None
     if not args.no_kernel_timer:
@@ -240,7 +295,7 @@ def main():
                                   if args.workload == "cfg2" else
                                   f"textured C={C} + antialias fwd/bwd{' + mip' if args.mip else ''}, Adam on weights+pose+texture"
                                   + (" + free-form vertex offsets" if args.workload == "cfg5" else "")),
-                   "frames_per_gpu": fpg, "views": n_cam, "resolution": [H, W], "triangles": int(sc.pos_idx.shape[0]),
+                   "coverage": coverage, "frames_per_gpu": fpg, "views": n_cam, "resolution": [H, W], "triangles": int(sc.pos_idx.shape[0]),
                    "blendshapes": int(sc.blendshapes.shape[1]), "texture": list(sc.texture.shape),
                    "parallelism": f"dp{world} (frames sharded, one RCCL all-reduce of {bucket.nbytes / 1e6:.1f} MB per step)"},
         "final_loss": float(loss) if loss is not None else None,
@@ -268,17 +323,54 @@ def main():
         if use_graph:
             out["kernels_note"] = "per-kernel HIP-event durations from an eager pass before the timed region; the timed steps replay two HIP graphs"
         px_ops = {k: v for k, v in table.items() if "algorithmic_GBps" in v}
+        # pixels the SPARSE objective has to touch: 1024 per bin on its lists (counts of the last step, ops._ListHints)
+        import fpc_diffrend_amd.ops as dr_ops
+        sparse_px = {}
+        for key, h in dr_ops._list_hints.items():
+            if key[1] == fpg * n_cam:
+                n_bwd, _, n_bins, n_fix = (int(v) for v in h.host.tolist())
+                sparse_px = {"fpcdr_render_loss_fwd": n_bins * 1024, "fpcdr_render_aa_bwd": n_bwd * 1024}
+                out["config"]["occupied_bins"] = {"rasteriser": n_bins, "antialias_fix": n_fix, "backward": n_bwd,
+                                                  "of": fpg * n_cam * ((H + 31) // 32) * ((W + 31) // 32)}
         if px_ops:
             dom = max(px_ops, key=lambda k: px_ops[k]["avg_ms"] * px_ops[k]["calls"])
-            a = px_ops[dom]["algorithmic_GBps"]
-            traffic = measured_traffic(dom, args.workload, fpg * n_cam, C)
+            t_s = px_ops[dom]["avg_ms"] * 1e-3
+            pmc = measured_counters(dom, args.workload, fpg * n_cam, C)
+            alg_bytes = bpp[dom] * sparse_px.get(dom, npix)
+            a = alg_bytes / t_s / 1e9
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": a / HBM_PEAK_GBS, "traffic": traffic,
-                               "traffic_GBps": (traffic / (px_ops[dom]["avg_ms"] * 1e-3) / 1e9) if traffic else None,
-                               "note": "achieved = dense-equivalent algorithmic bytes (every pixel of the batch counted) / "
-                                       "HIP-event time of the C-ABI call inside the timed region; traffic = HBM bytes the "
-                                       "call really moved (PMC): the sparse objective touches 17 % of the pixels, and its "
-                                       "kernels are bound by vector-ALU issue and LDS atomics, not by HBM (DESIGN.md 4.5)"}
+                               "frac": a / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
+                               "traffic": pmc["hbm_bytes"] if pmc else None,
+                               "traffic_GBps": (pmc["hbm_bytes"] / t_s / 1e9) if pmc else None,
+                               "traffic_frac": (pmc["hbm_bytes"] / t_s / 1e9 / HBM_PEAK_GBS) if pmc else None,
+                               "dense_equivalent_GBps": px_ops[dom]["algorithmic_GBps"],
+                               "note": "achieved = algorithmic bytes of the SPARSE call (B/px x 1024 px x the bins on its list, counted "
+                                       "live) / HIP-event time inside the timed region; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the "
+                                       "call's kernels from the committed PMC passes (profiles/r02_counters_cfg3.json); "
+                                       "dense_equivalent counts every pixel of the batch although 80 % are never touched. The "
+                                       "kernel is bound by vector-ALU issue, not HBM: see roofline_valu"}
+            if pmc and pmc.get("valu_issue_frac") is not None:
+                out["roofline_valu"] = {"kernel": dom, "bound": "valu-issue", "achieved": pmc["valu_insts"] / t_s / 1e9,
+                                        "unit": "G wave-instructions/s", "peak": N_SIMD * (pmc["gui_active"] / 8.0) / 4.0 / t_s / 1e9 if t_s else None,
+                                        "frac": pmc["valu_issue_frac"], "lds_bank_conflict_share": (pmc["lds_conflict"] / pmc["lds_active"]) if pmc["lds_active"] else None,
+                                        "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) from the committed PMC "
+                                                "passes: share of the chip's vector issue slots (a 64-wide f32 instruction holds its "
+                                                "SIMD16 for 4 cycles; f64 / transcendental / integer-multiply instructions longer, so the "
+                                                "true busy share is higher)"}
+        if "fpcdr_blend_fwd" in table or True:
+            bl = measured_counters("fpcdr_blend_fwd", args.workload, fpg * n_cam, C)
+            if bl and bl.get("mfma_busy_frac") is not None:
+                Mrows, Kb = 3 * (sc.v_base.shape[0] // 3), sc.blendshapes.shape[1]
+                cyc = bl["gui_active"] / 8.0
+                t_blend = cyc / 2.4e9       # (launch duration from the pass's own clock count at 2.4 GHz is only indicative)
+                out["roofline_blend_mfma"] = {"kernel": "k_blend_fwd_lds (V = v_base + W B^T, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                                              "flops": 2.0 * Mrows * Kb * fpg, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                              "mfma_busy_frac": bl["mfma_busy_frac"],
+                                              "hbm_bytes": bl["hbm_bytes"],
+                                              "note": "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) from "
+                                                      "the committed PMC pass; the contraction is 0.43 GFLOP against one 27 MB read of the "
+                                                      "blendshape basis: it is bounded by that read and by per-tile latency, not by the "
+                                                      "matrix cores"}
         if not args.mip and args.workload in ("cfg1", "cfg3") and world == 1:   # (scaling runs: all ranks leave together)
             try:
                 st = table_of(standalone_op_sweep(fitter))
@@ -287,7 +379,7 @@ def main():
                     a = st["fpcdr_antialias_bwd"]["algorithmic_GBps"]
                     out["roofline_antialias_bwd"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                      "frac": a / HBM_PEAK_GBS,
-                                                     "traffic": measured_traffic("fpcdr_antialias_bwd", args.workload, fpg * n_cam, C),
+                                                     "traffic": (measured_counters("fpcdr_antialias_bwd", args.workload, fpg * n_cam, C) or {}).get("hbm_bytes"),
                                                      "note": "stand-alone dr.antialias backward at the same batch, outside the timed region"}
             except Exception as e:   # the sweep must never take the measurement down
                 out["kernels_standalone_ops"] = {"error": repr(e)}

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc passes (counter_collection.csv + kernel_trace.csv) -> one JSON: per kernel, the mean of every counter per
+dispatch and the mean duration in that pass.   python scripts/make_counters_json.py DIR... > counters.json
+Only dispatches of the LARGEST grid of each kernel are averaged (prof_objective.py also renders its targets in small chunks)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+META = {"workload": "cfg3", "images": 288, "channels": 1}
+ARGS = [a for a in sys.argv[1:] if "=" not in a]
+for a in sys.argv[1:]:
+    if "=" in a:
+        k, v = a.split("=", 1)
+        META[k] = int(v) if v.isdigit() else v
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").split("(")[0]
+
+
+out = defaultdict(lambda: {"counters": {}, "duration_us": {}})
+for d in ARGS:
+    tag = os.path.basename(d.rstrip("/"))
+    dur = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            g = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) * max(int(r.get("Grid_Size_Y", 1) or 1), 1) * max(int(r.get("Grid_Size_Z", 1) or 1), 1)
+            dur[short(r["Kernel_Name"])].append((g, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    for k, v in dur.items():
+        gmax = max(g for g, _ in v)
+        sel = [t for g, t in v if g == gmax]
+        out[k]["duration_us"][tag] = sum(sel) / len(sel)
+        out[k]["dispatches"] = len(sel)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        vals = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            g = int(r.get("Grid_Size", 0) or 0)
+            vals[short(r["Kernel_Name"])][r["Counter_Name"]].append((g, float(r["Counter_Value"])))
+        for k, cs in vals.items():
+            for c, v in cs.items():
+                gmax = max(g for g, _ in v)
+                sel = [x for g, x in v if g == gmax]
+                out[k]["counters"][c] = sum(sel) / len(sel)
+keep = {k: v for k, v in out.items() if k.startswith(("k_", "void k_"))}
+print(json.dumps(dict(META, _comment="rocprofv3 --pmc passes of scripts/prof_objective.py (scripts/measure_round.sh): per kernel the mean "
+                       "counter value per dispatch (largest-grid dispatches only) and the mean duration in each pass; FETCH_SIZE / "
+                       "WRITE_SIZE in KB", kernels=keep), indent=1, sort_keys=True))

@@ -1,19 +1,30 @@
 #!/bin/bash
-# Official measurement of a round on the GPU box: bench line, rocprofv3 kernel stats, and the two PMC passes.
-# usage: bash scripts/measure_round.sh TAG      (outputs under gpurun_out/, to be copied into profiles/)
+# Official measurement of a round on the GPU box: bench line, rocprofv3 kernel stats, and the PMC passes (each counter set in a
+# pass of its own, with --kernel-trace only).   usage: bash scripts/measure_round.sh TAG [quick]
+# Outputs under gpurun_out/ (to be copied into profiles/): TAG_bench_cfg3_1gpu.json, TAG_rocprof_stats_cfg3.txt,
+# TAG_rocprof_pmc_cfg3.txt, TAG_counters.json
 set -e
 TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout -k 10 500 python bench.py > gpurun_out/${TAG}_bench_cfg3_1gpu.json 2> gpurun_out/${TAG}_bench.err
-echo "bench done"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/prof_stats.err
-python scripts/summarize_rocprof.py gpurun_out/prof_stats > gpurun_out/${TAG}_rocprof_stats_cfg3.txt
-rm -rf gpurun_out/prof_stats
-echo "stats done"
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer > /dev/null 2> gpurun_out/prof_fetch.err
-echo "fetch done"
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer > /dev/null 2> gpurun_out/prof_write.err
-python scripts/summarize_rocprof.py gpurun_out/prof_fetch gpurun_out/prof_write > gpurun_out/${TAG}_rocprof_pmc_cfg3.txt
-rm -rf gpurun_out/prof_fetch gpurun_out/prof_write
+if [ "$2" != quick ]; then
+  timeout -k 10 500 python bench.py > gpurun_out/${TAG}_bench_cfg3_1gpu.json 2> gpurun_out/${TAG}_bench.err
+  echo "bench done"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/prof_stats.err
+  python scripts/summarize_rocprof.py gpurun_out/prof_stats > gpurun_out/${TAG}_rocprof_stats_cfg3.txt
+  rm -rf gpurun_out/prof_stats
+  echo "stats done"
+fi
+# PMC passes over scripts/prof_objective.py (seven fit steps at cfg3, nothing else): one counter set per pass
+pass() {   # name, counters...
+  local name=$1; shift
+  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_$name -- python3 scripts/prof_objective.py > /dev/null 2> gpurun_out/pmc_$name.err || echo "pass $name FAILED"
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass sq1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE
+pass sq2 SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE
+python scripts/summarize_rocprof.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 > gpurun_out/${TAG}_rocprof_pmc_cfg3.txt
+python scripts/make_counters_json.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 > gpurun_out/${TAG}_counters.json
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2
 echo "pmc done"
