@@ -14,7 +14,7 @@ MAX_ATTR = 32
 MAX_MIP = 16
 LOSS_SLOTS = 256
 OCC_BIN = 32         # FPCDR_OCC_BIN
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
 BOUNDARY = {'wrap': 0, 'clamp': 1}
@@ -25,12 +25,12 @@ _i = ctypes.c_int32
 
 class RasterizeFwd(ctypes.Structure):
     _fields_ = [("pos", _p), ("tri", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i), ("scratch", _p),
-                ("rast", _p), ("rast_db", _p)]
+                ("rast", _p), ("rast_db", _p), ("hint", _p)]
 
 
 class RasterizeBwd(ctypes.Structure):
     _fields_ = [("pos", _p), ("tri", _p), ("rast", _p), ("dy", _p), ("ddb", _p), ("B", _i), ("V", _i), ("T", _i),
-                ("H", _i), ("W", _i), ("grad_pos", _p)]
+                ("H", _i), ("W", _i), ("grad_pos", _p), ("hint", _p)]
 
 
 class RenderFwd(ctypes.Structure):
@@ -63,19 +63,19 @@ class RenderAaBwd(ctypes.Structure):
 class InterpolateFwd(ctypes.Structure):
     _fields_ = [("attr", _p), ("rast", _p), ("tri", _p), ("rast_db", _p), ("B", _i), ("H", _i), ("W", _i), ("Ba", _i),
                 ("Vt", _i), ("A", _i), ("T", _i), ("n_diff", _i), ("diff_idx", _i * MAX_ATTR), ("out", _p),
-                ("out_da", _p)]
+                ("out_da", _p), ("hint", _p)]
 
 
 class InterpolateBwd(ctypes.Structure):
     _fields_ = [("attr", _p), ("rast", _p), ("tri", _p), ("rast_db", _p), ("dy", _p), ("dda", _p), ("B", _i),
                 ("H", _i), ("W", _i), ("Ba", _i), ("Vt", _i), ("A", _i), ("T", _i), ("n_diff", _i),
-                ("diff_idx", _i * MAX_ATTR), ("grad_attr", _p), ("grad_rast", _p), ("grad_rast_db", _p)]
+                ("diff_idx", _i * MAX_ATTR), ("grad_attr", _p), ("grad_rast", _p), ("grad_rast_db", _p), ("hint", _p)]
 
 
 class TextureFwd(ctypes.Structure):
     _fields_ = [("tex", _p * (MAX_MIP + 1)), ("n_levels", _i), ("uv", _p), ("uv_da", _p), ("mip_level_bias", _p),
                 ("B", _i), ("H", _i), ("W", _i), ("Bt", _i), ("Ht", _i), ("Wt", _i), ("C", _i), ("filter_mode", _i),
-                ("boundary_mode", _i), ("out", _p)]
+                ("boundary_mode", _i), ("out", _p), ("hint", _p), ("empty_color", _p)]
 
 
 class TextureBwd(ctypes.Structure):
@@ -87,7 +87,7 @@ class TextureBwd(ctypes.Structure):
 
 class AntialiasFwd(ctypes.Structure):
     _fields_ = [("color", _p), ("rast", _p), ("pos", _p), ("tri", _p), ("adj", _p), ("B", _i), ("H", _i), ("W", _i),
-                ("C", _i), ("V", _i), ("T", _i), ("sil", _p), ("flags", _p), ("out", _p)]
+                ("C", _i), ("V", _i), ("T", _i), ("sil", _p), ("flags", _p), ("out", _p), ("hint", _p), ("empty_color", _p)]
 
 
 class AntialiasBwd(ctypes.Structure):

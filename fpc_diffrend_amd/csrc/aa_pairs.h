@@ -82,7 +82,6 @@ __device__ __forceinline__ bool for_active_edges(const AAGeom &g, int x0, int y0
 }
 
 __device__ __forceinline__ float2 load_zid(const float4 *rast, size_t off) {
-    const float4 r = rast[off];
-    return make_float2(r.z, r.w);
+    return reinterpret_cast<const float2 *>(rast)[2 * off + 1];     // (z/w, id): the upper 8 bytes of the pixel
 }
 

@@ -132,22 +132,44 @@ __global__ void __launch_bounds__(256) k_sil(const float4 *__restrict__ pos, con
 
 #include "aa_pairs.h"
 
+constexpr int AROWS = 8;   // rows per wave of k_aa_fwd (4 waves: 32 rows = one hint bin)
+
 // ------------------------------------------------------------------------------------------------
 template <int CS>
 __global__ void __launch_bounds__(256) k_aa_fwd(const float *__restrict__ color, const float4 *__restrict__ rast,
                                                 const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                 const uint8_t *__restrict__ sil, int B, int H, int W, int C_dyn, int V, int T,
-                                                unsigned long long *__restrict__ flags, float *__restrict__ out) {
+                                                unsigned long long *__restrict__ flags, float *__restrict__ out,
+                                                const uint8_t *__restrict__ hint, const float *__restrict__ empty_color, int filled) {
+    // 64 x (4 AROWS) pixels per workgroup: a wave owns AROWS consecutive rows of a 64-pixel column strip (one 32-row hint bin)
+    // and has the (z/w, id) loads of all of them in flight at once (one pixel per thread: 2.3 M tiny workgroups, see
+    // k_interp_fwd in interpolate.hip)
     const int C = CS > 0 ? CS : C_dyn;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wave, b = blockIdx.z;
+    const int x = blockIdx.x * 64 + lane, ybase = (blockIdx.y * 4 + wave) * AROWS, b = blockIdx.z;
     const int Wq = FPCDR_AA_ROW_WORDS(W);
+    // region hint (plane 1): the pixel's bin and its eight neighbours are empty, so neither the pixel nor any of its four
+    // neighbours is covered -- no pair to blend: out = colour, without reading rast (nor colour, when its value there is known)
+    const bool skip = x < W && ybase < H && hint && !fpcdr_hint_on(hint, 1, B, H, W, b, ybase, x);
+    float2 mer[AROWS];
+#pragma unroll
+    for (int r = 0; r < AROWS; ++r)
+        mer[r] = (x < W && !skip && ybase + r < H) ? load_zid(rast, ((size_t)b * H + ybase + r) * W + x) : make_float2(0.f, 0.f);
+#pragma unroll 1
+    for (int r = 0; r < AROWS; ++r) {
+    const int y = ybase + r;
     bool fx_flag = false, fy_flag = false;
     if (y < H) {
-        if (x < W) {
+        if (skip) {
+            if (!filled) {      // (filled: k_aa_fill_bin1 has written these pixels with 16-byte stores)
+                const size_t off = ((size_t)b * H + y) * W + x;
+                if (empty_color) { for (int c = 0; c < C; ++c) out[off * C + c] = empty_color[c]; }
+                else { for (int c = 0; c < C; ++c) out[off * C + c] = color[off * C + c]; }
+            }
+        } else if (x < W) {
             const size_t img = (size_t)b * H * W;
             const size_t off = img + (size_t)y * W + x;
-            const float2 me = load_zid(rast, off);
+            const float2 me = mer[r];
             const int id = (int)me.y;
             const bool hasR = x + 1 < W, hasL = x > 0, hasU = y + 1 < H, hasD = y > 0;
             const float2 nR = hasR ? load_zid(rast, off + 1) : me;
@@ -210,6 +232,21 @@ __global__ void __launch_bounds__(256) k_aa_fwd(const float *__restrict__ color,
             flags[plane + wi] = by;
         }
     }
+    }
+}
+
+// C = 1, W % 4 == 0, with a region hint: the bins that (with their eight neighbours) are empty -- three quarters of a face-rig
+// frame -- are written here with one 16-byte store per lane, one workgroup per 32 x 32-pixel bin (4-byte-per-lane stores
+// reach ~1 TB/s, 16-byte ones 5); k_aa_fwd then leaves them alone.
+__global__ void __launch_bounds__(256) k_aa_fill_bin1(const float4 *__restrict__ color4, int B, int H, int W, float4 *__restrict__ out4,
+                                                      const uint8_t *__restrict__ hint, const float *__restrict__ empty_color) {
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int px = blockIdx.x * 32 + (tid & 7) * 4, py = blockIdx.y * 32 + (tid >> 3);
+    if (px >= W || py >= H) return;
+    if (fpcdr_hint_on(hint, 1, B, H, W, b, py, px)) return;
+    const size_t i4 = (((size_t)b * H + py) * W + px) / 4;
+    if (empty_color) { const float e = empty_color[0]; out4[i4] = make_float4(e, e, e, e); }
+    else out4[i4] = color4[i4];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -372,10 +409,17 @@ extern "C" int fpcdr_antialias_fwd(const fpcdr_antialias_fwd_params *p, void *st
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sil, dim3(fpcdr_cdiv((long long)p->B * p->T, 256)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil);
-    dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 4), p->B);
+    dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 4 * AROWS), p->B);
+    int filled = 0;
+    if (p->hint && p->C == 1 && (p->W & 3) == 0 && (((size_t)p->color | (size_t)p->out) & 15) == 0) {
+        hipLaunchKernelGGL(k_aa_fill_bin1, dim3(fpcdr_cdiv(p->W, 32), fpcdr_cdiv(p->H, 32), p->B), dim3(256), 0, st, (const float4 *)p->color,
+                           p->B, p->H, p->W, (float4 *)p->out, p->hint, p->empty_color);
+        filled = 1;
+    }
 #define LAUNCH_FWD(CS)                                                                                                   \
     hipLaunchKernelGGL(k_aa_fwd<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, \
-                       p->tri, p->sil, p->B, p->H, p->W, p->C, p->V, p->T, (unsigned long long *)p->flags, p->out)
+                       p->tri, p->sil, p->B, p->H, p->W, p->C, p->V, p->T, (unsigned long long *)p->flags, p->out, p->hint,   \
+                       p->hint ? p->empty_color : nullptr, filled)
     if (p->C == 1) LAUNCH_FWD(1);
     else if (p->C == 3) LAUNCH_FWD(3);
     else if (p->C == 4) LAUNCH_FWD(4);

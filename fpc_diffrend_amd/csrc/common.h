@@ -79,6 +79,13 @@ static inline int fpcdr_cu_count() {
     return n;
 }
 
+// ---- region hints (include/fpcdr.h) ----------------------------------------------------------
+// plane: 0 = the bin itself is occupied, 1 = the bin or one of its eight neighbours is
+__device__ __forceinline__ bool fpcdr_hint_on(const uint8_t *__restrict__ hint, int plane, int B, int H, int W, int b, int y, int x) {
+    const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
+    return hint[(((size_t)plane * B + b) * OY + (y >> 5)) * OX + (x >> 5)] != 0;
+}
+
 // ---- wave-level helpers ---------------------------------------------------------------------
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

@@ -15,34 +15,50 @@ namespace {
 
 struct DiffIdx { int32_t v[FPCDR_MAX_ATTR]; };
 
+constexpr int SROWS = 8;   // rows per thread of the streaming kernels (divides the 32-row hint bin)
+
 template <int A_STATIC>
 __global__ void __launch_bounds__(256) k_interp_fwd(const float *__restrict__ attr, const float4 *__restrict__ rast,
                                                     const int32_t *__restrict__ tri, const float4 *__restrict__ rast_db,
-                                                    long long npix_img, int B, int Ba, int Vt, int A_dyn, int T, int n_diff,
-                                                    DiffIdx didx, float *__restrict__ out, float *__restrict__ out_da) {
+                                                    int H, int W, int B, int Ba, int Vt, int A_dyn, int T, int n_diff,
+                                                    DiffIdx didx, float *__restrict__ out, float *__restrict__ out_da,
+                                                    const uint8_t *__restrict__ hint) {
+    // 256 x SROWS pixels per workgroup, grid (W / 256, H / SROWS, B): a thread owns SROWS vertically adjacent pixels and has all
+    // their rast loads in flight at once (one pixel per thread made 2.5 M tiny workgroups whose lifetime -- one memory round
+    // trip -- bounded the kernel at ~3.3 ms whatever it read).  The SROWS rows lie in one 32-row bin: one hint lookup.
     const int A = A_STATIC > 0 ? A_STATIC : A_dyn;
-    const long long total = npix_img * B;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const float4 r = rast[i];
+    const int px = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * SROWS, b = blockIdx.z;
+    if (px >= W) return;
+    // region hint: an empty bin holds rast = 0 -- its result is known without reading it
+    const bool known_empty = hint && !fpcdr_hint_on(hint, 0, B, H, W, b, y0, px);
+    float4 rr[SROWS];
+#pragma unroll
+    for (int k = 0; k < SROWS; ++k)
+        rr[k] = (known_empty || y0 + k >= H) ? make_float4(0.f, 0.f, 0.f, 0.f) : rast[((long long)b * H + y0 + k) * W + px];
+#pragma unroll
+    for (int k = 0; k < SROWS; ++k) {
+        const int py = y0 + k;
+        if (py >= H) break;
+        const long long i = ((long long)b * H + py) * W + px;
+        const float4 r = rr[k];
         const int t = (int)r.w - 1;
         float *o = out + i * A;
         if (t < 0 || t >= T) {
             if (A_STATIC == 2) {
                 *reinterpret_cast<float2 *>(o) = make_float2(0.f, 0.f);
             } else {
-                for (int k = 0; k < A; ++k) o[k] = 0.f;
+                for (int k2 = 0; k2 < A; ++k2) o[k2] = 0.f;
             }
             if (n_diff > 0) {
                 float *od = out_da + i * 2 * n_diff;
                 if (A_STATIC == 2 && n_diff == 2) {
                     *reinterpret_cast<float4 *>(od) = make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
-                    for (int k = 0; k < 2 * n_diff; ++k) od[k] = 0.f;
+                    for (int k2 = 0; k2 < 2 * n_diff; ++k2) od[k2] = 0.f;
                 }
             }
             continue;
         }
-        const int b = (int)(i / npix_img);
         const float *ab = attr + (Ba > 1 ? (size_t)b * Vt * A : 0);
         const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
         const float *a0 = ab + (size_t)i0 * A, *a1 = ab + (size_t)i1 * A, *a2 = ab + (size_t)i2 * A;
@@ -58,8 +74,8 @@ __global__ void __launch_bounds__(256) k_interp_fwd(const float *__restrict__ at
                 float r_[4];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int k = didx.v[j];
-                    const float f0 = k == 0 ? e0[0] : e0[1], f1 = k == 0 ? e1[0] : e1[1];
+                    const int kd = didx.v[j];
+                    const float f0 = kd == 0 ? e0[0] : e0[1], f1 = kd == 0 ? e1[0] : e1[1];
                     r_[2 * j] = d.x * f0 + d.z * f1;
                     r_[2 * j + 1] = d.y * f0 + d.w * f1;
                 }
@@ -67,14 +83,14 @@ __global__ void __launch_bounds__(256) k_interp_fwd(const float *__restrict__ at
                 continue;
             }
         } else {
-            for (int k = 0; k < A; ++k) o[k] = u * a0[k] + v * a1[k] + w * a2[k];
+            for (int k2 = 0; k2 < A; ++k2) o[k2] = u * a0[k2] + v * a1[k2] + w * a2[k2];
         }
         if (n_diff > 0) {
             const float4 d = rast_db[i];
             float *od = out_da + i * 2 * n_diff;
             for (int j = 0; j < n_diff; ++j) {
-                const int k = didx.v[j];
-                const float e0 = a0[k] - a2[k], e1 = a1[k] - a2[k];
+                const int kd = didx.v[j];
+                const float e0 = a0[kd] - a2[kd], e1 = a1[kd] - a2[kd];
                 od[2 * j] = d.x * e0 + d.z * e1;
                 od[2 * j + 1] = d.y * e0 + d.w * e1;
             }
@@ -90,7 +106,7 @@ __global__ void __launch_bounds__(256) k_interp_bwd(const float *__restrict__ at
                                                     const float *__restrict__ dy, const float *__restrict__ dda, int B,
                                                     int H, int W, int Ba, int Vt, int A, int T, int n_diff, DiffIdx didx,
                                                     float *__restrict__ grad_attr, float4 *__restrict__ grad_rast,
-                                                    float4 *__restrict__ grad_rast_db) {
+                                                    float4 *__restrict__ grad_rast_db, const uint8_t *__restrict__ hint) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // with an attribute gradient: 8x8 pixel tile per wave; without: 256 consecutive pixels of a row per block
     const int px = GRAD_ATTR ? blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7) : blockIdx.x * 256 + threadIdx.x;
@@ -100,7 +116,7 @@ __global__ void __launch_bounds__(256) k_interp_bwd(const float *__restrict__ at
     const size_t i = ((size_t)b * H + (inside ? py : 0)) * W + (inside ? px : 0);
     int t = -1;
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (inside) {
+    if (inside && !(hint && !fpcdr_hint_on(hint, 0, B, H, W, b, py, px))) {   // (an empty bin: rast = 0, zero gradients)
         r = rast[i];
         t = (int)r.w - 1;
         if (t >= T) t = -1;
@@ -170,6 +186,122 @@ __global__ void __launch_bounds__(256) k_interp_bwd(const float *__restrict__ at
     }
 }
 
+// Backward without an attribute gradient (the fit loop's case: uv carries none, fit.py:431): pure streaming, 256 x SROWS
+// pixels per workgroup like the forward kernel.
+__global__ void __launch_bounds__(256) k_interp_bwd_rows(const float *__restrict__ attr, const float4 *__restrict__ rast,
+                                                         const int32_t *__restrict__ tri, const float4 *__restrict__ rast_db,
+                                                         const float *__restrict__ dy, const float *__restrict__ dda, int B,
+                                                         int H, int W, int Ba, int Vt, int A, int T, int n_diff, DiffIdx didx,
+                                                         float4 *__restrict__ grad_rast, float4 *__restrict__ grad_rast_db,
+                                                         const uint8_t *__restrict__ hint) {
+    const int px = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * SROWS, b = blockIdx.z;
+    if (px >= W) return;
+    const bool known_empty = hint && !fpcdr_hint_on(hint, 0, B, H, W, b, y0, px);   // rast = 0 there: zero gradients, nothing read
+    float4 rr[SROWS];
+#pragma unroll
+    for (int k = 0; k < SROWS; ++k)
+        rr[k] = (known_empty || y0 + k >= H) ? make_float4(0.f, 0.f, 0.f, 0.f) : rast[((size_t)b * H + y0 + k) * W + px];
+    const float *ab = attr + (Ba > 1 ? (size_t)b * Vt * A : 0);
+#pragma unroll
+    for (int k = 0; k < SROWS; ++k) {
+        const int py = y0 + k;
+        if (py >= H) break;
+        const size_t i = ((size_t)b * H + py) * W + px;
+        int t = (int)rr[k].w - 1;
+        if (t >= T) t = -1;
+        float4 gr = make_float4(0.f, 0.f, 0.f, 0.f), gdb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0) {
+            const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+            const float *a0 = ab + (size_t)i0 * A, *a1 = ab + (size_t)i1 * A, *a2 = ab + (size_t)i2 * A;
+            const float *g = dy + i * A;
+            float gu = 0.f, gv = 0.f;
+            for (int c = 0; c < A; ++c) {
+                const float gk = g[c], c2 = a2[c];
+                gu += gk * (a0[c] - c2);
+                gv += gk * (a1[c] - c2);
+            }
+            gr.x = gu; gr.y = gv;
+            if (n_diff > 0) {
+                const float *gd = dda + i * 2 * n_diff;
+                for (int j = 0; j < n_diff; ++j) {
+                    const int c = didx.v[j];
+                    const float e0 = a0[c] - a2[c], e1 = a1[c] - a2[c];
+                    const float gx = gd[2 * j], gy = gd[2 * j + 1];
+                    gdb.x += gx * e0; gdb.y += gy * e0; gdb.z += gx * e1; gdb.w += gy * e1;
+                }
+            }
+        }
+        grad_rast[i] = gr;
+        if (n_diff > 0) grad_rast_db[i] = gdb;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bin-shaped fast paths for the shapes of the reference's render() (A = 2 texture coordinates, no pixel differentials,
+// W % 4 == 0): one workgroup per 32 x 32-pixel bin, a thread owns FOUR horizontally adjacent pixels, so every store is 16
+// bytes per lane (4- and 8-byte-per-lane stores reach ~1.2-1.7 TB/s on this chip, 16-byte ones 5 TB/s).  A bin the region
+// hint calls empty is written without reading anything.
+__device__ __forceinline__ float2 interp2(const float2 *__restrict__ ab, const int32_t *__restrict__ tri, float4 r, int T) {
+    const int t = (int)r.w - 1;
+    if (t < 0 || t >= T) return make_float2(0.f, 0.f);
+    const float2 q0 = ab[tri[3 * t]], q1 = ab[tri[3 * t + 1]], q2 = ab[tri[3 * t + 2]];
+    const float u = r.x, v = r.y, w = 1.0f - u - v;
+    return make_float2(u * q0.x + v * q1.x + w * q2.x, u * q0.y + v * q1.y + w * q2.y);
+}
+
+__global__ void __launch_bounds__(256) k_interp_fwd_bin2(const float2 *__restrict__ attr, const float4 *__restrict__ rast,
+                                                         const int32_t *__restrict__ tri, int H, int W, int B, int Ba, int Vt, int T,
+                                                         float4 *__restrict__ out4, const uint8_t *__restrict__ hint) {
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int px = blockIdx.x * 32 + (tid & 7) * 4, py = blockIdx.y * 32 + (tid >> 3);
+    if (px >= W || py >= H) return;
+    const size_t i = ((size_t)b * H + py) * W + px;       // first of the thread's four pixels
+    if (hint && !fpcdr_hint_on(hint, 0, B, H, W, b, py, px)) {
+        out4[i / 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        out4[i / 2 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float4 r0 = rast[i], r1 = rast[i + 1], r2 = rast[i + 2], r3 = rast[i + 3];
+    const float2 *ab = attr + (Ba > 1 ? (size_t)b * Vt : 0);
+    const float2 o0 = interp2(ab, tri, r0, T), o1 = interp2(ab, tri, r1, T), o2 = interp2(ab, tri, r2, T), o3 = interp2(ab, tri, r3, T);
+    out4[i / 2] = make_float4(o0.x, o0.y, o1.x, o1.y);
+    out4[i / 2 + 1] = make_float4(o2.x, o2.y, o3.x, o3.y);
+}
+
+__device__ __forceinline__ float4 interp2_bwd(const float2 *__restrict__ ab, const int32_t *__restrict__ tri, float4 r, float2 g, int T) {
+    const int t = (int)r.w - 1;
+    if (t < 0 || t >= T) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float2 q0 = ab[tri[3 * t]], q1 = ab[tri[3 * t + 1]], q2 = ab[tri[3 * t + 2]];
+    // (same order of operations as k_interp_bwd: sum over the two channels of g_k (a_k - a2_k))
+    float gu = 0.f, gv = 0.f;
+    gu += g.x * (q0.x - q2.x); gv += g.x * (q1.x - q2.x);
+    gu += g.y * (q0.y - q2.y); gv += g.y * (q1.y - q2.y);
+    return make_float4(gu, gv, 0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(256) k_interp_bwd_bin2(const float2 *__restrict__ attr, const float4 *__restrict__ rast,
+                                                         const int32_t *__restrict__ tri, const float4 *__restrict__ dy4, int H, int W,
+                                                         int B, int Ba, int Vt, int T, float4 *__restrict__ grad_rast,
+                                                         const uint8_t *__restrict__ hint) {
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int px = blockIdx.x * 32 + (tid & 7) * 4, py = blockIdx.y * 32 + (tid >> 3);
+    if (px >= W || py >= H) return;
+    const size_t i = ((size_t)b * H + py) * W + px;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hint && !fpcdr_hint_on(hint, 0, B, H, W, b, py, px)) {       // rast = 0 there: zero gradients, nothing read
+        grad_rast[i] = z; grad_rast[i + 1] = z; grad_rast[i + 2] = z; grad_rast[i + 3] = z;
+        return;
+    }
+    const float4 r0 = rast[i], r1 = rast[i + 1], r2 = rast[i + 2], r3 = rast[i + 3];
+    float4 g01 = z, g23 = z;
+    if (r0.w > 0.f || r1.w > 0.f || r2.w > 0.f || r3.w > 0.f) { g01 = dy4[i / 2]; g23 = dy4[i / 2 + 1]; }
+    const float2 *ab = attr + (Ba > 1 ? (size_t)b * Vt : 0);
+    grad_rast[i] = interp2_bwd(ab, tri, r0, make_float2(g01.x, g01.y), T);
+    grad_rast[i + 1] = interp2_bwd(ab, tri, r1, make_float2(g01.z, g01.w), T);
+    grad_rast[i + 2] = interp2_bwd(ab, tri, r2, make_float2(g23.x, g23.y), T);
+    grad_rast[i + 3] = interp2_bwd(ab, tri, r3, make_float2(g23.z, g23.w), T);
+}
+
 }  // namespace
 
 extern "C" int fpcdr_interpolate_fwd(const fpcdr_interpolate_fwd_params *p, void *stream) {
@@ -182,16 +314,24 @@ extern "C" int fpcdr_interpolate_fwd(const fpcdr_interpolate_fwd_params *p, void
     DiffIdx di;
     for (int j = 0; j < FPCDR_MAX_ATTR; ++j) di.v[j] = j < p->n_diff ? p->diff_idx[j] : 0;
     for (int j = 0; j < p->n_diff; ++j) FPCDR_REQUIRE(di.v[j] >= 0 && di.v[j] < p->A, "diff_idx out of range");
-    const long long npix = (long long)p->H * p->W;
-    const long long total = npix * p->B;
-    const int grid = (int)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
+    FPCDR_REQUIRE(p->B <= 65535 && p->H <= 65535, "image batch / height too large for one launch");
+    dim3 grid(fpcdr_cdiv(p->W, 256), fpcdr_cdiv(p->H, SROWS), p->B);
     hipStream_t st = (hipStream_t)stream;
+    if (p->A == 2 && p->n_diff == 0 && (p->W & 3) == 0 && (((size_t)p->out | (size_t)p->attr) & 15) == 0) {
+        hipLaunchKernelGGL(k_interp_fwd_bin2, dim3(fpcdr_cdiv(p->W, 32), fpcdr_cdiv(p->H, 32), p->B), dim3(256), 0, st,
+                           (const float2 *)p->attr, (const float4 *)p->rast, p->tri, p->H, p->W, p->B, p->Ba, p->Vt, p->T, (float4 *)p->out,
+                           p->hint);
+        FPCDR_CHECK_LAUNCH();
+        return FPCDR_OK;
+    }
     if (p->A == 2)
-        hipLaunchKernelGGL(k_interp_fwd<2>, dim3(grid), dim3(256), 0, st, p->attr, (const float4 *)p->rast, p->tri,
-                           (const float4 *)p->rast_db, npix, p->B, p->Ba, p->Vt, p->A, p->T, p->n_diff, di, p->out, p->out_da);
+        hipLaunchKernelGGL(k_interp_fwd<2>, grid, dim3(256), 0, st, p->attr, (const float4 *)p->rast, p->tri,
+                           (const float4 *)p->rast_db, p->H, p->W, p->B, p->Ba, p->Vt, p->A, p->T, p->n_diff, di, p->out, p->out_da,
+                           p->hint);
     else
-        hipLaunchKernelGGL(k_interp_fwd<0>, dim3(grid), dim3(256), 0, st, p->attr, (const float4 *)p->rast, p->tri,
-                           (const float4 *)p->rast_db, npix, p->B, p->Ba, p->Vt, p->A, p->T, p->n_diff, di, p->out, p->out_da);
+        hipLaunchKernelGGL(k_interp_fwd<0>, grid, dim3(256), 0, st, p->attr, (const float4 *)p->rast, p->tri,
+                           (const float4 *)p->rast_db, p->H, p->W, p->B, p->Ba, p->Vt, p->A, p->T, p->n_diff, di, p->out, p->out_da,
+                           p->hint);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }
@@ -209,15 +349,22 @@ extern "C" int fpcdr_interpolate_bwd(const fpcdr_interpolate_bwd_params *p, void
     for (int j = 0; j < p->n_diff; ++j) FPCDR_REQUIRE(di.v[j] >= 0 && di.v[j] < p->A, "diff_idx out of range");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
-    dim3 grid_rows(fpcdr_cdiv(p->W, 256), p->H, p->B);
+    dim3 grid_rows(fpcdr_cdiv(p->W, 256), fpcdr_cdiv(p->H, SROWS), p->B);
+    if (!p->grad_attr && p->A == 2 && p->n_diff == 0 && (p->W & 3) == 0 && (((size_t)p->dy | (size_t)p->attr) & 15) == 0) {
+        hipLaunchKernelGGL(k_interp_bwd_bin2, dim3(fpcdr_cdiv(p->W, 32), fpcdr_cdiv(p->H, 32), p->B), dim3(256), 0, st,
+                           (const float2 *)p->attr, (const float4 *)p->rast, p->tri, (const float4 *)p->dy, p->H, p->W, p->B, p->Ba, p->Vt,
+                           p->T, (float4 *)p->grad_rast, p->hint);
+        FPCDR_CHECK_LAUNCH();
+        return FPCDR_OK;
+    }
     if (p->grad_attr)
         hipLaunchKernelGGL(k_interp_bwd<true>, grid, dim3(256), 0, st, p->attr, (const float4 *)p->rast, p->tri,
                            (const float4 *)p->rast_db, p->dy, p->dda, p->B, p->H, p->W, p->Ba, p->Vt, p->A, p->T, p->n_diff, di,
-                           p->grad_attr, (float4 *)p->grad_rast, (float4 *)p->grad_rast_db);
+                           p->grad_attr, (float4 *)p->grad_rast, (float4 *)p->grad_rast_db, p->hint);
     else
-        hipLaunchKernelGGL(k_interp_bwd<false>, grid_rows, dim3(256), 0, st, p->attr, (const float4 *)p->rast, p->tri,
+        hipLaunchKernelGGL(k_interp_bwd_rows, grid_rows, dim3(256), 0, st, p->attr, (const float4 *)p->rast, p->tri,
                            (const float4 *)p->rast_db, p->dy, p->dda, p->B, p->H, p->W, p->Ba, p->Vt, p->A, p->T, p->n_diff, di,
-                           p->grad_attr, (float4 *)p->grad_rast, (float4 *)p->grad_rast_db);
+                           (float4 *)p->grad_rast, (float4 *)p->grad_rast_db, p->hint);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }

@@ -422,6 +422,7 @@ struct ShadeArgs {
     unsigned long long *edges;   // out [B*bins][4][32]: (z/w bits << 32 | silhouette bits << 24 | id + 1) of the four border lines
     double *loss_sum;        // [FPCDR_LOSS_SLOTS]
     float bg, color_scale, grad_scale;
+    uint8_t *op_hint;        // operator form (fpcdr_rasterize_fwd): out, plane 0 of the region hint, or null
 };
 
 // One 32x32 bin (bxi, byi) of image b; OX x OY bins per image.  Every branch that leaves is uniform over the workgroup.
@@ -685,6 +686,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         if (tid == 0) sh.occ[bin_lin] = total_hits > 0 ? 1 : 0;
         if (total_hits == 0) return;
     }
+    if (!SHADE && sh.op_hint && tid == 0) sh.op_hint[bin_lin] = total_hits > 0 ? 1 : 0;
     if (total_hits == 0) {
         // ---- nothing touches this bin (most bins of a dense call): stream the empty result, two full 512-byte rows of
         // rast per wave instruction instead of the shading loop's 8x8 quadrant pattern ----
@@ -941,13 +943,29 @@ __global__ void __launch_bounds__(256) k_occ_window(const uint8_t *__restrict__ 
     win[i] = (uint16_t)window_mask(raw, i, OY, OX);
 }
 
+// region hint, plane 1: plane 0 OR-ed over the 3 x 3 neighbourhood
+__global__ void __launch_bounds__(256) k_hint_dilate(const uint8_t *__restrict__ raw, int B, int OY, int OX, uint8_t *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * OY * OX) return;
+    const int x = (int)(i % OX), y = (int)((i / OX) % OY);
+    const uint8_t *img = raw + (i - (long long)y * OX - x);
+    uint8_t m = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int cx = x + dx, cy = y + dy;
+            if (cx >= 0 && cx < OX && cy >= 0 && cy < OY) m |= img[cy * OX + cx];
+        }
+    out[i] = m ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_DDB>
 __global__ void __launch_bounds__(256) k_grad(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               const float4 *__restrict__ rast, const float4 *__restrict__ dy,
                                               const float4 *__restrict__ ddb, int B, int V, int T, int H, int W,
-                                              float *__restrict__ grad_pos) {
+                                              float *__restrict__ grad_pos, const uint8_t *__restrict__ hint) {
     // block = 8 x 8 pixel tile per wave (4 waves = 16 x 16) so that lanes of a wave share triangles
+    if (hint && !fpcdr_hint_on(hint, 0, B, H, W, blockIdx.z, blockIdx.y * 16, blockIdx.x * 16)) return;   // empty bin: nothing to read
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
     const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
@@ -1109,12 +1127,19 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
+    ShadeArgs sh = {};
+    sh.op_hint = p->hint;
     if (p->rast_db)
         hipLaunchKernelGGL((k_bins<true, false>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
-                           recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)p->rast_db, ShadeArgs{});
+                           recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)p->rast_db, sh);
     else
         hipLaunchKernelGGL((k_bins<false, false>), grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W,
-                           recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr, ShadeArgs{});
+                           recs, boxes, cboxes, ibox, (float4 *)p->rast, (float4 *)nullptr, sh);
+    if (p->hint) {
+        const size_t nb = (size_t)p->B * grid.y * grid.x;
+        hipLaunchKernelGGL(k_hint_dilate, dim3(fpcdr_cdiv((long long)nb, 256)), dim3(256), 0, st, p->hint, p->B, (int)grid.y, (int)grid.x,
+                           p->hint + nb);
+    }
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }
@@ -1128,10 +1153,10 @@ extern "C" int fpcdr_rasterize_bwd(const fpcdr_rasterize_bwd_params *p, void *st
     dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
     if (p->ddb)
         hipLaunchKernelGGL(k_grad<true>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, (const float4 *)p->rast,
-                           (const float4 *)p->dy, (const float4 *)p->ddb, p->B, p->V, p->T, p->H, p->W, p->grad_pos);
+                           (const float4 *)p->dy, (const float4 *)p->ddb, p->B, p->V, p->T, p->H, p->W, p->grad_pos, p->hint);
     else
         hipLaunchKernelGGL(k_grad<false>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, (const float4 *)p->rast,
-                           (const float4 *)p->dy, (const float4 *)nullptr, p->B, p->V, p->T, p->H, p->W, p->grad_pos);
+                           (const float4 *)p->dy, (const float4 *)nullptr, p->B, p->V, p->T, p->H, p->W, p->grad_pos, p->hint);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }

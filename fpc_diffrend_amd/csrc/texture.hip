@@ -15,6 +15,8 @@ namespace {
 
 #include "texsample.h"
 
+constexpr int TROWS = 8;   // rows per thread of the forward kernel (divides the 32-row hint bin)
+
 struct TexLevels {
     const float *tex[FPCDR_MAX_MIP + 1];
     float *grad[FPCDR_MAX_MIP + 1];
@@ -38,16 +40,49 @@ __device__ __forceinline__ Lod compute_lod(float4 d, int Ht, int Wt, float bias)
     return L;
 }
 
+// the texture's value at uv = (0,0) (what every empty pixel of the fit loop samples): out [C]
+__global__ void k_tex_empty(TexLevels lv, int Ht, int Wt, int C, int filter, int boundary, float *__restrict__ out) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        if (filter == FPCDR_FILTER_NEAREST) {
+            const float x = prep_coord(0.0f, boundary) * (float)Wt - 0.5f, y = prep_coord(0.0f, boundary) * (float)Ht - 0.5f;
+            const int ix = wrap_i((int)floorf(x + 0.5f), Wt, boundary), iy = wrap_i((int)floorf(y + 0.5f), Ht, boundary);
+            out[c] = lv.tex[0][((size_t)iy * Wt + ix) * C + c];
+        } else {
+            const Taps t = make_taps(0.0f, 0.0f, Ht, Wt, C, boundary);
+            out[c] = bilerp(lv.tex[0], t, c, C);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_tex_fwd(TexLevels lv, int n_levels, const float2 *__restrict__ uv,
                                                  const float4 *__restrict__ uv_da, const float *__restrict__ bias,
                                                  int H, int W, int B, int Bt, int Ht, int Wt, int C, int filter,
-                                                 int boundary, float *__restrict__ out) {
-    // forward: 64 consecutive pixels of a row per wave, grid-stride (streams uv in / colour out in full lines)
-    const long long npix_img = (long long)H * W, total = npix_img * B;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const float2 q = uv[i];
-        const int b = Bt > 1 ? (int)(i / npix_img) : 0;
+                                                 int boundary, float *__restrict__ out, const uint8_t *__restrict__ hint,
+                                                 const float *__restrict__ empty_color) {
+    // forward: 256 x TROWS pixels per workgroup, grid (W / 256, H / TROWS, B); a thread owns TROWS vertically adjacent pixels and
+    // has all their uv loads in flight at once (see k_interp_fwd); the rows lie in one 32-row hint bin
+    const int px = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * TROWS;
+    if (px >= W) return;
+    const bool known_empty = hint && !fpcdr_hint_on(hint, 0, B, H, W, blockIdx.z, y0, px);
+    if (known_empty) {
+        // region hint: uv = (0,0) in an empty bin -- the texture's value there, without reading uv
+        for (int k = 0; k < TROWS && y0 + k < H; ++k) {
+            float *o = out + (((long long)blockIdx.z * H + y0 + k) * W + px) * C;
+            for (int c = 0; c < C; ++c) o[c] = empty_color[c];
+        }
+        return;
+    }
+    float2 qq[TROWS];
+#pragma unroll
+    for (int k = 0; k < TROWS; ++k)
+        qq[k] = y0 + k < H ? uv[((long long)blockIdx.z * H + y0 + k) * W + px] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < TROWS; ++k) {
+        if (y0 + k >= H) break;
+        const long long i = ((long long)blockIdx.z * H + y0 + k) * W + px;
         float *o = out + i * C;
+        const float2 q = qq[k];
+        const int b = Bt > 1 ? (int)blockIdx.z : 0;
         if (filter == FPCDR_FILTER_NEAREST) {
             const float x = prep_coord(q.x, boundary) * (float)Wt - 0.5f, y = prep_coord(q.y, boundary) * (float)Ht - 0.5f;
             const int ix = wrap_i((int)floorf(x + 0.5f), Wt, boundary), iy = wrap_i((int)floorf(y + 0.5f), Ht, boundary);
@@ -86,6 +121,30 @@ __global__ void __launch_bounds__(256) k_tex_fwd(TexLevels lv, int n_levels, con
             }
         }
     }
+}
+
+// Bin-shaped fast path for the reference's texture call (fit.py:158: one 1-channel texture, 'linear', W % 4 == 0): one
+// workgroup per 32 x 32-pixel bin, four horizontally adjacent pixels per thread, one 16-byte store per lane (see
+// k_interp_fwd_bin2 in interpolate.hip); a bin the region hint calls empty gets the texture's value at uv = (0,0) unread.
+__global__ void __launch_bounds__(256) k_tex_fwd_bin1(const float *__restrict__ tex, const float4 *__restrict__ uv4, int H, int W, int B,
+                                                      int Ht, int Wt, int boundary, float4 *__restrict__ out4,
+                                                      const uint8_t *__restrict__ hint, const float *__restrict__ empty_color) {
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int px = blockIdx.x * 32 + (tid & 7) * 4, py = blockIdx.y * 32 + (tid >> 3);
+    if (px >= W || py >= H) return;
+    const size_t i = ((size_t)b * H + py) * W + px;
+    if (hint && !fpcdr_hint_on(hint, 0, B, H, W, b, py, px)) {
+        const float e = empty_color[0];
+        out4[i / 4] = make_float4(e, e, e, e);
+        return;
+    }
+    const float4 a = uv4[i / 2], c = uv4[i / 2 + 1];
+    float4 o;
+    o.x = bilerp(tex, make_taps(a.x, a.y, Ht, Wt, 1, boundary), 0, 1);
+    o.y = bilerp(tex, make_taps(a.z, a.w, Ht, Wt, 1, boundary), 0, 1);
+    o.z = bilerp(tex, make_taps(c.x, c.y, Ht, Wt, 1, boundary), 0, 1);
+    o.w = bilerp(tex, make_taps(c.z, c.w, Ht, Wt, 1, boundary), 0, 1);
+    out4[i / 4] = o;
 }
 
 // scatter dy * weight into the four taps of one level and return (d out / d fx, d out / d fy) summed over channels
@@ -279,9 +338,24 @@ extern "C" int fpcdr_texture_fwd(const fpcdr_texture_fwd_params *p, void *stream
         lv.grad[l] = nullptr;
         if (l <= p->n_levels) FPCDR_REQUIRE(p->tex[l] != nullptr, "missing mip level");
     }
-    hipLaunchKernelGGL(k_tex_fwd, dim3(grid_for((long long)p->B * p->H * p->W)), dim3(256), 0, (hipStream_t)stream, lv, p->n_levels,
+    FPCDR_REQUIRE(p->B <= 65535 && p->H <= 65535, "image batch / height too large for one launch");
+    const uint8_t *hint = nullptr;
+    if (p->hint) {
+        FPCDR_REQUIRE(!mip && p->Bt == 1 && p->empty_color, "a region hint needs filter nearest / linear, one texture and empty_color");
+        hint = p->hint;
+        hipLaunchKernelGGL(k_tex_empty, dim3(1), dim3(64), 0, (hipStream_t)stream, lv, p->Ht, p->Wt, p->C, p->filter_mode, p->boundary_mode,
+                           p->empty_color);
+    }
+    if (p->filter_mode == FPCDR_FILTER_LINEAR && p->C == 1 && p->Bt == 1 && (p->W & 3) == 0 && (((size_t)p->uv | (size_t)p->out) & 15) == 0) {
+        hipLaunchKernelGGL(k_tex_fwd_bin1, dim3(fpcdr_cdiv(p->W, 32), fpcdr_cdiv(p->H, 32), p->B), dim3(256), 0, (hipStream_t)stream,
+                           p->tex[0], (const float4 *)p->uv, p->H, p->W, p->B, p->Ht, p->Wt, p->boundary_mode, (float4 *)p->out, hint,
+                           p->empty_color);
+        FPCDR_CHECK_LAUNCH();
+        return FPCDR_OK;
+    }
+    hipLaunchKernelGGL(k_tex_fwd, dim3(fpcdr_cdiv(p->W, 256), fpcdr_cdiv(p->H, TROWS), p->B), dim3(256), 0, (hipStream_t)stream, lv, p->n_levels,
                        (const float2 *)p->uv, mip ? (const float4 *)p->uv_da : nullptr, mip ? p->mip_level_bias : nullptr, p->H, p->W,
-                       p->B, p->Bt, p->Ht, p->Wt, p->C, p->filter_mode, p->boundary_mode, p->out);
+                       p->B, p->Bt, p->Ht, p->Wt, p->C, p->filter_mode, p->boundary_mode, p->out, hint, p->empty_color);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }

@@ -20,6 +20,7 @@ autograd), supplies the stream, and runs autograd bookkeeping.  All pixel work h
 libfpcdr.so; there is no CPU or eager-torch fallback.
 """
 import ctypes
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -47,6 +48,42 @@ def _check_tensor(name, t, dtype, dims=None):
         raise ValueError(f"{name} must have dtype {dtype} (got {t.dtype})")
     if dims is not None and t.dim() != dims:
         raise ValueError(f"{name} must have {dims} dimensions (got shape {tuple(t.shape)})")
+
+
+# ----------------------------------------------------------------------------------------------
+# region hints (include/fpcdr.h): which 32 x 32-pixel bins of an image tensor are known to be empty
+# ----------------------------------------------------------------------------------------------
+# rasterize() leaves a byte map of the bins no triangle touches.  It rides with the tensors of the operator chain of the
+# reference's render() (fit.py:151-160) -- rast ('rast': zero there), the interpolated texture coordinates ('zero') and the
+# sampled colour ('const': one known value there) -- in this registry, keyed by the tensor OBJECT: a consumer that is handed
+# the very tensor an operator returned, unmodified (same object, same version counter), does not read it in empty bins.
+# Anything else (a clone, a slice, an in-place edit, a tensor from elsewhere) simply finds no hint and takes the dense path.
+# Results are identical either way; set `region_hints = False` to switch the mechanism off.
+region_hints = True
+_hints = {}
+
+
+def _tag(t, hint, kind, const=None):
+    if len(_hints) > 256:
+        for k in [k for k, e in _hints.items() if e[0]() is None]:
+            del _hints[k]
+    _hints[t.data_ptr()] = (weakref.ref(t), t._version, tuple(t.shape), hint, kind, const)
+
+
+def _hint_of(t, kind):
+    if not region_hints:
+        return None
+    e = _hints.get(t.data_ptr())
+    if e is None:
+        return None
+    ref, version, shape, hint, k, const = e
+    if ref() is not t or t._version != version or tuple(t.shape) != shape or k != kind:
+        return None
+    return hint, const
+
+
+def _hint_bytes(B, H, W):
+    return 2 * B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN)     # FPCDR_HINT_BYTES
 
 
 # ----------------------------------------------------------------------------------------------
@@ -89,7 +126,7 @@ RasterizeCudaContext = RasterizeHipContext
 
 class _rasterize_func(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pos, tri, H, W, output_db, grad_db):
+    def forward(ctx, pos, tri, H, W, output_db, grad_db, hint):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -98,9 +135,10 @@ class _rasterize_func(torch.autograd.Function):
         rast_db = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev) if output_db else None
         scratch = torch.empty(lib.fpcdr_rasterize_scratch_bytes(B, T), dtype=torch.uint8, device=dev)
         p = _lib.RasterizeFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch),
-                              rast=_ptr(rast), rast_db=_ptr(rast_db))
+                              rast=_ptr(rast), rast_db=_ptr(rast_db), hint=_ptr(hint))
         _lib.call("fpcdr_rasterize_fwd", ctypes.byref(p), _stream())
         ctx.save_for_backward(pos, tri, rast)
+        ctx.hint = hint
         ctx.grad_db = bool(grad_db and output_db)
         if rast_db is None:
             rast_db = torch.zeros(B, H, W, 0, dtype=torch.float32, device=dev)
@@ -116,9 +154,9 @@ class _rasterize_func(torch.autograd.Function):
         dy = dy.contiguous()
         ddb = ddb.contiguous() if (ctx.grad_db and ddb is not None and ddb.numel() > 0) else None
         p = _lib.RasterizeBwd(pos=_ptr(pos), tri=_ptr(tri), rast=_ptr(rast), dy=_ptr(dy), ddb=_ptr(ddb), B=B, V=V,
-                              T=tri.shape[0], H=H, W=W, grad_pos=_ptr(g_pos))
+                              T=tri.shape[0], H=H, W=W, grad_pos=_ptr(g_pos), hint=_ptr(ctx.hint))
         _lib.call("fpcdr_rasterize_bwd", ctypes.byref(p), _stream())
-        return g_pos, None, None, None, None, None
+        return g_pos, None, None, None, None, None, None
 
 
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
@@ -140,8 +178,12 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
         raise ValueError(f"tri must have shape [>0, 3] (got {tuple(tri.shape)})")
     if glctx.device is not None and pos.device != glctx.device:
         raise ValueError(f"pos is on {pos.device} but the context was created for {glctx.device}")
-    return _rasterize_func.apply(pos.contiguous(), tri.contiguous(), resolution[0], resolution[1], glctx.output_db,
-                                 grad_db)
+    hint = torch.empty(_hint_bytes(pos.shape[0], *resolution), dtype=torch.uint8, device=pos.device) if region_hints else None
+    rast, rast_db = _rasterize_func.apply(pos.contiguous(), tri.contiguous(), resolution[0], resolution[1], glctx.output_db,
+                                          grad_db, hint)
+    if hint is not None:
+        _tag(rast, hint, 'rast')
+    return rast, rast_db
 
 
 # ----------------------------------------------------------------------------------------------
@@ -375,7 +417,7 @@ def _diff_array(diff_list):
 
 class _interpolate_func(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, attr, rast, tri, rast_db, diff_list):
+    def forward(ctx, attr, rast, tri, rast_db, diff_list, hint):
         lib = _lib.load()
         B, H, W, _ = rast.shape
         Ba, Vt, A = attr.shape
@@ -385,10 +427,12 @@ class _interpolate_func(torch.autograd.Function):
         out_da = torch.empty(B, H, W, 2 * n_diff, dtype=torch.float32, device=dev)
         p = _lib.InterpolateFwd(attr=_ptr(attr), rast=_ptr(rast), tri=_ptr(tri), rast_db=_ptr(rast_db) if n_diff else None,
                                 B=B, H=H, W=W, Ba=Ba, Vt=Vt, A=A, T=tri.shape[0], n_diff=n_diff,
-                                diff_idx=_diff_array(diff_list), out=_ptr(out), out_da=_ptr(out_da) if n_diff else None)
+                                diff_idx=_diff_array(diff_list), out=_ptr(out), out_da=_ptr(out_da) if n_diff else None,
+                                hint=_ptr(hint))
         _lib.call("fpcdr_interpolate_fwd", ctypes.byref(p), _stream())
         ctx.save_for_backward(attr, rast, tri, rast_db if n_diff else None)
         ctx.diff_list = diff_list
+        ctx.hint = hint
         return out, out_da
 
     @staticmethod
@@ -410,9 +454,9 @@ class _interpolate_func(torch.autograd.Function):
         p = _lib.InterpolateBwd(attr=_ptr(attr), rast=_ptr(rast), tri=_ptr(tri), rast_db=_ptr(rast_db) if n_diff else None,
                                 dy=_ptr(dy), dda=_ptr(dda) if n_diff else None, B=B, H=H, W=W, Ba=Ba, Vt=Vt, A=A,
                                 T=tri.shape[0], n_diff=n_diff, diff_idx=_diff_array(diff_list), grad_attr=_ptr(g_attr),
-                                grad_rast=_ptr(g_rast), grad_rast_db=_ptr(g_db))
+                                grad_rast=_ptr(g_rast), grad_rast_db=_ptr(g_db), hint=_ptr(ctx.hint))
         _lib.call("fpcdr_interpolate_bwd", ctypes.byref(p), _stream())
-        return g_attr, g_rast, None, g_db, None
+        return g_attr, g_rast, None, g_db, None, None
 
 
 def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
@@ -452,7 +496,12 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
         rast_db = rast_db.contiguous()
     else:
         rast_db = None
-    return _interpolate_func.apply(attr.contiguous(), rast.contiguous(), tri.contiguous(), rast_db, diff_list)
+    h = _hint_of(rast, 'rast')
+    out, out_da = _interpolate_func.apply(attr.contiguous(), rast.contiguous(), tri.contiguous(), rast_db, diff_list,
+                                          h[0] if h else None)
+    if h:
+        _tag(out, h[0], 'zero')       # no triangle, no attribute: zeros in empty bins
+    return out, out_da
 
 
 # ----------------------------------------------------------------------------------------------
@@ -502,7 +551,7 @@ def _ptr_array(tensors):
 
 class _texture_func(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tex, uv, uv_da, bias, filter_mode, boundary_mode, n_levels, *mips):
+    def forward(ctx, tex, uv, uv_da, bias, filter_mode, boundary_mode, n_levels, hint, empty_color, *mips):
         lib = _lib.load()
         B, H, W, _ = uv.shape
         Bt, Ht, Wt, C = tex.shape
@@ -510,7 +559,8 @@ class _texture_func(torch.autograd.Function):
         out = torch.empty(B, H, W, C, dtype=torch.float32, device=uv.device)
         p = _lib.TextureFwd(tex=_ptr_array(chain), n_levels=n_levels, uv=_ptr(uv), uv_da=_ptr(uv_da),
                             mip_level_bias=_ptr(bias), B=B, H=H, W=W, Bt=Bt, Ht=Ht, Wt=Wt, C=C,
-                            filter_mode=filter_mode, boundary_mode=boundary_mode, out=_ptr(out))
+                            filter_mode=filter_mode, boundary_mode=boundary_mode, out=_ptr(out), hint=_ptr(hint),
+                            empty_color=_ptr(empty_color))
         _lib.call("fpcdr_texture_fwd", ctypes.byref(p), _stream())
         ctx.save_for_backward(tex, uv, uv_da, bias, *chain[1:])
         ctx.cfg = (filter_mode, boundary_mode, n_levels)
@@ -540,7 +590,7 @@ class _texture_func(torch.autograd.Function):
             for l in range(n_levels, 0, -1):
                 N, h, w, _ = chain[l - 1].shape
                 _lib.call("fpcdr_mip_downsample_bwd", _ptr(g_levels[l]), _ptr(g_levels[l - 1]), N, h, w, C, _stream())
-        return (g_levels[0], g_uv, g_da, g_bias, None, None, None) + (None,) * (len(chain) - 1)
+        return (g_levels[0], g_uv, g_da, g_bias, None, None, None, None, None) + (None,) * (len(chain) - 1)
 
 
 def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='auto', boundary_mode='wrap',
@@ -589,8 +639,13 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
     else:
         uv_da = None
         mip_level_bias = None
-    return _texture_func.apply(tex.contiguous(), uv.contiguous(), uv_da, mip_level_bias, _lib.FILTER[filter_mode],
-                               _lib.BOUNDARY[boundary_mode], n_levels, *mips)
+    h = _hint_of(uv, 'zero') if (not mipped and tex.shape[0] == 1) else None
+    empty_color = torch.empty(tex.shape[3], dtype=torch.float32, device=uv.device) if h else None
+    out = _texture_func.apply(tex.contiguous(), uv.contiguous(), uv_da, mip_level_bias, _lib.FILTER[filter_mode],
+                              _lib.BOUNDARY[boundary_mode], n_levels, h[0] if h else None, empty_color, *mips)
+    if h:
+        _tag(out, h[0], 'const', empty_color)     # uv = (0,0) in empty bins: the texture's value there
+    return out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -645,7 +700,7 @@ def _cached_topology(tri):
 
 class _antialias_func(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, color, rast, pos, tri, adj, boost):
+    def forward(ctx, color, rast, pos, tri, adj, boost, hint, empty_color):
         lib = _lib.load()
         B, H, W, C = color.shape
         V, T = pos.shape[1], tri.shape[0]
@@ -654,7 +709,8 @@ class _antialias_func(torch.autograd.Function):
         sil = torch.empty(B, T, dtype=torch.uint8, device=dev)
         flags = torch.empty(lib.fpcdr_antialias_flags_bytes(B, H, W) // 8, dtype=torch.int64, device=dev)
         p = _lib.AntialiasFwd(color=_ptr(color), rast=_ptr(rast), pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), B=B, H=H,
-                              W=W, C=C, V=V, T=T, sil=_ptr(sil), flags=_ptr(flags), out=_ptr(out))
+                              W=W, C=C, V=V, T=T, sil=_ptr(sil), flags=_ptr(flags), out=_ptr(out), hint=_ptr(hint),
+                              empty_color=_ptr(empty_color))
         _lib.call("fpcdr_antialias_fwd", ctypes.byref(p), _stream())
         ctx.save_for_backward(color, rast, pos, tri, adj, sil, flags)
         ctx.boost = float(boost)
@@ -673,7 +729,7 @@ class _antialias_func(torch.autograd.Function):
                               B=B, H=H, W=W, C=C, V=V, T=T, sil=_ptr(sil), flags=_ptr(flags),
                               pos_gradient_boost=ctx.boost, grad_color=_ptr(g_color), grad_pos=_ptr(g_pos))
         _lib.call("fpcdr_antialias_bwd", ctypes.byref(p), _stream())
-        return g_color, None, g_pos, None, None, None
+        return g_color, None, g_pos, None, None, None, None, None
 
 
 def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
@@ -698,4 +754,9 @@ def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0)
         _check_tensor('topology_hash', adj, torch.int32, 2)
         if adj.shape != tri.shape:
             raise ValueError("topology_hash does not belong to this tri tensor")
-    return _antialias_func.apply(color.contiguous(), rast.contiguous(), pos.contiguous(), tri, adj, pos_gradient_boost)
+    hr = _hint_of(rast, 'rast')
+    hc = _hint_of(color, 'const') if hr else None
+    if hc is not None and hc[0] is not hr[0]:     # a colour image from another rasterisation
+        hc = None
+    return _antialias_func.apply(color.contiguous(), rast.contiguous(), pos.contiguous(), tri, adj, pos_gradient_boost,
+                                 hr[0] if hr else None, hc[1] if hc else None)

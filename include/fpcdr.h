@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FPCDR_ABI_VERSION 3
+#define FPCDR_ABI_VERSION 4
 
 enum {
     FPCDR_OK = 0,
@@ -43,6 +43,15 @@ const char *fpcdr_last_error(void);
 /* rasterize -- dr.rasterize(glctx, pos, tri, resolution)        reference fit.py:151 (ctx :484) */
 /* ------------------------------------------------------------------------------------------ */
 
+/* REGION HINTS.  A face rig covers ~12 % of a 1080p frame; the other pixels of rast are zero, of the texture-coordinate image
+ * zero, of the colour image one constant.  fpcdr_rasterize_fwd can leave a map of that: two planes of B x OY x OX bytes
+ * (OY, OX = FPCDR_OCC_DIM(H), (W): 32 x 32-pixel bins); plane 0: 1 = some triangle's bounding box touches the bin (else every
+ * pixel of the bin is EMPTY); plane 1: plane 0 OR-ed over the 3 x 3 neighbourhood.  An operator that is handed the hint of its
+ * input (`hint` fields below; NULL = none) does not READ that input in empty bins -- it writes what the input implies -- which
+ * halves the HBM traffic of the operator chain of fit.py:151-160.  Results are identical with and without hints.  A hint is
+ * valid only for the very tensor it was produced with (the Python binding drops it when the tensor was modified). */
+#define FPCDR_HINT_BYTES(B, H, W) ((size_t)2 * (B) * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W))
+
 /* bytes of scratch fpcdr_rasterize_fwd needs for B images of T triangles */
 size_t fpcdr_rasterize_scratch_bytes(int32_t B, int32_t T);
 
@@ -53,6 +62,7 @@ typedef struct {
     void *scratch;        /* fpcdr_rasterize_scratch_bytes(B,T) bytes, 16-byte aligned */
     float *rast;          /* out [B,H,W,4] = (u, v, z/w, triangle index + 1; 0 = empty) */
     float *rast_db;       /* out [B,H,W,4] = (du/dx, du/dy, dv/dx, dv/dy) per pixel, or NULL */
+    uint8_t *hint;        /* optional out, FPCDR_HINT_BYTES(B,H,W): REGION HINT of rast (see below), or NULL */
 } fpcdr_rasterize_fwd_params;
 int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *stream);
 
@@ -64,6 +74,7 @@ typedef struct {
     const float *ddb;     /* [B,H,W,4] dL/d rast_db, or NULL */
     int32_t B, V, T, H, W;
     float *grad_pos;      /* [B,V,4] accumulated (x, y, w components; z receives nothing) */
+    const uint8_t *hint;  /* optional: region hint of rast (empty bins are skipped without reading dy / rast) */
 } fpcdr_rasterize_bwd_params;
 int fpcdr_rasterize_bwd(const fpcdr_rasterize_bwd_params *p, void *stream);
 
@@ -215,6 +226,7 @@ typedef struct {
     int32_t diff_idx[FPCDR_MAX_ATTR];   /* their indices into A (diff_attrs='all' -> 0..A-1) */
     float *out;           /* out [B,H,W,A] */
     float *out_da;        /* out [B,H,W,2*n_diff] = (da/dx, da/dy) per selected attribute, or NULL */
+    const uint8_t *hint;  /* optional: region hint of rast -- empty bins are written as zeros without reading rast */
 } fpcdr_interpolate_fwd_params;
 int fpcdr_interpolate_fwd(const fpcdr_interpolate_fwd_params *p, void *stream);
 
@@ -230,6 +242,7 @@ typedef struct {
     float *grad_attr;     /* [Ba,Vt,A] accumulated, or NULL (attr needs no gradient, as in fit.py:431) */
     float *grad_rast;     /* out [B,H,W,4] (.z .w are written as 0) */
     float *grad_rast_db;  /* out [B,H,W,4], or NULL when n_diff == 0 */
+    const uint8_t *hint;  /* optional: region hint of rast -- empty bins get zero gradients without reading dy / rast */
 } fpcdr_interpolate_bwd_params;
 int fpcdr_interpolate_bwd(const fpcdr_interpolate_bwd_params *p, void *stream);
 
@@ -258,6 +271,9 @@ typedef struct {
     int32_t B, H, W, Bt, Ht, Wt, C;
     int32_t filter_mode, boundary_mode;
     float *out;                           /* out [B,H,W,C] */
+    const uint8_t *hint;                  /* optional (filter nearest / linear, Bt = 1): region hint of uv -- uv is (0,0) in empty
+                                             bins, which get the texture's value there without reading uv */
+    float *empty_color;                   /* with hint: out [C], that value (the hint of `out` for fpcdr_antialias_fwd) */
 } fpcdr_texture_fwd_params;
 int fpcdr_texture_fwd(const fpcdr_texture_fwd_params *p, void *stream);
 
@@ -301,6 +317,10 @@ typedef struct {
     uint8_t *sil;         /* scratch+saved [B,T]: per image, bit e set = edge e of t is a silhouette edge */
     uint64_t *flags;      /* saved, fpcdr_antialias_flags_bytes(): plane 0 = pair (p, p+x) blended, plane 1 = (p, p+y) */
     float *out;           /* out [B,H,W,C] */
+    const uint8_t *hint;  /* optional: region hint of rast.  Where a bin and its eight neighbours are empty no pixel pair can be
+                             blended: out = color there without reading rast */
+    const float *empty_color; /* optional, with hint: [C], the value of `color` in empty bins (fpcdr_texture_fwd): it is then not
+                             read there either */
 } fpcdr_antialias_fwd_params;
 int fpcdr_antialias_fwd(const fpcdr_antialias_fwd_params *p, void *stream);
 

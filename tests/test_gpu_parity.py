@@ -236,3 +236,69 @@ def test_rasterize_depth_ties_go_to_the_smaller_index(dr, ctx, oracle_ops):
         first[src[j]] = min(first[src[j]], j)
     win = ids[ids > 0].long() - 1
     assert torch.equal(first[src[win]], win)
+
+
+@pytest.mark.parametrize("C,res", [(1, (150, 200)), (3, (97, 131))])
+def test_region_hints_do_not_change_the_operator_chain(dr, oracle_ops, C, res):
+    """rasterize() tags its output with the map of bins no triangle touches; interpolate / texture / antialias and the
+    backward kernels then skip the reads of those bins (include/fpcdr.h, REGION HINTS).  With and without the mechanism the
+    chain of fit.py:151-160 gives bit-identical images and the same gradients -- also when a caller edits a tensor in
+    between (the hint is then dropped) or feeds the operators tensors that never carried one."""
+    from fpc_diffrend_amd import scene
+    sc = scene.cfg('cfg1', n_frames=2)
+    pos, _ = clip_positions(sc, [0, 3, 7], frames=[0, 1])
+    dev = 'cuda'
+    tri = torch.tensor(sc.pos_idx, device=dev)
+    uv = torch.tensor(sc.uv, device=dev) * 1.1 + 0.03
+    uv_idx = torch.tensor(sc.uv_idx, device=dev)
+    g = torch.Generator().manual_seed(2)
+    tex0 = torch.rand(48, 64, C, generator=g)
+    gy = torch.randn(pos.shape[0], res[0], res[1], C, generator=g).to(dev)
+
+    def chain(hints, edit=False):
+        dr.region_hints = hints
+        try:
+            ctx = dr.RasterizeGLContext(device=dev)
+            p = pos.to(dev).clone().requires_grad_(True)
+            t = tex0.to(dev).clone().requires_grad_(True)
+            if edit:
+                with torch.no_grad():                   # (no graph through the edited tensor)
+                    rast, _ = dr.rasterize(ctx, p, tri, res)
+                    assert (dr._hint_of(rast, 'rast') is not None) == hints
+                    rast[0, :40, :40, 3] = 0.0          # wipe a corner: the version counter moves, the hint must go
+                assert dr._hint_of(rast, 'rast') is None
+            else:
+                rast, _ = dr.rasterize(ctx, p, tri, res)
+            tagged = dr._hint_of(rast, 'rast') is not None
+            texc, _ = dr.interpolate(uv[None], rast, uv_idx)
+            col = dr.texture(t[None], texc, filter_mode='linear')
+            aa = dr.antialias(col, rast, p, tri)
+            (aa * gy).sum().backward()
+            return tagged, [x.detach().clone() for x in (rast, texc, col, aa)], p.grad.clone(), t.grad.clone()
+        finally:
+            dr.region_hints = True
+
+    on, imgs_on, gp_on, gt_on = chain(True)
+    off, imgs_off, gp_off, gt_off = chain(False)
+    assert on and not off
+    cov = (imgs_on[0][..., 3] > 0).float().mean().item()
+    assert 0.02 < cov < 0.9          # both empty and covered bins exist
+    for a, b in zip(imgs_on, imgs_off):
+        assert torch.equal(a, b)
+    assert rel_l2(gp_on, gp_off) < 1e-6 and rel_l2(gt_on, gt_off) < 1e-5
+    # an edited rast: same result as the dense path on the same edit
+    _, imgs_e, gp_e, gt_e = chain(True, edit=True)
+    _, imgs_d, gp_d, gt_d = chain(False, edit=True)
+    for a, b in zip(imgs_e, imgs_d):
+        assert torch.equal(a, b)
+    assert rel_l2(gp_e, gp_d) < 1e-6 and rel_l2(gt_e, gt_d) < 1e-5
+    assert not torch.equal(imgs_e[3], imgs_on[3])
+    # foreign tensors (a clone carries no hint) take the dense path and agree
+    dr.region_hints = True
+    ctx = dr.RasterizeGLContext(device=dev)
+    rast, _ = dr.rasterize(ctx, pos.to(dev), tri, res)
+    texc, _ = dr.interpolate(uv[None], rast.clone(), uv_idx)
+    assert dr._hint_of(texc, 'zero') is None and torch.equal(texc, imgs_on[1])
+    # ... and against the oracle
+    r_ref, _ = oracle_ops.rasterize(pos, tri.cpu(), res)
+    assert torch.equal(imgs_on[0][..., 3].cpu(), r_ref[..., 3])

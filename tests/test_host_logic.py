@@ -127,9 +127,31 @@ def test_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} not exported"
     assert _lib.load().fpcdr_abi_version() == _lib.ABI_VERSION
-    # struct sizes agree with the C layout (spot check via the compiler)
-    assert ctypes.sizeof(_lib.RasterizeFwd) == 64
-    assert ctypes.sizeof(_lib.InterpolateFwd) == 4 * 8 + 8 * 4 + 32 * 4 + 2 * 8
+    # every parameter struct of the header has the size (and so the trailing-field layout) of its ctypes mirror: ask the C
+    # compiler
+    import subprocess
+    import tempfile
+    pairs = {"fpcdr_rasterize_fwd_params": _lib.RasterizeFwd, "fpcdr_rasterize_bwd_params": _lib.RasterizeBwd,
+             "fpcdr_render_fwd_params": _lib.RenderFwd, "fpcdr_render_bwd_params": _lib.RenderBwd,
+             "fpcdr_aa_loss_fwd_params": _lib.AaLossFwd, "fpcdr_render_aa_bwd_params": _lib.RenderAaBwd,
+             "fpcdr_interpolate_fwd_params": _lib.InterpolateFwd, "fpcdr_interpolate_bwd_params": _lib.InterpolateBwd,
+             "fpcdr_texture_fwd_params": _lib.TextureFwd, "fpcdr_texture_bwd_params": _lib.TextureBwd,
+             "fpcdr_antialias_fwd_params": _lib.AntialiasFwd, "fpcdr_antialias_bwd_params": _lib.AntialiasBwd,
+             "fpcdr_pixel_loss_params": _lib.PixelLoss}
+    structs = set(re.findall(r"\}\s*(fpcdr_[a-z0-9_]+_params)\s*;", header))
+    assert structs == set(pairs), structs ^ set(pairs)
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "sz.c")
+        with open(src, "w") as f:
+            f.write('#include <stdio.h>\n#include "fpcdr.h"\nint main(void) {\n')
+            for name in sorted(pairs):
+                f.write(f'    printf("{name} %zu\\n", sizeof({name}));\n')
+            f.write("    return 0;\n}\n")
+        exe = os.path.join(td, "sz")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        sizes = dict(l.split() for l in subprocess.check_output([exe]).decode().splitlines())
+    for name, cls in pairs.items():
+        assert ctypes.sizeof(cls) == int(sizes[name]), (name, ctypes.sizeof(cls), sizes[name])
 
 
 def test_ops_reject_cpu_tensors_and_missing_gpu():
