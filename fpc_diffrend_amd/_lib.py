@@ -57,7 +57,7 @@ class RenderAaBwd(ctypes.Structure):
                 ("grad_aa", _p), ("sil", _p), ("flags", _p), ("occ", _p), ("empty_color", _p), ("B", _i), ("V", _i), ("T", _i),
                 ("H", _i), ("W", _i),
                 ("Vt", _i), ("Ht", _i), ("Wt", _i), ("C", _i), ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p),
-                ("tri_uv", _p), ("upstream", _p), ("queued", _i), ("cap_bwd", _i)]
+                ("tri_uv", _p), ("upstream", _p), ("queued", _i), ("cap_bwd", _i), ("binflags", _i)]
 
 
 class InterpolateFwd(ctypes.Structure):

@@ -40,11 +40,12 @@ int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask
 #define FPCDR_SWEEP_WGS 256
 
 // Byte offsets inside the two buffers of the sparse objective (include/fpcdr.h: fpcdr_occ_bytes / fpcdr_cmask_bytes).
-//   occ   (saved for the backward call): window masks u16[nb] | raw occupancy u8[nb] | header i32[16] | backward bin list i32[nb]
+//   occ   (saved for the backward call): window masks u16[nb] | raw occupancy u8[nb] | "bin holds antialias flags" u8[nb] |
+//         header i32[16] | backward bin list i32[nb]
 //   cmask (forward scratch): candidate row masks u32[nb*32] | border lines u64[nb*128] | header i32[16] | live bin list i32[nb] |
 //         antialias-fix bin list i32[nb] | live map u8[nb] | per-block counts i32[2][ceil(nb / 256)]
 struct fpcdr_queue_layout {
-    size_t occ_raw, occ_hdr, occ_bwd_list, occ_bytes;
+    size_t occ_raw, occ_binflag, occ_hdr, occ_bwd_list, occ_bytes;
     size_t cm_edges, cm_hdr, cm_bin_list, cm_fix_list, cm_live, cm_blk, cm_bytes;
 };
 static inline fpcdr_queue_layout fpcdr_queue_layout_of(int B, int H, int W) {
@@ -52,7 +53,8 @@ static inline fpcdr_queue_layout fpcdr_queue_layout_of(int B, int H, int W) {
     const size_t nb4 = (nb + 3) / 4 * 4;
     fpcdr_queue_layout q;
     q.occ_raw = 2 * nb;
-    q.occ_hdr = (3 * nb + 3) / 4 * 4;
+    q.occ_binflag = 3 * nb;
+    q.occ_hdr = (4 * nb + 3) / 4 * 4;
     q.occ_bwd_list = q.occ_hdr + 64;
     q.occ_bytes = q.occ_bwd_list + 4 * nb;
     q.cm_edges = nb * 128;
@@ -84,6 +86,30 @@ static inline int fpcdr_cu_count() {
 __device__ __forceinline__ bool fpcdr_hint_on(const uint8_t *__restrict__ hint, int plane, int B, int H, int W, int b, int y, int x) {
     const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
     return hint[(((size_t)plane * B + b) * OY + (y >> 5)) * OX + (x >> 5)] != 0;
+}
+
+// ---- LDS float accumulation ------------------------------------------------------------------
+// ds_add_f32 costs 3 cycles PER ACTIVE LANE on gfx950 (192 cycles for a full wave, whatever the addresses), while integer LDS
+// atomics run at 6-11 cycles per wave-instruction (scripts/micro/lds_atomic_bench.hip: int add 5.7, u64 min 7.9, 32-bit
+// compare-and-swap 11.4).  A float add built from a read and a compare-and-swap loop is therefore several times faster; lanes
+// that share an address simply go round again.
+__device__ __forceinline__ void lds_add_f32(float *addr, float v) {
+    unsigned int *a = reinterpret_cast<unsigned int *>(addr);
+    unsigned int old = *a, assumed;
+    do {
+        assumed = old;
+        old = atomicCAS(a, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+    } while (old != assumed);
+}
+// two adjacent floats (8-byte aligned) in one 64-bit compare-and-swap
+__device__ __forceinline__ void lds_add_f32x2(float *addr, float vx, float vy) {
+    unsigned long long *a = reinterpret_cast<unsigned long long *>(addr);
+    unsigned long long old = *a, assumed;
+    do {
+        assumed = old;
+        const float x = __uint_as_float((unsigned int)assumed) + vx, y = __uint_as_float((unsigned int)(assumed >> 32)) + vy;
+        old = atomicCAS(a, assumed, ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x));
+    } while (old != assumed);
 }
 
 // ---- wave-level helpers ---------------------------------------------------------------------

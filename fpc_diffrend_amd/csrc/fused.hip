@@ -276,9 +276,9 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                                                        int B, int V, int T, int H,
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
-                                                       const float *__restrict__ upstream) {
+                                                       const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
     __shared__ int s_vkey[VSLOTS];
-    __shared__ float s_vacc[VSLOTS][4];
+    __shared__ __attribute__((aligned(16))) float s_vacc[VSLOTS][4];
     __shared__ float s_tex[TEXH * TEXW * CS];
     __shared__ int s_org[2];            // smallest tap x, y of the bin (unwrapped texel coordinates)
     __shared__ float s_esum[CS];        // gradient arriving at EMPTY pixels' colour (they all sample uv = (0,0))
@@ -306,6 +306,17 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
     const bool v_me = ow.bin(0, 0);
     const size_t img = (size_t)b * H * W;
     const float up = upstream ? upstream[0] : 1.0f;   // d(final loss)/d(this objective), a device scalar
+    // flag words are loaded only where this bin, its left or its lower neighbour holds a blended pair (binflag: per-bin summary
+    // written by k_aa_fix; null = unknown, load everywhere)
+    bool flags_here = true;
+    if (binflag) {
+        const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
+        const size_t bl = ((size_t)b * OY + byi) * OX + bxi;
+        unsigned int f = binflag[bl];
+        if (bxi > 0) f |= binflag[bl - 1];
+        if (byi > 0) f |= binflag[bl - OX];
+        flags_here = __builtin_amdgcn_readfirstlane((int)f) != 0;
+    }
     if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
     if (tid < CS) s_esum[tid] = 0.0f;
     // (both are read only behind the barriers below; in the work-queue form the pop's barriers separate one bin's reads from
@@ -325,10 +336,13 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
             const size_t plane = (size_t)B * H * Wq;
             const size_t wi = ((size_t)b * H + y) * Wq + (x >> 6);
             const int bit = x & 63;
-            const unsigned long long fxw = flags[wi], fyw = flags[plane + wi];
-            const bool own_x = (fxw >> bit) & 1ull, own_y = (fyw >> bit) & 1ull;
-            const bool left_x = bit > 0 ? ((fxw >> (bit - 1)) & 1ull) : (x > 0 ? ((flags[wi - 1] >> 63) & 1ull) : false);
-            const bool down_y = y > 0 ? ((flags[plane + wi - Wq] >> bit) & 1ull) : false;
+            bool own_x = false, own_y = false, left_x = false, down_y = false;
+            if (flags_here) {
+                const unsigned long long fxw = flags[wi], fyw = flags[plane + wi];
+                own_x = (fxw >> bit) & 1ull; own_y = (fyw >> bit) & 1ull;
+                left_x = bit > 0 ? ((fxw >> (bit - 1)) & 1ull) : (x > 0 ? ((flags[wi - 1] >> 63) & 1ull) : false);
+                down_y = y > 0 ? ((flags[plane + wi - Wq] >> bit) & 1ull) : false;
+            }
             const size_t off = img + (size_t)y * W + x;
 #pragma unroll
             for (int c = 0; c < CS; ++c) { go[k][c] = v_me ? g_aa[off * CS + c] * up : 0.0f; any[k] |= (go[k][c] != 0.0f); }
@@ -481,10 +495,10 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
 #endif
                     if (in_win) {
                         float *w = s_tex + (ly * TEXW + lx) * CS + c;
-                        atomicAdd(w, gc * w00);
-                        atomicAdd(w + CS, gc * w10);
-                        atomicAdd(w + TEXW * CS, gc * w01);
-                        atomicAdd(w + TEXW * CS + CS, gc * w11);
+                        lds_add_f32(w, gc * w00);
+                        lds_add_f32(w + CS, gc * w10);
+                        lds_add_f32(w + TEXW * CS, gc * w01);
+                        lds_add_f32(w + TEXW * CS + CS, gc * w11);
                     } else {
                         atomicAdd(grad_tex + tp.i00 + c, gc * w00);
                         atomicAdd(grad_tex + tp.i10 + c, gc * w10);
@@ -510,6 +524,12 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
         int vk[3] = {0, 0, 0};   // the triangle's vertex ids: the run's last lane emits with them
         if (tkey >= 0) {
             vk[0] = tri[3 * tkey]; vk[1] = tri[3 * tkey + 1]; vk[2] = tri[3 * tkey + 2];
+#ifdef FPCDR_ABL_NOSHADEBWD
+            gv9[0] = gu; gv9[4] = gvv;
+            if (false) {
+#else
+            {
+#endif
             const float4 *p = pos + (size_t)b * V;
             const float fx = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
             const float fy = (2.0f * (float)(by0 + rowk0 + 2 * k) + 1.0f) / (float)H - 1.0f;
@@ -519,7 +539,12 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
             gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
             gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
             gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
+            }
         }
+#ifdef FPCDR_ABL_NOVERT
+        { float sink = 0.f; for (int q = 0; q < 9; ++q) sink += gv9[q]; asm volatile("" :: "v"(sink)); }
+        if (false)
+#endif
         wave_segment_reduce<9>(tkey, gv9, [&](int, const float (&sm)[9]) {
             // the three slots are claimed with three INDEPENDENT compare-and-swaps in flight (one LDS round trip instead of
             // three); only a vertex whose home slot is taken by another walks on
@@ -539,8 +564,8 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                     done = (o == -1 || o == key);
                 }
                 if (done) {
-                    atomicAdd(&s_vacc[slot[kk]][0], sm[3 * kk]); atomicAdd(&s_vacc[slot[kk]][1], sm[3 * kk + 1]);
-                    atomicAdd(&s_vacc[slot[kk]][3], sm[3 * kk + 2]);
+                    lds_add_f32x2(&s_vacc[slot[kk]][0], sm[3 * kk], sm[3 * kk + 1]);
+                    lds_add_f32(&s_vacc[slot[kk]][3], sm[3 * kk + 2]);
                 } else {   // table full: straight to memory
                     atomicAdd(gp + 4 * (size_t)key + 0, sm[3 * kk]); atomicAdd(gp + 4 * (size_t)key + 1, sm[3 * kk + 1]);
                     atomicAdd(gp + 4 * (size_t)key + 3, sm[3 * kk + 2]);
@@ -596,9 +621,9 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
                                                        int B, int V, int T, int H,
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
-                                                       const float *__restrict__ upstream) {
+                                                       const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
     render_aa_bwd_body<CS>(blockIdx.z, blockIdx.x, blockIdx.y, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ, empty_color,
-                           B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream);
+                           B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag);
 }
 
 // list form (after fpcdr_render_loss_fwd): one workgroup per entry of the list k_occ_window built (own or a 4-neighbour bin
@@ -615,13 +640,13 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd_list(con
                                                        int B, int V, int T, int H,
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
-                                                       const float *__restrict__ upstream) {
+                                                       const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
     const int item = blockIdx.x;
     if (item >= *count) return;
     const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
     const int lin = __builtin_amdgcn_readfirstlane(list[item]);
     render_aa_bwd_body<CS>(lin / (OX * OY), lin % OX, (lin / OX) % OY, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ,
-                           empty_color, B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream);
+                           empty_color, B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag);
 }
 
 #ifndef FPCDR_BWDQ_WPE
@@ -640,13 +665,13 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWDQ_WPE k_render_aa_bwd_queue(c
                                                        int B, int V, int T, int H,
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
-                                                       const float *__restrict__ upstream) {
+                                                       const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
     const int n = *count;
     const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
     for (int item = first + blockIdx.x; item < n; item += gridDim.x) {      // scalar loop variable: uniform for the compiler
         const int lin = __builtin_amdgcn_readfirstlane(list[item]);
         render_aa_bwd_body<CS>(lin / (OX * OY), lin % OX, (lin / OX) % OY, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ,
-                               empty_color, B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream);
+                               empty_color, B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag);
         __syncthreads();     // the next bin's first LDS writes must not overtake this bin's last LDS reads
     }
 }
@@ -668,7 +693,7 @@ __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const in
                                             unsigned long long *__restrict__ flags, float *__restrict__ g_aa,
                                             const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
                                             const uint32_t *__restrict__ cmask, const unsigned long long *__restrict__ edges,
-                                            double *__restrict__ loss_sum) {
+                                            double *__restrict__ loss_sum, uint8_t *__restrict__ binflag) {
     __shared__ unsigned int s_mask[BBIN];
     __shared__ int s_list[BBIN * BBIN];
     __shared__ int s_n;
@@ -731,6 +756,7 @@ __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const in
     const size_t plane = (size_t)B * H * Wq;
     const AAGeom g = {pos + (size_t)b * V, tri, silb, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
     float lsum = 0.0f;
+    bool any_flag = false;
     for (int i = tid; i < n; i += 256) {
         const int pix = s_list[i];
         const int x = bx0 + (pix & 31), y = by0 + (pix >> 5);
@@ -758,7 +784,11 @@ __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const in
         const size_t wi = ((size_t)b * H + y) * Wq + (x >> 6);
         if (fx_flag) atomicOr(flags + wi, 1ull << (x & 63));
         if (fy_flag) atomicOr(flags + plane + wi, 1ull << (x & 63));
+        any_flag |= fx_flag | fy_flag;
     }
+    // per-bin summary of the flag planes (zero-filled by the caller's k_init_queue): the backward kernel loads flag words only
+    // where a bin or its left / lower neighbour holds a blended pair -- one bin in seven on a face rig
+    if (__builtin_amdgcn_readfirstlane(__syncthreads_or(any_flag ? 1 : 0)) && tid == 0) binflag[bin_id] = 1;
     lsum = wave_sum_dpp(lsum);
     if (lane == 0) s_part[wave] = lsum;
     __syncthreads();
@@ -775,9 +805,9 @@ __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const in
     const uint8_t *__restrict__ sil, const uint8_t *__restrict__ ref, int B, int H, int W, int V, int T, float bg, float color_scale,  \
     float grad_scale, unsigned long long *__restrict__ flags, float *__restrict__ g_aa, const uint16_t *__restrict__ occ,              \
     const float *__restrict__ empty_color, const uint32_t *__restrict__ cmask, const unsigned long long *__restrict__ edges,           \
-    double *__restrict__ loss_sum
+    double *__restrict__ loss_sum, uint8_t *__restrict__ binflag
 #define FPCDR_AA_FIX_PASS                                                                                                       \
-    color, rast, pos, tri, sil, ref, B, H, W, V, T, bg, color_scale, grad_scale, flags, g_aa, occ, empty_color, cmask, edges, loss_sum
+    color, rast, pos, tri, sil, ref, B, H, W, V, T, bg, color_scale, grad_scale, flags, g_aa, occ, empty_color, cmask, edges, loss_sum, binflag
 template <int CS>
 __global__ void __launch_bounds__(256) k_aa_fix_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, FPCDR_AA_FIX_ARGS) {
     const int item = blockIdx.x;
@@ -849,7 +879,8 @@ int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask
     const int cap = (p->cap_fix > 0 && p->cap_fix < nbins) ? p->cap_fix : nbins;
 #define ARGS                                                                                                                   \
     p->color, (const float4 *)p->rast, (const float4 *)p->pos, p->tri, p->sil, p->ref, p->B, p->H, p->W, p->V, p->T, p->bg,   \
-    p->color_scale, p->grad_scale, (unsigned long long *)p->flags, p->grad_aa, p->occ, p->empty_color, cmask, edges, p->loss_sum
+    p->color_scale, p->grad_scale, (unsigned long long *)p->flags, p->grad_aa, p->occ, p->empty_color, cmask, edges, p->loss_sum,   \
+    (uint8_t *)p->occ + fpcdr_queue_layout_of(p->B, p->H, p->W).occ_binflag
 #define LAUNCH(CS)                                                                                                             \
     do {                                                                                                                       \
         hipLaunchKernelGGL(k_aa_fix_list<CS>, dim3(cap), dim3(256), 0, st, fix_list, fix_count, ARGS);                        \
@@ -916,8 +947,9 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
     FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
     FPCDR_REQUIRE(!p->occ || p->empty_color, "sparse mode needs empty_color");
     hipStream_t st = (hipStream_t)stream;
+    FPCDR_REQUIRE(!(p->queued || p->binflags) || p->occ != nullptr, "queued / binflags need the occupancy buffer of fpcdr_render_loss_fwd");
+    const uint8_t *binflag = p->binflags ? (const uint8_t *)p->occ + fpcdr_queue_layout_of(p->B, p->H, p->W).occ_binflag : nullptr;
     if (p->queued) {
-        FPCDR_REQUIRE(p->occ != nullptr, "queued = 1 needs the occupancy buffer of fpcdr_render_loss_fwd");
         const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W);
         const int32_t *hdr = (const int32_t *)((const char *)p->occ + q.occ_hdr);      // [0] = number of listed bins
         const int32_t *list = (const int32_t *)((const char *)p->occ + q.occ_bwd_list);
@@ -926,7 +958,7 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
 #define ARGSQ                                                                                                               \
         (const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa,  \
         p->sil, (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,        \
-        p->boundary_mode, p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream
+        p->boundary_mode, p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream, binflag
 #define LAUNCHQ(CS)                                                                                                         \
         do {                                                                                                                \
             hipLaunchKernelGGL(k_render_aa_bwd_list<CS>, dim3(cap), dim3(BWD_NT), 0, st, list, hdr, ARGSQ);                  \
@@ -947,7 +979,7 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
                        (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa, p->sil,     \
                        (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,   \
                        p->boundary_mode,                                                                                        \
-                       p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream)
+                       p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream, binflag)
     if (p->C == 1) LAUNCH(1);
     else if (p->C == 3) LAUNCH(3);
     else LAUNCH(4);

@@ -319,7 +319,7 @@ class _pixel_objective_func(torch.autograd.Function):
             _lib.call("fpcdr_render_loss_fwd", ctypes.byref(p), ctypes.byref(q), _ptr(cmask), _stream())
             if hints is not None:
                 nb = B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN)
-                off = (3 * nb + 3) // 4 * 4                       # FPCDR_OCC_COUNTS_OFFSET
+                off = (4 * nb + 3) // 4 * 4                       # FPCDR_OCC_COUNTS_OFFSET
                 hints.update(occ[off:off + 16].view(torch.int32))
         else:
             _lib.call("fpcdr_render_fwd", ctypes.byref(p), _stream())
@@ -331,6 +331,7 @@ class _pixel_objective_func(torch.autograd.Function):
         # nothing from it (2.69 vs 2.64 ms: its dead workgroups' dispatch hides behind the live ones' work), so the grid form is
         # the default and the list form stays selectable
         ctx.queued = 1 if (sparse and queued_backward) else 0
+        # (sparse => the one-call forward, which also leaves the per-bin summary of the antialias flags in `occ`)
         total = acc.sum()
         if sparse:
             # the kernel summed only the difference to an all-background image; the rest depends on ref alone
@@ -353,7 +354,7 @@ class _pixel_objective_func(torch.autograd.Function):
                              T=tri.shape[0],
                              H=H, W=W, Vt=uv.shape[0], Ht=Ht, Wt=Wt, C=C, boundary_mode=ctx.boundary, grad_pos=_ptr(g_pos),
                              grad_tex=_ptr(g_tex), tri_uv=_ptr(tri_uv), upstream=_ptr(g),    # g: applied inside the kernel
-                             queued=ctx.queued, cap_bwd=ctx.cap_bwd)
+                             queued=ctx.queued, cap_bwd=ctx.cap_bwd, binflags=1 if occ is not None else 0)
         _lib.call("fpcdr_render_aa_bwd", ctypes.byref(p), _stream())
         if not ctx.needs_input_grad[0]:
             g_pos = None

@@ -134,7 +134,7 @@ int fpcdr_render_bwd(const fpcdr_render_bwd_params *p, void *stream);
 /* After fpcdr_render_loss_fwd, int32 counts[4] at byte offset FPCDR_OCC_COUNTS_OFFSET(B,H,W) of occ hold: [0] bins the backward
  * call visits, [2] live bins of the rasteriser, [3] bins of the antialias pass -- what a caller feeds back (with a margin) as
  * cap_bwd / cap_bins / cap_fix of its NEXT calls. */
-#define FPCDR_OCC_COUNTS_OFFSET(B, H, W) ((((size_t)(B) * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W) * 3) + 3) / 4 * 4)
+#define FPCDR_OCC_COUNTS_OFFSET(B, H, W) ((((size_t)(B) * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W) * 4) + 3) / 4 * 4)
 size_t fpcdr_occ_bytes(int32_t B, int32_t H, int32_t W);
 size_t fpcdr_cmask_bytes(int32_t B, int32_t H, int32_t W);
 
@@ -207,6 +207,8 @@ typedef struct {
     int32_t queued;        /* 1: occ was filled by fpcdr_render_loss_fwd -- visit only the bins on its list;
                               0: one workgroup per bin of the batch (dense mode, or occ from fpcdr_render_fwd) */
     int32_t cap_bwd;       /* queued = 1: launch-size hint for the list kernel, as cap_bins above (0 = none) */
+    int32_t binflags;      /* 1: occ was filled by fpcdr_render_loss_fwd, which also left a per-bin summary of the flag planes:
+                              flag words are then loaded only near bins that hold a blended pair */
 } fpcdr_render_aa_bwd_params;
 int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *stream);
 
