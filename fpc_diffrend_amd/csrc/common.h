@@ -200,13 +200,15 @@ __device__ __forceinline__ void wave_group_reduce(int key, const float (&val)[N]
 // 6-step segmented scan (DPP row_shr 1,2,4,8 + row_bcast15/31) whose cost does not depend on the number of segments.
 // Lanes with key < 0 are skipped.  Convergent: every lane of the wave must call it.  Callers order their lanes so that
 // pixels of one triangle sit next to each other (rows of a tile, serpentine).
-template <int N, typename Emit>
+// ROW16: segments are additionally cut at every 16-lane DPP row: four scan steps instead of six (the two cross-row broadcast
+// steps go), at the price of one more tail wherever a run crosses a row boundary.
+template <int N, bool ROW16 = false, typename Emit>
 __device__ __forceinline__ void wave_segment_reduce(int key, const float (&val)[N], Emit &&emit) {
     const int l = lane_id();
     const int prev = __builtin_amdgcn_update_dpp(key, key, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps its own)
-    int f = (l == 0 || prev != key) ? 1 : 0;                                            // segment start
+    int f = ((ROW16 ? (l & 15) == 0 : l == 0) || prev != key) ? 1 : 0;                  // segment start
     const int next = __builtin_amdgcn_update_dpp(key, key, 0x130, 0xF, 0xF, false);   // wave_shl:1 (lane 63 keeps its own)
-    const bool tail = (l == 63 || next != key);
+    const bool tail = ((ROW16 ? (l & 15) == 15 : l == 63) || next != key);
     float v[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = val[i];
@@ -224,10 +226,52 @@ __device__ __forceinline__ void wave_segment_reduce(int key, const float (&val)[
     FPCDR_SEG_STEP(0x112, 0xF)
     FPCDR_SEG_STEP(0x114, 0xF)
     FPCDR_SEG_STEP(0x118, 0xF)
-    FPCDR_SEG_STEP(0x142, 0xA)   // row_bcast15: lane 15 of rows 0, 2 into rows 1, 3
-    FPCDR_SEG_STEP(0x143, 0xC)   // row_bcast31: lane 31 into rows 2, 3
+    if (!ROW16) {
+        FPCDR_SEG_STEP(0x142, 0xA)   // row_bcast15: lane 15 of rows 0, 2 into rows 1, 3
+        FPCDR_SEG_STEP(0x143, 0xC)   // row_bcast31: lane 31 into rows 2, 3
+    }
 #undef FPCDR_SEG_STEP
     if (tail && key >= 0) emit(key, v);
+}
+
+// The same segmented sums for N = 9 with the scan written out as v_fmac_f32_dpp (one instruction per value and step: the
+// shifted neighbour times the lane's 0 / 1 "no segment start since" mask is added in place; v_mul_f32_dpp carries the mask).
+// 6 x 10 instructions instead of ~250 through update_dpp + select + add: the backward kernel is vector-issue bound
+// (profiles/r02: 80 % of the issue slots) and a quarter of its instructions were this scan.  Lanes without a DPP source are
+// disabled for that instruction (no bound_ctrl), which leaves value and mask unchanged -- the neutral element of both.
+template <typename Emit>
+__device__ __forceinline__ void wave_segment_reduce9(int key, const float (&val)[9], Emit &&emit) {
+    const int l = lane_id();
+    const int prev = __builtin_amdgcn_update_dpp(key, key, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps its own)
+    const int next = __builtin_amdgcn_update_dpp(key, key, 0x130, 0xF, 0xF, false);   // wave_shl:1 (lane 63 keeps its own)
+    const bool tail = (l == 63 || next != key);
+    float m = (l == 0 || prev != key) ? 0.0f : 1.0f;      // 1 while no segment start lies between the source lane and this one
+    float v0 = val[0], v1 = val[1], v2 = val[2], v3 = val[3], v4 = val[4], v5 = val[5], v6 = val[6], v7 = val[7], v8 = val[8];
+#define FPCDR_SCAN_STEP(CTRL)                           \
+    "v_fmac_f32_dpp %0, %0, %9 " CTRL "\n\t"            \
+    "v_fmac_f32_dpp %1, %1, %9 " CTRL "\n\t"            \
+    "v_fmac_f32_dpp %2, %2, %9 " CTRL "\n\t"            \
+    "v_fmac_f32_dpp %3, %3, %9 " CTRL "\n\t"            \
+    "v_fmac_f32_dpp %4, %4, %9 " CTRL "\n\t"            \
+    "v_fmac_f32_dpp %5, %5, %9 " CTRL "\n\t"            \
+    "v_fmac_f32_dpp %6, %6, %9 " CTRL "\n\t"            \
+    "v_fmac_f32_dpp %7, %7, %9 " CTRL "\n\t"            \
+    "v_fmac_f32_dpp %8, %8, %9 " CTRL "\n\t"            \
+    "v_mul_f32_dpp %9, %9, %9 " CTRL "\n\t"             \
+    "s_nop 1\n\t"
+    asm volatile("s_nop 1\n\t"        // (a DPP read needs two wait states after the VALU write of its source)
+                 FPCDR_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 FPCDR_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 FPCDR_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 FPCDR_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 FPCDR_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 FPCDR_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(m));
+#undef FPCDR_SCAN_STEP
+    if (tail && key >= 0) {
+        const float v[9] = {v0, v1, v2, v3, v4, v5, v6, v7, v8};
+        emit(key, v);
+    }
 }
 
 // Full-wave integer min / max with DPP (same structure as wave_sum_dpp); result in every lane.

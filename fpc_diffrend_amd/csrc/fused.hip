@@ -545,7 +545,11 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
         { float sink = 0.f; for (int q = 0; q < 9; ++q) sink += gv9[q]; asm volatile("" :: "v"(sink)); }
         if (false)
 #endif
+#ifdef FPCDR_SEG_GENERIC
         wave_segment_reduce<9>(tkey, gv9, [&](int, const float (&sm)[9]) {
+#else
+        wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) {
+#endif
             // the three slots are claimed with three INDEPENDENT compare-and-swaps in flight (one LDS round trip instead of
             // three); only a vertex whose home slot is taken by another walks on
             unsigned int slot[3];

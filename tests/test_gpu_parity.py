@@ -285,13 +285,14 @@ def test_region_hints_do_not_change_the_operator_chain(dr, oracle_ops, C, res):
     assert 0.02 < cov < 0.9          # both empty and covered bins exist
     for a, b in zip(imgs_on, imgs_off):
         assert torch.equal(a, b)
-    assert rel_l2(gp_on, gp_off) < 1e-6 and rel_l2(gt_on, gt_off) < 1e-5
+    # (the corner texels collect the random gradients of every empty pixel: float32 atomic-order noise ~1e-5)
+    assert rel_l2(gp_on, gp_off) < 1e-6 and rel_l2(gt_on, gt_off) < 1e-4
     # an edited rast: same result as the dense path on the same edit
     _, imgs_e, gp_e, gt_e = chain(True, edit=True)
     _, imgs_d, gp_d, gt_d = chain(False, edit=True)
     for a, b in zip(imgs_e, imgs_d):
         assert torch.equal(a, b)
-    assert rel_l2(gp_e, gp_d) < 1e-6 and rel_l2(gt_e, gt_d) < 1e-5
+    assert rel_l2(gp_e, gp_d) < 1e-6 and rel_l2(gt_e, gt_d) < 1e-4
     assert not torch.equal(imgs_e[3], imgs_on[3])
     # foreign tensors (a clone carries no hint) take the dense path and agree
     dr.region_hints = True
