@@ -82,7 +82,7 @@ class TextureBwd(ctypes.Structure):
     _fields_ = [("tex", _p * (MAX_MIP + 1)), ("n_levels", _i), ("uv", _p), ("uv_da", _p), ("mip_level_bias", _p),
                 ("dy", _p), ("B", _i), ("H", _i), ("W", _i), ("Bt", _i), ("Ht", _i), ("Wt", _i), ("C", _i),
                 ("filter_mode", _i), ("boundary_mode", _i), ("grad_tex", _p * (MAX_MIP + 1)), ("grad_uv", _p),
-                ("grad_uv_da", _p), ("grad_mip_level_bias", _p)]
+                ("grad_uv_da", _p), ("grad_mip_level_bias", _p), ("hint", _p)]
 
 
 class AntialiasFwd(ctypes.Structure):

@@ -127,29 +127,6 @@ __device__ __forceinline__ float wave_sum_masked(float v, unsigned long long mas
     return x;
 }
 
-// Group-reduce-then-atomic: lanes of a wave that share `key` (>= 0) sum their `n` values and the
-// group leader issues the atomics.  Lanes with key < 0 do not participate.  All lanes of the wave
-// must call this (convergent).
-template <int N>
-__device__ __forceinline__ void wave_group_atomic_add(int key, float *const (&dst)[N], const float (&val)[N]) {
-    unsigned long long todo = __ballot(key >= 0);
-    int l = lane_id();
-    while (todo) {
-        int leader = __ffsll((long long)todo) - 1;
-        int k = __shfl(key, leader, 64);
-        unsigned long long grp = __ballot(key == k) & todo;
-        bool mine = (grp >> l) & 1ull;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            float x = mine ? val[i] : 0.0f;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
-            if (l == leader && x != 0.0f) atomicAdd(dst[i], x);
-        }
-        todo &= ~grp;
-    }
-}
-
 // Full-wave (64 lanes) f32 sum with DPP row operations (VALU rate; __shfl_xor lowers to ds_bpermute, several
 // times slower).  gfx9 family: row_bcast15 / row_bcast31 exist.  The total is returned in every lane.
 __device__ __forceinline__ float wave_sum_dpp(float v) {
@@ -164,6 +141,28 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false)); x = __float_as_int(v);
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Group-reduce-then-atomic: lanes of a wave that share `key` (>= 0) sum their `n` values and the
+// group leader issues the atomics.  Lanes with key < 0 do not participate.  All lanes of the wave
+// must call this (convergent).  Sums with DPP row operations (the __shfl_xor butterflies this used to run lower to
+// ds_bpermute, several times slower, and made the operator backward kernels LDS-bound).
+template <int N>
+__device__ __forceinline__ void wave_group_atomic_add(int key, float *const (&dst)[N], const float (&val)[N]) {
+    unsigned long long todo = __ballot(key >= 0);
+    const int l = lane_id();
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __builtin_amdgcn_readlane(key, leader);
+        const unsigned long long grp = __ballot(key == k) & todo;
+        const bool mine = (grp >> l) & 1ull;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float x = wave_sum_dpp(mine ? val[i] : 0.0f);
+            if (l == leader && x != 0.0f) atomicAdd(dst[i], x);
+        }
+        todo &= ~grp;
+    }
 }
 
 // Lanes of a wave that share `key` (>= 0) sum their N values; the group's first lane calls emit(key, sums).
@@ -271,6 +270,58 @@ __device__ __forceinline__ void wave_segment_reduce9(int key, const float (&val)
     if (tail && key >= 0) {
         const float v[9] = {v0, v1, v2, v3, v4, v5, v6, v7, v8};
         emit(key, v);
+    }
+}
+
+// ---- per-workgroup vertex-gradient table in LDS (shared by the backward kernels) ------------------------------------
+// Scattered global f32 atomics retire slowly (one per run tail tripled the time of rasterize backward), so a workgroup sums
+// the (x, y, w) gradients of its vertices in a small open-addressed LDS table first and flushes every slot once.
+constexpr int FPCDR_VT_SLOTS = 256;
+struct VTable {
+    int *key;             // [FPCDR_VT_SLOTS], -1 = free
+    float (*acc)[4];      // [FPCDR_VT_SLOTS][4] = (x, y, -, w), 16-byte aligned
+};
+__device__ __forceinline__ void vtable_init(const VTable &t, int tid, int nthreads) {
+    for (int k = tid; k < FPCDR_VT_SLOTS; k += nthreads) {
+        t.key[k] = -1;
+        t.acc[k][0] = 0.f; t.acc[k][1] = 0.f; t.acc[k][2] = 0.f; t.acc[k][3] = 0.f;
+    }
+}
+// add the nine sums of one triangle run (three vertices x (x, y, w)); gp = the image's grad_pos rows
+__device__ __forceinline__ void vtable_add(const VTable &t, float *gp, const int (&vk)[3], const float (&sm)[9]) {
+    unsigned int slot[3];
+    int old[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) slot[kk] = (((unsigned int)vk[kk] * 2654435761u) >> 16) & (FPCDR_VT_SLOTS - 1);
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) old[kk] = atomicCAS(&t.key[slot[kk]], -1, vk[kk]);     // three claims in flight
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+        const int key = vk[kk];
+        bool done = (old[kk] == -1 || old[kk] == key);
+        for (int probe = 1; probe < FPCDR_VT_SLOTS && !done; ++probe) {
+            slot[kk] = (slot[kk] + 1) & (FPCDR_VT_SLOTS - 1);
+            const int o = atomicCAS(&t.key[slot[kk]], -1, key);
+            done = (o == -1 || o == key);
+        }
+        if (done) {
+            lds_add_f32x2(&t.acc[slot[kk]][0], sm[3 * kk], sm[3 * kk + 1]);
+            lds_add_f32(&t.acc[slot[kk]][3], sm[3 * kk + 2]);
+        } else {   // table full: straight to memory
+            atomicAdd(gp + 4 * (size_t)key + 0, sm[3 * kk]); atomicAdd(gp + 4 * (size_t)key + 1, sm[3 * kk + 1]);
+            atomicAdd(gp + 4 * (size_t)key + 3, sm[3 * kk + 2]);
+        }
+    }
+}
+// lane = (slot, component): the four dwords of a vertex are one contiguous 16-byte access
+__device__ __forceinline__ void vtable_flush(const VTable &t, float *gp, int tid, int nthreads) {
+    for (int k = tid; k < FPCDR_VT_SLOTS * 4; k += nthreads) {
+        const int slot = k >> 2, comp = k & 3;
+        const int key = t.key[slot];
+        if (key >= 0) {
+            const float v = t.acc[slot][comp];
+            if (v != 0.0f) atomicAdd(gp + 4 * (size_t)key + comp, v);
+        }
     }
 }
 

@@ -280,26 +280,33 @@ __device__ __forceinline__ float4 interp2_bwd(const float2 *__restrict__ ab, con
 }
 
 __global__ void __launch_bounds__(256) k_interp_bwd_bin2(const float2 *__restrict__ attr, const float4 *__restrict__ rast,
-                                                         const int32_t *__restrict__ tri, const float4 *__restrict__ dy4, int H, int W,
+                                                         const int32_t *__restrict__ tri, const float2 *__restrict__ dy2, int H, int W,
                                                          int B, int Ba, int Vt, int T, float4 *__restrict__ grad_rast,
                                                          const uint8_t *__restrict__ hint) {
+    // rast and grad_rast are 16 bytes per PIXEL: one pixel per lane and instruction is already the widest access, and 32 lanes
+    // of a row segment make it 512 contiguous bytes.  A thread owns pixels (col, rowgroup + 8 k), k = 0..3.
     const int tid = threadIdx.x, b = blockIdx.z;
-    const int px = blockIdx.x * 32 + (tid & 7) * 4, py = blockIdx.y * 32 + (tid >> 3);
-    if (px >= W || py >= H) return;
-    const size_t i = ((size_t)b * H + py) * W + px;
+    const int px = blockIdx.x * 32 + (tid & 31), py0 = blockIdx.y * 32 + (tid >> 5);
+    if (px >= W) return;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (hint && !fpcdr_hint_on(hint, 0, B, H, W, b, py, px)) {       // rast = 0 there: zero gradients, nothing read
-        grad_rast[i] = z; grad_rast[i + 1] = z; grad_rast[i + 2] = z; grad_rast[i + 3] = z;
+    if (hint && !fpcdr_hint_on(hint, 0, B, H, W, b, blockIdx.y * 32, blockIdx.x * 32)) {   // rast = 0 there: zero gradients, nothing read
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (py0 + 8 * k < H) grad_rast[((size_t)b * H + py0 + 8 * k) * W + px] = z;
         return;
     }
-    const float4 r0 = rast[i], r1 = rast[i + 1], r2 = rast[i + 2], r3 = rast[i + 3];
-    float4 g01 = z, g23 = z;
-    if (r0.w > 0.f || r1.w > 0.f || r2.w > 0.f || r3.w > 0.f) { g01 = dy4[i / 2]; g23 = dy4[i / 2 + 1]; }
+    float4 rr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rr[k] = py0 + 8 * k < H ? rast[((size_t)b * H + py0 + 8 * k) * W + px] : z;
     const float2 *ab = attr + (Ba > 1 ? (size_t)b * Vt : 0);
-    grad_rast[i] = interp2_bwd(ab, tri, r0, make_float2(g01.x, g01.y), T);
-    grad_rast[i + 1] = interp2_bwd(ab, tri, r1, make_float2(g01.z, g01.w), T);
-    grad_rast[i + 2] = interp2_bwd(ab, tri, r2, make_float2(g23.x, g23.y), T);
-    grad_rast[i + 3] = interp2_bwd(ab, tri, r3, make_float2(g23.z, g23.w), T);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (py0 + 8 * k >= H) break;
+        const size_t i = ((size_t)b * H + py0 + 8 * k) * W + px;
+        float4 o = z;
+        if (rr[k].w > 0.f) o = interp2_bwd(ab, tri, rr[k], dy2[i], T);
+        grad_rast[i] = o;
+    }
 }
 
 }  // namespace
@@ -352,7 +359,7 @@ extern "C" int fpcdr_interpolate_bwd(const fpcdr_interpolate_bwd_params *p, void
     dim3 grid_rows(fpcdr_cdiv(p->W, 256), fpcdr_cdiv(p->H, SROWS), p->B);
     if (!p->grad_attr && p->A == 2 && p->n_diff == 0 && (p->W & 3) == 0 && (((size_t)p->dy | (size_t)p->attr) & 15) == 0) {
         hipLaunchKernelGGL(k_interp_bwd_bin2, dim3(fpcdr_cdiv(p->W, 32), fpcdr_cdiv(p->H, 32), p->B), dim3(256), 0, st,
-                           (const float2 *)p->attr, (const float4 *)p->rast, p->tri, (const float4 *)p->dy, p->H, p->W, p->B, p->Ba, p->Vt,
+                           (const float2 *)p->attr, (const float4 *)p->rast, p->tri, (const float2 *)p->dy, p->H, p->W, p->B, p->Ba, p->Vt,
                            p->T, (float4 *)p->grad_rast, p->hint);
         FPCDR_CHECK_LAUNCH();
         return FPCDR_OK;

@@ -964,49 +964,67 @@ __global__ void __launch_bounds__(256) k_grad(const float4 *__restrict__ pos, co
                                               const float4 *__restrict__ rast, const float4 *__restrict__ dy,
                                               const float4 *__restrict__ ddb, int B, int V, int T, int H, int W,
                                               float *__restrict__ grad_pos, const uint8_t *__restrict__ hint) {
-    // block = 8 x 8 pixel tile per wave (4 waves = 16 x 16) so that lanes of a wave share triangles
-    if (hint && !fpcdr_hint_on(hint, 0, B, H, W, blockIdx.z, blockIdx.y * 16, blockIdx.x * 16)) return;   // empty bin: nothing to read
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    // One workgroup per 32 x 32-pixel bin, four pixels per thread.  A wave pass covers two adjacent 32-pixel rows, the second
+    // one right to left, so that the pixels of one triangle sit next to each other in lane order: ONE segmented scan sums the
+    // nine gradient components of every run of equal triangle (common.h wave_segment_reduce9), the run tails add into the
+    // workgroup's LDS vertex table, which is flushed once.  (The per-vertex loop with shuffle butterflies this replaces made
+    // the kernel LDS-bound at 3.9 ms for cfg3; nine global atomics per run tail instead of the table: 7.4 ms.)
+    if (hint && !fpcdr_hint_on(hint, 0, B, H, W, blockIdx.z, blockIdx.y * 32, blockIdx.x * 32)) return;   // empty bin: nothing to read
+    __shared__ int s_vkey[FPCDR_VT_SLOTS];
+    __shared__ __attribute__((aligned(16))) float s_vacc[FPCDR_VT_SLOTS][4];
+    const VTable vt = {s_vkey, s_vacc};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = (lane & 32) ? 63 - lane : lane;
+    const int px = blockIdx.x * 32 + col;
     const int b = blockIdx.z;
-    int key0 = -1, key1 = -1, key2 = -1;
-    float g0[3] = {0, 0, 0}, g1[3] = {0, 0, 0}, g2[3] = {0, 0, 0};  // (x, y, w) per vertex
-    if (px < W && py < H) {
-        const size_t off = ((size_t)b * H + py) * W + px;
-        const float4 r = rast[off];
-        const int t = (int)r.w - 1;
-        if (t >= 0 && t < T) {
-            const float4 g = dy[off];
-            float4 gd = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (HAS_DDB) gd = ddb[off];
-            if (g.x != 0.f || g.y != 0.f || gd.x != 0.f || gd.y != 0.f || gd.z != 0.f || gd.w != 0.f) {
-                const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-                const float4 *p = pos + (size_t)b * V;
-                const float4 v0 = p[i0], v1 = p[i1], v2 = p[i2];
-                const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
-                const float fy = (2.0f * (float)py + 1.0f) / (float)H - 1.0f;
-                const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
-                shade_pixel_bwd<HAS_DDB>(v0, v1, v2, fx, fy, sx, sy, g, gd, g0, g1, g2);
-                key0 = i0; key1 = i1; key2 = i2;
+    // pass 1: which of this thread's four pixels carry a gradient (most bins of an image: none at all)
+    float4 rr[4], gg[4], gdd[4];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int py = blockIdx.y * 32 + wave * 8 + 2 * k + (lane >> 5);
+        rr[k] = make_float4(0.f, 0.f, 0.f, 0.f); gg[k] = rr[k]; gdd[k] = rr[k];
+        if (px < W && py < H) {
+            const size_t off = ((size_t)b * H + py) * W + px;
+            rr[k] = rast[off];
+            const int t = (int)rr[k].w - 1;
+            if (t >= 0 && t < T) {
+                gg[k] = dy[off];
+                if (HAS_DDB) gdd[k] = ddb[off];
+                any |= gg[k].x != 0.f || gg[k].y != 0.f || gdd[k].x != 0.f || gdd[k].y != 0.f || gdd[k].z != 0.f || gdd[k].w != 0.f;
+            } else {
+                rr[k].w = 0.f;
             }
         }
     }
-    // wave-uniform early out (most waves of an image see no gradient at all)
-    if (__ballot(key0 >= 0) == 0ull) return;
+    if (!__builtin_amdgcn_readfirstlane(__syncthreads_or(any ? 1 : 0))) return;
+    vtable_init(vt, tid, 256);
+    __syncthreads();
     float *gp = grad_pos + (size_t)b * V * 4;
-    {
-        float *const d[3] = {gp + 4 * (size_t)max(key0, 0), gp + 4 * (size_t)max(key0, 0) + 1, gp + 4 * (size_t)max(key0, 0) + 3};
-        wave_group_atomic_add<3>(key0, d, g0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int py = blockIdx.y * 32 + wave * 8 + 2 * k + (lane >> 5);
+        int tkey = -1;
+        int vk[3] = {0, 0, 0};
+        float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const float4 g = gg[k], gd = gdd[k];
+        if (rr[k].w > 0.f && (g.x != 0.f || g.y != 0.f || gd.x != 0.f || gd.y != 0.f || gd.z != 0.f || gd.w != 0.f)) {
+            const int t = (int)rr[k].w - 1;
+            vk[0] = tri[3 * t]; vk[1] = tri[3 * t + 1]; vk[2] = tri[3 * t + 2];
+            const float4 *p = pos + (size_t)b * V;
+            const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
+            const float fy = (2.0f * (float)py + 1.0f) / (float)H - 1.0f;
+            float g0[3], g1[3], g2[3];
+            shade_pixel_bwd<HAS_DDB>(p[vk[0]], p[vk[1]], p[vk[2]], fx, fy, 2.0f / (float)W, 2.0f / (float)H, g, gd, g0, g1, g2);
+            gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
+            gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
+            gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
+            tkey = t;
+        }
+        wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) { vtable_add(vt, gp, vk, sm); });
     }
-    {
-        float *const d[3] = {gp + 4 * (size_t)max(key1, 0), gp + 4 * (size_t)max(key1, 0) + 1, gp + 4 * (size_t)max(key1, 0) + 3};
-        wave_group_atomic_add<3>(key1, d, g1);
-    }
-    {
-        float *const d[3] = {gp + 4 * (size_t)max(key2, 0), gp + 4 * (size_t)max(key2, 0) + 1, gp + 4 * (size_t)max(key2, 0) + 3};
-        wave_group_atomic_add<3>(key2, d, g2);
-    }
+    __syncthreads();
+    vtable_flush(vt, gp, tid, 256);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1150,7 +1168,7 @@ extern "C" int fpcdr_rasterize_bwd(const fpcdr_rasterize_bwd_params *p, void *st
     FPCDR_REQUIRE(p->B > 0 && p->V > 0 && p->T > 0 && p->H > 0 && p->W > 0, "sizes must be positive");
     FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
+    dim3 grid(fpcdr_cdiv(p->W, 32), fpcdr_cdiv(p->H, 32), p->B);
     if (p->ddb)
         hipLaunchKernelGGL(k_grad<true>, grid, dim3(256), 0, st, (const float4 *)p->pos, p->tri, (const float4 *)p->rast,
                            (const float4 *)p->dy, (const float4 *)p->ddb, p->B, p->V, p->T, p->H, p->W, p->grad_pos, p->hint);

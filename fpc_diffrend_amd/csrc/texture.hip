@@ -258,6 +258,113 @@ __global__ void __launch_bounds__(256) k_tex_bwd(TexLevels lv, int n_levels, con
     }
 }
 
+// Bin-shaped backward for the reference's texture call (one 1-channel texture, 'linear', W % 4 == 0): one workgroup per
+// 32 x 32-pixel bin, four horizontally adjacent pixels per thread (16-byte loads of dy / uv, 16-byte stores of grad_uv).  The
+// texel gradient goes through a TW x TW LDS window anchored at the bin's smallest tap (compare-and-swap adds: ds_add_f32 costs
+// 3 cycles per lane on gfx950) and is flushed once, row-contiguously; taps outside the window (uv seams) and the empty
+// pixels' share (uv = (0,0): summed per workgroup) go to memory directly.  4 global atomics per covered pixel -- the
+// generic kernel -- bound the operator at 4.3 ms for cfg3.
+constexpr int TW = 40;
+__global__ void __launch_bounds__(256) k_tex_bwd_bin1(const float *__restrict__ tex, float *__restrict__ grad_tex,
+                                                      const float4 *__restrict__ uv4, const float4 *__restrict__ dy4, int H, int W, int B,
+                                                      int Ht, int Wt, int boundary, float4 *__restrict__ grad_uv4,
+                                                      const uint8_t *__restrict__ hint) {
+    __shared__ float s_tex[TW * TW];
+    __shared__ int s_org[2];
+    __shared__ float s_esum;
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.z;
+    const int px = blockIdx.x * 32 + (tid & 7) * 4, py = blockIdx.y * 32 + (tid >> 3);
+    const bool inside = px < W && py < H;
+    const size_t i = ((size_t)b * H + (inside ? py : 0)) * W + (inside ? px : 0);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g = inside ? dy4[i / 4] : z4;
+    const bool any = g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f;
+    if (!__builtin_amdgcn_readfirstlane(__syncthreads_or(any ? 1 : 0))) {      // no gradient arrives in this bin
+        if (inside && grad_uv4) { grad_uv4[i / 2] = z4; grad_uv4[i / 2 + 1] = z4; }
+        return;
+    }
+    // region hint: uv = (0,0) in an empty bin -- not read
+    const bool known_zero = hint && !fpcdr_hint_on(hint, 0, B, H, W, b, blockIdx.y * 32, blockIdx.x * 32);
+    float4 ua = z4, ub = z4;
+    if (inside && any && !known_zero) { ua = uv4[i / 2]; ub = uv4[i / 2 + 1]; }
+    const float qu[4] = {ua.x, ua.z, ub.x, ub.z}, qv[4] = {ua.y, ua.w, ub.y, ub.w}, gq[4] = {g.x, g.y, g.z, g.w};
+    if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; s_esum = 0.0f; }
+    for (int k = tid; k < TW * TW; k += 256) s_tex[k] = 0.0f;
+    // window origin: the smallest tap of the pixels with a gradient and a texture coordinate other than (0,0)
+    int ux0 = 0x7fffffff, uy0 = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (inside && gq[k] != 0.0f && (qu[k] != 0.0f || qv[k] != 0.0f)) {
+            ux0 = min(ux0, (int)floorf(prep_coord(qu[k], boundary) * (float)Wt - 0.5f));
+            uy0 = min(uy0, (int)floorf(prep_coord(qv[k], boundary) * (float)Ht - 0.5f));
+        }
+    __syncthreads();
+    {
+        const int mx = wave_min_dpp(ux0), my = wave_min_dpp(uy0);
+        if (lane == 0 && mx != 0x7fffffff) { atomicMin(&s_org[0], mx); atomicMin(&s_org[1], my); }
+    }
+    __syncthreads();
+    const int ox = s_org[0], oy = s_org[1];
+    float gu[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f}, esum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float gc = gq[k];
+        if (!inside || gc == 0.0f) continue;
+        const Taps t = make_taps(qu[k], qv[k], Ht, Wt, 1, boundary);
+        float t00, t10, t01, t11;
+        load_taps(tex, t, 0, 1, t00, t10, t01, t11);
+        const float gfx = gc * ((t10 - t00) * (1.0f - t.fy) + (t11 - t01) * t.fy);
+        const float gfy = gc * ((t01 + (t11 - t01) * t.fx) - (t00 + (t10 - t00) * t.fx));
+        // clamp mode: no uv gradient outside [0,1] (torch.clamp semantics of the oracle)
+        const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(qu[k] >= 0.0f && qu[k] <= 1.0f)) ? 0.0f : 1.0f;
+        const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(qv[k] >= 0.0f && qv[k] <= 1.0f)) ? 0.0f : 1.0f;
+        gu[k] = gfx * (float)Wt * mu;
+        gv[k] = gfy * (float)Ht * mv;
+        if (!grad_tex) continue;
+        if (qu[k] == 0.0f && qv[k] == 0.0f) { esum += gc; continue; }     // the four texels at uv = (0,0): once per workgroup
+        const float w00 = (1.0f - t.fx) * (1.0f - t.fy), w10 = t.fx * (1.0f - t.fy), w01 = (1.0f - t.fx) * t.fy, w11 = t.fx * t.fy;
+        const int lx = (int)floorf(prep_coord(qu[k], boundary) * (float)Wt - 0.5f) - ox;
+        const int ly = (int)floorf(prep_coord(qv[k], boundary) * (float)Ht - 0.5f) - oy;
+        if (lx >= 0 && ly >= 0 && lx + 1 < TW && ly + 1 < TW) {
+            float *w = s_tex + ly * TW + lx;
+            lds_add_f32(w, gc * w00);
+            lds_add_f32(w + 1, gc * w10);
+            lds_add_f32(w + TW, gc * w01);
+            lds_add_f32(w + TW + 1, gc * w11);
+        } else {
+            atomicAdd(grad_tex + t.i00, gc * w00);
+            atomicAdd(grad_tex + t.i10, gc * w10);
+            atomicAdd(grad_tex + t.i01, gc * w01);
+            atomicAdd(grad_tex + t.i11, gc * w11);
+        }
+    }
+    if (inside && grad_uv4) {
+        grad_uv4[i / 2] = make_float4(gu[0], gv[0], gu[1], gv[1]);
+        grad_uv4[i / 2 + 1] = make_float4(gu[2], gv[2], gu[3], gv[3]);
+    }
+    if (!grad_tex) return;
+    esum = wave_sum_dpp(esum);
+    if (lane == 0 && esum != 0.0f) lds_add_f32(&s_esum, esum);
+    __syncthreads();
+    if (tid == 0 && s_esum != 0.0f) {
+        const Taps t0 = make_taps(0.0f, 0.0f, Ht, Wt, 1, boundary);
+        const float e = s_esum;
+        atomicAdd(grad_tex + t0.i00, e * ((1.0f - t0.fx) * (1.0f - t0.fy)));
+        atomicAdd(grad_tex + t0.i10, e * (t0.fx * (1.0f - t0.fy)));
+        atomicAdd(grad_tex + t0.i01, e * ((1.0f - t0.fx) * t0.fy));
+        atomicAdd(grad_tex + t0.i11, e * (t0.fx * t0.fy));
+    }
+    if (ox != 0x7fffffff) {
+        for (int k = tid; k < TW * TW; k += 256) {
+            const float v = s_tex[k];
+            if (v != 0.0f) {
+                const int gx = wrap_near(ox + k % TW, Wt, boundary), gy = wrap_near(oy + k / TW, Ht, boundary);
+                atomicAdd(grad_tex + (size_t)gy * Wt + gx, v);
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_mip_down(const float *__restrict__ src, float *__restrict__ dst, int N, int Ht,
                                                   int Wt, int C) {
     const int ho = Ht / 2, wo = Wt / 2;
@@ -374,6 +481,14 @@ extern "C" int fpcdr_texture_bwd(const fpcdr_texture_bwd_params *p, void *stream
         if (l <= p->n_levels) FPCDR_REQUIRE(p->tex[l] != nullptr, "missing mip level");
     }
     FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 16) <= 65535, "image batch / height too large for one launch");
+    if (p->filter_mode == FPCDR_FILTER_LINEAR && p->C == 1 && p->Bt == 1 && (p->W & 3) == 0 &&
+        (((size_t)p->uv | (size_t)p->dy | (size_t)p->grad_uv) & 15) == 0) {
+        hipLaunchKernelGGL(k_tex_bwd_bin1, dim3(fpcdr_cdiv(p->W, 32), fpcdr_cdiv(p->H, 32), p->B), dim3(256), 0, (hipStream_t)stream,
+                           p->tex[0], p->grad_tex[0], (const float4 *)p->uv, (const float4 *)p->dy, p->H, p->W, p->B, p->Ht, p->Wt,
+                           p->boundary_mode, (float4 *)p->grad_uv, p->hint);
+        FPCDR_CHECK_LAUNCH();
+        return FPCDR_OK;
+    }
     dim3 grid(fpcdr_cdiv(p->W, 16), fpcdr_cdiv(p->H, 16), p->B);
     hipLaunchKernelGGL(k_tex_bwd, grid, dim3(256), 0, (hipStream_t)stream, lv, p->n_levels,
                        (const float2 *)p->uv, mip ? (const float4 *)p->uv_da : nullptr, mip ? p->mip_level_bias : nullptr, p->dy,

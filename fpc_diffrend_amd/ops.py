@@ -568,6 +568,7 @@ class _texture_func(torch.autograd.Function):
         _lib.call("fpcdr_texture_fwd", ctypes.byref(p), _stream())
         ctx.save_for_backward(tex, uv, uv_da, bias, *chain[1:])
         ctx.cfg = (filter_mode, boundary_mode, n_levels)
+        ctx.hint = hint
         return out
 
     @staticmethod
@@ -587,7 +588,7 @@ class _texture_func(torch.autograd.Function):
         p = _lib.TextureBwd(tex=_ptr_array(chain), n_levels=n_levels, uv=_ptr(uv), uv_da=_ptr(uv_da),
                             mip_level_bias=_ptr(bias), dy=_ptr(dy), B=B, H=H, W=W, Bt=Bt, Ht=Ht, Wt=Wt, C=C,
                             filter_mode=filter_mode, boundary_mode=boundary_mode, grad_tex=_ptr_array(g_levels),
-                            grad_uv=_ptr(g_uv), grad_uv_da=_ptr(g_da), grad_mip_level_bias=_ptr(g_bias))
+                            grad_uv=_ptr(g_uv), grad_uv_da=_ptr(g_da), grad_mip_level_bias=_ptr(g_bias), hint=_ptr(ctx.hint))
         _lib.call("fpcdr_texture_bwd", ctypes.byref(p), _stream())
         if need_tex:
             # collapse the mip gradients down to level 0

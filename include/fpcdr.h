@@ -290,6 +290,8 @@ typedef struct {
     float *grad_uv;                       /* out [B,H,W,2] or NULL */
     float *grad_uv_da;                    /* out [B,H,W,4] or NULL */
     float *grad_mip_level_bias;           /* out [B,H,W] or NULL */
+    const uint8_t *hint;                  /* optional (filter linear, C = 1, Bt = 1): region hint of uv, which is then not read
+                                             in empty bins */
 } fpcdr_texture_bwd_params;
 int fpcdr_texture_bwd(const fpcdr_texture_bwd_params *p, void *stream);
 
