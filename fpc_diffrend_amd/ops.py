@@ -330,9 +330,6 @@ class _pixel_objective_func(torch.autograd.Function):
         # the one-call sparse forward leaves the list of bins the backward visits in `occ`; measured at cfg3 the backward gains
         # nothing from it (2.69 vs 2.64 ms: its dead workgroups' dispatch hides behind the live ones' work), so the grid form is
         # the default and the list form stays selectable
-        import os as _os
-        if _os.environ.get("FPCDR_QUEUED_BWD"):
-            queued_backward = _os.environ["FPCDR_QUEUED_BWD"] == "1"
         ctx.queued = 1 if (sparse and queued_backward) else 0
         # (sparse => the one-call forward, which also leaves the per-bin summary of the antialias flags in `occ`)
         total = acc.sum()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc passes (counter_collection.csv + kernel_trace.csv) -> one JSON: per kernel, the mean of every counter per
 dispatch and the mean duration in that pass.   python scripts/make_counters_json.py DIR... > counters.json
-Only dispatches of the LARGEST grid of each kernel are averaged (prof_objective.py also renders its targets in small chunks)."""
+Only dispatches of at least half the LARGEST grid of each kernel are averaged: prof_objective.py also renders its targets in
+small chunks, and the list kernels' grids follow the launch hints from step to step."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -27,7 +28,7 @@ for d in ARGS:
             dur[short(r["Kernel_Name"])].append((g, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     for k, v in dur.items():
         gmax = max(g for g, _ in v)
-        sel = [t for g, t in v if g == gmax]
+        sel = [t for g, t in v if 2 * g >= gmax]
         out[k]["duration_us"][tag] = sum(sel) / len(sel)
         out[k]["dispatches"] = len(sel)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -38,9 +39,9 @@ for d in ARGS:
         for k, cs in vals.items():
             for c, v in cs.items():
                 gmax = max(g for g, _ in v)
-                sel = [x for g, x in v if g == gmax]
+                sel = [x for g, x in v if 2 * g >= gmax]
                 out[k]["counters"][c] = sum(sel) / len(sel)
 keep = {k: v for k, v in out.items() if k.startswith(("k_", "void k_"))}
 print(json.dumps(dict(META, _comment="rocprofv3 --pmc passes of scripts/prof_objective.py (scripts/measure_round.sh): per kernel the mean "
-                       "counter value per dispatch (largest-grid dispatches only) and the mean duration in each pass; FETCH_SIZE / "
+                       "counter value per dispatch (dispatches of at least half the largest grid) and the mean duration in each pass; FETCH_SIZE / "
                        "WRITE_SIZE in KB", kernels=keep), indent=1, sort_keys=True))
