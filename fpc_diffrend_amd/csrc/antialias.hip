@@ -135,43 +135,87 @@ __global__ void __launch_bounds__(256) k_sil(const float4 *__restrict__ pos, con
 constexpr int AROWS = 8;   // rows per wave of k_aa_fwd (4 waves: 32 rows = one hint bin)
 
 // ------------------------------------------------------------------------------------------------
+// does pair (p0 first pixel, p1 second) have a triangle to analyse that owns a silhouette edge?  (one byte load)
+__device__ __forceinline__ bool pair_candidate(const uint8_t *__restrict__ sil, int T, float2 p0, float2 p1) {
+    if ((int)p0.y == (int)p1.y) return false;
+    const PairSel ps = pair_select((int)p0.y, p0.x, (int)p1.y, p1.x, T);
+    return ps.tau >= 0 && sil[ps.tau] != 0;
+}
+
 template <int CS>
 __global__ void __launch_bounds__(256) k_aa_fwd(const float *__restrict__ color, const float4 *__restrict__ rast,
                                                 const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                 const uint8_t *__restrict__ sil, int B, int H, int W, int C_dyn, int V, int T,
                                                 unsigned long long *__restrict__ flags, float *__restrict__ out,
-                                                const uint8_t *__restrict__ hint, const float *__restrict__ empty_color, int filled) {
+                                                const uint8_t *__restrict__ hint, const float *__restrict__ empty_color, int filled,
+                                                int flags_zeroed) {
     // 64 x (4 AROWS) pixels per workgroup: a wave owns AROWS consecutive rows of a 64-pixel column strip (one 32-row hint bin)
-    // and has the (z/w, id) loads of all of them in flight at once (one pixel per thread: 2.3 M tiny workgroups, see
-    // k_interp_fwd in interpolate.hip)
+    // and has the (z/w, id) loads of all of them and of the rows above and below in flight at once (one pixel per thread:
+    // 2.3 M tiny workgroups, see k_interp_fwd in interpolate.hip).
+    // Phase 1, every pixel: out = colour unless one of its four pairs is a CANDIDATE -- different ids and the triangle to
+    // analyse owns a silhouette edge (a byte per (image, triangle)): ~3 % of the covered pixels of a closed mesh, while ~40 %
+    // see an id discontinuity.  Phase 2, rows with a candidate: the pair analysis (divergent, a dozen dependent loads).
     const int C = CS > 0 ? CS : C_dyn;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane, ybase = (blockIdx.y * 4 + wave) * AROWS, b = blockIdx.z;
+    if (ybase >= H) return;
     const int Wq = FPCDR_AA_ROW_WORDS(W);
+    const size_t img = (size_t)b * H * W;
+    const uint8_t *silb = sil + (size_t)b * T;
     // region hint (plane 1): the pixel's bin and its eight neighbours are empty, so neither the pixel nor any of its four
     // neighbours is covered -- no pair to blend: out = colour, without reading rast (nor colour, when its value there is known)
-    const bool skip = x < W && ybase < H && hint && !fpcdr_hint_on(hint, 1, B, H, W, b, ybase, x);
-    float2 mer[AROWS];
+    const bool skip = x < W && hint && !fpcdr_hint_on(hint, 1, B, H, W, b, ybase, x);
+    const bool live = x < W && !skip;
+    if (filled && flags_zeroed && !__builtin_amdgcn_readfirstlane(__ballot(live) != 0ull)) return;   // nothing left to do for this wave
+    float2 mer[AROWS + 2];
 #pragma unroll
-    for (int r = 0; r < AROWS; ++r)
-        mer[r] = (x < W && !skip && ybase + r < H) ? load_zid(rast, ((size_t)b * H + ybase + r) * W + x) : make_float2(0.f, 0.f);
-#pragma unroll 1
+    for (int r = -1; r <= AROWS; ++r) {
+        const int y = min(max(ybase + r, 0), H - 1);      // (clamped: a pixel is its own neighbour beyond the image)
+        mer[r + 1] = live ? load_zid(rast, img + (size_t)y * W + x) : make_float2(0.f, 0.f);
+    }
+    unsigned int cand = 0;
+#pragma unroll
     for (int r = 0; r < AROWS; ++r) {
-    const int y = ybase + r;
-    bool fx_flag = false, fy_flag = false;
-    if (y < H) {
+        const int y = ybase + r;
+        if (y >= H) break;
+        const size_t off = img + (size_t)y * W + x;
+        if (!flags_zeroed && lane == 0) {
+            const size_t wi = ((size_t)b * H + y) * Wq + blockIdx.x;
+            flags[wi] = 0ull;
+            flags[(size_t)B * H * Wq + wi] = 0ull;
+        }
         if (skip) {
             if (!filled) {      // (filled: k_aa_fill_bin1 has written these pixels with 16-byte stores)
-                const size_t off = ((size_t)b * H + y) * W + x;
                 if (empty_color) { for (int c = 0; c < C; ++c) out[off * C + c] = empty_color[c]; }
                 else { for (int c = 0; c < C; ++c) out[off * C + c] = color[off * C + c]; }
             }
         } else if (x < W) {
-            const size_t img = (size_t)b * H * W;
-            const size_t off = img + (size_t)y * W + x;
-            const float2 me = mer[r];
+            const float2 me = mer[r + 1];
             const int id = (int)me.y;
+            const float2 nR = x + 1 < W ? load_zid(rast, off + 1) : me;
+            const float2 nL = x > 0 ? load_zid(rast, off - 1) : me;
+            const float2 nU = mer[r + 2], nD = mer[r];
+            bool c4 = false;
+            if (((int)nR.y != id) | ((int)nL.y != id) | ((int)nU.y != id) | ((int)nD.y != id))
+                c4 = (int)pair_candidate(silb, T, me, nR) | (int)pair_candidate(silb, T, me, nU) | (int)pair_candidate(silb, T, nL, me) |
+                     (int)pair_candidate(silb, T, nD, me);
+            if (c4) cand |= 1u << r;
+            else { for (int c = 0; c < C; ++c) out[off * C + c] = color[off * C + c]; }
+        }
+    }
+    unsigned int rows = 0;
+#pragma unroll
+    for (int r = 0; r < AROWS; ++r)
+        if (__ballot((cand >> r) & 1u)) rows |= 1u << r;
+#pragma unroll 1
+    for (int r = 0; r < AROWS; ++r) {
+        if (!((rows >> r) & 1u)) continue;
+        const int y = ybase + r;
+        bool fx_flag = false, fy_flag = false;
+        if ((cand >> r) & 1u) {
+            const size_t off = img + (size_t)y * W + x;
             const bool hasR = x + 1 < W, hasL = x > 0, hasU = y + 1 < H, hasD = y > 0;
+            const float2 me = load_zid(rast, off);
             const float2 nR = hasR ? load_zid(rast, off + 1) : me;
             const float2 nL = hasL ? load_zid(rast, off - 1) : me;
             const float2 nU = hasU ? load_zid(rast, off + W) : me;
@@ -182,56 +226,44 @@ __global__ void __launch_bounds__(256) k_aa_fwd(const float *__restrict__ color,
 #pragma unroll
                 for (int c = 0; c < CS; ++c) acc[c] = cme[c];
             }
-            const bool disc = ((int)nR.y != id) | ((int)nL.y != id) | ((int)nU.y != id) | ((int)nD.y != id);
-            if (!disc) {
-                if (CS > 0) {
+            AAGeom g = {pos + (size_t)b * V, tri, silb, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
+            // gather: add what THIS pixel receives from each of its four pairs
+            auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own, bool &flag) {
+                if ((int)p0.y == (int)p1.y) return;
+                bool hit = for_active_edges(g, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
+                    [&](float t, int Px, int Py, int Qx, int Qy, int, int, const EdgeEval &, float) {
+                        const bool far = t >= 0.5f;
+                        const int rx = far ? Qx : Px, ry = far ? Qy : Py;
+                        if (rx != x || ry != y) return;
+                        const int ox = far ? Px : Qx, oy = far ? Py : Qy;
+                        const float amt = far ? t - 0.5f : 0.5f - t;
+                        const float *co = color + (img + (size_t)oy * W + ox) * C;
+                        if (CS > 0) {
 #pragma unroll
-                    for (int c = 0; c < CS; ++c) out[off * C + c] = acc[c];
-                } else {
-                    for (int c = 0; c < C; ++c) out[off * C + c] = cme[c];
-                }
-            } else {
-                AAGeom g = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
-                // gather: add what THIS pixel receives from each of its four pairs
-                auto visit = [&](int x0, int y0, int d, float2 p0, float2 p1, bool own, bool &flag) {
-                    if ((int)p0.y == (int)p1.y) return;
-                    bool hit = for_active_edges(g, x0, y0, d, (int)p0.y, p0.x, (int)p1.y, p1.x,
-                        [&](float t, int Px, int Py, int Qx, int Qy, int, int, const EdgeEval &, float) {
-                            const bool far = t >= 0.5f;
-                            const int rx = far ? Qx : Px, ry = far ? Qy : Py;
-                            if (rx != x || ry != y) return;
-                            const int ox = far ? Px : Qx, oy = far ? Py : Qy;
-                            const float amt = far ? t - 0.5f : 0.5f - t;
-                            const float *co = color + (img + (size_t)oy * W + ox) * C;
-                            if (CS > 0) {
+                            for (int c = 0; c < CS; ++c) acc[c] += amt * (co[c] - cme[c]);
+                        } else {
+                            for (int c = 0; c < C; ++c) out[off * C + c] += amt * (co[c] - cme[c]);
+                        }
+                    });
+                if (own && hit) flag = true;
+            };
+            if (CS == 0) for (int c = 0; c < C; ++c) out[off * C + c] = cme[c];
+            bool dummy = false;
+            if (hasR) visit(x, y, 0, me, nR, true, fx_flag);
+            if (hasU) visit(x, y, 1, me, nU, true, fy_flag);
+            if (hasL) visit(x - 1, y, 0, nL, me, false, dummy);
+            if (hasD) visit(x, y - 1, 1, nD, me, false, dummy);
+            if (CS > 0) {
 #pragma unroll
-                                for (int c = 0; c < CS; ++c) acc[c] += amt * (co[c] - cme[c]);
-                            } else {
-                                for (int c = 0; c < C; ++c) out[off * C + c] += amt * (co[c] - cme[c]);
-                            }
-                        });
-                    if (own && hit) flag = true;
-                };
-                if (CS == 0) for (int c = 0; c < C; ++c) out[off * C + c] = cme[c];
-                bool dummy = false;
-                if (hasR) visit(x, y, 0, me, nR, true, fx_flag);
-                if (hasU) visit(x, y, 1, me, nU, true, fy_flag);
-                if (hasL) visit(x - 1, y, 0, nL, me, false, dummy);
-                if (hasD) visit(x, y - 1, 1, nD, me, false, dummy);
-                if (CS > 0) {
-#pragma unroll
-                    for (int c = 0; c < CS; ++c) out[off * C + c] = acc[c];
-                }
+                for (int c = 0; c < CS; ++c) out[off * C + c] = acc[c];
             }
         }
         const unsigned long long bx = __ballot(fx_flag), by = __ballot(fy_flag);
-        if (lane == 0) {
-            const size_t plane = (size_t)B * H * Wq;
+        if (lane == 0 && (bx | by)) {
             const size_t wi = ((size_t)b * H + y) * Wq + blockIdx.x;
             flags[wi] = bx;
-            flags[plane + wi] = by;
+            flags[(size_t)B * H * Wq + wi] = by;
         }
-    }
     }
 }
 
@@ -410,7 +442,11 @@ extern "C" int fpcdr_antialias_fwd(const fpcdr_antialias_fwd_params *p, void *st
     hipLaunchKernelGGL(k_sil, dim3(fpcdr_cdiv((long long)p->B * p->T, 256)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil);
     dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 4 * AROWS), p->B);
-    int filled = 0;
+    int filled = 0, flags_zeroed = 0;
+    if (p->hint) {      // most waves will find nothing to do and leave without touching their flag words
+        FPCDR_REQUIRE(hipMemsetAsync(p->flags, 0, fpcdr_antialias_flags_bytes(p->B, p->H, p->W), st) == hipSuccess, "memset of the flag planes failed");
+        flags_zeroed = 1;
+    }
     if (p->hint && p->C == 1 && (p->W & 3) == 0 && (((size_t)p->color | (size_t)p->out) & 15) == 0) {
         hipLaunchKernelGGL(k_aa_fill_bin1, dim3(fpcdr_cdiv(p->W, 32), fpcdr_cdiv(p->H, 32), p->B), dim3(256), 0, st, (const float4 *)p->color,
                            p->B, p->H, p->W, (float4 *)p->out, p->hint, p->empty_color);
@@ -419,7 +455,7 @@ extern "C" int fpcdr_antialias_fwd(const fpcdr_antialias_fwd_params *p, void *st
 #define LAUNCH_FWD(CS)                                                                                                   \
     hipLaunchKernelGGL(k_aa_fwd<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, \
                        p->tri, p->sil, p->B, p->H, p->W, p->C, p->V, p->T, (unsigned long long *)p->flags, p->out, p->hint,   \
-                       p->hint ? p->empty_color : nullptr, filled)
+                       p->hint ? p->empty_color : nullptr, filled, flags_zeroed)
     if (p->C == 1) LAUNCH_FWD(1);
     else if (p->C == 3) LAUNCH_FWD(3);
     else if (p->C == 4) LAUNCH_FWD(4);

@@ -268,17 +268,6 @@ __global__ void __launch_bounds__(256) k_interp_fwd_bin2(const float2 *__restric
     out4[i / 2 + 1] = make_float4(o2.x, o2.y, o3.x, o3.y);
 }
 
-__device__ __forceinline__ float4 interp2_bwd(const float2 *__restrict__ ab, const int32_t *__restrict__ tri, float4 r, float2 g, int T) {
-    const int t = (int)r.w - 1;
-    if (t < 0 || t >= T) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const float2 q0 = ab[tri[3 * t]], q1 = ab[tri[3 * t + 1]], q2 = ab[tri[3 * t + 2]];
-    // (same order of operations as k_interp_bwd: sum over the two channels of g_k (a_k - a2_k))
-    float gu = 0.f, gv = 0.f;
-    gu += g.x * (q0.x - q2.x); gv += g.x * (q1.x - q2.x);
-    gu += g.y * (q0.y - q2.y); gv += g.y * (q1.y - q2.y);
-    return make_float4(gu, gv, 0.f, 0.f);
-}
-
 __global__ void __launch_bounds__(256) k_interp_bwd_bin2(const float2 *__restrict__ attr, const float4 *__restrict__ rast,
                                                          const int32_t *__restrict__ tri, const float2 *__restrict__ dy2, int H, int W,
                                                          int B, int Ba, int Vt, int T, float4 *__restrict__ grad_rast,
@@ -295,17 +284,48 @@ __global__ void __launch_bounds__(256) k_interp_bwd_bin2(const float2 *__restric
             if (py0 + 8 * k < H) grad_rast[((size_t)b * H + py0 + 8 * k) * W + px] = z;
         return;
     }
-    float4 rr[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) rr[k] = py0 + 8 * k < H ? rast[((size_t)b * H + py0 + 8 * k) * W + px] : z;
+    // four pixels per thread, every stage of the dependent chain (rast -> triangle -> vertex indices -> attributes) issued for
+    // all four before the next stage is consumed
     const float2 *ab = attr + (Ba > 1 ? (size_t)b * Vt : 0);
+    size_t idx[4];
+    bool in[4];
+    float4 rr[4];
+    float2 g[4];
+    int t[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (py0 + 8 * k >= H) break;
-        const size_t i = ((size_t)b * H + py0 + 8 * k) * W + px;
-        float4 o = z;
-        if (rr[k].w > 0.f) o = interp2_bwd(ab, tri, rr[k], dy2[i], T);
-        grad_rast[i] = o;
+        in[k] = py0 + 8 * k < H;
+        idx[k] = ((size_t)b * H + (in[k] ? py0 + 8 * k : py0)) * W + px;
+        rr[k] = rast[idx[k]];
+        g[k] = dy2[idx[k]];
+    }
+    int v0[4], v1[4], v2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        t[k] = (int)rr[k].w - 1;
+        if (t[k] < 0 || t[k] >= T) t[k] = -1;
+    }
+    if (!__builtin_amdgcn_readfirstlane(__ballot((t[0] & t[1] & t[2] & t[3]) >= 0) != 0ull)) {     // a wave of empty pixels (no hint given)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (in[k]) grad_rast[idx[k]] = z;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int tt = max(t[k], 0);
+        v0[k] = tri[3 * tt]; v1[k] = tri[3 * tt + 1]; v2[k] = tri[3 * tt + 2];
+    }
+    float2 q0[4], q1[4], q2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { q0[k] = ab[v0[k]]; q1[k] = ab[v1[k]]; q2[k] = ab[v2[k]]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // (same order of operations as k_interp_bwd: sum over the two channels of g_k (a_k - a2_k))
+        float gu = 0.f, gv = 0.f;
+        gu += g[k].x * (q0[k].x - q2[k].x); gv += g[k].x * (q1[k].x - q2[k].x);
+        gu += g[k].y * (q0[k].y - q2[k].y); gv += g[k].y * (q1[k].y - q2[k].y);
+        if (in[k]) grad_rast[idx[k]] = t[k] >= 0 ? make_float4(gu, gv, 0.f, 0.f) : z;
     }
 }
 

@@ -8,8 +8,8 @@ import fpc_diffrend_amd.ops as dr
 sc = scene.cfg('cfg3', n_frames=int(os.environ.get("FRAMES", 32)))
 ft = fit.Fitter(sc, fit.FitConfig(max_iter=80000, init_texture="random"), device="cuda")
 ids = slice(0, ft.n_frames)
-for hints in (True, False, True):
-    dr.region_hints = hints
+for hints in (True, False, True, 'empty'):   # 'empty': hint map zeroed after rasterize = the floor of writing the outputs
+    dr.region_hints = bool(hints)
     timer = _lib.KernelTimer()
     for rep in range(3):
         if rep == 1:
@@ -19,6 +19,8 @@ for hints in (True, False, True):
         tex = ft.tex_opt.detach().clone().requires_grad_(True)
         ctx = dr.RasterizeGLContext(output_db=False, device=ft.device)
         rast, _ = dr.rasterize(ctx, pos, ft.pos_idx, ft.resolution)
+        if hints == 'empty':
+            dr._hint_of(rast, 'rast')[0].zero_()
         texc, _ = dr.interpolate(ft.uv[None], rast, ft.uv_idx)
         col = dr.texture(tex[None], texc, filter_mode='linear')
         aa = dr.antialias(col, rast, pos, ft.pos_idx)
