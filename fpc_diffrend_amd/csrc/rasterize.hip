@@ -488,9 +488,13 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         // triangles arrive: lists are filled with one LDS atomic per wave and consumed from the top, no ordered compaction.
         auto process_batch = [&](const int n) {
             // consumes entries [pending - n, pending) of s_list; a barrier has been passed since they were appended
-            // ---- lane path: thread `tid` rasterises triangle `tid` of the batch over its bounding box ----
-            if (tid < n) {
-                const int t = s_list[pending - n + tid];
+            // ---- lane path: a thread rasterises one triangle of the batch over its bounding box; a batch of at most 128 (64)
+            // triangles -- the usual bin of a face mesh holds ~120 -- is walked by 2 (4) threads per triangle, rows interleaved,
+            // so that all four waves share the work ----
+            const int split = n <= 64 ? 4 : (n <= 128 ? 2 : 1);
+            if (tid < n * split) {
+                const int part = (tid >= n) + (tid >= 2 * n) + (tid >= 3 * n);
+                const int t = s_list[pending - n + (tid - part * n)];
                 const TriRec r = rc[t];
                 const TriBox q = bx[t];
                 const int ext_x = max(r.X0, max(r.X1, r.X2)) - min(r.X0, min(r.X1, r.X2));
@@ -510,14 +514,14 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                     const int n0 = ((-A0 > 0) || (A0 == 0 && B0 < 0)) ? 0 : 1;
                     const int n1 = ((-A1 > 0) || (A1 == 0 && B1 < 0)) ? 0 : 1;
                     const int n2 = ((-A2 > 0) || (A2 == 0 && B2 < 0)) ? 0 : 1;
-                    const int Px = x0 * SUBPIX + HALFPIX, Py = y0 * SUBPIX + HALFPIX;
+                    const int Px = x0 * SUBPIX + HALFPIX, Py = (y0 + part) * SUBPIX + HALFPIX;
                     int R0 = __mul24(A0, Px - r.X1) + __mul24(B0, Py - r.Y1) - n0;   // edge functions at the row start
                     int R1 = __mul24(A1, Px - r.X2) + __mul24(B1, Py - r.Y2) - n1;
                     int R2 = __mul24(A2, Px - r.X0) + __mul24(B2, Py - r.Y0) - n2;
                     const int A0s = A0 * SUBPIX, A1s = A1 * SUBPIX, A2s = A2 * SUBPIX;
                     const int rx0 = Px - r.X0;
                     int ry = Py - r.Y0;
-                    unsigned long long *zrow = &s_z[(y0 - bin_y0) * BIN + (x0 - bin_x0)];
+                    unsigned long long *zrow = &s_z[(y0 + part - bin_y0) * BIN + (x0 - bin_x0)];
 #ifdef FPCDR_ABL_NOLANE
                     const int bh = 0;
 #else
@@ -525,7 +529,8 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
 #endif
                     // rows outside, columns inside: the inner trip is three additions and one test (the flattened loop that
                     // this replaces spent two thirds of its instructions on wrap-around selects)
-                    for (int rr = 0; rr < bh; ++rr) {
+                    const int B0s = B0 * SUBPIX * split, B1s = B1 * SUBPIX * split, B2s = B2 * SUBPIX * split;
+                    for (int rr = part; rr < bh; rr += split) {
                         int E0 = R0, E1 = R1, E2 = R2, rx = rx0;
                         const float dzr = __fmaf_rn(r.zB, (float)ry, r.z0);
                         for (int c = 0; c < bw; ++c) {
@@ -535,11 +540,11 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                             }
                             E0 += A0s; E1 += A1s; E2 += A2s; rx += SUBPIX;
                         }
-                        R0 += B0 * SUBPIX; R1 += B1 * SUBPIX; R2 += B2 * SUBPIX;
-                        ry += SUBPIX;
-                        zrow += BIN;
+                        R0 += B0s; R1 += B1s; R2 += B2s;
+                        ry += SUBPIX * split;
+                        zrow += BIN * split;
                     }
-                } else {
+                } else if (part == 0) {
                     s_big[atomicAdd(&s_nbig, 1)] = t;
                 }
             }
@@ -712,6 +717,9 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         return;
     }
     // ---- fold the tile path's register winners into the depth buffer, then read every pixel's winner ----
+    // From here on a thread owns the four pixels (tid & 31, (tid >> 5) + 8 k) of the bin: the 32 lanes of a half wave write
+    // one 512-byte row segment of rast per instruction (the raster's 8 x 8 quadrant pattern gave 128-byte pieces).
+    int win[4];
     if (bin_live) {
 #pragma unroll
         for (int k = 0; k < TILES_PER_WAVE; ++k) {
@@ -723,24 +731,22 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
             }
         }
         __syncthreads();
+    }
+    const int zx = tid & 31, zy0 = tid >> 5;
 #pragma unroll
-        for (int k = 0; k < TILES_PER_WAVE; ++k) {
-            const int tile = wave * TILES_PER_WAVE + k;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int zx = (tile % TILES_X) * TILE + (q & 1) * QUAD + lx, zy = (tile / TILES_X) * TILE + (q >> 1) * QUAD + ly;
-                const unsigned long long z = s_z[zy * BIN + zx];
-                best_id[k][q] = z == Z_EMPTY ? -1 : (int)(unsigned int)z;
-            }
-        }
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long z = bin_live ? s_z[(zy0 + 8 * k) * BIN + zx] : Z_EMPTY;
+        win[k] = z == Z_EMPTY ? -1 : (int)(unsigned int)z;
     }
 
     // ---- shade + write (every pixel of the bin is written exactly once) ----
-    float col0[TILES_PER_WAVE][4];   // LOSS: channel 0 of this thread's pixels (re-reading a just-written line stalls)
-#pragma unroll
-    for (int k = 0; k < TILES_PER_WAVE; ++k)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) col0[k][q] = 0.0f;
+    // One-channel colour and its loss gradient are 4 bytes per pixel: stores of 4 bytes per lane reach a quarter of the rate of
+    // 16-byte ones, so both are staged in LDS (the raster phase's lists are dead by now) and leave as float4 at the end.
+    static_assert(sizeof(s_list) >= BIN * BIN * sizeof(float) && sizeof(s_tri) >= BIN * BIN * sizeof(float), "staging aliases the raster lists");
+    float *s_col = reinterpret_cast<float *>(s_list);
+    float *s_gaa = reinterpret_cast<float *>(s_tri);
+    const bool stage = SHADE && sh.C == 1;
+    float col0[4] = {0.f, 0.f, 0.f, 0.f};   // LOSS: channel 0 of this thread's pixels (re-reading a just-written line stalls)
     const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
     const float4 *p = pos + (size_t)b * V;
     Taps empty_tp = {};
@@ -749,59 +755,72 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         empty_tp = make_taps(0.0f, 0.0f, sh.Ht, sh.Wt, sh.C, sh.boundary);
         for (int c = 0; c < min(sh.C, 4); ++c) empty_col[c] = bilerp(sh.tex, empty_tp, c, sh.C);
     }
+    const int px = bin_x0 + zx;
 #pragma unroll
-    for (int k = 0; k < TILES_PER_WAVE; ++k) {
-        const int tile = wave * TILES_PER_WAVE + k;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int px = bin_x0 + (tile % TILES_X) * TILE + (q & 1) * QUAD + lx, py = bin_y0 + (tile / TILES_X) * TILE + (q >> 1) * QUAD + ly;
-            if (px >= W || py >= H) continue;
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < 4; ++k) {
+        const int zy = zy0 + 8 * k, py = bin_y0 + zy;
+        if (px >= W || py >= H) continue;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifdef FPCDR_ABL_NOSHADE
-            const int t = -1;
-            if (best_id[k][q] >= 0) o.w = (float)(best_id[k][q] + 1);
+        const int t = -1;
+        if (win[k] >= 0) o.w = (float)(win[k] + 1);
 #else
-            const int t = best_id[k][q];
+        const int t = win[k];
 #endif
+        if (t >= 0) {
+            const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+            const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
+            const float fy = (2.0f * (float)py + 1.0f) / (float)H - 1.0f;
+            Shade sd = shade_pixel(p[i0], p[i1], p[i2], fx, fy, sx, sy);
+            o = make_float4(sd.u, sd.v, sd.zw, (float)(t + 1));
+            d = make_float4(sd.dudx, sd.dudy, sd.dvdx, sd.dvdy);
+        }
+        const size_t off = ((size_t)b * H + py) * W + px;
+        rast[off] = o;
+        if (WRITE_DB) rast_db[off] = d;
+        if (LOSS) {   // (z/w, id) of the bin's pixels for the neighbour tests below; this thread owns the entry
+            // id + 1 in 24 bits (ids are exact in rast's float anyway), the triangle's silhouette bits above them
+            const unsigned int sb = t >= 0 ? (unsigned int)sh.sil[(size_t)b * T + t] : 0u;
+            s_z[zy * BIN + zx] = ((unsigned long long)__float_as_uint(o.z) << 32) | (sb << 24) | (unsigned int)(t + 1);
+        }
+        if (SHADE) {
+            // interpolate (reference fit.py:157) + texture 'linear' (fit.py:158), same arithmetic as the stand-alone
+            // kernels; an empty pixel samples uv = (0,0) exactly as they do (one tap set, hoisted out of the loops)
             if (t >= 0) {
-                const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-                const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
-                const float fy = (2.0f * (float)py + 1.0f) / (float)H - 1.0f;
-                Shade s = shade_pixel(p[i0], p[i1], p[i2], fx, fy, sx, sy);
-                o = make_float4(s.u, s.v, s.zw, (float)(t + 1));
-                d = make_float4(s.dudx, s.dudy, s.dvdx, s.dvdy);
-            }
-            const size_t off = ((size_t)b * H + py) * W + px;
-            rast[off] = o;
-            if (WRITE_DB) rast_db[off] = d;
-            if (LOSS) {   // (z/w, id) of the bin's pixels for the neighbour tests below; this thread owns the entry
-                const int zx = (tile % TILES_X) * TILE + (q & 1) * QUAD + lx, zy = (tile / TILES_X) * TILE + (q >> 1) * QUAD + ly;
-                // id + 1 in 24 bits (ids are exact in rast's float anyway), the triangle's silhouette bits above them
-                const unsigned int sb = t >= 0 ? (unsigned int)sh.sil[(size_t)b * T + t] : 0u;
-                s_z[zy * BIN + zx] = ((unsigned long long)__float_as_uint(o.z) << 32) | (sb << 24) | (unsigned int)(t + 1);
-            }
-            if (SHADE) {
-                // interpolate (reference fit.py:157) + texture 'linear' (fit.py:158), same arithmetic as the stand-alone
-                // kernels; an empty pixel samples uv = (0,0) exactly as they do (one tap set, hoisted out of the loops)
-                if (t >= 0) {
-                    float2 q0, q1, q2;
-                    if (sh.tri_uv) { q0 = sh.tri_uv[3 * t]; q1 = sh.tri_uv[3 * t + 1]; q2 = sh.tri_uv[3 * t + 2]; }
-                    else { q0 = sh.uv[sh.uv_tri[3 * t]]; q1 = sh.uv[sh.uv_tri[3 * t + 1]]; q2 = sh.uv[sh.uv_tri[3 * t + 2]]; }
-                    const float w = 1.0f - o.x - o.y;
-                    const float tu = o.x * q0.x + o.y * q1.x + w * q2.x;
-                    const float tv = o.x * q0.y + o.y * q1.y + w * q2.y;
-                    const Taps tp = make_taps(tu, tv, sh.Ht, sh.Wt, sh.C, sh.boundary);
-                    for (int c = 0; c < sh.C; ++c) {
-                        const float v = bilerp(sh.tex, tp, c, sh.C);
-                        sh.color[off * sh.C + c] = v;
-                        if (LOSS && c == 0) col0[k][q] = v;
-                    }
-                } else {
-                    for (int c = 0; c < sh.C; ++c) sh.color[off * sh.C + c] = c < 4 ? empty_col[c] : bilerp(sh.tex, empty_tp, c, sh.C);
+                float2 q0, q1, q2;
+                if (sh.tri_uv) { q0 = sh.tri_uv[3 * t]; q1 = sh.tri_uv[3 * t + 1]; q2 = sh.tri_uv[3 * t + 2]; }
+                else { q0 = sh.uv[sh.uv_tri[3 * t]]; q1 = sh.uv[sh.uv_tri[3 * t + 1]]; q2 = sh.uv[sh.uv_tri[3 * t + 2]]; }
+                const float w = 1.0f - o.x - o.y;
+                const float tu = o.x * q0.x + o.y * q1.x + w * q2.x;
+                const float tv = o.x * q0.y + o.y * q1.y + w * q2.y;
+                const Taps tp = make_taps(tu, tv, sh.Ht, sh.Wt, sh.C, sh.boundary);
+                for (int c = 0; c < sh.C; ++c) {
+                    const float v = bilerp(sh.tex, tp, c, sh.C);
+                    if (stage) s_col[zy * BIN + zx] = v;
+                    else sh.color[off * sh.C + c] = v;
+                    if (LOSS && c == 0) col0[k] = v;
                 }
+            } else if (stage) {
+                s_col[zy * BIN + zx] = empty_col[0];
+            } else {
+                for (int c = 0; c < sh.C; ++c) sh.color[off * sh.C + c] = c < 4 ? empty_col[c] : bilerp(sh.tex, empty_tp, c, sh.C);
             }
         }
     }
+    // the staged planes leave as 16-byte stores: thread -> four adjacent pixels of row tid >> 3
+    auto flush_plane = [&](const float *s_plane, float *__restrict__ dst) {
+        const int r = tid >> 3, c4 = (tid & 7) * 4;
+        const int fx0 = bin_x0 + c4, fy = bin_y0 + r;
+        if (fy >= H || fx0 >= W) return;
+        const size_t off = ((size_t)b * H + fy) * W + fx0;
+        const float4 v = *reinterpret_cast<const float4 *>(s_plane + r * BIN + c4);
+        if ((W & 3) == 0 && (((size_t)dst) & 15) == 0) *reinterpret_cast<float4 *>(dst + off) = v;
+        else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < 4; ++j)
+                if (fx0 + j < W) dst[off + j] = e[j];
+        }
+    };
 #ifdef FPCDR_ABL_NOLOSSPASS
     if (LOSS) {
         const size_t bin_id0 = bin_lin;
@@ -809,6 +828,12 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         return;
     }
 #endif
+    if (SHADE && !LOSS) {
+        if (stage) {     // (uniform)
+            __syncthreads();
+            flush_plane(s_col, sh.color);
+        }
+    }
     if (LOSS) {
         // ---- every pixel gets the loss term and gradient of its UN-antialiased colour; CANDIDATES are marked ----
         // A pixel's antialiased colour differs from its colour only if one of its four pixel pairs has different ids AND
@@ -819,59 +844,62 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         __shared__ unsigned int s_cmask[BIN];
         __shared__ float s_lpart[4];
         if (tid < BIN) s_cmask[tid] = 0u;
-        __syncthreads();   // (z/w, id) entries and the cleared masks are visible
+        __syncthreads();   // (z/w, id) entries, the staged colour and the cleared masks are visible
         const size_t bin_id = bin_lin;
         unsigned long long *edge = sh.edges + bin_id * (4 * BIN);   // [left col | right col | bottom row | top row][32]
         float lsum = 0.0f;
 #pragma unroll
-        for (int k = 0; k < TILES_PER_WAVE; ++k) {
-            const int tile = wave * TILES_PER_WAVE + k;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int zx = (tile % TILES_X) * TILE + (q & 1) * QUAD + lx, zy = (tile / TILES_X) * TILE + (q >> 1) * QUAD + ly;
-                const int px = bin_x0 + zx, py = bin_y0 + zy;
-                const bool inimg = px < W && py < H;
-                const int idx = zy * BIN + zx;
-                const unsigned long long me = inimg ? s_z[idx] : 0ull;
-                if (zx == 0) edge[zy] = me;
-                if (zx == BIN - 1) edge[BIN + zy] = me;
-                if (zy == 0) edge[2 * BIN + zx] = me;
-                if (zy == BIN - 1) edge[3 * BIN + zx] = me;
-                if (!inimg) continue;
-                const int id = (int)((unsigned int)me & 0xffffffu);
-                const float z = __uint_as_float((unsigned int)(me >> 32));
-                // pair_select keeps the FIRST pixel's triangle on a depth tie: right / upper pairs are (me, n), left / lower
-                // pairs (n, me), as for_active_edges is called; the chosen triangle's silhouette bits ride in the entries
-                auto pair = [&](int nidx, bool me_first) {
-                    const unsigned long long n = s_z[nidx];
-                    const int nid = (int)((unsigned int)n & 0xffffffu);
-                    if (nid == id) return false;
-                    const float nz = __uint_as_float((unsigned int)(n >> 32));
-                    const PairSel ps = me_first ? pair_select(id, z, nid, nz, T) : pair_select(nid, nz, id, z, T);
-                    const bool takes_n = me_first ? ps.use1 : !ps.use1;
-                    return ps.tau >= 0 && (((unsigned int)(takes_n ? n : me) >> 24) & 0xffu) != 0;
-                };
-                const bool cand = (zx < BIN - 1 && px + 1 < W && pair(idx + 1, true)) || (zy < BIN - 1 && py + 1 < H && pair(idx + BIN, true)) ||
-                                  (zx > 0 && pair(idx - 1, false)) || (zy > 0 && pair(idx - BIN, false));
-                if (cand) atomicOr(&s_cmask[zy], 1u << zx);
-                const size_t off = ((size_t)b * H + py) * W + px;
-                if (id > 0) {
-                    const float rf = (float)sh.ref[off];
-                    const float d0 = rf - sh.bg * sh.color_scale;
-                    for (int c = 0; c < sh.C; ++c) {
-                        const float cv = c == 0 ? col0[k][q] : sh.color[off * sh.C + c];   // this thread wrote it above
-                        const float dd = rf - cv * sh.color_scale;
-                        lsum += dd * dd - d0 * d0;
-                        sh.g_aa[off * sh.C + c] = (-2.0f * sh.color_scale * sh.grad_scale) * dd;
-                    }
-                } else {
-                    for (int c = 0; c < sh.C; ++c) sh.g_aa[off * sh.C + c] = 0.0f;
+        for (int k = 0; k < 4; ++k) {
+            const int zy = zy0 + 8 * k, py = bin_y0 + zy;
+            const bool inimg = px < W && py < H;
+            const int idx = zy * BIN + zx;
+            const unsigned long long me = inimg ? s_z[idx] : 0ull;
+            if (zx == 0) edge[zy] = me;
+            if (zx == BIN - 1) edge[BIN + zy] = me;
+            if (zy == 0) edge[2 * BIN + zx] = me;
+            if (zy == BIN - 1) edge[3 * BIN + zx] = me;
+            if (!inimg) continue;
+            const int id = (int)((unsigned int)me & 0xffffffu);
+            const float z = __uint_as_float((unsigned int)(me >> 32));
+            // pair_select keeps the FIRST pixel's triangle on a depth tie: right / upper pairs are (me, n), left / lower
+            // pairs (n, me), as for_active_edges is called; the chosen triangle's silhouette bits ride in the entries
+            auto pair = [&](int nidx, bool me_first) {
+                const unsigned long long n = s_z[nidx];
+                const int nid = (int)((unsigned int)n & 0xffffffu);
+                if (nid == id) return false;
+                const float nz = __uint_as_float((unsigned int)(n >> 32));
+                const PairSel ps = me_first ? pair_select(id, z, nid, nz, T) : pair_select(nid, nz, id, z, T);
+                const bool takes_n = me_first ? ps.use1 : !ps.use1;
+                return ps.tau >= 0 && (((unsigned int)(takes_n ? n : me) >> 24) & 0xffu) != 0;
+            };
+            const bool cand = (zx < BIN - 1 && px + 1 < W && pair(idx + 1, true)) || (zy < BIN - 1 && py + 1 < H && pair(idx + BIN, true)) ||
+                              (zx > 0 && pair(idx - 1, false)) || (zy > 0 && pair(idx - BIN, false));
+            if (cand) atomicOr(&s_cmask[zy], 1u << zx);
+            const size_t off = ((size_t)b * H + py) * W + px;
+            if (id > 0) {
+                const float rf = (float)sh.ref[off];
+                const float d0 = rf - sh.bg * sh.color_scale;
+                for (int c = 0; c < sh.C; ++c) {
+                    const float cv = c == 0 ? col0[k] : sh.color[off * sh.C + c];   // this thread wrote it above
+                    const float dd = rf - cv * sh.color_scale;
+                    lsum += dd * dd - d0 * d0;
+                    const float gq = (-2.0f * sh.color_scale * sh.grad_scale) * dd;
+                    if (stage) s_gaa[idx] = gq;
+                    else sh.g_aa[off * sh.C + c] = gq;
                 }
+            } else if (stage) {
+                s_gaa[idx] = 0.0f;
+            } else {
+                for (int c = 0; c < sh.C; ++c) sh.g_aa[off * sh.C + c] = 0.0f;
             }
         }
         lsum = wave_sum_dpp(lsum);
         if (lane == 0) s_lpart[wave] = lsum;
         __syncthreads();
+        if (stage) {
+            flush_plane(s_col, sh.color);
+            flush_plane(s_gaa, sh.g_aa);
+        }
         if (tid < BIN) sh.cmask[bin_id * BIN + tid] = s_cmask[tid];
         if (tid == 0) {
             const double tot = (double)s_lpart[0] + (double)s_lpart[1] + (double)s_lpart[2] + (double)s_lpart[3];
