@@ -688,6 +688,13 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWDQ_WPE k_render_aa_bwd_queue(c
 // antialias + loss pixel, which overwrites its gradient and CORRECTS the loss; flag bits are OR-ed into the
 // (zero-filled) planes.  An unoccupied bin was never rasterised (its pixels are empty) but still owns the pairs
 // across its right / top border.
+// Threads per bin: the kernel is a chain of dependent loads (masks -> border lines -> candidate list -> (z/w, id) -> silhouette
+// byte -> triangle -> vertices -> colours) for ~30 candidate pixels per bin, i.e. latency-bound with most lanes idle; one wave per
+// bin keeps four times as many bins in flight per CU as four waves do (measured at cfg3: 256 threads 0.26 ms, 64 threads see DESIGN.md).
+#ifndef FPCDR_FIX_NT
+#define FPCDR_FIX_NT 64
+#endif
+constexpr int FIX_NT = FPCDR_FIX_NT;
 template <int CS>
 __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const int byi, const int OX, const int OY,
                                             const float *__restrict__ color, const float4 *__restrict__ rast,
@@ -701,20 +708,20 @@ __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const in
     __shared__ unsigned int s_mask[BBIN];
     __shared__ int s_list[BBIN * BBIN];
     __shared__ int s_n;
-    __shared__ float s_part[4];
+    __shared__ float s_part[FIX_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bx0 = bxi * BBIN, by0 = byi * BBIN;
     const OccWin ow = load_occ(occ, b, H, W, bxi, byi);
     const bool v_me = ow.bin(0, 0);
     if (!(v_me || ow.bin(1, 0) || ow.bin(0, 1))) return;
     const size_t bin_id = ((size_t)b * OY + byi) * OX + bxi;
-    if (tid < BBIN) s_mask[tid] = v_me ? cmask[bin_id * BBIN + tid] : 0u;
+    for (int r = tid; r < BBIN; r += FIX_NT) s_mask[r] = v_me ? cmask[bin_id * BBIN + r] : 0u;
     if (tid == 0) s_n = 0;
     __syncthreads();
     const uint8_t *silb = sil + (size_t)b * T;
-    if (tid < 4 * BBIN) {
+    for (int e = tid; e < 4 * BBIN; e += FIX_NT) {
         // pair across the border: side 0 left column, 1 right column, 2 bottom row, 3 top row; the neighbour's facing line
-        const int side = tid >> 5, i = tid & 31;
+        const int side = e >> 5, i = e & 31;
         const int dx = side == 0 ? -1 : (side == 1 ? 1 : 0), dy = side == 2 ? -1 : (side == 3 ? 1 : 0);
         const int zx = side == 0 ? 0 : (side == 1 ? BBIN - 1 : i), zy = side == 2 ? 0 : (side == 3 ? BBIN - 1 : i);
         const int x = bx0 + zx, y = by0 + zy;
@@ -740,8 +747,8 @@ __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const in
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < BBIN * BBIN / 256; ++k) {
-        const int pix = k * 256 + tid;
+    for (int k = 0; k < BBIN * BBIN / FIX_NT; ++k) {
+        const int pix = k * FIX_NT + tid;
         const bool c = (s_mask[pix >> 5] >> (pix & 31)) & 1u;
         const unsigned long long bal = __ballot(c);
         int base = 0;
@@ -761,7 +768,7 @@ __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const in
     const AAGeom g = {pos + (size_t)b * V, tri, silb, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
     float lsum = 0.0f;
     bool any_flag = false;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += FIX_NT) {
         const int pix = s_list[i];
         const int x = bx0 + (pix & 31), y = by0 + (pix >> 5);
         if (x >= W || y >= H) continue;
@@ -797,7 +804,8 @@ __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const in
     if (lane == 0) s_part[wave] = lsum;
     __syncthreads();
     if (tid == 0) {
-        const double tot = (double)s_part[0] + (double)s_part[1] + (double)s_part[2] + (double)s_part[3];
+        double tot = 0.0;
+        for (int w = 0; w < FIX_NT / 64; ++w) tot += (double)s_part[w];
         const unsigned int slot = ((unsigned int)bxi + 31u * (unsigned int)byi + 977u * (unsigned int)b + 128u) % FPCDR_LOSS_SLOTS;
         if (tot != 0.0) atomicAdd(loss_sum + slot, tot);
     }
@@ -813,7 +821,7 @@ __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const in
 #define FPCDR_AA_FIX_PASS                                                                                                       \
     color, rast, pos, tri, sil, ref, B, H, W, V, T, bg, color_scale, grad_scale, flags, g_aa, occ, empty_color, cmask, edges, loss_sum, binflag
 template <int CS>
-__global__ void __launch_bounds__(256) k_aa_fix_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, FPCDR_AA_FIX_ARGS) {
+__global__ void __launch_bounds__(FIX_NT) k_aa_fix_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, FPCDR_AA_FIX_ARGS) {
     const int item = blockIdx.x;
     if (item >= *count) return;
     const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
@@ -821,7 +829,7 @@ __global__ void __launch_bounds__(256) k_aa_fix_list(const int32_t *__restrict__
     aa_fix_body<CS>(lin / (OX * OY), lin % OX, (lin / OX) % OY, OX, OY, FPCDR_AA_FIX_PASS);
 }
 template <int CS>
-__global__ void __launch_bounds__(256) k_aa_fix_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int first,
+__global__ void __launch_bounds__(FIX_NT) k_aa_fix_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int first,
                                                       FPCDR_AA_FIX_ARGS) {
     const int n = *count;
     const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
@@ -887,8 +895,8 @@ int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask
     (uint8_t *)p->occ + fpcdr_queue_layout_of(p->B, p->H, p->W).occ_binflag
 #define LAUNCH(CS)                                                                                                             \
     do {                                                                                                                       \
-        hipLaunchKernelGGL(k_aa_fix_list<CS>, dim3(cap), dim3(256), 0, st, fix_list, fix_count, ARGS);                        \
-        if (cap < nbins) hipLaunchKernelGGL(k_aa_fix_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(256), 0, st, fix_list, fix_count, cap, ARGS); \
+        hipLaunchKernelGGL(k_aa_fix_list<CS>, dim3(cap), dim3(FIX_NT), 0, st, fix_list, fix_count, ARGS);                        \
+        if (cap < nbins) hipLaunchKernelGGL(k_aa_fix_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(FIX_NT), 0, st, fix_list, fix_count, cap, ARGS); \
     } while (0)
     if (p->C == 1) LAUNCH(1);
     else if (p->C == 3) LAUNCH(3);

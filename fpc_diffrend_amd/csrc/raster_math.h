@@ -30,7 +30,10 @@ __device__ __forceinline__ Shade shade_pixel(float4 v0, float4 v1, float4 v2, fl
     s.dvdx = (da1x - b1 * datx) * iw * sx;
     s.dvdy = (da1y - b1 * daty) * iw * sy;
     float uc = fminf(fmaxf(b0, 0.0f), 1.0f), vc = fminf(fmaxf(b1, 0.0f), 1.0f);
-    float sc = 1.0f / fmaxf(uc + vc, 1.0f);
+    // u = uc / max(uc + vc, 1): the division is by exactly 1 unless rounding pushed the sum past it -- waves without such a
+    // pixel skip it (x * (1 / 1) == x, so the values are the same)
+    float sc = 1.0f;
+    if (uc + vc > 1.0f) sc = 1.0f / (uc + vc);
     s.u = uc * sc;
     s.v = vc * sc;
     return s;

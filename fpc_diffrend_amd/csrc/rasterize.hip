@@ -862,18 +862,28 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
             const int id = (int)((unsigned int)me & 0xffffffu);
             const float z = __uint_as_float((unsigned int)(me >> 32));
             // pair_select keeps the FIRST pixel's triangle on a depth tie: right / upper pairs are (me, n), left / lower
-            // pairs (n, me), as for_active_edges is called; the chosen triangle's silhouette bits ride in the entries
-            auto pair = [&](int nidx, bool me_first) {
-                const unsigned long long n = s_z[nidx];
-                const int nid = (int)((unsigned int)n & 0xffffffu);
-                if (nid == id) return false;
-                const float nz = __uint_as_float((unsigned int)(n >> 32));
-                const PairSel ps = me_first ? pair_select(id, z, nid, nz, T) : pair_select(nid, nz, id, z, T);
-                const bool takes_n = me_first ? ps.use1 : !ps.use1;
-                return ps.tau >= 0 && (((unsigned int)(takes_n ? n : me) >> 24) & 0xffu) != 0;
+            // pairs (n, me), as for_active_edges is called; the chosen triangle's silhouette bits ride in the entries.
+            // First the cheap part for all four pairs: ids differ AND one of the two triangles owns a silhouette edge at all
+            // (interior triangles of a closed mesh own none, so most id discontinuities end here); only such pairs decide
+            // which of the two triangles is analysed.
+            const bool hR = zx < BIN - 1 && px + 1 < W, hU = zy < BIN - 1 && py + 1 < H, hL = zx > 0, hD = zy > 0;
+            const unsigned long long nR = hR ? s_z[idx + 1] : me, nU = hU ? s_z[idx + BIN] : me;
+            const unsigned long long nL = hL ? s_z[idx - 1] : me, nD = hD ? s_z[idx - BIN] : me;
+            auto maybe = [&](unsigned long long n) {
+                return ((unsigned int)n & 0xffffffu) != (unsigned int)id && ((((unsigned int)n | (unsigned int)me) >> 24) & 0xffu) != 0;
             };
-            const bool cand = (zx < BIN - 1 && px + 1 < W && pair(idx + 1, true)) || (zy < BIN - 1 && py + 1 < H && pair(idx + BIN, true)) ||
-                              (zx > 0 && pair(idx - 1, false)) || (zy > 0 && pair(idx - BIN, false));
+            bool cand = false;
+            if ((int)maybe(nR) | (int)maybe(nU) | (int)maybe(nL) | (int)maybe(nD)) {
+                auto pair = [&](unsigned long long n, bool me_first) {
+                    const int nid = (int)((unsigned int)n & 0xffffffu);
+                    if (nid == id) return false;
+                    const float nz = __uint_as_float((unsigned int)(n >> 32));
+                    const PairSel ps = me_first ? pair_select(id, z, nid, nz, T) : pair_select(nid, nz, id, z, T);
+                    const bool takes_n = me_first ? ps.use1 : !ps.use1;
+                    return ps.tau >= 0 && (((unsigned int)(takes_n ? n : me) >> 24) & 0xffu) != 0;
+                };
+                cand = (hR && pair(nR, true)) || (hU && pair(nU, true)) || (hL && pair(nL, false)) || (hD && pair(nD, false));
+            }
             if (cand) atomicOr(&s_cmask[zy], 1u << zx);
             const size_t off = ((size_t)b * H + py) * W + px;
             if (id > 0) {
