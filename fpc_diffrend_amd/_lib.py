@@ -14,7 +14,7 @@ MAX_ATTR = 32
 MAX_MIP = 16
 LOSS_SLOTS = 256
 OCC_BIN = 32         # FPCDR_OCC_BIN
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
 BOUNDARY = {'wrap': 0, 'clamp': 1}
@@ -102,6 +102,19 @@ class PixelLoss(ctypes.Structure):
                 ("loss_sum", _p), ("grad_color", _p)]
 
 
+ADAM_MAX_TENSORS = 16     # FPCDR_ADAM_MAX_TENSORS
+
+
+class AdamTensor(ctypes.Structure):
+    _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("n", ctypes.c_int64),
+                ("step_size", ctypes.c_float), ("bc2_sqrt", ctypes.c_float), ("renorm", _i)]
+
+
+class AdamParams(ctypes.Structure):
+    _fields_ = [("n_tensors", _i), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("one_minus_beta1", ctypes.c_float), ("one_minus_beta2", ctypes.c_float), ("t", AdamTensor * ADAM_MAX_TENSORS)]
+
+
 # every symbol include/fpcdr.h declares: name -> (restype, argtypes)
 _sz = ctypes.c_size_t
 _int = ctypes.c_int
@@ -139,6 +152,7 @@ SYMBOLS = {
     "fpcdr_blend_bwd_w": (_int, [_p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_blend_bwd_basis": (_int, [_p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_pixel_loss": (_int, [ctypes.POINTER(PixelLoss), _p]),
+    "fpcdr_adam_step": (_int, [ctypes.POINTER(AdamParams), _p]),
 }
 
 _lib = None

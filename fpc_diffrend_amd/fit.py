@@ -23,6 +23,7 @@ Reference quirks are reproduced and flagged where they 
 """
 import ctypes
 import json
+import math
 import os
 import time
 from dataclasses import dataclass
@@ -327,6 +328,55 @@ def mesh_edge_loss(verts, topo, target_length=0.0):
 # configuration / parameters
 # ----------------------------------------------------------------------------------------------
 
+class GroupedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam's update (betas 0.9 / 0.999, eps 1e-8, no weight decay, no amsgrad) for all parameter groups in ONE
+    launch of `fpcdr_adam_step`, the whole-tensor quaternion division of the reference's loop folded in (reference
+    fit.py:493-505 ten groups with their own learning rates, :610-618 step + division).  torch's fused Adam launches twice
+    per group, and the two divisions are four small launches each: two dozen ~5 us launches in the serial tail of a 5 ms
+    step.  State layout and names are torch.optim.Adam's ('step', 'exp_avg', 'exp_avg_sq'), so LambdaLR, state_dict() and
+    checkpoints work unchanged.  `renorm` = the parameters divided by their whole-tensor norm after every step."""
+
+    def __init__(self, groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, renorm=()):
+        super().__init__(groups, dict(lr=lr, betas=betas, eps=eps))
+        self._renorm = {id(p) for p in renorm}
+        n = sum(len(g['params']) for g in self.param_groups)
+        assert n <= _lib.ADAM_MAX_TENSORS, "more parameter tensors than one fpcdr_adam_step call takes"
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        P = _lib.AdamParams()
+        k = 0
+        keep = []
+        for g in self.param_groups:
+            b1, b2 = g['betas']
+            P.beta1, P.beta2, P.eps, P.one_minus_beta1, P.one_minus_beta2 = b1, b2, g['eps'], 1.0 - b1, 1.0 - b2
+            for p in g['params']:
+                ren = id(p) in self._renorm
+                if p.grad is None and not ren:
+                    continue
+                assert p.is_contiguous() and p.dtype == torch.float32
+                t = P.t[k]
+                t.param, t.n, t.renorm = p.data_ptr(), p.numel(), 1 if ren else 0
+                t.step_size, t.bc2_sqrt = 0.0, 1.0
+                if p.grad is not None:
+                    st = self.state[p]
+                    if len(st) == 0:
+                        st['step'] = torch.zeros((), dtype=torch.float32)
+                        st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['step'] += 1
+                    n_step = float(st['step'])
+                    grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    keep.append(grad)
+                    t.grad, t.exp_avg, t.exp_avg_sq = grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
+                    t.step_size, t.bc2_sqrt = float(g['lr']) / (1.0 - b1 ** n_step), math.sqrt(1.0 - b2 ** n_step)
+                k += 1
+        P.n_tensors = k
+        _lib.call("fpcdr_adam_step", ctypes.byref(P), _stream())
+        return None
+
+
 @dataclass
 class FitConfig:
     """Keyword arguments of the reference's fitTake (fit.py:323-357) that act on the live loop, with the
@@ -355,6 +405,7 @@ class FitConfig:
     fused_loss: bool = True         # False = reference-style torch.where + torch.mean chain
     fused_render: bool = True       # rasterize + interpolate + texture as one kernel pair (non-mip); False = four separate ops
     fused_objective: bool = True    # with fused_render and fused_loss: the whole pixel term as three kernels (ops.pixel_objective)
+    grouped_adam: bool = True       # all ten Adam groups + the quaternion division as one launch (False: torch.optim.Adam(fused=True))
     sparse_objective: bool = True   # the three kernels skip image regions far from any geometry (same result)
     overlap_regularisers: bool = True   # fused path: mesh regularisers on a second stream beside the pixel objective
     hip_graph: bool = False         # capture forward+backward and the Adam update as two HIP graphs (launch-bound
@@ -456,7 +507,8 @@ class Fitter:
                 g['lr'] = torch.tensor(float(g['lr']), dtype=torch.float32, device=dev)
             self.optimizer = torch.optim.Adam(groups, lr=torch.tensor(cfg.lr_base, dtype=torch.float32, device=dev), capturable=True)
         else:
-            self.optimizer = torch.optim.Adam(groups, lr=cfg.lr_base, fused=True)
+            self.optimizer = GroupedAdam(groups, lr=cfg.lr_base, renorm=(self.q_opt, self.per_frame_q)) if cfg.grouped_adam \
+                else torch.optim.Adam(groups, lr=cfg.lr_base, fused=True)
         self._graphs, self._graph_key, self._frame_idx = None, None, None
         self._side_stream = torch.cuda.Stream(device=dev)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
@@ -647,6 +699,8 @@ class Fitter:
 
     def _update(self):
         self.optimizer.step()
+        if isinstance(self.optimizer, GroupedAdam):     # (the division of fit.py:616-618 happened inside the launch)
+            return
         with torch.no_grad():   # fit.py:616-618 (Q3: whole-tensor norm)
             self.q_opt /= torch.sum(self.q_opt ** 2) ** 0.5
             self.per_frame_q /= torch.sum(self.per_frame_q ** 2) ** 0.5

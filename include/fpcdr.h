@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FPCDR_ABI_VERSION 4
+#define FPCDR_ABI_VERSION 5
 
 enum {
     FPCDR_OK = 0,
@@ -401,6 +401,35 @@ typedef struct {
     float *grad_color;     /* out [B,H,W,C], or NULL */
 } fpcdr_pixel_loss_params;
 int fpcdr_pixel_loss(const fpcdr_pixel_loss_params *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* optimiser update        reference fit.py:493-505 (Adam, ten parameter groups), :610-618       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* One Adam step (torch.optim.Adam arithmetic: betas, eps; no weight decay, no amsgrad) of up to FPCDR_ADAM_MAX_TENSORS
+ * parameter tensors in ONE launch, each with its own learning rate and bias corrections (tensors that start training later
+ * -- the learned basis of the combined mode, fit.py:603-608 -- count their own steps).  A tensor with `renorm` set is
+ * afterwards divided by the Euclidean norm of the WHOLE tensor, the reference's quaternion "normalisation" (fit.py:616-618);
+ * it may come without a gradient (grad = NULL), then only the division happens.  Everything is updated in place.          */
+#define FPCDR_ADAM_MAX_TENSORS 16
+typedef struct {
+    float *param;          /* [n] */
+    const float *grad;     /* [n], or NULL */
+    float *exp_avg;        /* [n] first moment  (unused when grad is NULL) */
+    float *exp_avg_sq;     /* [n] second moment */
+    int64_t n;
+    float step_size;       /* lr / (1 - beta1^step): the group's learning rate of this step (schedule applied by the caller) over
+                              the first bias correction, divided in double precision as torch does */
+    float bc2_sqrt;        /* sqrt(1 - beta2^step) */
+    int32_t renorm;
+} fpcdr_adam_tensor;
+typedef struct {
+    int32_t n_tensors;
+    float beta1, beta2, eps;
+    float one_minus_beta1, one_minus_beta2;   /* rounded from the double-precision differences, as torch does */
+    fpcdr_adam_tensor t[FPCDR_ADAM_MAX_TENSORS];
+} fpcdr_adam_params;
+int fpcdr_adam_step(const fpcdr_adam_params *p, void *stream);
 
 #ifdef __cplusplus
 }

@@ -539,3 +539,41 @@ def test_objective_launch_hints_do_not_change_the_result():
         assert abs(r[0] - base[0]) <= 1e-6 * abs(base[0])
         assert rel_l2(r[1], base[1]) < 1e-5 and rel_l2(r[2], base[2]) < 1e-5
     dr._list_hints.clear()
+
+
+@pytest.mark.gpu
+def test_grouped_adam_equals_torch_adam_and_renormalises():
+    """fpcdr_adam_step (all groups in one launch, reference fit.py:493-505, 610-618) against torch.optim.Adam on the same
+    tensors: several steps, different learning rates, a tensor that starts receiving gradients later (its own step count, as
+    the learned basis of the combined mode), odd sizes (scalar tail of the float4 loop), and the whole-tensor quaternion
+    division (quirk Q3) -- also for a quaternion tensor that receives no gradient in a step."""
+    from fpc_diffrend_amd import fit
+    g = torch.Generator().manual_seed(3)
+    shapes = [(150, 7), (1001,), (9, 4), (5, 4), (64, 64, 1)]
+    lrs = [1e-2, 3e-3, 1e-3, 1e-4, 5e-3]
+    a = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    oa = fit.GroupedAdam([{"params": p, "lr": lr} for p, lr in zip(a, lrs)], lr=1e-3, renorm=(a[2], a[3]))
+    ob = torch.optim.Adam([{"params": p, "lr": lr} for p, lr in zip(b, lrs)], lr=1e-3)
+    sched_a = torch.optim.lr_scheduler.LambdaLR(oa, lr_lambda=lambda x: 0.5 ** (x / 3))
+    sched_b = torch.optim.lr_scheduler.LambdaLR(ob, lr_lambda=lambda x: 0.5 ** (x / 3))
+    for it in range(5):
+        for k, (p, q) in enumerate(zip(a, b)):
+            late = (k == 1 and it < 2) or (k == 3 and it == 1)      # no gradient in these steps
+            gr = None if late else torch.randn(p.shape, generator=g).cuda() * (10.0 ** (k - 2))
+            p.grad = gr
+            q.grad = None if gr is None else gr.clone()
+        oa.step()
+        ob.step()
+        with torch.no_grad():
+            for q in (b[2], b[3]):
+                q /= torch.sum(q ** 2) ** 0.5
+        sched_a.step()
+        sched_b.step()
+        for k, (p, q) in enumerate(zip(a, b)):
+            assert rel_l2(p, q) < 2e-6, (it, k, rel_l2(p, q))
+    assert float(oa.state[a[1]]['step']) == 3 and float(oa.state[a[0]]['step']) == 5
+    # the state is torch.optim.Adam's: it round-trips through state_dict into a fresh optimiser
+    oc = fit.GroupedAdam([{"params": p, "lr": lr} for p, lr in zip(a, lrs)], lr=1e-3, renorm=(a[2], a[3]))
+    oc.load_state_dict(oa.state_dict())
+    assert torch.equal(oc.state[a[0]]['exp_avg'], oa.state[a[0]]['exp_avg']) and float(oc.state[a[1]]['step']) == 3
