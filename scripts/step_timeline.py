@@ -7,7 +7,7 @@ import csv, glob, os, sys
 rows = []
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:60], r.get("Queue_Id", "?")))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:100], r.get("Queue_Id", "?")))
 rows.sort()
 starts = [i for i, r in enumerate(rows) if r[2] == "k_setup"]
 a, b = starts[-2], starts[-1]

@@ -26,3 +26,13 @@ def bwd():
     out.backward(go)
 t_fb = timed(bwd)
 print(f"blend fwd {t_f:.1f} us ({M * K * 4 / t_f / 1e6:.2f} TB/s of Bmat, {2 * M * K * F / t_f / 1e6:.1f} TFLOP/s); fwd+bwd_w {t_fb:.1f} us")
+# the backward-to-weights kernel alone (fpcdr_blend_bwd_w), straight through the C ABI
+import ctypes
+from fpc_diffrend_amd import _lib
+gw = torch.zeros(F, K, device='cuda')
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+t_bw = timed(lambda: _lib.call("fpcdr_blend_bwd_w", P(Bm), P(go), P(gw), M, K, F, st))
+ref = (go.double() @ Bm.double())
+gw.zero_(); _lib.call("fpcdr_blend_bwd_w", P(Bm), P(go), P(gw), M, K, F, st)
+print(f"blend bwd_w {t_bw:.1f} us ({M * K * 4 / t_bw / 1e6:.2f} TB/s of Bmat); rel err {float((gw.double() - ref).norm() / ref.norm()):.1e}")
