@@ -84,9 +84,9 @@ constexpr int SMALL_EXTENT = 16384;
 #endif
 constexpr int LANE_MAX = FPCDR_LANE_MAX;
 constexpr int BIGB = 64;         // triangles per round of the tile path
-// latency-bound: never fewer than 6 waves per SIMD (the LOSS variant otherwise lands on 81 VGPRs = 5 waves: +0.3 ms)
+// latency-bound: 7 waves per SIMD (r2 sweep of the LOSS list kernel: 5 -> 2.23 ms, 6 -> 2.23, 7 -> 2.11, 8 -> 2.20; its 22 KB of LDS allow 7 workgroups per CU)
 #ifndef FPCDR_BINS_WPE
-#define FPCDR_BINS_WPE __attribute__((amdgpu_waves_per_eu(6, 8)))
+#define FPCDR_BINS_WPE __attribute__((amdgpu_waves_per_eu(7, 8)))
 #endif
 #ifndef FPCDR_SCAN_K
 #define FPCDR_SCAN_K 4
