@@ -379,7 +379,7 @@ def main():
                     a = st["fpcdr_antialias_bwd"]["algorithmic_GBps"]
                     out["roofline_antialias_bwd"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                      "frac": a / HBM_PEAK_GBS,
-                                                     "traffic": (measured_counters("fpcdr_antialias_bwd", args.workload, fpg * n_cam, C) or {}).get("hbm_bytes"),
+                                                     "traffic": (measured_counters("fpcdr_antialias_bwd", args.workload, fpg * n_cam, C) or {}).get("hbm_bytes") or None,
                                                      "note": "stand-alone dr.antialias backward at the same batch, outside the timed region"}
             except Exception as e:   # the sweep must never take the measurement down
                 out["kernels_standalone_ops"] = {"error": repr(e)}

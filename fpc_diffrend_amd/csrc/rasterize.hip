@@ -426,7 +426,10 @@ struct ShadeArgs {
 };
 
 // One 32x32 bin (bxi, byi) of image b; OX x OY bins per image.  Every branch that leaves is uniform over the workgroup.
-template <bool WRITE_DB, bool SHADE, bool LOSS, bool QUEUE>
+// CS / BMODE: channel count and texture boundary mode as compile-time constants (0 / -1 = read them from ShadeArgs); the list
+// kernels of the objective are instantiated for the reference's case (one channel, 'wrap'), which strips the channel loops, the
+// index scaling and the mode branches from the ~200 instructions a shaded pixel costs
+template <bool WRITE_DB, bool SHADE, bool LOSS, bool QUEUE, int CS = 0, int BMODE = -1>
 __device__ __forceinline__ void bins_body(const int b, const int bxi, const int byi, const int OX, const int OY,
                                           const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                           int V, int T, int H, int W, const TriRec *__restrict__ recs,
@@ -716,6 +719,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         }
         return;
     }
+    const int C = CS > 0 ? CS : sh.C, boundary = BMODE >= 0 ? BMODE : sh.boundary;
     // ---- fold the tile path's register winners into the depth buffer, then read every pixel's winner ----
     // From here on a thread owns the four pixels (tid & 31, (tid >> 5) + 8 k) of the bin: the 32 lanes of a half wave write
     // one 512-byte row segment of rast per instruction (the raster's 8 x 8 quadrant pattern gave 128-byte pieces).
@@ -745,15 +749,15 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
     static_assert(sizeof(s_list) >= BIN * BIN * sizeof(float) && sizeof(s_tri) >= BIN * BIN * sizeof(float), "staging aliases the raster lists");
     float *s_col = reinterpret_cast<float *>(s_list);
     float *s_gaa = reinterpret_cast<float *>(s_tri);
-    const bool stage = SHADE && sh.C == 1;
+    const bool stage = SHADE && C == 1;
     float col0[4] = {0.f, 0.f, 0.f, 0.f};   // LOSS: channel 0 of this thread's pixels (re-reading a just-written line stalls)
     const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
     const float4 *p = pos + (size_t)b * V;
     Taps empty_tp = {};
     float empty_col[4] = {0.f, 0.f, 0.f, 0.f};
     if (SHADE) {
-        empty_tp = make_taps(0.0f, 0.0f, sh.Ht, sh.Wt, sh.C, sh.boundary);
-        for (int c = 0; c < min(sh.C, 4); ++c) empty_col[c] = bilerp(sh.tex, empty_tp, c, sh.C);
+        empty_tp = make_taps(0.0f, 0.0f, sh.Ht, sh.Wt, C, boundary);
+        for (int c = 0; c < min(C, 4); ++c) empty_col[c] = bilerp(sh.tex, empty_tp, c, C);
     }
     const int px = bin_x0 + zx;
 #pragma unroll
@@ -793,17 +797,17 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                 const float w = 1.0f - o.x - o.y;
                 const float tu = o.x * q0.x + o.y * q1.x + w * q2.x;
                 const float tv = o.x * q0.y + o.y * q1.y + w * q2.y;
-                const Taps tp = make_taps(tu, tv, sh.Ht, sh.Wt, sh.C, sh.boundary);
-                for (int c = 0; c < sh.C; ++c) {
-                    const float v = bilerp(sh.tex, tp, c, sh.C);
+                const Taps tp = make_taps(tu, tv, sh.Ht, sh.Wt, C, boundary);
+                for (int c = 0; c < C; ++c) {
+                    const float v = bilerp(sh.tex, tp, c, C);
                     if (stage) s_col[zy * BIN + zx] = v;
-                    else sh.color[off * sh.C + c] = v;
+                    else sh.color[off * C + c] = v;
                     if (LOSS && c == 0) col0[k] = v;
                 }
             } else if (stage) {
                 s_col[zy * BIN + zx] = empty_col[0];
             } else {
-                for (int c = 0; c < sh.C; ++c) sh.color[off * sh.C + c] = c < 4 ? empty_col[c] : bilerp(sh.tex, empty_tp, c, sh.C);
+                for (int c = 0; c < C; ++c) sh.color[off * C + c] = c < 4 ? empty_col[c] : bilerp(sh.tex, empty_tp, c, C);
             }
         }
     }
@@ -889,18 +893,18 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
             if (id > 0) {
                 const float rf = (float)sh.ref[off];
                 const float d0 = rf - sh.bg * sh.color_scale;
-                for (int c = 0; c < sh.C; ++c) {
-                    const float cv = c == 0 ? col0[k] : sh.color[off * sh.C + c];   // this thread wrote it above
+                for (int c = 0; c < C; ++c) {
+                    const float cv = c == 0 ? col0[k] : sh.color[off * C + c];   // this thread wrote it above
                     const float dd = rf - cv * sh.color_scale;
                     lsum += dd * dd - d0 * d0;
                     const float gq = (-2.0f * sh.color_scale * sh.grad_scale) * dd;
                     if (stage) s_gaa[idx] = gq;
-                    else sh.g_aa[off * sh.C + c] = gq;
+                    else sh.g_aa[off * C + c] = gq;
                 }
             } else if (stage) {
                 s_gaa[idx] = 0.0f;
             } else {
-                for (int c = 0; c < sh.C; ++c) sh.g_aa[off * sh.C + c] = 0.0f;
+                for (int c = 0; c < C; ++c) sh.g_aa[off * C + c] = 0.0f;
             }
         }
         lsum = wave_sum_dpp(lsum);
@@ -937,7 +941,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
 #ifndef FPCDR_BINSQ_WPE
 #define FPCDR_BINSQ_WPE
 #endif
-template <bool WRITE_DB, bool SHADE, bool LOSS>
+template <bool WRITE_DB, bool SHADE, bool LOSS, int CS = 0, int BMODE = -1>
 __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
                                               int OX, int OY,
                                               const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
@@ -948,8 +952,8 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t 
     const int item = blockIdx.x;
     if (item >= *count) return;
     const int lin = __builtin_amdgcn_readfirstlane(list[item]);
-    bins_body<WRITE_DB, SHADE, LOSS, true>(lin / (OX * OY), lin % OX, (lin / OX) % OY, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox,
-                                           rast, rast_db, sh);
+    bins_body<WRITE_DB, SHADE, LOSS, true, CS, BMODE>(lin / (OX * OY), lin % OX, (lin / OX) % OY, OX, OY, pos, tri, V, T, H, W, recs, boxes,
+                                                      cboxes, ibox, rast, rast_db, sh);
 }
 
 // strided form: entries first, first + gridDim.x, ... of the list.  The loop variable is scalar by construction, so the loop
@@ -1323,7 +1327,12 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
                     l->grad_scale};
     // hinted single-shot launch + strided sweep of the rest (l->cap_bins <= 0: no hint, one workgroup per possible entry)
     const int cap_bins = (l->cap_bins > 0 && (size_t)l->cap_bins < nbins) ? l->cap_bins : (int)nbins;
-    hipLaunchKernelGGL((k_bins_list<false, true, true>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY,
+    if (p->C == 1 && p->boundary_mode == FPCDR_BOUNDARY_WRAP)     // the reference's case, with both as compile-time constants
+        hipLaunchKernelGGL((k_bins_list<false, true, true, 1, FPCDR_BOUNDARY_WRAP>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY,
+                       (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
+                       (float4 *)nullptr, sh);
+    else
+        hipLaunchKernelGGL((k_bins_list<false, true, true>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY,
                        (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
                        (float4 *)nullptr, sh);
     if ((size_t)cap_bins < nbins)

@@ -5,6 +5,6 @@ for spec in "$@"; do
   n=${spec%%:*}; envs=""
   if [[ "$spec" == *:* ]]; then envs=$(echo "${spec#*:}" | tr ',' ' '); fi
   if [ "$n" = default ]; then lib=""; else lib="FPCDR_LIB_PATH=$PWD/fpc_diffrend_amd/libfpcdr_$n.so"; fi
-  out=$(env $lib $envs timeout -k 10 200 python scripts/prof_objective.py 2>/dev/null | tail -1) || { echo "FAILED $spec"; exit 1; }
+  out=$(env $lib $envs timeout -k 10 200 python scripts/prof_objective.py --ops 0 2>/dev/null | tail -1) || { echo "FAILED $spec"; exit 1; }
   echo "$spec $out"
 done

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc passes (counter_collection.csv + kernel_trace.csv) -> one JSON: per kernel, the mean of every counter per
 dispatch and the mean duration in that pass.   python scripts/make_counters_json.py DIR... > counters.json
-Only dispatches of at least half the LARGEST grid of each kernel are averaged: prof_objective.py also renders its targets in
-small chunks, and the list kernels' grids follow the launch hints from step to step."""
+Dispatches up to and including the first k_render_aa_bwd are ignored (set-up, the targets rendered in small chunks, and the first
+fit step, whose list kernels run without launch hints at the full grid); of the rest, only dispatches of at least half the
+largest grid of each kernel are averaged (the list kernels' grids follow the hints from step to step)."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -22,8 +23,17 @@ out = defaultdict(lambda: {"counters": {}, "duration_us": {}})
 for d in ARGS:
     tag = os.path.basename(d.rstrip("/"))
     dur = defaultdict(list)
+    first = None    # dispatch id of the first backward call
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
+            if "k_render_aa_bwd" in r["Kernel_Name"]:
+                i = int(r["Dispatch_Id"])
+                first = i if first is None else min(first, i)
+    first = first or 0
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if int(r["Dispatch_Id"]) <= first:
+                continue
             g = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) * max(int(r.get("Grid_Size_Y", 1) or 1), 1) * max(int(r.get("Grid_Size_Z", 1) or 1), 1)
             dur[short(r["Kernel_Name"])].append((g, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     for k, v in dur.items():
@@ -34,6 +44,8 @@ for d in ARGS:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         vals = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(f)):
+            if int(r["Dispatch_Id"]) <= first:
+                continue
             g = int(r.get("Grid_Size", 0) or 0)
             vals[short(r["Kernel_Name"])][r["Counter_Name"]].append((g, float(r["Counter_Value"])))
         for k, cs in vals.items():
@@ -43,5 +55,5 @@ for d in ARGS:
                 out[k]["counters"][c] = sum(sel) / len(sel)
 keep = {k: v for k, v in out.items() if k.startswith(("k_", "void k_"))}
 print(json.dumps(dict(META, _comment="rocprofv3 --pmc passes of scripts/prof_objective.py (scripts/measure_round.sh): per kernel the mean "
-                       "counter value per dispatch (dispatches of at least half the largest grid) and the mean duration in each pass; FETCH_SIZE / "
+                       "counter value per dispatch (after the first fit step; dispatches of at least half the largest grid) and the mean duration in each pass; FETCH_SIZE / "
                        "WRITE_SIZE in KB", kernels=keep), indent=1, sort_keys=True))

@@ -9,6 +9,7 @@ ap.add_argument("--workload", default="cfg3")
 ap.add_argument("--frames", type=int, default=32)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--fill", type=float, default=0.0, help="head height as a fraction of the image height (default: the scene's 0.6)")
+ap.add_argument("--ops", type=int, default=1, help="also run the eight operator calls of render() + backward once at the full batch (their kernels' counters)")
 a = ap.parse_args()
 sc = scene.cfg(a.workload, n_frames=a.frames)
 if a.fill:
@@ -24,5 +25,20 @@ for _ in range(a.steps):
 _lib.TIMER = None
 print(json.dumps({k: v[1] / v[0] for k, v in t.summary().items()}))
 import fpc_diffrend_amd.ops as _dr
+if a.ops:
+    from fpc_diffrend_amd import camera
+    ids = slice(0, ft.n_frames)
+    for _ in range(2):
+        verts = ft.vertices(ids).reshape(ft.n_frames, -1, 3).detach()
+        pos = camera.transform_clip(ft.mvp(ids).detach(), verts).requires_grad_(True)
+        tex = ft.tex_opt.detach().clone().requires_grad_(True)
+        ctx = _dr.RasterizeGLContext(output_db=False, device=ft.device)
+        rast, _ = _dr.rasterize(ctx, pos, ft.pos_idx, ft.resolution)
+        texc, _ = _dr.interpolate(ft.uv[None], rast, ft.uv_idx)
+        col = _dr.texture(tex[None], texc, filter_mode='linear')
+        aa = _dr.antialias(col, rast, pos, ft.pos_idx)
+        (aa * (rast[..., 3:] > 0)).sum().backward()
+        del rast, texc, col, aa, pos, tex
+    torch.cuda.synchronize()
 for k, h in _dr._list_hints.items():
     print("hints", k, "host counts [bwd,-,bins,fix]:", h.host.tolist(), "caps", h.caps, file=sys.stderr)

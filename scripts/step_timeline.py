@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timeline of ONE fit step from a rocprofv3 kernel trace of scripts/prof_objective.py:
-   rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 scripts/prof_objective.py ;  python scripts/step_timeline.py DIR
+   rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 scripts/prof_objective.py --ops 0 ;  python scripts/step_timeline.py DIR
 Prints every dispatch of the last complete step (k_setup to k_setup) with its start offset, duration, queue and the idle
 gap before it, so that launch gaps and what overlaps with the two objective calls become visible."""
 import csv, glob, os, sys
