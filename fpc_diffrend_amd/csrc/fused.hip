@@ -264,7 +264,7 @@ constexpr int BBIN = 32;
 constexpr int BWD_NT = FPCDR_BWD_NT;          // threads per bin workgroup (measured: 128 -> 3.08 ms, 256 -> 2.61, 512 -> 3.28)
 constexpr int BWD_NPX = BBIN * BBIN / BWD_NT;  // pixels per thread
 
-template <int CS>
+template <int CS, int BMODE = -1>      // BMODE >= 0: the texture boundary mode as a compile-time constant
 __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, const int byi,
                                                        const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
@@ -274,9 +274,10 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                                                        const unsigned long long *__restrict__ flags,
                                                        const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
                                                        int B, int V, int T, int H,
-                                                       int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
+                                                       int W, int Ht, int Wt, int boundary_arg, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
                                                        const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
+    const int boundary = BMODE >= 0 ? BMODE : boundary_arg;
     __shared__ int s_vkey[VSLOTS];
     __shared__ __attribute__((aligned(16))) float s_vacc[VSLOTS][4];
     __shared__ float s_tex[TEXH * TEXW * CS];
@@ -614,7 +615,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
 }
 
 // grid form (dense mode, and sparse mode after the two-call forward): one workgroup per bin, grid (OX, OY, B)
-template <int CS>
+template <int CS, int BMODE = -1>
 __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
                                                        const float *__restrict__ tex, const float4 *__restrict__ rast,
@@ -626,7 +627,7 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
                                                        const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
-    render_aa_bwd_body<CS>(blockIdx.z, blockIdx.x, blockIdx.y, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ, empty_color,
+    render_aa_bwd_body<CS, BMODE>(blockIdx.z, blockIdx.x, blockIdx.y, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ, empty_color,
                            B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag);
 }
 
@@ -992,7 +993,12 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
                        (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,   \
                        p->boundary_mode,                                                                                        \
                        p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream, binflag)
-    if (p->C == 1) LAUNCH(1);
+    if (p->C == 1 && p->boundary_mode == FPCDR_BOUNDARY_WRAP) {     // the reference's case
+        hipLaunchKernelGGL((k_render_aa_bwd<1, FPCDR_BOUNDARY_WRAP>), grid, dim3(BWD_NT), 0, st, (const float4 *)p->pos, p->tri,
+                           (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa, p->sil,
+                           (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,
+                           p->boundary_mode, p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream, binflag);
+    } else if (p->C == 1) LAUNCH(1);
     else if (p->C == 3) LAUNCH(3);
     else LAUNCH(4);
 #undef LAUNCH
