@@ -56,12 +56,12 @@ def algorithmic_bytes_per_px(C, with_db):
 
 COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_counters_cfg3.json")
 # kernels behind each C-ABI entry point (the PMC passes are per kernel)
+# kernels of each entry point, by name prefix (template arguments vary with the instantiation the launch picked)
 ENTRY_KERNELS = {
-    "fpcdr_render_loss_fwd": ["k_sil2", "k_init_queue", "k_setup", "void k_list_count<false>", "k_list_scan", "void k_list_write<false>",
-                              "void k_bins_list<false, true, true>", "void k_bins_queue<false, true, true>", "void k_list_count<true>",
-                              "void k_list_write<true>", "void k_aa_fix_list<1>", "void k_aa_fix_queue<1>"],
-    "fpcdr_render_aa_bwd": ["void k_render_aa_bwd<1>"],
-    "fpcdr_antialias_bwd": ["k_copy_f4_chunk", "void k_aa_bwd_fix<1>"],
+    "fpcdr_render_loss_fwd": ["k_sil2", "k_init_queue", "k_setup", "k_list_count<", "k_list_scan", "k_list_write<",
+                              "k_bins_list<false, true, true", "k_bins_queue<false, true, true", "k_aa_fix_list<", "k_aa_fix_queue<"],
+    "fpcdr_render_aa_bwd": ["k_render_aa_bwd<"],
+    "fpcdr_antialias_bwd": ["k_copy_f4_chunk", "k_aa_bwd_fix<"],
     "fpcdr_blend_fwd": ["k_blend_fwd_lds"],
 }
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
@@ -80,9 +80,10 @@ def measured_counters(name, workload, n_images, C):
         if t["workload"] != workload or t["images"] != n_images or t["channels"] != C:
             return None
         tot = {"fetch_kb": 0.0, "write_kb": 0.0, "valu_insts": 0.0, "gui_active": 0.0, "mfma_busy": 0.0, "lds_conflict": 0.0, "lds_active": 0.0}
-        for k in ENTRY_KERNELS[name]:
-            c = t["kernels"].get(k, {}).get("counters")
-            if not c:
+        for kname, entry in t["kernels"].items():
+            short = kname[5:] if kname.startswith("void ") else kname
+            c = entry.get("counters")
+            if not c or not any(short == pre or (pre.endswith(("<", "true", "false")) and short.startswith(pre)) for pre in ENTRY_KERNELS[name]):
                 continue
             tot["fetch_kb"] += c.get("FETCH_SIZE", 0.0)
             tot["write_kb"] += c.get("WRITE_SIZE", 0.0)

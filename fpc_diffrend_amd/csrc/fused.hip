@@ -422,12 +422,12 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
     }
     for (int k = tid; k < TEXH * TEXW * CS; k += BWD_NT) s_tex[k] = 0.0f;
     int pt[BWD_NPX];
-    float tu[BWD_NPX], tv[BWD_NPX], ru[BWD_NPX], rv[BWD_NPX];
+    float tu[BWD_NPX], tv[BWD_NPX];
     {
         int ux0 = 0x7fffffff, uy0 = 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < BWD_NPX; ++k) {
-            pt[k] = -1; tu[k] = 0.f; tv[k] = 0.f; ru[k] = 0.f; rv[k] = 0.f;
+            pt[k] = -1; tu[k] = 0.f; tv[k] = 0.f;
             if (any[k] && v_me) {
                 const float4 r = rast[img + (size_t)(by0 + rowk0 + 2 * k) * W + x];
                 int t = (int)r.w - 1;
@@ -439,7 +439,6 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                     const float w = 1.0f - r.x - r.y;
                     tu[k] = r.x * q0.x + r.y * q1.x + w * q2.x;
                     tv[k] = r.x * q0.y + r.y * q1.y + w * q2.y;
-                    ru[k] = r.x; rv[k] = r.y;
                     pt[k] = t;
                     if (grad_tex) {
                         ux0 = min(ux0, (int)floorf(prep_coord(tu[k], boundary) * (float)Wt - 0.5f));
