@@ -238,7 +238,7 @@ def test_rasterize_depth_ties_go_to_the_smaller_index(dr, ctx, oracle_ops):
     assert torch.equal(first[src[win]], win)
 
 
-@pytest.mark.parametrize("C,res", [(1, (150, 200)), (3, (97, 131))])
+@pytest.mark.parametrize("C,res", [(1, (150, 200)), (3, (97, 131)), (1, (75, 101))])
 def test_region_hints_do_not_change_the_operator_chain(dr, oracle_ops, C, res):
     """rasterize() tags its output with the map of bins no triangle touches; interpolate / texture / antialias and the
     backward kernels then skip the reads of those bins (include/fpcdr.h, REGION HINTS).  With and without the mechanism the
