@@ -23,12 +23,15 @@ __device__ __forceinline__ int wrap_near(int i, int n, int mode) {
 
 __device__ __forceinline__ float prep_coord(float u, int mode) {
     if (mode == FPCDR_BOUNDARY_WRAP) return u - floorf(u);
+    if (mode == FPCDR_BOUNDARY_ZERO) return u;             // the texture is padded with zeros: coordinates stay as they are
     return fminf(fmaxf(u, 0.0f), 1.0f);
 }
 
 struct Taps {
     int i00, i10, i01, i11;  // element offsets (texel index * C) within one texture image
     float fx, fy;
+    unsigned int valid;      // boundary mode 'zero': bit k set = tap k (00, 10, 01, 11) lies inside the texture; else 0xF.  The
+                             // offsets are always in range, so loads are safe; consumers of 'zero' mask values and skip scatters
 };
 
 __device__ __forceinline__ Taps make_taps(float u, float v, int Ht, int Wt, int C, int mode) {
@@ -39,8 +42,13 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int Ht, int Wt, int 
     t.fx = x - x0f;
     t.fy = y - y0f;
     const int x0 = (int)x0f, y0 = (int)y0f;
-    const int ix0 = wrap_near(x0, Wt, mode), ix1 = wrap_near(x0 + 1, Wt, mode);
-    const int iy0 = wrap_near(y0, Ht, mode), iy1 = wrap_near(y0 + 1, Ht, mode);
+    t.valid = 0xFu;
+    if (mode == FPCDR_BOUNDARY_ZERO) {      // (a NaN or huge coordinate converts to INT_MIN / INT_MAX: every tap outside)
+        const bool vx0 = x0 >= 0 && x0 < Wt, vx1 = x0 >= -1 && x0 < Wt - 1, vy0 = y0 >= 0 && y0 < Ht, vy1 = y0 >= -1 && y0 < Ht - 1;
+        t.valid = (vx0 && vy0 ? 1u : 0u) | (vx1 && vy0 ? 2u : 0u) | (vx0 && vy1 ? 4u : 0u) | (vx1 && vy1 ? 8u : 0u);
+    }
+    const int ix0 = wrap_near(x0, Wt, mode), ix1 = wrap_near(x0 == 0x7fffffff ? x0 : x0 + 1, Wt, mode);
+    const int iy0 = wrap_near(y0, Ht, mode), iy1 = wrap_near(y0 == 0x7fffffff ? y0 : y0 + 1, Ht, mode);
     t.i00 = (iy0 * Wt + ix0) * C; t.i10 = (iy0 * Wt + ix1) * C;
     t.i01 = (iy1 * Wt + ix0) * C; t.i11 = (iy1 * Wt + ix1) * C;
     return t;
@@ -61,9 +69,20 @@ __device__ __forceinline__ void load_taps(const float *tx, const Taps &t, int c,
     }
 }
 
+// boundary mode 'zero': taps outside the texture read as 0
+__device__ __forceinline__ void mask_taps(const Taps &t, float &t00, float &t10, float &t01, float &t11) {
+    if (t.valid != 0xFu) {
+        if (!(t.valid & 1u)) t00 = 0.0f;
+        if (!(t.valid & 2u)) t10 = 0.0f;
+        if (!(t.valid & 4u)) t01 = 0.0f;
+        if (!(t.valid & 8u)) t11 = 0.0f;
+    }
+}
+
 __device__ __forceinline__ float bilerp(const float *tx, const Taps &t, int c, int C) {
     float t00, t10, t01, t11;
     load_taps(tx, t, c, C, t00, t10, t01, t11);
+    mask_taps(t, t00, t10, t01, t11);
     const float top = t00 + (t10 - t00) * t.fx;
     const float bot = t01 + (t11 - t01) * t.fx;
     return top + (bot - top) * t.fy;

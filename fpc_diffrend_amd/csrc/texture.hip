@@ -45,8 +45,10 @@ __global__ void k_tex_empty(TexLevels lv, int Ht, int Wt, int C, int filter, int
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         if (filter == FPCDR_FILTER_NEAREST) {
             const float x = prep_coord(0.0f, boundary) * (float)Wt - 0.5f, y = prep_coord(0.0f, boundary) * (float)Ht - 0.5f;
-            const int ix = wrap_i((int)floorf(x + 0.5f), Wt, boundary), iy = wrap_i((int)floorf(y + 0.5f), Ht, boundary);
-            out[c] = lv.tex[0][((size_t)iy * Wt + ix) * C + c];
+            const int rx = (int)floorf(x + 0.5f), ry = (int)floorf(y + 0.5f);
+            const int ix = wrap_i(rx, Wt, boundary), iy = wrap_i(ry, Ht, boundary);
+            const bool in = boundary != FPCDR_BOUNDARY_ZERO || (rx >= 0 && rx < Wt && ry >= 0 && ry < Ht);
+            out[c] = in ? lv.tex[0][((size_t)iy * Wt + ix) * C + c] : 0.0f;
         } else {
             const Taps t = make_taps(0.0f, 0.0f, Ht, Wt, C, boundary);
             out[c] = bilerp(lv.tex[0], t, c, C);
@@ -85,9 +87,11 @@ __global__ void __launch_bounds__(256) k_tex_fwd(TexLevels lv, int n_levels, con
         const int b = Bt > 1 ? (int)blockIdx.z : 0;
         if (filter == FPCDR_FILTER_NEAREST) {
             const float x = prep_coord(q.x, boundary) * (float)Wt - 0.5f, y = prep_coord(q.y, boundary) * (float)Ht - 0.5f;
-            const int ix = wrap_i((int)floorf(x + 0.5f), Wt, boundary), iy = wrap_i((int)floorf(y + 0.5f), Ht, boundary);
+            const int rx = (int)floorf(x + 0.5f), ry = (int)floorf(y + 0.5f);
+            const int ix = wrap_i(rx, Wt, boundary), iy = wrap_i(ry, Ht, boundary);
+            const bool in = boundary != FPCDR_BOUNDARY_ZERO || (rx >= 0 && rx < Wt && ry >= 0 && ry < Ht);
             const float *tx = lv.tex[0] + (size_t)b * Ht * Wt * C + ((size_t)iy * Wt + ix) * C;
-            for (int c = 0; c < C; ++c) o[c] = tx[c];
+            for (int c = 0; c < C; ++c) o[c] = in ? tx[c] : 0.0f;
         } else if (filter == FPCDR_FILTER_LINEAR) {
             const Taps t = make_taps(q.x, q.y, Ht, Wt, C, boundary);
             const float *tx = lv.tex[0] + (size_t)b * Ht * Wt * C;
@@ -155,13 +159,14 @@ __device__ __forceinline__ void taps_bwd(const float *tx, float *gtx, const Taps
         const float gc = g[c] * scale;
         float t00, t10, t01, t11;
         load_taps(tx, t, c, C, t00, t10, t01, t11);
+        mask_taps(t, t00, t10, t01, t11);
         gfx += gc * ((t10 - t00) * (1.0f - t.fy) + (t11 - t01) * t.fy);
         gfy += gc * ((t01 + (t11 - t01) * t.fx) - (t00 + (t10 - t00) * t.fx));
-        if (gtx && gc != 0.0f) {
-            atomicAdd(gtx + t.i00 + c, gc * w00);
-            atomicAdd(gtx + t.i10 + c, gc * w10);
-            atomicAdd(gtx + t.i01 + c, gc * w01);
-            atomicAdd(gtx + t.i11 + c, gc * w11);
+        if (gtx && gc != 0.0f) {      // (boundary mode 'zero': the padding receives no gradient)
+            if (t.valid & 1u) atomicAdd(gtx + t.i00 + c, gc * w00);
+            if (t.valid & 2u) atomicAdd(gtx + t.i10 + c, gc * w10);
+            if (t.valid & 4u) atomicAdd(gtx + t.i01 + c, gc * w01);
+            if (t.valid & 8u) atomicAdd(gtx + t.i11 + c, gc * w11);
         }
     }
 }
@@ -192,10 +197,12 @@ __global__ void __launch_bounds__(256) k_tex_bwd(TexLevels lv, int n_levels, con
             if (filter == FPCDR_FILTER_NEAREST) {
                 if (lv.grad[0]) {
                     const float x = prep_coord(q.x, boundary) * (float)Wt - 0.5f, y = prep_coord(q.y, boundary) * (float)Ht - 0.5f;
-                    const int ix = wrap_i((int)floorf(x + 0.5f), Wt, boundary), iy = wrap_i((int)floorf(y + 0.5f), Ht, boundary);
+                    const int rx = (int)floorf(x + 0.5f), ry = (int)floorf(y + 0.5f);
+                    const int ix = wrap_i(rx, Wt, boundary), iy = wrap_i(ry, Ht, boundary);
+                    const bool in = boundary != FPCDR_BOUNDARY_ZERO || (rx >= 0 && rx < Wt && ry >= 0 && ry < Ht);
                     float *gt = lv.grad[0] + (size_t)b * Ht * Wt * C + ((size_t)iy * Wt + ix) * C;
                     for (int c = 0; c < C; ++c)
-                        if (g[c] != 0.0f) atomicAdd(gt + c, g[c]);
+                        if (in && g[c] != 0.0f) atomicAdd(gt + c, g[c]);
                 }
             } else if (filter == FPCDR_FILTER_LINEAR) {
                 const Taps t = make_taps(q.x, q.y, Ht, Wt, C, boundary);
@@ -404,7 +411,7 @@ int check_common(int B, int H, int W, int Bt, int Ht, int Wt, int C, int n_level
     if (!(Bt == 1 || Bt == B)) return 2;
     if (n_levels < 0 || n_levels > FPCDR_MAX_MIP) return 3;
     if (filter < FPCDR_FILTER_NEAREST || filter > FPCDR_FILTER_LINEAR_MIPMAP_LINEAR) return 4;
-    if (boundary != FPCDR_BOUNDARY_WRAP && boundary != FPCDR_BOUNDARY_CLAMP) return 5;
+    if (boundary != FPCDR_BOUNDARY_WRAP && boundary != FPCDR_BOUNDARY_CLAMP && boundary != FPCDR_BOUNDARY_ZERO) return 5;
     if ((long long)Ht * Wt * C > 0x7fffffffLL) return 6;
     for (int l = 0; l < n_levels; ++l)
         if (((Ht >> l) & 1) || ((Wt >> l) & 1)) return 7;
@@ -481,7 +488,7 @@ extern "C" int fpcdr_texture_bwd(const fpcdr_texture_bwd_params *p, void *stream
         if (l <= p->n_levels) FPCDR_REQUIRE(p->tex[l] != nullptr, "missing mip level");
     }
     FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 16) <= 65535, "image batch / height too large for one launch");
-    if (p->filter_mode == FPCDR_FILTER_LINEAR && p->C == 1 && p->Bt == 1 && (p->W & 3) == 0 &&
+    if (p->filter_mode == FPCDR_FILTER_LINEAR && p->C == 1 && p->Bt == 1 && (p->W & 3) == 0 && p->boundary_mode != FPCDR_BOUNDARY_ZERO &&
         (((size_t)p->uv | (size_t)p->dy | (size_t)p->grad_uv) & 15) == 0) {
         hipLaunchKernelGGL(k_tex_bwd_bin1, dim3(fpcdr_cdiv(p->W, 32), fpcdr_cdiv(p->H, 32), p->B), dim3(256), 0, (hipStream_t)stream,
                            p->tex[0], p->grad_tex[0], (const float4 *)p->uv, (const float4 *)p->dy, p->H, p->W, p->B, p->Ht, p->Wt,

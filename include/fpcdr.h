@@ -255,7 +255,7 @@ int fpcdr_interpolate_bwd(const fpcdr_interpolate_bwd_params *p, void *stream);
 
 enum { FPCDR_FILTER_NEAREST = 0, FPCDR_FILTER_LINEAR = 1, FPCDR_FILTER_LINEAR_MIPMAP_NEAREST = 2,
        FPCDR_FILTER_LINEAR_MIPMAP_LINEAR = 3 };
-enum { FPCDR_BOUNDARY_WRAP = 0, FPCDR_BOUNDARY_CLAMP = 1 };
+enum { FPCDR_BOUNDARY_WRAP = 0, FPCDR_BOUNDARY_CLAMP = 1, FPCDR_BOUNDARY_ZERO = 2 };   /* ZERO: texture padded with zeros (texture op only) */
 #define FPCDR_MAX_MIP 16
 
 /* level l+1 [N,Ht/2,Wt/2,C] = 2x2 box filter of level l [N,Ht,Wt,C] (Ht, Wt even) */

@@ -196,9 +196,16 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
 def _wrap_idx(i, n, boundary_mode):
     if boundary_mode == 'wrap':
         return torch.remainder(i, n)
-    if boundary_mode == 'clamp':
+    if boundary_mode in ('clamp', 'zero'):      # 'zero': a safe index; _inside() says whether the texel exists
         return torch.clamp(i, 0, n - 1)
     raise NotImplementedError(boundary_mode)
+
+
+def _inside(ix, iy, Wt, Ht, boundary_mode, dtype):
+    """Boundary mode 'zero' (texture padded with zeros): 1 where texel (ix, iy) lies inside the texture, else 0; [N,1]."""
+    if boundary_mode != 'zero':
+        return 1.0
+    return ((ix >= 0) & (ix < Wt) & (iy >= 0) & (iy < Ht)).to(dtype).unsqueeze(-1)
 
 
 def _tex_coords(uv, Ht, Wt, boundary_mode):
@@ -227,10 +234,10 @@ def _bilinear(tex, tb, x, y, boundary_mode):
     ix1 = _wrap_idx(x0 + 1, Wt, boundary_mode)
     iy0 = _wrap_idx(y0, Ht, boundary_mode)
     iy1 = _wrap_idx(y0 + 1, Ht, boundary_mode)
-    t00 = tex[tb, iy0, ix0]
-    t10 = tex[tb, iy0, ix1]
-    t01 = tex[tb, iy1, ix0]
-    t11 = tex[tb, iy1, ix1]
+    t00 = tex[tb, iy0, ix0] * _inside(x0, y0, Wt, Ht, boundary_mode, tex.dtype)
+    t10 = tex[tb, iy0, ix1] * _inside(x0 + 1, y0, Wt, Ht, boundary_mode, tex.dtype)
+    t01 = tex[tb, iy1, ix0] * _inside(x0, y0 + 1, Wt, Ht, boundary_mode, tex.dtype)
+    t11 = tex[tb, iy1, ix1] * _inside(x0 + 1, y0 + 1, Wt, Ht, boundary_mode, tex.dtype)
     top = t00 + (t10 - t00) * fx
     bot = t01 + (t11 - t01) * fx
     return top + (bot - top) * fy
@@ -264,9 +271,10 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
     tb = torch.arange(B).repeat_interleave(H * W) if tex.shape[0] > 1 else torch.zeros(B * H * W, dtype=torch.long)
     if filter_mode == 'nearest':
         x, y = _tex_coords(flat_uv, Ht, Wt, boundary_mode)
-        ix = _wrap_idx(torch.floor(x + 0.5).long(), Wt, boundary_mode)
-        iy = _wrap_idx(torch.floor(y + 0.5).long(), Ht, boundary_mode)
-        return tex[tb, iy, ix].reshape(B, H, W, C)
+        rx, ry = torch.floor(x + 0.5).long(), torch.floor(y + 0.5).long()
+        ix = _wrap_idx(rx, Wt, boundary_mode)
+        iy = _wrap_idx(ry, Ht, boundary_mode)
+        return (tex[tb, iy, ix] * _inside(rx, ry, Wt, Ht, boundary_mode, tex.dtype)).reshape(B, H, W, C)
     if filter_mode == 'linear':
         x, y = _tex_coords(flat_uv, Ht, Wt, boundary_mode)
         return _bilinear(tex, tb, x, y, boundary_mode).reshape(B, H, W, C)

@@ -109,7 +109,8 @@ def test_interpolate_fwd_bwd(dr, ctx, oracle_ops, A, Ba, diff):
 
 @pytest.mark.parametrize("mode,C,Bt,boundary", [('linear', 1, 1, 'wrap'), ('linear', 3, 2, 'clamp'), ('nearest', 1, 1, 'wrap'),
                                                ('linear-mipmap-linear', 1, 1, 'wrap'), ('linear-mipmap-linear', 3, 1, 'clamp'),
-                                               ('linear-mipmap-nearest', 2, 1, 'wrap')])
+                                               ('linear-mipmap-nearest', 2, 1, 'wrap'), ('linear', 1, 1, 'zero'), ('nearest', 3, 2, 'zero'),
+                                               ('linear-mipmap-linear', 2, 1, 'zero')])
 def test_texture_fwd_bwd(dr, oracle_ops, mode, C, Bt, boundary):
     g = torch.Generator().manual_seed(3)
     B, H, W = 2, 40, 56

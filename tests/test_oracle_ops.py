@@ -200,6 +200,26 @@ def test_fd_texture(oracle_ops):
         assert torch.allclose(o, torch.full_like(o, 0.37), atol=1e-6)
 
 
+def test_texture_boundary_zero(oracle_ops):
+    """boundary_mode='zero' pads the texture with zeros: inside it equals 'clamp' away from the border, more than one texel
+    outside it is 0, across the border a constant texture fades linearly, and the uv gradient is that of the padded image."""
+    g = torch.Generator().manual_seed(4)
+    const = torch.full((1, 8, 8, 1), 0.5)
+    uv = torch.tensor([[[[0.5, 0.5], [-0.2, 0.5], [1.3, 0.5], [0.5, 1.2], [0.0, 0.5], [0.5 / 8, 0.5]]]])     # [1,1,6,2]
+    o = oracle_ops.texture(const, uv, filter_mode='linear', boundary_mode='zero')[0, 0, :, 0]
+    assert torch.allclose(o, torch.tensor([0.5, 0.0, 0.0, 0.0, 0.25, 0.5]), atol=1e-6), o
+    o = oracle_ops.texture(const, uv, filter_mode='nearest', boundary_mode='zero')[0, 0, :, 0]
+    assert torch.allclose(o, torch.tensor([0.5, 0.0, 0.0, 0.0, 0.5, 0.5]), atol=1e-6), o
+    tex = torch.rand(1, 8, 8, 2, generator=g)
+    inner = torch.rand(1, 5, 5, 2, generator=g) * 0.7 + 0.15          # all four taps inside
+    assert torch.allclose(oracle_ops.texture(tex, inner, filter_mode='linear', boundary_mode='zero'),
+                          oracle_ops.texture(tex, inner, filter_mode='linear', boundary_mode='clamp'), atol=1e-6)
+    wide = torch.rand(1, 6, 6, 2, generator=g) * 1.6 - 0.3
+    gy = torch.randn(1, 6, 6, 2, generator=g)
+    _fd_check(lambda x: oracle_ops.texture(tex, x, filter_mode='linear', boundary_mode='zero'), wide, gy, 1e-3)
+    _fd_check(lambda x: oracle_ops.texture(x, wide, filter_mode='linear', boundary_mode='zero'), tex, gy, 1e-2)
+
+
 def test_antialias_invariants_and_fd(oracle_ops):
     # single triangle over a background: axis-aligned-ish edge moves the blended pixel linearly
     H = W = 16
