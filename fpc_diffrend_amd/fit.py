@@ -692,7 +692,11 @@ class Fitter:
             loss = sum_sq[0].to(torch.float32) / n_total + reg.detach()
         else:
             col = torch.where(rast_out[..., 3:] > 0, colour, torch.tensor(BACKGROUND, device=self.device))
-            loss = torch.mean((ref[..., None].to(torch.float32) - col * 255) ** 2) / self.world + reg
+            # the reference holds its target image as float32 on the GPU (fit.py:531-532); the 8-bit batch is converted once
+            if getattr(self, "_targets_f32", None) is None:
+                self._targets_f32 = self.targets.to(torch.float32)
+            ref_f = self._targets_f32[local].reshape(Fb * Nc, *self.resolution, 1)
+            loss = torch.mean((ref_f - col * 255) ** 2) / self.world + reg
             loss.backward()
         self.result[frame_ids] = vtx_pos.detach()
         return loss.detach()
