@@ -350,6 +350,8 @@ class GroupedAdam(torch.optim.Optimizer):
         keep = []
         for g in self.param_groups:
             b1, b2 = g['betas']
+            assert (b1, b2, g['eps']) == (self.param_groups[0]['betas'] + (self.param_groups[0]['eps'],)), \
+                "one launch takes one (betas, eps) for all groups"
             P.beta1, P.beta2, P.eps, P.one_minus_beta1, P.one_minus_beta2 = b1, b2, g['eps'], 1.0 - b1, 1.0 - b2
             for p in g['params']:
                 ren = id(p) in self._renorm
