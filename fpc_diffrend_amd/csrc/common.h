@@ -101,6 +101,10 @@ __device__ __forceinline__ void lds_add_f32(float *addr, float v) {
         old = atomicCAS(a, assumed, __float_as_uint(__uint_as_float(assumed) + v));
     } while (old != assumed);
 }
+// ds_add_f64, on the other hand, is a native 8-cycle instruction (same microbenchmark): an LDS accumulator kept in DOUBLE takes a
+// float term with one conversion and one non-returning atomic -- no read, no compare-and-swap loop -- and the sum no longer
+// depends (to float precision) on the order in which lanes arrive.  Costs twice the LDS space.
+__device__ __forceinline__ void lds_add_f64(double *addr, float v) { atomicAdd(addr, (double)v); }
 // two adjacent floats (8-byte aligned) in one 64-bit compare-and-swap
 __device__ __forceinline__ void lds_add_f32x2(float *addr, float vx, float vy) {
     unsigned long long *a = reinterpret_cast<unsigned long long *>(addr);

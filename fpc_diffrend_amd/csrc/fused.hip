@@ -279,8 +279,8 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                                                        const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
     const int boundary = BMODE >= 0 ? BMODE : boundary_arg;
     __shared__ int s_vkey[VSLOTS];
-    __shared__ __attribute__((aligned(16))) float s_vacc[VSLOTS][4];
-    __shared__ float s_tex[TEXH * TEXW * CS];
+    __shared__ double s_vacc[VSLOTS][3];           // (x, y, w) sums per vertex slot, in double: ds_add_f64 (common.h lds_add_f64)
+    __shared__ double s_tex[TEXH * TEXW * CS];
     __shared__ int s_org[2];            // smallest tap x, y of the bin (unwrapped texel coordinates)
     __shared__ float s_esum[CS];        // gradient arriving at EMPTY pixels' colour (they all sample uv = (0,0))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -418,9 +418,9 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
     // ---- tables; texture coordinate of every pixel with a gradient; origin of the texel window ----
     for (int k = tid; k < VSLOTS; k += BWD_NT) {
         s_vkey[k] = -1;
-        s_vacc[k][0] = 0.f; s_vacc[k][1] = 0.f; s_vacc[k][2] = 0.f; s_vacc[k][3] = 0.f;
+        s_vacc[k][0] = 0.0; s_vacc[k][1] = 0.0; s_vacc[k][2] = 0.0;
     }
-    for (int k = tid; k < TEXH * TEXW * CS; k += BWD_NT) s_tex[k] = 0.0f;
+    for (int k = tid; k < TEXH * TEXW * CS; k += BWD_NT) s_tex[k] = 0.0;
     int pt[BWD_NPX];
     float tu[BWD_NPX], tv[BWD_NPX];
     {
@@ -494,11 +494,11 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                 if (grad_tex && gc != 0.0f) {
 #endif
                     if (in_win) {
-                        float *w = s_tex + (ly * TEXW + lx) * CS + c;
-                        lds_add_f32(w, gc * w00);
-                        lds_add_f32(w + CS, gc * w10);
-                        lds_add_f32(w + TEXW * CS, gc * w01);
-                        lds_add_f32(w + TEXW * CS + CS, gc * w11);
+                        double *w = s_tex + (ly * TEXW + lx) * CS + c;
+                        lds_add_f64(w, gc * w00);
+                        lds_add_f64(w + CS, gc * w10);
+                        lds_add_f64(w + TEXW * CS, gc * w01);
+                        lds_add_f64(w + TEXW * CS + CS, gc * w11);
                     } else {
                         atomicAdd(grad_tex + tp.i00 + c, gc * w00);
                         atomicAdd(grad_tex + tp.i10 + c, gc * w10);
@@ -568,8 +568,9 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                     done = (o == -1 || o == key);
                 }
                 if (done) {
-                    lds_add_f32x2(&s_vacc[slot[kk]][0], sm[3 * kk], sm[3 * kk + 1]);
-                    lds_add_f32(&s_vacc[slot[kk]][3], sm[3 * kk + 2]);
+                    lds_add_f64(&s_vacc[slot[kk]][0], sm[3 * kk]);
+                    lds_add_f64(&s_vacc[slot[kk]][1], sm[3 * kk + 1]);
+                    lds_add_f64(&s_vacc[slot[kk]][2], sm[3 * kk + 2]);
                 } else {   // table full: straight to memory
                     atomicAdd(gp + 4 * (size_t)key + 0, sm[3 * kk]); atomicAdd(gp + 4 * (size_t)key + 1, sm[3 * kk + 1]);
                     atomicAdd(gp + 4 * (size_t)key + 3, sm[3 * kk + 2]);
@@ -595,14 +596,14 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
     for (int k = tid; k < VSLOTS * 4; k += BWD_NT) {
         const int slot = k >> 2, comp = k & 3;
         const int key = s_vkey[slot];
-        if (key >= 0) {
-            const float v = s_vacc[slot][comp];
+        if (key >= 0 && comp != 2) {      // (x, y, -, w): z receives no gradient
+            const float v = (float)s_vacc[slot][comp == 3 ? 2 : comp];
             if (v != 0.0f) atomicAdd(gp + 4 * (size_t)key + comp, v);
         }
     }
     if (grad_tex && ox != 0x7fffffff) {
         for (int k = tid; k < TEXH * TEXW * CS; k += BWD_NT) {
-            const float v = s_tex[k];
+            const float v = (float)s_tex[k];
             if (v != 0.0f) {
                 const int c = k % CS, cell = k / CS;
                 const int colx = cell % TEXW, row = cell / TEXW;

@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(256) k2(float *out, int iters, long long *cycl
     __shared__ unsigned long long s64[1024];
     __shared__ int s32[2048];
     __shared__ float sf[2048];
-    for (int i = threadIdx.x; i < 1024; i += 256) s64[i] = ~0ull;
+    __shared__ double sd[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) { s64[i] = ~0ull; sd[i] = 0.0; }
     for (int i = threadIdx.x; i < 2048; i += 256) { s32[i] = 0; sf[i] = 0.f; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -54,12 +55,15 @@ __global__ void __launch_bounds__(256) k2(float *out, int iters, long long *cycl
         else if (OP == 3) acc += (float)atomicCAS(&s32[idx], it, it + 1);
         else if (OP == 4) sf[idx] = (float)it;
         else if (OP == 5) { if (lane < 16) atomicAdd(&sf[idx], 1.0f); }
+        else if (OP == 6) atomicAdd(&sd[idx], 1.0);                                   // double add (ds_add_f64)
+        else if (OP == 7) atomicAdd(reinterpret_cast<unsigned long long *>(&sd[idx]), (unsigned long long)it);   // 64-bit integer add
+        else if (OP == 8) atomicMax(&sf[idx], (float)it);                                 // float max
         idx ^= (it & 1) << 6;
     }
     __syncthreads();
     const long long t1 = clock64();
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
-    out[blockIdx.x * 256 + threadIdx.x] = acc + sf[threadIdx.x] + (float)s32[threadIdx.x] + (float)s64[threadIdx.x];
+    out[blockIdx.x * 256 + threadIdx.x] = acc + sf[threadIdx.x] + (float)s32[threadIdx.x] + (float)s64[threadIdx.x] + (float)sd[threadIdx.x];
 }
 
 template <int OP>
@@ -105,5 +109,8 @@ int main() {
     run2<3>("32-bit compare-and-swap (returns)", out, cyc, iters);
     run2<4>("plain 4-byte store", out, cyc, iters);
     run2<5>("float add, 16 active lanes", out, cyc, iters);
+    run2<6>("double add, 64 consecutive", out, cyc, iters);
+    run2<7>("u64 add, 64 consecutive", out, cyc, iters);
+    run2<8>("float max, 64 consecutive", out, cyc, iters);
     return 0;
 }
