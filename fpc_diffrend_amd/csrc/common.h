@@ -283,12 +283,12 @@ __device__ __forceinline__ void wave_segment_reduce9(int key, const float (&val)
 constexpr int FPCDR_VT_SLOTS = 256;
 struct VTable {
     int *key;             // [FPCDR_VT_SLOTS], -1 = free
-    float (*acc)[4];      // [FPCDR_VT_SLOTS][4] = (x, y, -, w), 16-byte aligned
+    double (*acc)[3];     // [FPCDR_VT_SLOTS][3] = (x, y, w) sums in double (lds_add_f64)
 };
 __device__ __forceinline__ void vtable_init(const VTable &t, int tid, int nthreads) {
     for (int k = tid; k < FPCDR_VT_SLOTS; k += nthreads) {
         t.key[k] = -1;
-        t.acc[k][0] = 0.f; t.acc[k][1] = 0.f; t.acc[k][2] = 0.f; t.acc[k][3] = 0.f;
+        t.acc[k][0] = 0.0; t.acc[k][1] = 0.0; t.acc[k][2] = 0.0;
     }
 }
 // add the nine sums of one triangle run (three vertices x (x, y, w)); gp = the image's grad_pos rows
@@ -309,8 +309,9 @@ __device__ __forceinline__ void vtable_add(const VTable &t, float *gp, const int
             done = (o == -1 || o == key);
         }
         if (done) {
-            lds_add_f32x2(&t.acc[slot[kk]][0], sm[3 * kk], sm[3 * kk + 1]);
-            lds_add_f32(&t.acc[slot[kk]][3], sm[3 * kk + 2]);
+            lds_add_f64(&t.acc[slot[kk]][0], sm[3 * kk]);
+            lds_add_f64(&t.acc[slot[kk]][1], sm[3 * kk + 1]);
+            lds_add_f64(&t.acc[slot[kk]][2], sm[3 * kk + 2]);
         } else {   // table full: straight to memory
             atomicAdd(gp + 4 * (size_t)key + 0, sm[3 * kk]); atomicAdd(gp + 4 * (size_t)key + 1, sm[3 * kk + 1]);
             atomicAdd(gp + 4 * (size_t)key + 3, sm[3 * kk + 2]);
@@ -322,8 +323,8 @@ __device__ __forceinline__ void vtable_flush(const VTable &t, float *gp, int tid
     for (int k = tid; k < FPCDR_VT_SLOTS * 4; k += nthreads) {
         const int slot = k >> 2, comp = k & 3;
         const int key = t.key[slot];
-        if (key >= 0) {
-            const float v = t.acc[slot][comp];
+        if (key >= 0 && comp != 2) {      // (x, y, -, w): z receives no gradient
+            const float v = (float)t.acc[slot][comp == 3 ? 2 : comp];
             if (v != 0.0f) atomicAdd(gp + 4 * (size_t)key + comp, v);
         }
     }

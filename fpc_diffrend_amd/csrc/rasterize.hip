@@ -1013,7 +1013,7 @@ __global__ void __launch_bounds__(256) k_grad(const float4 *__restrict__ pos, co
     // the kernel LDS-bound at 3.9 ms for cfg3; nine global atomics per run tail instead of the table: 7.4 ms.)
     if (hint && !fpcdr_hint_on(hint, 0, B, H, W, blockIdx.z, blockIdx.y * 32, blockIdx.x * 32)) return;   // empty bin: nothing to read
     __shared__ int s_vkey[FPCDR_VT_SLOTS];
-    __shared__ __attribute__((aligned(16))) float s_vacc[FPCDR_VT_SLOTS][4];
+        __shared__ double s_vacc[FPCDR_VT_SLOTS][3];
     const VTable vt = {s_vkey, s_vacc};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = (lane & 32) ? 63 - lane : lane;

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) k_tex_bwd(TexLevels lv, int n_levels, con
 
 // Bin-shaped backward for the reference's texture call (one 1-channel texture, 'linear', W % 4 == 0): one workgroup per
 // 32 x 32-pixel bin, four horizontally adjacent pixels per thread (16-byte loads of dy / uv, 16-byte stores of grad_uv).  The
-// texel gradient goes through a TW x TW LDS window anchored at the bin's smallest tap (compare-and-swap adds: ds_add_f32 costs
+// texel gradient goes through a TW x TW LDS window of DOUBLES anchored at the bin's smallest tap (ds_add_f64; ds_add_f32 costs
 // 3 cycles per lane on gfx950) and is flushed once, row-contiguously; taps outside the window (uv seams) and the empty
 // pixels' share (uv = (0,0): summed per workgroup) go to memory directly.  4 global atomics per covered pixel -- the
 // generic kernel -- bound the operator at 4.3 ms for cfg3.
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) k_tex_bwd_bin1(const float *__restrict__ 
                                                       const float4 *__restrict__ uv4, const float4 *__restrict__ dy4, int H, int W, int B,
                                                       int Ht, int Wt, int boundary, float4 *__restrict__ grad_uv4,
                                                       const uint8_t *__restrict__ hint) {
-    __shared__ float s_tex[TW * TW];
+    __shared__ double s_tex[TW * TW];      // in double: ds_add_f64 (common.h lds_add_f64)
     __shared__ int s_org[2];
     __shared__ float s_esum;
     const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.z;
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256) k_tex_bwd_bin1(const float *__restrict__ 
     if (inside && any && !known_zero) { ua = uv4[i / 2]; ub = uv4[i / 2 + 1]; }
     const float qu[4] = {ua.x, ua.z, ub.x, ub.z}, qv[4] = {ua.y, ua.w, ub.y, ub.w}, gq[4] = {g.x, g.y, g.z, g.w};
     if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; s_esum = 0.0f; }
-    for (int k = tid; k < TW * TW; k += 256) s_tex[k] = 0.0f;
+    for (int k = tid; k < TW * TW; k += 256) s_tex[k] = 0.0;
     // window origin: the smallest tap of the pixels with a gradient and a texture coordinate other than (0,0)
     int ux0 = 0x7fffffff, uy0 = 0x7fffffff;
 #pragma unroll
@@ -313,31 +313,41 @@ __global__ void __launch_bounds__(256) k_tex_bwd_bin1(const float *__restrict__ 
     __syncthreads();
     const int ox = s_org[0], oy = s_org[1];
     float gu[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f}, esum = 0.0f;
+    // The eight lanes of a row own pixels 4 j .. 4 j + 3.  Visiting them in the same order would put the lanes of one LDS
+    // instruction 4 texels = 8 words apart: with the eight rows of the wave 64 lanes on 4 double-wide banks.  Each lane
+    // therefore starts at a different pixel of its four (neighbouring lanes end up 5 texels apart: distinct banks); the
+    // thread's values are picked / put back with selects, there is no register indexing.
+    const int rot = tid & 3;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float gc = gq[k];
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = (s4 + rot) & 3;
+        const bool k0 = k == 0, k1 = k == 1, k2 = k == 2;
+        const float gc = k0 ? gq[0] : (k1 ? gq[1] : (k2 ? gq[2] : gq[3]));
         if (!inside || gc == 0.0f) continue;
-        const Taps t = make_taps(qu[k], qv[k], Ht, Wt, 1, boundary);
+        const float qu_k = k0 ? qu[0] : (k1 ? qu[1] : (k2 ? qu[2] : qu[3]));
+        const float qv_k = k0 ? qv[0] : (k1 ? qv[1] : (k2 ? qv[2] : qv[3]));
+        const Taps t = make_taps(qu_k, qv_k, Ht, Wt, 1, boundary);
         float t00, t10, t01, t11;
         load_taps(tex, t, 0, 1, t00, t10, t01, t11);
         const float gfx = gc * ((t10 - t00) * (1.0f - t.fy) + (t11 - t01) * t.fy);
         const float gfy = gc * ((t01 + (t11 - t01) * t.fx) - (t00 + (t10 - t00) * t.fx));
         // clamp mode: no uv gradient outside [0,1] (torch.clamp semantics of the oracle)
-        const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(qu[k] >= 0.0f && qu[k] <= 1.0f)) ? 0.0f : 1.0f;
-        const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(qv[k] >= 0.0f && qv[k] <= 1.0f)) ? 0.0f : 1.0f;
-        gu[k] = gfx * (float)Wt * mu;
-        gv[k] = gfy * (float)Ht * mv;
+        const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(qu_k >= 0.0f && qu_k <= 1.0f)) ? 0.0f : 1.0f;
+        const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(qv_k >= 0.0f && qv_k <= 1.0f)) ? 0.0f : 1.0f;
+        const float gu_k = gfx * (float)Wt * mu, gv_k = gfy * (float)Ht * mv;
+        gu[0] = k0 ? gu_k : gu[0]; gu[1] = k1 ? gu_k : gu[1]; gu[2] = k2 ? gu_k : gu[2]; gu[3] = (k0 | k1 | k2) ? gu[3] : gu_k;
+        gv[0] = k0 ? gv_k : gv[0]; gv[1] = k1 ? gv_k : gv[1]; gv[2] = k2 ? gv_k : gv[2]; gv[3] = (k0 | k1 | k2) ? gv[3] : gv_k;
         if (!grad_tex) continue;
-        if (qu[k] == 0.0f && qv[k] == 0.0f) { esum += gc; continue; }     // the four texels at uv = (0,0): once per workgroup
+        if (qu_k == 0.0f && qv_k == 0.0f) { esum += gc; continue; }     // the four texels at uv = (0,0): once per workgroup
         const float w00 = (1.0f - t.fx) * (1.0f - t.fy), w10 = t.fx * (1.0f - t.fy), w01 = (1.0f - t.fx) * t.fy, w11 = t.fx * t.fy;
-        const int lx = (int)floorf(prep_coord(qu[k], boundary) * (float)Wt - 0.5f) - ox;
-        const int ly = (int)floorf(prep_coord(qv[k], boundary) * (float)Ht - 0.5f) - oy;
+        const int lx = (int)floorf(prep_coord(qu_k, boundary) * (float)Wt - 0.5f) - ox;
+        const int ly = (int)floorf(prep_coord(qv_k, boundary) * (float)Ht - 0.5f) - oy;
         if (lx >= 0 && ly >= 0 && lx + 1 < TW && ly + 1 < TW) {
-            float *w = s_tex + ly * TW + lx;
-            lds_add_f32(w, gc * w00);
-            lds_add_f32(w + 1, gc * w10);
-            lds_add_f32(w + TW, gc * w01);
-            lds_add_f32(w + TW + 1, gc * w11);
+            double *w = s_tex + ly * TW + lx;
+            lds_add_f64(w, gc * w00);
+            lds_add_f64(w + 1, gc * w10);
+            lds_add_f64(w + TW, gc * w01);
+            lds_add_f64(w + TW + 1, gc * w11);
         } else {
             atomicAdd(grad_tex + t.i00, gc * w00);
             atomicAdd(grad_tex + t.i10, gc * w10);
@@ -363,7 +373,7 @@ __global__ void __launch_bounds__(256) k_tex_bwd_bin1(const float *__restrict__ 
     }
     if (ox != 0x7fffffff) {
         for (int k = tid; k < TW * TW; k += 256) {
-            const float v = s_tex[k];
+            const float v = (float)s_tex[k];
             if (v != 0.0f) {
                 const int gx = wrap_near(ox + k % TW, Wt, boundary), gy = wrap_near(oy + k / TW, Ht, boundary);
                 atomicAdd(grad_tex + (size_t)gy * Wt + gx, v);
