@@ -58,6 +58,9 @@ __global__ void __launch_bounds__(256) k2(float *out, int iters, long long *cycl
         else if (OP == 6) atomicAdd(&sd[idx], 1.0);                                   // double add (ds_add_f64)
         else if (OP == 7) atomicAdd(reinterpret_cast<unsigned long long *>(&sd[idx]), (unsigned long long)it);   // 64-bit integer add
         else if (OP == 8) atomicMax(&sf[idx], (float)it);                                 // float max
+        else if (OP == 9) atomicAdd(&sd[wave * 128 + (lane >> 3) + ((it & 1) << 6)], 1.0);   // double add, 8 lanes share an address
+        else if (OP == 10) atomicAdd(&sd[wave * 128 + ((lane * 5) & 63) * 2 % 128], 1.0);   // double add, scattered
+        else if (OP == 11) { if ((lane % 7) == 0) atomicAdd(&sd[idx], 1.0); }               // double add, 10 scattered active lanes
         idx ^= (it & 1) << 6;
     }
     __syncthreads();
@@ -112,5 +115,8 @@ int main() {
     run2<6>("double add, 64 consecutive", out, cyc, iters);
     run2<7>("u64 add, 64 consecutive", out, cyc, iters);
     run2<8>("float max, 64 consecutive", out, cyc, iters);
+    run2<9>("double add, 8 lanes share an address", out, cyc, iters);
+    run2<10>("double add, scattered (stride 10 words)", out, cyc, iters);
+    run2<11>("double add, 10 active lanes", out, cyc, iters);
     return 0;
 }
