@@ -724,6 +724,8 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
     // From here on a thread owns the four pixels (tid & 31, (tid >> 5) + 8 k) of the bin: the 32 lanes of a half wave write
     // one 512-byte row segment of rast per instruction (the raster's 8 x 8 quadrant pattern gave 128-byte pieces).
     int win[4];
+    __shared__ float s_fy[BIN];      // NDC y of the bin's 32 rows: one IEEE division per row instead of one per pixel
+    if (tid < BIN) s_fy[tid] = (2.0f * (float)(bin_y0 + tid) + 1.0f) / (float)H - 1.0f;
     if (bin_live) {
 #pragma unroll
         for (int k = 0; k < TILES_PER_WAVE; ++k) {
@@ -774,7 +776,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         if (t >= 0) {
             const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
             const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
-            const float fy = (2.0f * (float)py + 1.0f) / (float)H - 1.0f;
+            const float fy = s_fy[zy];
             Shade sd = shade_pixel(p[i0], p[i1], p[i2], fx, fy, sx, sy);
             o = make_float4(sd.u, sd.v, sd.zw, (float)(t + 1));
             d = make_float4(sd.dudx, sd.dudy, sd.dvdx, sd.dvdy);
@@ -851,6 +853,11 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         __syncthreads();   // (z/w, id) entries, the staged colour and the cleared masks are visible
         const size_t bin_id = bin_lin;
         unsigned long long *edge = sh.edges + bin_id * (4 * BIN);   // [left col | right col | bottom row | top row][32]
+        if (tid < 4 * BIN) {      // the four border lines: one entry per thread (pixels beyond the image export 0)
+            const int side = tid >> 5, i = tid & 31;
+            const int ex = side == 0 ? 0 : (side == 1 ? BIN - 1 : i), ey = side == 2 ? 0 : (side == 3 ? BIN - 1 : i);
+            edge[tid] = (bin_x0 + ex < W && bin_y0 + ey < H) ? s_z[ey * BIN + ex] : 0ull;
+        }
         float lsum = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -858,10 +865,6 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
             const bool inimg = px < W && py < H;
             const int idx = zy * BIN + zx;
             const unsigned long long me = inimg ? s_z[idx] : 0ull;
-            if (zx == 0) edge[zy] = me;
-            if (zx == BIN - 1) edge[BIN + zy] = me;
-            if (zy == 0) edge[2 * BIN + zx] = me;
-            if (zy == BIN - 1) edge[3 * BIN + zx] = me;
             if (!inimg) continue;
             const int id = (int)((unsigned int)me & 0xffffffu);
             const float z = __uint_as_float((unsigned int)(me >> 32));
