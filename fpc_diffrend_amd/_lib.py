@@ -25,7 +25,7 @@ _i = ctypes.c_int32
 
 class RasterizeFwd(ctypes.Structure):
     _fields_ = [("pos", _p), ("tri", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i), ("scratch", _p),
-                ("rast", _p), ("rast_db", _p), ("hint", _p)]
+                ("rast", _p), ("rast_db", _p), ("hint", _p), ("ranges", _p)]
 
 
 class RasterizeBwd(ctypes.Structure):

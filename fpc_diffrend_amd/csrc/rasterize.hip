@@ -108,7 +108,8 @@ __device__ __forceinline__ long long floordiv256(long long a) { return a >> 8; }
 __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                 int B, int V, int T, int H, int W, TriRec *__restrict__ recs,
                                                 TriBox *__restrict__ boxes, TriBox *__restrict__ cboxes,
-                                                ImgBox *__restrict__ ibox, uint8_t *__restrict__ live) {
+                                                ImgBox *__restrict__ ibox, uint8_t *__restrict__ live,
+                                                const int32_t *__restrict__ ranges) {
     // grid: x over 256-triangle chunks, y = image.  A block never straddles two images, so the union of
     // its triangles' bounding boxes can be reduced in the block: it is stored as the CHUNK box (meshes
     // keep neighbouring triangles at neighbouring indices, so a bin later skips most chunks with one
@@ -122,6 +123,10 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
         TriBox box = {1, 1, 0, 0};
         int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
         bool ok = !(i0 < 0 || i0 >= V || i1 < 0 || i1 >= V || i2 < 0 || i2 >= V);
+        if (ranges) {      // range mode: the image renders its own slice of the triangle list
+            const long long first = ranges[2 * b], count = ranges[2 * b + 1];
+            ok = ok && t >= first && t < first + count;
+        }
         long long X[3], Y[3];
         double zw[3];
         if (ok) {
@@ -1188,7 +1193,7 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
     ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr);
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, p->ranges);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     ShadeArgs sh = {};
     sh.op_hint = p->hint;
@@ -1242,7 +1247,7 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
     ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr);
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, (const int32_t *)nullptr);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
                     nullptr, p->empty_color, (const float2 *)p->tri_uv};
@@ -1316,7 +1321,7 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     hipLaunchKernelGGL(k_init_queue, dim3(256), dim3(256), 0, st, ibox, p->B, (uint32_t *)live, (long long)(align_up(nbins, 4) / 4),
                        (uint32_t *)oc, (long long)(q.occ_hdr / 4), hdr, hdr_bwd);
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, live);
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, live, (const int32_t *)nullptr);
     int32_t *n_bins = hdr_bwd + 2, *n_fix = hdr_bwd + 3;     // all three counts live in the occ header, where the caller finds them
     const int nblk = fpcdr_cdiv((long long)nbins, 256);
     int32_t *blk = (int32_t *)(cm + q.cm_blk);          // [2][nblk] per-block counts, then offsets

@@ -13,7 +13,7 @@ The reference's fit loop calls exactly these names on `import nvdiffrast.torch a
 so `import fpc_diffrend_amd.ops as dr` lets the reference's render() (fit.py:134-162) run
 unchanged.  Signatures, argument meaning, defaults and error behaviour follow nvdiffrast's
 documented API; arguments the reference never passes are accepted with upstream defaults.
-Only instanced mode (pos [B,V,4]) is implemented; range mode raises NotImplementedError.
+Instanced mode (pos [B,V,4]) and range mode (pos [V,4] + ranges [B,2]) are implemented.
 
 PyTorch is plumbing here: it owns the HBM buffers (including kernel scratch, so lifetimes follow
 autograd), supplies the stream, and runs autograd bookkeeping.  All pixel work happens in
@@ -126,7 +126,7 @@ RasterizeCudaContext = RasterizeHipContext
 
 class _rasterize_func(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pos, tri, H, W, output_db, grad_db, hint):
+    def forward(ctx, pos, tri, H, W, output_db, grad_db, hint, ranges):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -135,7 +135,7 @@ class _rasterize_func(torch.autograd.Function):
         rast_db = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev) if output_db else None
         scratch = torch.empty(lib.fpcdr_rasterize_scratch_bytes(B, T), dtype=torch.uint8, device=dev)
         p = _lib.RasterizeFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch),
-                              rast=_ptr(rast), rast_db=_ptr(rast_db), hint=_ptr(hint))
+                              rast=_ptr(rast), rast_db=_ptr(rast_db), hint=_ptr(hint), ranges=_ptr(ranges))
         _lib.call("fpcdr_rasterize_fwd", ctypes.byref(p), _stream())
         ctx.save_for_backward(pos, tri, rast)
         ctx.hint = hint
@@ -156,7 +156,7 @@ class _rasterize_func(torch.autograd.Function):
         p = _lib.RasterizeBwd(pos=_ptr(pos), tri=_ptr(tri), rast=_ptr(rast), dy=_ptr(dy), ddb=_ptr(ddb), B=B, V=V,
                               T=tri.shape[0], H=H, W=W, grad_pos=_ptr(g_pos), hint=_ptr(ctx.hint))
         _lib.call("fpcdr_rasterize_bwd", ctypes.byref(p), _stream())
-        return g_pos, None, None, None, None, None, None
+        return g_pos, None, None, None, None, None, None, None
 
 
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
@@ -165,8 +165,23 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
     Returns (rast [B,H,W,4] = (u, v, z/w, triangle_id + 1), rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY)).
     """
     assert isinstance(glctx, RasterizeHipContext), "glctx must be a Rasterize*Context"
-    if ranges is not None or (isinstance(pos, torch.Tensor) and pos.dim() == 2):
-        raise NotImplementedError("range mode (pos [V,4] + ranges) is not implemented; use instanced mode pos [B,V,4]")
+    ranges_dev = None
+    if isinstance(pos, torch.Tensor) and pos.dim() == 2:
+        # range mode (nvdiffrast): one shared vertex array pos [V,4]; image b renders triangles ranges[b] = (first, count).
+        # The vertex array is broadcast over the minibatch (its gradient is the sum over the images); the kernel only needs
+        # to know which slice of `tri` each image draws.  Triangle ids in rast stay indices into `tri`.
+        if ranges is None:
+            raise ValueError("range mode (pos [V,4]) needs ranges [B,2]")
+        ranges = torch.as_tensor(ranges)
+        if ranges.dim() != 2 or ranges.shape[1] != 2 or ranges.shape[0] < 1 or ranges.dtype != torch.int32:
+            raise ValueError("ranges must be an int32 tensor of shape [minibatch, 2]")
+        r = ranges.cpu()
+        if int(r.min()) < 0 or int((r[:, 0] + r[:, 1]).max()) > tri.shape[0]:
+            raise ValueError("ranges reach outside the triangle tensor")
+        ranges_dev = ranges.to(pos.device).contiguous()
+        pos = pos[None].expand(ranges.shape[0], -1, -1)
+    elif ranges is not None:
+        raise ValueError("ranges is for range mode only (pos [V,4]); instanced mode takes pos [B,V,4]")
     assert grad_db is True or grad_db is False
     resolution = tuple(int(r) for r in resolution)
     assert len(resolution) == 2 and resolution[0] > 0 and resolution[1] > 0, "resolution must be (height, width)"
@@ -180,7 +195,7 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
         raise ValueError(f"pos is on {pos.device} but the context was created for {glctx.device}")
     hint = torch.empty(_hint_bytes(pos.shape[0], *resolution), dtype=torch.uint8, device=pos.device) if region_hints else None
     rast, rast_db = _rasterize_func.apply(pos.contiguous(), tri.contiguous(), resolution[0], resolution[1], glctx.output_db,
-                                          grad_db, hint)
+                                          grad_db, hint, ranges_dev)
     if hint is not None:
         _tag(rast, hint, 'rast')
     return rast, rast_db
@@ -469,8 +484,8 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
     _check_tensor('attr', attr, torch.float32)
     _check_tensor('rast', rast, torch.float32, 4)
     _check_tensor('tri', tri, torch.int32, 2)
-    if attr.dim() == 2:
-        raise NotImplementedError("range mode (attr [Vt,A]) is not implemented; use instanced mode attr [1|B,Vt,A]")
+    if attr.dim() == 2:     # range mode: one shared attribute array
+        attr = attr[None]
     if attr.dim() != 3:
         raise ValueError(f"attr must have shape [1|B,Vt,A] (got {tuple(attr.shape)})")
     if rast.shape[3] != 4:
@@ -742,8 +757,8 @@ def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0)
     _check_tensor('rast', rast, torch.float32, 4)
     _check_tensor('pos', pos, torch.float32)
     _check_tensor('tri', tri, torch.int32, 2)
-    if pos.dim() == 2:
-        raise NotImplementedError("range mode (pos [V,4]) is not implemented; use instanced mode pos [B,V,4]")
+    if pos.dim() == 2:      # range mode: one shared vertex array for the whole minibatch (its gradient sums over the images)
+        pos = pos[None].expand(color.shape[0], -1, -1)
     if pos.dim() != 3 or pos.shape[2] != 4:
         raise ValueError("pos must have shape [B,V,4]")
     if color.shape[:3] != rast.shape[:3] or rast.shape[3] != 4:

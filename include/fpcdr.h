@@ -63,6 +63,8 @@ typedef struct {
     float *rast;          /* out [B,H,W,4] = (u, v, z/w, triangle index + 1; 0 = empty) */
     float *rast_db;       /* out [B,H,W,4] = (du/dx, du/dy, dv/dx, dv/dy) per pixel, or NULL */
     uint8_t *hint;        /* optional out, FPCDR_HINT_BYTES(B,H,W): REGION HINT of rast (see below), or NULL */
+    const int32_t *ranges; /* optional [B,2] on the device: image b renders triangles [ranges[b][0], ranges[b][0] + ranges[b][1]) only
+                              (nvdiffrast's range mode; triangle ids stay indices into tri), or NULL: every image renders all T */
 } fpcdr_rasterize_fwd_params;
 int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *stream);
 

@@ -133,14 +133,31 @@ def _bary(pos, tri, ids, H, W):
     return bidx, yy, xx, t, u, v, zw, db
 
 
-def rasterize(pos, tri, resolution, grad_db=True, ids=None):
+def rasterize_ids_ranges(pos2d, tri, resolution, ranges):
+    """Range mode: image b shows triangles [first, first + count) of `tri` over the shared vertex array pos2d [V,4]; the ids
+    stay indices into `tri` (+ 1)."""
+    out = []
+    for first, count in ranges.tolist():
+        ids = rasterize_ids(pos2d[None], tri[first:first + count], resolution)[0] if count > 0 else \
+            torch.zeros(int(resolution[0]), int(resolution[1]), dtype=torch.int32)
+        out.append(torch.where(ids > 0, ids + first, ids))
+    return torch.stack(out)
+
+
+def rasterize(pos, tri, resolution, grad_db=True, ids=None, ranges=None):
     """dr.rasterize(glctx, pos[B,V,4], tri[T,3], resolution=(H,W)) -> (rast[B,H,W,4], rast_db[B,H,W,4]).
+    Range mode: pos [V,4] + ranges [B,2] (first triangle, count) per image.
 
     Float outputs follow pos.dtype (float32 like the product; float64 gives a high-precision gradient
     reference).  `ids` overrides the visibility buffer (used to evaluate a float64 run on the float32 run's
     visibility, which is always decided on float32 positions)."""
-    assert pos.dim() == 3 and pos.shape[2] == 4, "instanced mode only: pos must be [B,V,4]"
     H, W = int(resolution[0]), int(resolution[1])
+    if pos.dim() == 2:
+        assert ranges is not None, "range mode needs ranges"
+        if ids is None:
+            ids = rasterize_ids_ranges(pos.to(torch.float32), tri, (H, W), ranges)
+        pos = pos[None].expand(ranges.shape[0], -1, -1)
+    assert pos.dim() == 3 and pos.shape[2] == 4
     B = pos.shape[0]
     if ids is None:
         ids = rasterize_ids(pos.to(torch.float32), tri, (H, W))
@@ -159,7 +176,8 @@ def rasterize(pos, tri, resolution, grad_db=True, ids=None):
 
 def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
     """dr.interpolate(attr[1|B,Vt,A], rast, tri[T,3], rast_db=None, diff_attrs=None) -> (out, out_da)."""
-    assert attr.dim() == 3, "instanced mode only"
+    if attr.dim() == 2:
+        attr = attr[None]
     B, H, W, _ = rast.shape
     A = attr.shape[2]
     T = tri.shape[0]
@@ -447,7 +465,8 @@ def _aa_pairs(color, rast, pos, tri, sil, d, out, flags):
 
 def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0, return_flags=False):
     """dr.antialias(color[B,H,W,C], rast[B,H,W,4], pos[B,V,4], tri[T,3]) -> [B,H,W,C]."""
-    assert pos.dim() == 3, "instanced mode only"
+    if pos.dim() == 2:      # range mode: one shared vertex array
+        pos = pos[None].expand(color.shape[0], -1, -1)
     cnt, oth = edge_table(tri) if topology_hash is None else topology_hash
     if pos_gradient_boost != 1.0:
         # value-neutral gradient scaling

@@ -304,3 +304,46 @@ def test_region_hints_do_not_change_the_operator_chain(dr, oracle_ops, C, res):
     # ... and against the oracle
     r_ref, _ = oracle_ops.rasterize(pos, tri.cpu(), res)
     assert torch.equal(imgs_on[0][..., 3].cpu(), r_ref[..., 3])
+
+
+@pytest.mark.gpu
+def test_range_mode_matches_oracle(dr, oracle_ops):
+    """nvdiffrast's range mode: ONE vertex array pos [V,4] and per image a slice (first, count) of the triangle list (SURVEY
+    section 8b lists `ranges` among the optional arguments of the boundary).  Ids (indices into the whole `tri`) bit-exact,
+    rast floats, the interpolate / antialias chain on the shared arrays, and the gradient of the shared positions (the sum
+    over the images) against the oracle."""
+    from fpc_diffrend_amd import scene
+    sc = scene.cfg('cfg1', n_frames=1)
+    pos3, _ = clip_positions(sc, [2], frames=[0])
+    pos = pos3[0]                                          # [V,4]
+    tri = torch.tensor(sc.pos_idx)
+    T = tri.shape[0]
+    ranges = torch.tensor([[0, T], [T // 3, T // 2], [5, 0], [T - 40, 40]], dtype=torch.int32)
+    res = (96, 128)
+    g = torch.Generator().manual_seed(5)
+    attr = torch.rand(pos.shape[0], 3, generator=g)
+    gy = torch.randn(ranges.shape[0], res[0], res[1], 3, generator=g)
+    p_ref = pos.clone().requires_grad_(True)
+    a_ref = attr.clone().requires_grad_(True)
+    rast_o, _ = oracle_ops.rasterize(p_ref, tri, res, ranges=ranges)
+    col_o, _ = oracle_ops.interpolate(a_ref, rast_o, tri)
+    aa_o = oracle_ops.antialias(col_o, rast_o, p_ref, tri)
+    (aa_o * gy).sum().backward()
+    ctx = dr.RasterizeGLContext(device='cuda')
+    p_gpu = pos.cuda().requires_grad_(True)
+    a_gpu = attr.cuda().requires_grad_(True)
+    rast, _ = dr.rasterize(ctx, p_gpu, tri.cuda(), res, ranges=ranges)
+    col, _ = dr.interpolate(a_gpu, rast, tri.cuda())
+    aa = dr.antialias(col, rast, p_gpu, tri.cuda())
+    (aa * gy.cuda()).sum().backward()
+    assert torch.equal(rast[..., 3].cpu().int(), rast_o[..., 3].int())
+    ids = rast[..., 3].cpu().int()
+    assert int(ids[2].max()) == 0                                          # an empty range draws nothing
+    assert int(ids[1][ids[1] > 0].min()) > T // 3 and int(ids[1].max()) <= T // 3 + T // 2     # ids index the whole list
+    assert int(ids[3][ids[3] > 0].min()) > T - 40 if int(ids[3].max()) > 0 else True
+    assert rel_l2(rast, rast_o) < TOL and rel_l2(aa, aa_o) < TOL
+    assert rel_l2(p_gpu.grad, p_ref.grad) < TOL and rel_l2(a_gpu.grad, a_ref.grad) < TOL
+    with pytest.raises(ValueError):
+        dr.rasterize(ctx, p_gpu, tri.cuda(), res)                           # range mode without ranges
+    with pytest.raises(ValueError):
+        dr.rasterize(ctx, p_gpu, tri.cuda(), res, ranges=torch.tensor([[0, T + 1]], dtype=torch.int32))
