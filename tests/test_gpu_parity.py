@@ -347,3 +347,44 @@ def test_range_mode_matches_oracle(dr, oracle_ops):
         dr.rasterize(ctx, p_gpu, tri.cuda(), res)                           # range mode without ranges
     with pytest.raises(ValueError):
         dr.rasterize(ctx, p_gpu, tri.cuda(), res, ranges=torch.tensor([[0, T + 1]], dtype=torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_rasterize_fuzz_bin_population(dr, ctx, oracle_ops, seed):
+    """Ids bit-exact for soups built to exercise every batch shape of the bin kernel: a few / ~100 / several hundred tiny
+    triangles inside one 32 x 32-pixel bin (the lane path's 4-, 2- and 1-thread-per-triangle forms and more than one batch),
+    mixed with large ones (tile path), depth ties (z quantised to 1/8), back faces and vertices behind the camera; odd
+    resolutions; through the operator and through the fused forward (which carries the same rasteriser in its list form)."""
+    import fpc_diffrend_amd.ops as ops
+    g = torch.Generator().manual_seed(100 + seed)
+    res = [(64, 96), (97, 131), (150, 200), (33, 65), (128, 128), (200, 72)][seed]
+    B = 2
+    n_small = [40, 110, 300, 700, 64, 129][seed]
+    H, W = res
+    # clusters of tiny triangles (2-6 px) around a few bin centres, in NDC
+    centres = (torch.rand(B, 3, 2, generator=g) * 1.6 - 0.8)
+    which = torch.randint(0, 3, (B, n_small), generator=g)
+    c = torch.gather(centres, 1, which[..., None].expand(-1, -1, 2))                      # [B,n,2]
+    half = torch.tensor([32.0 / W, 32.0 / H])                                             # half a bin in NDC
+    c = c + (torch.rand(B, n_small, 2, generator=g) * 2 - 1) * half
+    small = c[:, :, None, :] + (torch.rand(B, n_small, 3, 2, generator=g) * 2 - 1) * torch.tensor([6.0 / W, 6.0 / H])
+    n_big = 12
+    big = (torch.rand(B, n_big, 1, 2, generator=g) * 2 - 1) + (torch.rand(B, n_big, 3, 2, generator=g) * 2 - 1) * 0.9
+    xy = torch.cat([small, big], dim=1)
+    T = n_small + n_big
+    z = torch.round((torch.rand(B, T, 3, 1, generator=g) * 2 - 1) * 0.9 * 8) / 8            # many exact depth ties
+    z[:, ::7] = z[:, ::7, :1]                                                             # whole triangles at one depth
+    w = torch.rand(B, T, 3, 1, generator=g) * 2.5 + 0.5
+    w[:, 5::31, 0] = -0.3                                                                 # a vertex behind the camera: dropped (R1)
+    pos = torch.cat([xy * w, z * w, w], dim=-1).reshape(B, T * 3, 4).contiguous()
+    tri = torch.arange(T * 3, dtype=torch.int32).reshape(T, 3)
+    ids_ref = oracle_ops.rasterize_ids(pos, tri, res)
+    rast, _ = dr.rasterize(ctx, pos.cuda(), tri.cuda(), res)
+    assert torch.equal(_ids(rast), ids_ref)
+    # the fused forward (dense grid and sparse list forms of the same body)
+    uv = torch.rand(T * 3, 2, generator=g).cuda()
+    tex = torch.rand(16, 16, 1, generator=g).cuda()
+    col, rast2 = ops.render_textured(ctx, pos.cuda(), tri.cuda(), uv, tri.cuda(), tex, res)
+    assert torch.equal(_ids(rast2), ids_ref)
+    assert int((ids_ref > 0).sum()) > 0
