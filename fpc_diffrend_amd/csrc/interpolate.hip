@@ -295,7 +295,8 @@ __global__ void __launch_bounds__(256) k_interp_bwd_bin2(const float2 *__restric
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         in[k] = py0 + 8 * k < H;
-        idx[k] = ((size_t)b * H + (in[k] ? py0 + 8 * k : py0)) * W + px;
+        // (rows beyond the image re-read a row inside it: with H % 32 in 1..7 even py0 itself lies outside in the last bin row)
+        idx[k] = ((size_t)b * H + (in[k] ? py0 + 8 * k : min(py0, H - 1))) * W + px;
         rr[k] = rast[idx[k]];
         g[k] = dy2[idx[k]];
     }
