@@ -17,12 +17,20 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None):
+def init(backend=None, force_group=False):
     """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
-    Returns (rank, world, local_rank).  A single process (no env) returns (0, 1, 0) without a process group."""
+    Returns (rank, world, local_rank).  A single process (no env) returns (0, 1, 0) without a process group, unless
+    force_group (or FPCDR_DIST_FORCE_GROUP=1) asks for a one-rank group: the collective library is then loaded and a
+    communicator created exactly as on a multi-GPU node (tests/test_gpu_dist.py uses it to run RCCL on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    force_group = force_group or os.environ.get("FPCDR_DIST_FORCE_GROUP", "0") == "1"
+    if world <= 1 and not force_group:
         return 0, 1, 0
+    if world <= 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        world = 1
     rank = int(os.environ["RANK"])
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -41,10 +49,14 @@ class GradBucket:
     """Flat gradient bucket.  `bucket(params)` packs every existing .grad into one contiguous f32 buffer,
     all-reduces it (sum) and unpacks -- exactly one collective per optimisation step."""
 
-    def __init__(self, params, device):
+    def __init__(self, params, device, always_reduce=False, timed=False):
         self.all_params = list(params)
         self.device = device
         self.calls = 0
+        self.always_reduce = always_reduce     # issue the collective even in a one-rank group (RCCL smoke test)
+        # timed: HIP events around the collective alone (bench.py reports allreduce_ms / bucket_bytes per rank)
+        self.timed = bool(timed) and torch.device(device).type == 'cuda'
+        self._events = []
         self._layout(None)
 
     def _layout(self, sig):
@@ -69,8 +81,15 @@ class GradBucket:
                 v.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [p.grad.reshape(-1) for _, p in have])
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if dist.is_initialized() and (dist.get_world_size() > 1 or self.always_reduce):
+            if self.timed and not torch.cuda.is_current_stream_capturing():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                e1.record()
+                self._events.append((e0, e1))
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.calls += 1
         if have:
             torch._foreach_copy_([p.grad.view(-1) if p.grad.is_contiguous() else p.grad for _, p in have],
@@ -82,6 +101,16 @@ class GradBucket:
     @property
     def nbytes(self):
         return self.flat.numel() * 4
+
+    def reduce_ms(self, reset=True):
+        """Mean HIP-event time of the timed collectives since the last call (None if none were timed).  Synchronises."""
+        if not self._events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._events]
+        if reset:
+            self._events = []
+        return sum(ms) / len(ms)
 
 
 def barrier():

@@ -552,14 +552,28 @@ def _build_mips(tex, n_levels):
     return chain
 
 
+class MipStack(list):
+    """Levels 1..n of the box-filtered mip chain of `base`, as texture_construct_mip() returns it.  texture(base, ..., mip=stack)
+    recognises the pairing (same tensor object, unmodified) and lets the levels' gradients flow back into `base`, as
+    nvdiffrast's opaque mip wrapper does; any other list of tensors passed as `mip` is a CUSTOM stack."""
+
+    def __init__(self, levels, base):
+        super().__init__(levels)
+        self._base = weakref.ref(base)
+        self._version = base._version
+
+    def built_from(self, tex):
+        return self._base() is tex and tex._version == self._version
+
+
 def texture_construct_mip(tex, max_mip_level=None, cube_mode=False):
-    """Pre-build a mip stack for `texture(..., mip=...)`.  Returns a list of tensors (level 1..n)."""
+    """Pre-build a mip stack for `texture(..., mip=...)`.  Returns a MipStack (a list of the level tensors 1..n)."""
     if cube_mode:
         raise NotImplementedError("cube maps are not implemented")
     _check_tensor('tex', tex, torch.float32, 4)
     n = _num_mip_levels(tex.shape[1], tex.shape[2], max_mip_level)
     with torch.no_grad():
-        return _build_mips(tex.contiguous(), n)[1:]
+        return MipStack(_build_mips(tex.contiguous(), n)[1:], tex)
 
 
 def _ptr_array(tensors):
@@ -571,7 +585,7 @@ def _ptr_array(tensors):
 
 class _texture_func(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tex, uv, uv_da, bias, filter_mode, boundary_mode, n_levels, hint, empty_color, *mips):
+    def forward(ctx, tex, uv, uv_da, bias, filter_mode, boundary_mode, n_levels, hint, empty_color, custom, *mips):
         lib = _lib.load()
         B, H, W, _ = uv.shape
         Bt, Ht, Wt, C = tex.shape
@@ -585,6 +599,7 @@ class _texture_func(torch.autograd.Function):
         ctx.save_for_backward(tex, uv, uv_da, bias, *chain[1:])
         ctx.cfg = (filter_mode, boundary_mode, n_levels)
         ctx.hint = hint
+        ctx.custom = bool(custom)     # a caller's own mip tensors: each level keeps its gradient (nvdiffrast: not propagated to tex)
         return out
 
     @staticmethod
@@ -596,7 +611,11 @@ class _texture_func(torch.autograd.Function):
         B, H, W, _ = uv.shape
         Bt, Ht, Wt, C = tex.shape
         need_tex = ctx.needs_input_grad[0]
-        g_levels = [torch.zeros_like(t) if need_tex else None for t in chain]
+        if ctx.custom:
+            need = [need_tex] + [bool(ctx.needs_input_grad[10 + l]) for l in range(len(chain) - 1)]
+        else:
+            need = [need_tex] * len(chain)
+        g_levels = [torch.zeros_like(t) if n else None for t, n in zip(chain, need)]
         g_uv = torch.empty_like(uv) if ctx.needs_input_grad[1] else None
         g_da = torch.empty_like(uv_da) if (uv_da is not None and ctx.needs_input_grad[2]) else None
         g_bias = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[3]) else None
@@ -606,12 +625,14 @@ class _texture_func(torch.autograd.Function):
                             filter_mode=filter_mode, boundary_mode=boundary_mode, grad_tex=_ptr_array(g_levels),
                             grad_uv=_ptr(g_uv), grad_uv_da=_ptr(g_da), grad_mip_level_bias=_ptr(g_bias), hint=_ptr(ctx.hint))
         _lib.call("fpcdr_texture_bwd", ctypes.byref(p), _stream())
+        if ctx.custom:
+            return (g_levels[0], g_uv, g_da, g_bias, None, None, None, None, None, None) + tuple(g_levels[1:])
         if need_tex:
             # collapse the mip gradients down to level 0
             for l in range(n_levels, 0, -1):
                 N, h, w, _ = chain[l - 1].shape
                 _lib.call("fpcdr_mip_downsample_bwd", _ptr(g_levels[l]), _ptr(g_levels[l - 1]), N, h, w, C, _stream())
-        return (g_levels[0], g_uv, g_da, g_bias, None, None, None, None, None) + (None,) * (len(chain) - 1)
+        return (g_levels[0], g_uv, g_da, g_bias, None, None, None, None, None, None) + (None,) * (len(chain) - 1)
 
 
 def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='auto', boundary_mode='wrap',
@@ -634,6 +655,7 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
     mipped = filter_mode in ('linear-mipmap-nearest', 'linear-mipmap-linear')
     n_levels = 0
     mips = ()
+    custom = False
     if mipped:
         if uv_da is None and mip_level_bias is None:
             raise ValueError("mipmapped filter modes need uv_da and/or mip_level_bias")
@@ -648,11 +670,20 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
                 raise ValueError("mip_level_bias must have shape [B,H,W]")
             mip_level_bias = mip_level_bias.contiguous()
         if mip is not None:
+            # a stack texture_construct_mip() built from this very tensor behaves like the internal chain (its gradient
+            # collapses into tex); any other list of tensors is a custom stack whose levels receive their own gradients
+            custom = not (isinstance(mip, MipStack) and mip.built_from(tex))
             mips = tuple(m.contiguous() for m in mip)
-            n_levels = len(mips)
+            n_levels = min(len(mips), _lib.MAX_MIP)
             if max_mip_level is not None:
                 n_levels = min(n_levels, int(max_mip_level))
-                mips = mips[:n_levels]
+            mips = mips[:n_levels]
+            h, w = tex.shape[1], tex.shape[2]
+            for l, m in enumerate(mips):
+                _check_tensor(f'mip[{l}]', m, torch.float32, 4)
+                h, w = h // 2, w // 2
+                if tuple(m.shape) != (tex.shape[0], h, w, tex.shape[3]):
+                    raise ValueError(f"mip level {l + 1} must have shape {(tex.shape[0], h, w, tex.shape[3])} (got {tuple(m.shape)})")
         else:
             n_levels = _num_mip_levels(tex.shape[1], tex.shape[2], max_mip_level)
     else:
@@ -661,7 +692,7 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
     h = _hint_of(uv, 'zero') if (not mipped and tex.shape[0] == 1) else None
     empty_color = torch.empty(tex.shape[3], dtype=torch.float32, device=uv.device) if h else None
     out = _texture_func.apply(tex.contiguous(), uv.contiguous(), uv_da, mip_level_bias, _lib.FILTER[filter_mode],
-                              _lib.BOUNDARY[boundary_mode], n_levels, h[0] if h else None, empty_color, *mips)
+                              _lib.BOUNDARY[boundary_mode], n_levels, h[0] if h else None, empty_color, custom, *mips)
     if h:
         _tag(out, h[0], 'const', empty_color)     # uv = (0,0) in empty bins: the texture's value there
     return out

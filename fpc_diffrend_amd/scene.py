@@ -275,6 +275,8 @@ def cfg(name, n_frames=None, seed=0):
     if name in ('cfg2', 'cfg3', 'cfg4'):
         nf = n_frames or (1 if name == 'cfg2' else 32)
         return make_scene(MESH_30K, 150, nf, (1080, 1920), (1024, 1024, 1), seed)
+    if name == 'ref':      # the reference's own run shape (main.py:28-30): ONE 1600 x 1200 image per step, 1024^2 x 1 texture
+        return make_scene(MESH_30K, 150, n_frames or 4, (1600, 1200), (1024, 1024, 1), seed)
     if name == 'cfg5':
         return make_scene(MESH_30K, 150, n_frames or 4, (2160, 3840), (1024, 1024, 1), seed)
     raise ValueError(name)

@@ -297,7 +297,11 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
         x, y = _tex_coords(flat_uv, Ht, Wt, boundary_mode)
         return _bilinear(tex, tb, x, y, boundary_mode).reshape(B, H, W, C)
     if filter_mode in ('linear-mipmap-linear', 'linear-mipmap-nearest'):
-        chain = build_mip_chain(tex, max_mip_level)
+        if mip is not None:       # a caller's own stack (levels 1..n); autograd gives every level its own gradient
+            mips = list(mip) if max_mip_level is None else list(mip)[:int(max_mip_level)]
+            chain = [tex] + mips
+        else:
+            chain = build_mip_chain(tex, max_mip_level)
         nlev = len(chain) - 1
         # level of detail from the uv footprint (uv_da = du/dx du/dy dv/dx dv/dy), in texels of level 0
         if uv_da is not None:

@@ -92,3 +92,29 @@ def test_grad_bucket_tracks_requires_grad_changes():
     b.grad = torch.full((2,), 2.0)
     bk()
     assert bk.nbytes == 20 and torch.equal(b.grad, torch.full((2,), 2.0))
+
+
+def _one_rank_worker(port, ret):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from fpc_diffrend_amd import dist as fdist
+    assert fdist.init(backend="gloo") == (0, 1, 0) and not tdist.is_initialized()      # a single process: no group
+    assert fdist.init(backend="gloo", force_group=True) == (0, 1, 0) and tdist.is_initialized()
+    p = torch.nn.Parameter(torch.arange(6.0))
+    p.grad = torch.ones(6) * 3
+    bucket = fdist.GradBucket([p], "cpu", always_reduce=True, timed=True)      # (timing is a GPU feature: off on the CPU)
+    bucket()
+    assert bucket.calls == 1 and torch.equal(p.grad, torch.ones(6) * 3) and bucket.reduce_ms() is None
+    ret[0] = True
+    tdist.destroy_process_group()
+
+
+def test_forced_one_rank_group():
+    """dist.init(force_group=True): a one-rank process group (what the GPU test drives through RCCL), here over gloo."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), ret))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0 and ret.get(0) is True

@@ -1,0 +1,302 @@
+"""GPU parity of what earlier rounds advertised but never compared with the oracle ("Next round" item 1):
+the optional nvdiffrast arguments (mip_level_bias, a prebuilt / custom mip stack, pos_gradient_boost, an explicit
+topology_hash), the reference's mip chain end to end (fit.py:153-155), one image at the reference's own run shape
+(main.py:28-30: 1600 x 1200, 1024^2 x 1 texture), the strided sweep kernels at 1080p, a last-bin-row case of the bin-shaped
+interpolate backward, and one collective through RCCL itself."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import clip_positions, random_soup, rel_l2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dr():
+    import fpc_diffrend_amd.ops as dr
+    return dr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# optional arguments of dr.texture
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _tex_inputs(C=2, seed=13):
+    g = torch.Generator().manual_seed(seed)
+    B, H, W = 2, 36, 52
+    tex = torch.rand(1, 32, 64, C, generator=g)
+    uv = torch.rand(B, H, W, 2, generator=g) * 1.4 - 0.2
+    uv_da = (torch.rand(B, H, W, 4, generator=g) - 0.5) * 0.15
+    bias = (torch.rand(B, H, W, generator=g) - 0.4) * 3.0        # pushes levels below 0 and above the chain too
+    gy = torch.randn(B, H, W, C, generator=g)
+    return tex, uv, uv_da, bias, gy
+
+
+@pytest.mark.parametrize("with_da,mode", [(True, 'linear-mipmap-linear'), (False, 'linear-mipmap-linear'), (True, 'linear-mipmap-nearest'),
+                                          (False, 'auto')])
+def test_texture_mip_level_bias_matches_oracle(dr, oracle_ops, with_da, mode):
+    """mip_level_bias [B,H,W] added to the level of detail (alone: the level IS the bias), forward and the gradients to the
+    texture, uv, uv_da and the bias itself."""
+    tex, uv, uv_da, bias, gy = _tex_inputs()
+    kw = dict(filter_mode=mode, max_mip_level=4)
+    ref = [t.clone().requires_grad_(True) for t in (tex, uv, uv_da, bias)]
+    o = oracle_ops.texture(ref[0], ref[1], ref[2] if with_da else None, mip_level_bias=ref[3], **kw)
+    (o * gy).sum().backward()
+    gpu = [t.cuda().requires_grad_(True) for t in (tex, uv, uv_da, bias)]
+    o2 = dr.texture(gpu[0], gpu[1], gpu[2] if with_da else None, mip_level_bias=gpu[3], **kw)
+    (o2 * gy.cuda()).sum().backward()
+    assert rel_l2(o2, o) < TOL
+    assert rel_l2(gpu[0].grad, ref[0].grad) < TOL and rel_l2(gpu[1].grad, ref[1].grad) < TOL
+    if with_da and mode != 'linear-mipmap-nearest':
+        assert rel_l2(gpu[2].grad, ref[2].grad) < TOL
+    if mode != 'linear-mipmap-nearest':          # (nearest level: piecewise constant in the level)
+        assert float(ref[3].grad.abs().sum()) > 0 and rel_l2(gpu[3].grad, ref[3].grad) < TOL
+
+
+def test_texture_prebuilt_and_custom_mip_stacks_match_oracle(dr, oracle_ops):
+    """mip=texture_construct_mip(tex): same values and the same texture gradient as the internally built chain.
+    mip=[own tensors]: the levels are sampled as given and receive their own gradients, none of which reaches tex
+    (nvdiffrast's documented behaviour for a custom stack); the oracle differentiates the same list with autograd."""
+    tex, uv, uv_da, _, gy = _tex_inputs(C=1, seed=17)
+    kw = dict(filter_mode='linear-mipmap-linear', max_mip_level=3)
+    t_ref, uv_ref, da_ref = (t.clone().requires_grad_(True) for t in (tex, uv, uv_da))
+    o = oracle_ops.texture(t_ref, uv_ref, da_ref, **kw)
+    (o * gy).sum().backward()
+    t_gpu, uv_gpu, da_gpu = (t.cuda().requires_grad_(True) for t in (tex, uv, uv_da))
+    stack = dr.texture_construct_mip(t_gpu, max_mip_level=3)
+    assert len(stack) == 3 and tuple(stack[2].shape) == (1, 4, 8, 1)
+    for lvl, want in zip(stack, oracle_ops.build_mip_chain(tex, 3)[1:]):
+        assert rel_l2(lvl, want) < 1e-6
+    o2 = dr.texture(t_gpu, uv_gpu, da_gpu, mip=stack, **kw)
+    (o2 * gy.cuda()).sum().backward()
+    assert rel_l2(o2, o) < TOL and rel_l2(t_gpu.grad, t_ref.grad) < TOL
+    assert rel_l2(uv_gpu.grad, uv_ref.grad) < TOL and rel_l2(da_gpu.grad, da_ref.grad) < TOL
+    # a custom stack: unrelated level contents
+    g = torch.Generator().manual_seed(5)
+    own = [torch.rand(1, 32 >> l, 64 >> l, 1, generator=g) for l in (1, 2, 3)]
+    t_ref.grad = None
+    own_ref = [m.clone().requires_grad_(True) for m in own]
+    o = oracle_ops.texture(t_ref, uv, uv_da, mip=own_ref, **kw)
+    (o * gy).sum().backward()
+    t_gpu.grad = None
+    own_gpu = [m.cuda().requires_grad_(True) for m in own]
+    o2 = dr.texture(t_gpu, uv.cuda(), uv_da.cuda(), mip=own_gpu, **kw)
+    (o2 * gy.cuda()).sum().backward()
+    assert rel_l2(o2, o) < TOL and rel_l2(t_gpu.grad, t_ref.grad) < TOL
+    for a, b in zip(own_gpu, own_ref):
+        assert float(b.grad.abs().sum()) > 0 and rel_l2(a.grad, b.grad) < TOL
+    with pytest.raises(ValueError):
+        dr.texture(t_gpu, uv.cuda(), uv_da.cuda(), mip=[own_gpu[1]], **kw)      # level 1 of the wrong size
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# optional arguments of dr.antialias
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_antialias_pos_gradient_boost_and_explicit_topology_hash(dr, oracle_ops):
+    """pos_gradient_boost scales the position gradient and nothing else; topology_hash=<antialias_construct_topology_hash(tri)>
+    gives the result of the cached, implicit one; a hash of another index buffer is refused."""
+    pos, tri = random_soup(2, 50, 21, size=0.55)
+    res = (88, 104)
+    rast, _ = oracle_ops.rasterize(pos, tri, res)
+    rast = rast.detach()
+    g = torch.Generator().manual_seed(6)
+    color = torch.rand(2, res[0], res[1], 3, generator=g)
+    gy = torch.randn(color.shape, generator=g)
+    out = {}
+    for boost in (1.0, 3.5):
+        c_ref, p_ref = color.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+        o = oracle_ops.antialias(c_ref, rast, p_ref, tri, pos_gradient_boost=boost)
+        (o * gy).sum().backward()
+        c_gpu, p_gpu = color.cuda().requires_grad_(True), pos.cuda().requires_grad_(True)
+        topo = dr.antialias_construct_topology_hash(tri.cuda())
+        o2 = dr.antialias(c_gpu, rast.cuda(), p_gpu, tri.cuda(), topology_hash=topo, pos_gradient_boost=boost)
+        (o2 * gy.cuda()).sum().backward()
+        assert rel_l2(o2, o) < TOL and rel_l2(c_gpu.grad, c_ref.grad) < TOL and rel_l2(p_gpu.grad, p_ref.grad) < TOL
+        out[boost] = (o2.detach(), c_gpu.grad.clone(), p_gpu.grad.clone())
+        # the implicit (cached) topology: identical
+        c3, p3 = color.cuda().requires_grad_(True), pos.cuda().requires_grad_(True)
+        o3 = dr.antialias(c3, rast.cuda(), p3, tri.cuda(), pos_gradient_boost=boost)
+        (o3 * gy.cuda()).sum().backward()
+        assert torch.equal(o3, o2) and rel_l2(p3.grad, p_gpu.grad) < 1e-6
+    assert torch.equal(out[1.0][0], out[3.5][0]) and rel_l2(out[3.5][1], out[1.0][1]) < 1e-6
+    assert rel_l2(out[3.5][2], 3.5 * out[1.0][2]) < 1e-6
+    with pytest.raises(ValueError):
+        dr.antialias(color.cuda(), rast.cuda(), pos.cuda(), tri.cuda(), topology_hash=topo[:-1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's mip chain end to end (fit.py:153-155, 160-161, 579) at cfg1
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_mip_chain_end_to_end_matches_oracle(dr, oracle_ops):
+    """rasterize (with rast_db) -> interpolate(diff_attrs='all') -> texture('linear-mipmap-linear', max_mip_level) ->
+    antialias -> background -> pixel loss: image, loss, d loss / d pos_clip and d loss / d tex against
+    oracle.fit.forward_from_clip(enable_mip=True) on the same clip positions; ids bit-exact."""
+    from fpc_diffrend_amd import fit, scene
+    from oracle import fit as ofit
+    sc = scene.cfg('cfg1', n_frames=2)
+    cams = (0, 4, 7)
+    pos, _ = clip_positions(sc, list(cams), frames=[1])
+    H, W = sc.resolution
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    targets = (70 + 60 * torch.sin(0.05 * xx + 0.3) * torch.cos(0.07 * yy)).clamp(0, 140).to(torch.uint8)
+    targets = targets.reshape(1, 1, H, W).expand(1, len(cams), H, W).contiguous()
+    st = ofit.State(sc, cams)
+    p_ref = pos.clone().requires_grad_(True)
+    loss_o, image_o, rast_o = ofit.forward_from_clip(st, p_ref, targets, enable_mip=True, max_mip_level=4)
+    loss_o.backward()
+    dev = 'cuda'
+    ctx = dr.RasterizeGLContext(device=dev)
+    tri, uv, uv_idx = (torch.tensor(a, device=dev) for a in (sc.pos_idx, sc.uv, sc.uv_idx))
+    p = pos.to(dev).requires_grad_(True)
+    tex = torch.tensor(sc.texture, device=dev).requires_grad_(True)
+    colour, rast = fit.render_from_clip(ctx, p, tri, uv, uv_idx, tex, sc.resolution, True, 4)
+    image = torch.where(rast[..., 3:] > 0, colour, torch.tensor(fit.BACKGROUND, device=dev))       # fit.py:161
+    ref = targets.reshape(len(cams), H, W, 1).to(dev).float()
+    loss = torch.mean((ref - image * 255) ** 2)                                                    # fit.py:579
+    loss.backward()
+    assert torch.equal(rast[..., 3].int().cpu(), rast_o[..., 3].int())
+    assert rel_l2(image, image_o) < TOL
+    assert abs(float(loss) - float(loss_o)) < TOL * float(loss_o)
+    assert rel_l2(p.grad, p_ref.grad) < TOL, rel_l2(p.grad, p_ref.grad)
+    assert rel_l2(tex.grad, st.tex.grad) < TOL, rel_l2(tex.grad, st.tex.grad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's own run shape: ONE 1600 x 1200 image, 1024^2 x 1 texture (main.py:28-30, fit.py:525-526)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_reference_run_shape_one_image_matches_oracle(dr, oracle_ops):
+    """H = 1600 is 50 bins, W = 1200 is 37.5: a ragged right edge over the full height.  Operators and fused objective,
+    forward + backward, against the float32 oracle (ids and antialias flags bit-exact, floats 1e-4)."""
+    from fpc_diffrend_amd import scene
+    from test_gpu_large import _one_image_against_oracle
+    sc = scene.cfg('ref', n_frames=2)
+    assert tuple(sc.resolution) == (1600, 1200) and sc.texture.shape == (1024, 1024, 1)
+    pos, _ = clip_positions(sc, [6], frames=[1])
+    _one_image_against_oracle(dr, sc, pos, torch.tensor(sc.pos_idx), cam=6, seed=8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the strided sweep kernels at 1080p (the residual shape of the r2 work-queue faults)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_1080p_sweep_kernels_equal_the_hinted_launch():
+    """k_bins_queue / k_aa_fix_queue / k_render_aa_bwd_queue loop over thousands of bins per workgroup when the launch hints
+    are far too small: 18 images of 1920 x 1080 with the hints forced to (3, 2, 5) and the list-form backward give the loss
+    and gradients of the default launch."""
+    import fpc_diffrend_amd.ops as dr
+    from fpc_diffrend_amd import scene
+    sc = scene.cfg('cfg3', n_frames=2)
+    pos, _ = clip_positions(sc, list(range(9)), frames=[0, 1])
+    dev = 'cuda'
+    tri, uv, uv_idx = (torch.tensor(a, device=dev) for a in (sc.pos_idx, sc.uv, sc.uv_idx))
+    g = torch.Generator().manual_seed(11)
+    ref = torch.randint(0, 141, (pos.shape[0],) + tuple(sc.resolution), generator=g, dtype=torch.uint8).to(dev)
+    ctx = dr.RasterizeGLContext(device=dev)
+
+    def run(**kw):
+        p = pos.to(dev).clone().requires_grad_(True)
+        t = torch.tensor(sc.texture, device=dev).clone().requires_grad_(True)
+        loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, sc.resolution, **kw)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), p.grad.double().cpu(), t.grad.double().cpu()
+
+    dr._list_hints.clear()
+    try:
+        base = run(launch_hints=False)
+        run(queued_backward=True)                     # leaves its counts behind
+        hints = dr._list_hints[next(iter(dr._list_hints))]
+        caps = hints.poll()
+        assert min(caps) > 1000, caps                 # thousands of bins per list at this size
+        hints.event = None
+        hints.caps = (3, 2, 5)
+        hints.update = lambda counts: None
+        swept = run(queued_backward=True)
+        assert abs(swept[0] - base[0]) <= 1e-6 * abs(base[0])
+        assert rel_l2(swept[1], base[1]) < 1e-5 and rel_l2(swept[2], base[2]) < 1e-5
+    finally:
+        dr._list_hints.clear()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bin-shaped interpolate backward: last bin row with H % 32 in 1..7 (rows past the image were read)
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("res", [(100, 100), (36, 64), (900, 1600)])
+def test_interpolate_backward_last_bin_row(dr, oracle_ops, res):
+    B = 1 if res[0] > 500 else 2
+    pos, tri = random_soup(B, 120, 31, size=0.7)
+    g = torch.Generator().manual_seed(8)
+    attr = torch.randn(1, 360, 2, generator=g)
+    rast, _ = oracle_ops.rasterize(pos, tri, res)
+    rast = rast.detach()
+    gy = torch.randn(B, res[0], res[1], 2, generator=g)
+    r_ref = rast.clone().requires_grad_(True)
+    o, _ = oracle_ops.interpolate(attr, r_ref, tri)
+    (o * gy).sum().backward()
+    # rast is the LAST allocation made before the call: a read past its end is a read past the image batch
+    r_gpu = rast.cuda().requires_grad_(True)
+    o2, _ = dr.interpolate(attr.cuda(), r_gpu, tri.cuda())
+    (o2 * gy.cuda()).sum().backward()
+    assert rel_l2(o2, o) < TOL and rel_l2(r_gpu.grad, r_ref.grad) < TOL
+    assert torch.equal(r_gpu.grad[:, -1].cpu() != 0, r_ref.grad[:, -1] != 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one collective through RCCL (backend "nccl") on the one GPU: a one-rank group in a fresh child process
+# ---------------------------------------------------------------------------------------------------------------------
+
+RCCL_CHILD = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch
+import torch.distributed as tdist
+from fpc_diffrend_amd import dist as fdist, _lib
+_lib.load()                                    # libfpcdr.so (bound to torch's HIP runtime) is resident beside RCCL
+rank, world, _ = fdist.init(backend="nccl", force_group=True)
+assert (rank, world) == (0, 1) and tdist.is_initialized() and tdist.get_backend() == "nccl"
+dev = torch.device("cuda", 0)
+params = [torch.nn.Parameter(torch.randn(n, device=dev)) for n in (150 * 256, 63, 1024 * 1024)]
+for i, p in enumerate(params):
+    p.grad = torch.full_like(p, float(i + 1))
+bucket = fdist.GradBucket(params, dev, always_reduce=True, timed=True)
+bucket()
+torch.cuda.synchronize()
+for i, p in enumerate(params):
+    assert torch.equal(p.grad, torch.full_like(p, float(i + 1))), i       # sum over one rank
+ms = bucket.reduce_ms()
+assert bucket.calls == 1 and ms is not None and ms >= 0.0
+maps = open("/proc/self/maps").read()
+assert "librccl" in maps, "RCCL was not loaded"
+assert "libfpcdr.so" in maps
+print("RCCL_OK bytes", bucket.nbytes, "ms", ms)
+tdist.destroy_process_group()
+"""
+
+
+def test_rccl_backend_reduces_the_gradient_bucket(tmp_path):
+    """backend='nccl' IS RCCL on ROCm.  RCCL refuses two ranks on one device, so the one-GPU box runs a ONE-rank group: the
+    library loads beside libfpcdr.so and torch's bundled HIP runtime, builds a communicator and all-reduces dist.GradBucket's
+    flat buffer (4.4 MB, the prior-mode payload) once.  The test process itself never touches the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "rccl_child.py"
+    script.write_text(RCCL_CHILD.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    env.pop("FPCDR_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "RCCL_OK" in out, out[-3000:]

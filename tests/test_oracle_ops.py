@@ -275,3 +275,21 @@ def test_edge_table(oracle_ops):
     assert cnt[1, 2] == 2 and oth[1, 2] == 0
     # boundary
     assert cnt[1, 0] == 1 and oth[1, 0] == -1
+
+
+def test_texture_custom_mip_stack(oracle_ops):
+    """texture(mip=[...]): handing the oracle its own box-filtered chain reproduces the internal chain; other level contents
+    are sampled as given, and every level receives its own gradient."""
+    g = torch.Generator().manual_seed(2)
+    tex = torch.rand(1, 16, 32, 2, generator=g, dtype=torch.float64)
+    uv = torch.rand(1, 9, 11, 2, generator=g, dtype=torch.float64)
+    da = (torch.rand(1, 9, 11, 4, generator=g, dtype=torch.float64) - 0.5) * 0.3
+    kw = dict(filter_mode='linear-mipmap-linear', max_mip_level=3)
+    a = oracle_ops.texture(tex, uv, da, **kw)
+    b = oracle_ops.texture(tex, uv, da, mip=oracle_ops.build_mip_chain(tex, 3)[1:], **kw)
+    assert torch.equal(a, b)
+    own = [torch.rand(1, 16 >> l, 32 >> l, 2, generator=g, dtype=torch.float64).requires_grad_(True) for l in (1, 2, 3)]
+    c = oracle_ops.texture(tex, uv, da, mip=own, **kw)
+    assert not torch.allclose(a, c)
+    c.sum().backward()
+    assert all(float(m.grad.abs().sum()) > 0 for m in own[:2])
