@@ -67,6 +67,31 @@ static inline fpcdr_queue_layout fpcdr_queue_layout_of(int B, int H, int W) {
     return q;
 }
 
+// ---- exact division of a list entry by a launch constant ----------------------------------------------------------
+// The list kernels turn a linear bin index into (image, bin row, bin column).  The hardware has no integer division: the
+// compiler's expansion costs ~25 vector instructions (several of them quarter rate) per division and wave, three per
+// workgroup.  With a host-made reciprocal it is one multiply-high and a shift, on the scalar unit when the index is uniform.
+// q = (n * m) >> (31 + l), l = ceil(log2 d), m = floor(2^(31+l) / d) + 1: exact for every 0 <= n < 2^31, 1 <= d < 2^31.
+struct fpcdr_div { uint32_t m, sh, d; };
+static inline fpcdr_div fpcdr_make_div(uint32_t d) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    fpcdr_div r;
+    r.m = (uint32_t)(((1ull << (31 + l)) / d) + 1ull);
+    r.sh = 31 + l;
+    r.d = d;
+    return r;
+}
+__device__ __forceinline__ uint32_t fpcdr_divide(uint32_t n, const fpcdr_div &v) { return (uint32_t)(((unsigned long long)n * v.m) >> v.sh); }
+// linear bin index -> (image, bin row, bin column) for OX x OY bins per image
+struct fpcdr_bin_decode { fpcdr_div per_image, per_row; };
+static inline fpcdr_bin_decode fpcdr_make_bin_decode(int OX, int OY) { return {fpcdr_make_div((uint32_t)OX * (uint32_t)OY), fpcdr_make_div((uint32_t)OX)}; }
+__device__ __forceinline__ void fpcdr_decode_bin(int lin, const fpcdr_bin_decode &dc, int &b, int &byi, int &bxi) {
+    const uint32_t q = fpcdr_divide((uint32_t)lin, dc.per_image), rem = (uint32_t)lin - q * dc.per_image.d;
+    const uint32_t y = fpcdr_divide(rem, dc.per_row);
+    b = (int)q; byi = (int)y; bxi = (int)(rem - y * dc.per_row.d);
+}
+
 // tuning override for the number of resident workgroups per CU of a work-queue kernel (experiments; default = dflt)
 static inline int fpcdr_env_int(const char *name, int dflt) {
     const char *v = getenv(name);

@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
 // occupied); the launch is sized by the caller's hint, the strided form sweeps up the rest (see k_bins_list, rasterize.hip)
 template <int CS>
 __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
-                                                       const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                       fpcdr_bin_decode dc, const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
                                                        const float *__restrict__ tex, const float4 *__restrict__ rast,
                                                        const float *__restrict__ color, const float *__restrict__ g_aa,
@@ -648,9 +648,10 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd_list(con
                                                        const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
     const int item = blockIdx.x;
     if (item >= *count) return;
-    const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
     const int lin = __builtin_amdgcn_readfirstlane(list[item]);
-    render_aa_bwd_body<CS>(lin / (OX * OY), lin % OX, (lin / OX) % OY, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ,
+    int b, byi, bxi;
+    fpcdr_decode_bin(lin, dc, b, byi, bxi);
+    render_aa_bwd_body<CS>(b, bxi, byi, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ,
                            empty_color, B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag);
 }
 
@@ -659,7 +660,7 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd_list(con
 #endif
 template <int CS>
 __global__ void __launch_bounds__(BWD_NT) FPCDR_BWDQ_WPE k_render_aa_bwd_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
-                                                       int first,
+                                                       int first, fpcdr_bin_decode dc,
                                                        const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
                                                        const float *__restrict__ tex, const float4 *__restrict__ rast,
@@ -672,10 +673,11 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWDQ_WPE k_render_aa_bwd_queue(c
                                                        float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
                                                        const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
     const int n = *count;
-    const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
     for (int item = first + blockIdx.x; item < n; item += gridDim.x) {      // scalar loop variable: uniform for the compiler
         const int lin = __builtin_amdgcn_readfirstlane(list[item]);
-        render_aa_bwd_body<CS>(lin / (OX * OY), lin % OX, (lin / OX) % OY, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ,
+        int b, byi, bxi;
+        fpcdr_decode_bin(lin, dc, b, byi, bxi);
+        render_aa_bwd_body<CS>(b, bxi, byi, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ,
                                empty_color, B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag);
         __syncthreads();     // the next bin's first LDS writes must not overtake this bin's last LDS reads
     }
@@ -822,21 +824,26 @@ __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const in
 #define FPCDR_AA_FIX_PASS                                                                                                       \
     color, rast, pos, tri, sil, ref, B, H, W, V, T, bg, color_scale, grad_scale, flags, g_aa, occ, empty_color, cmask, edges, loss_sum, binflag
 template <int CS>
-__global__ void __launch_bounds__(FIX_NT) k_aa_fix_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, FPCDR_AA_FIX_ARGS) {
+__global__ void __launch_bounds__(FIX_NT) k_aa_fix_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, fpcdr_bin_decode dc,
+                                                        FPCDR_AA_FIX_ARGS) {
     const int item = blockIdx.x;
     if (item >= *count) return;
     const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
     const int lin = __builtin_amdgcn_readfirstlane(list[item]);
-    aa_fix_body<CS>(lin / (OX * OY), lin % OX, (lin / OX) % OY, OX, OY, FPCDR_AA_FIX_PASS);
+    int b, byi, bxi;
+    fpcdr_decode_bin(lin, dc, b, byi, bxi);
+    aa_fix_body<CS>(b, bxi, byi, OX, OY, FPCDR_AA_FIX_PASS);
 }
 template <int CS>
 __global__ void __launch_bounds__(FIX_NT) k_aa_fix_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int first,
-                                                      FPCDR_AA_FIX_ARGS) {
+                                                      fpcdr_bin_decode dc, FPCDR_AA_FIX_ARGS) {
     const int n = *count;
     const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
     for (int item = first + blockIdx.x; item < n; item += gridDim.x) {
         const int lin = __builtin_amdgcn_readfirstlane(list[item]);
-        aa_fix_body<CS>(lin / (OX * OY), lin % OX, (lin / OX) % OY, OX, OY, FPCDR_AA_FIX_PASS);
+        int b, byi, bxi;
+        fpcdr_decode_bin(lin, dc, b, byi, bxi);
+        aa_fix_body<CS>(b, bxi, byi, OX, OY, FPCDR_AA_FIX_PASS);
         __syncthreads();
     }
 }
@@ -845,9 +852,10 @@ __global__ void __launch_bounds__(FIX_NT) k_aa_fix_queue(const int32_t *__restri
 __global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               const int32_t *__restrict__ adj, int B, int V, int T, float hw, float hh,
                                               uint8_t *__restrict__ sil) {
-    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)B * T) return;
-    const int b = (int)(gid / T), t = (int)(gid - (long long)b * T);
+    // grid (triangle chunks, images): a flat thread index would cost every thread a 64-bit division
+    const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const size_t gid = (size_t)b * T + t;
     const float4 *p = pos + (size_t)b * V;
     int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
     unsigned int bits = 0;
@@ -881,7 +889,7 @@ __global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, co
 // ---- pieces of fpcdr_render_loss_fwd (rasterize.hip) that live in this file; not part of the C ABI ----
 int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, int B, int V, int T, int H, int W, uint8_t *sil,
                      hipStream_t st) {
-    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv((long long)B * T, 256)), dim3(256), 0, st, (const float4 *)pos, tri, adj, B, V, T,
+    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv(T, 256), B), dim3(256), 0, st, (const float4 *)pos, tri, adj, B, V, T,
                        0.5f * (float)W, 0.5f * (float)H, sil);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
@@ -890,14 +898,15 @@ int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, i
 int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask, const unsigned long long *edges,
                         const int32_t *fix_list, const int32_t *fix_count, int nbins, hipStream_t st) {
     const int cap = (p->cap_fix > 0 && p->cap_fix < nbins) ? p->cap_fix : nbins;
+    const fpcdr_bin_decode dc = fpcdr_make_bin_decode(FPCDR_OCC_DIM(p->W), FPCDR_OCC_DIM(p->H));
 #define ARGS                                                                                                                   \
     p->color, (const float4 *)p->rast, (const float4 *)p->pos, p->tri, p->sil, p->ref, p->B, p->H, p->W, p->V, p->T, p->bg,   \
     p->color_scale, p->grad_scale, (unsigned long long *)p->flags, p->grad_aa, p->occ, p->empty_color, cmask, edges, p->loss_sum,   \
     (uint8_t *)p->occ + fpcdr_queue_layout_of(p->B, p->H, p->W).occ_binflag
 #define LAUNCH(CS)                                                                                                             \
     do {                                                                                                                       \
-        hipLaunchKernelGGL(k_aa_fix_list<CS>, dim3(cap), dim3(FIX_NT), 0, st, fix_list, fix_count, ARGS);                        \
-        if (cap < nbins) hipLaunchKernelGGL(k_aa_fix_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(FIX_NT), 0, st, fix_list, fix_count, cap, ARGS); \
+        hipLaunchKernelGGL(k_aa_fix_list<CS>, dim3(cap), dim3(FIX_NT), 0, st, fix_list, fix_count, dc, ARGS);                    \
+        if (cap < nbins) hipLaunchKernelGGL(k_aa_fix_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(FIX_NT), 0, st, fix_list, fix_count, cap, dc, ARGS); \
     } while (0)
     if (p->C == 1) LAUNCH(1);
     else if (p->C == 3) LAUNCH(3);
@@ -916,7 +925,7 @@ extern "C" int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream
     FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
     FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 32) <= 65535, "image batch / height too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv((long long)p->B * p->T, 256)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil);
     dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 32), p->B);
 #define LAUNCH(CS, SP)                                                                                                         \
@@ -968,15 +977,16 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
         const int32_t *list = (const int32_t *)((const char *)p->occ + q.occ_bwd_list);
         const long long nbins = (long long)p->B * FPCDR_OCC_DIM(p->H) * FPCDR_OCC_DIM(p->W);
         const int cap = (p->cap_bwd > 0 && p->cap_bwd < nbins) ? p->cap_bwd : (int)nbins;
+        const fpcdr_bin_decode dc = fpcdr_make_bin_decode(FPCDR_OCC_DIM(p->W), FPCDR_OCC_DIM(p->H));
 #define ARGSQ                                                                                                               \
         (const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, p->tex, (const float4 *)p->rast, p->color, p->grad_aa,  \
         p->sil, (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt,        \
         p->boundary_mode, p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream, binflag
 #define LAUNCHQ(CS)                                                                                                         \
         do {                                                                                                                \
-            hipLaunchKernelGGL(k_render_aa_bwd_list<CS>, dim3(cap), dim3(BWD_NT), 0, st, list, hdr, ARGSQ);                  \
+            hipLaunchKernelGGL(k_render_aa_bwd_list<CS>, dim3(cap), dim3(BWD_NT), 0, st, list, hdr, dc, ARGSQ);              \
             if (cap < nbins)                                                                                                \
-                hipLaunchKernelGGL(k_render_aa_bwd_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(BWD_NT), 0, st, list, hdr, cap, ARGSQ); \
+                hipLaunchKernelGGL(k_render_aa_bwd_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(BWD_NT), 0, st, list, hdr, cap, dc, ARGSQ); \
         } while (0)
         if (p->C == 1) LAUNCHQ(1);
         else if (p->C == 3) LAUNCHQ(3);

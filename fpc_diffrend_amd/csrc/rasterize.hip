@@ -758,6 +758,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
     float *s_gaa = reinterpret_cast<float *>(s_tri);
     const bool stage = SHADE && C == 1;
     float col0[4] = {0.f, 0.f, 0.f, 0.f};   // LOSS: channel 0 of this thread's pixels (re-reading a just-written line stalls)
+    unsigned int any_sil = 0u;              // LOSS: silhouette bits of the triangles this thread's pixels show, OR-ed
     const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
     const float4 *p = pos + (size_t)b * V;
     Taps empty_tp = {};
@@ -792,6 +793,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         if (LOSS) {   // (z/w, id) of the bin's pixels for the neighbour tests below; this thread owns the entry
             // id + 1 in 24 bits (ids are exact in rast's float anyway), the triangle's silhouette bits above them
             const unsigned int sb = t >= 0 ? (unsigned int)sh.sil[(size_t)b * T + t] : 0u;
+            any_sil |= sb;
             s_z[zy * BIN + zx] = ((unsigned long long)__float_as_uint(o.z) << 32) | (sb << 24) | (unsigned int)(t + 1);
         }
         if (SHADE) {
@@ -855,7 +857,10 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         __shared__ unsigned int s_cmask[BIN];
         __shared__ float s_lpart[4];
         if (tid < BIN) s_cmask[tid] = 0u;
-        __syncthreads();   // (z/w, id) entries, the staged colour and the cleared masks are visible
+        // (barrier: (z/w, id) entries, the staged colour and the cleared masks are visible.)  A pair inside the bin can only be a
+        // candidate if one of its two triangles owns a silhouette edge: most bins of a face show none at all -- the interior of the
+        // mesh -- and skip the neighbour tests of their 1024 pixels altogether (the pairs across the border are k_aa_fix's)
+        const bool bin_has_sil = __builtin_amdgcn_readfirstlane(__syncthreads_or(any_sil != 0u ? 1 : 0)) != 0;
         const size_t bin_id = bin_lin;
         unsigned long long *edge = sh.edges + bin_id * (4 * BIN);   // [left col | right col | bottom row | top row][32]
         if (tid < 4 * BIN) {      // the four border lines: one entry per thread (pixels beyond the image export 0)
@@ -878,23 +883,25 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
             // First the cheap part for all four pairs: ids differ AND one of the two triangles owns a silhouette edge at all
             // (interior triangles of a closed mesh own none, so most id discontinuities end here); only such pairs decide
             // which of the two triangles is analysed.
-            const bool hR = zx < BIN - 1 && px + 1 < W, hU = zy < BIN - 1 && py + 1 < H, hL = zx > 0, hD = zy > 0;
-            const unsigned long long nR = hR ? s_z[idx + 1] : me, nU = hU ? s_z[idx + BIN] : me;
-            const unsigned long long nL = hL ? s_z[idx - 1] : me, nD = hD ? s_z[idx - BIN] : me;
-            auto maybe = [&](unsigned long long n) {
-                return ((unsigned int)n & 0xffffffu) != (unsigned int)id && ((((unsigned int)n | (unsigned int)me) >> 24) & 0xffu) != 0;
-            };
             bool cand = false;
-            if ((int)maybe(nR) | (int)maybe(nU) | (int)maybe(nL) | (int)maybe(nD)) {
-                auto pair = [&](unsigned long long n, bool me_first) {
-                    const int nid = (int)((unsigned int)n & 0xffffffu);
-                    if (nid == id) return false;
-                    const float nz = __uint_as_float((unsigned int)(n >> 32));
-                    const PairSel ps = me_first ? pair_select(id, z, nid, nz, T) : pair_select(nid, nz, id, z, T);
-                    const bool takes_n = me_first ? ps.use1 : !ps.use1;
-                    return ps.tau >= 0 && (((unsigned int)(takes_n ? n : me) >> 24) & 0xffu) != 0;
+            if (bin_has_sil) {      // (uniform)
+                const bool hR = zx < BIN - 1 && px + 1 < W, hU = zy < BIN - 1 && py + 1 < H, hL = zx > 0, hD = zy > 0;
+                const unsigned long long nR = hR ? s_z[idx + 1] : me, nU = hU ? s_z[idx + BIN] : me;
+                const unsigned long long nL = hL ? s_z[idx - 1] : me, nD = hD ? s_z[idx - BIN] : me;
+                auto maybe = [&](unsigned long long n) {
+                    return ((unsigned int)n & 0xffffffu) != (unsigned int)id && ((((unsigned int)n | (unsigned int)me) >> 24) & 0xffu) != 0;
                 };
-                cand = (hR && pair(nR, true)) || (hU && pair(nU, true)) || (hL && pair(nL, false)) || (hD && pair(nD, false));
+                if (((int)maybe(nR) | (int)maybe(nU) | (int)maybe(nL) | (int)maybe(nD))) {
+                    auto pair = [&](unsigned long long n, bool me_first) {
+                        const int nid = (int)((unsigned int)n & 0xffffffu);
+                        if (nid == id) return false;
+                        const float nz = __uint_as_float((unsigned int)(n >> 32));
+                        const PairSel ps = me_first ? pair_select(id, z, nid, nz, T) : pair_select(nid, nz, id, z, T);
+                        const bool takes_n = me_first ? ps.use1 : !ps.use1;
+                        return ps.tau >= 0 && (((unsigned int)(takes_n ? n : me) >> 24) & 0xffu) != 0;
+                    };
+                    cand = (hR && pair(nR, true)) || (hU && pair(nU, true)) || (hL && pair(nL, false)) || (hD && pair(nD, false));
+                }
             }
             if (cand) atomicOr(&s_cmask[zy], 1u << zx);
             const size_t off = ((size_t)b * H + py) * W + px;
@@ -951,7 +958,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
 #endif
 template <bool WRITE_DB, bool SHADE, bool LOSS, int CS = 0, int BMODE = -1>
 __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
-                                              int OX, int OY,
+                                              int OX, int OY, fpcdr_bin_decode dc,
                                               const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               int V, int T, int H, int W, const TriRec *__restrict__ recs,
                                               const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
@@ -960,8 +967,9 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t 
     const int item = blockIdx.x;
     if (item >= *count) return;
     const int lin = __builtin_amdgcn_readfirstlane(list[item]);
-    bins_body<WRITE_DB, SHADE, LOSS, true, CS, BMODE>(lin / (OX * OY), lin % OX, (lin / OX) % OY, OX, OY, pos, tri, V, T, H, W, recs, boxes,
-                                                      cboxes, ibox, rast, rast_db, sh);
+    int b, byi, bxi;
+    fpcdr_decode_bin(lin, dc, b, byi, bxi);
+    bins_body<WRITE_DB, SHADE, LOSS, true, CS, BMODE>(b, bxi, byi, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox, rast, rast_db, sh);
 }
 
 // strided form: entries first, first + gridDim.x, ... of the list.  The loop variable is scalar by construction, so the loop
@@ -971,7 +979,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t 
 // is why this form only sweeps up what the hinted launch above did not reach.)
 template <bool WRITE_DB, bool SHADE, bool LOSS>
 __global__ void __launch_bounds__(256) FPCDR_BINSQ_WPE k_bins_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
-                                              int first, int OX, int OY,
+                                              int first, int OX, int OY, fpcdr_bin_decode dc,
                                               const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               int V, int T, int H, int W, const TriRec *__restrict__ recs,
                                               const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
@@ -980,7 +988,8 @@ __global__ void __launch_bounds__(256) FPCDR_BINSQ_WPE k_bins_queue(const int32_
     const int n = *count;
     for (int item = first + blockIdx.x; item < n; item += gridDim.x) {
         const int lin = __builtin_amdgcn_readfirstlane(list[item]);
-        const int bxi = lin % OX, byi = (lin / OX) % OY, b = lin / (OX * OY);
+        int b, byi, bxi;
+        fpcdr_decode_bin(lin, dc, b, byi, bxi);
         bins_body<WRITE_DB, SHADE, LOSS, true>(b, bxi, byi, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox, rast, rast_db, sh);
         __syncthreads();     // the next bin's first LDS writes must not overtake this bin's last LDS reads
     }
@@ -1183,6 +1192,7 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
     FPCDR_REQUIRE(p->B > 0 && p->V > 0 && p->T > 0 && p->H > 0 && p->W > 0, "sizes must be positive");
     FPCDR_REQUIRE(p->H <= 32767 && p->W <= 32767, "resolution above 32767 is not supported");
     FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
+    FPCDR_REQUIRE(p->T < (1 << 24), "more than 2^24 triangles (rast stores triangle index + 1 as a float)");
     hipStream_t st = (hipStream_t)stream;
     size_t n = (size_t)p->B * p->T;
     char *s = (char *)p->scratch;
@@ -1235,6 +1245,7 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
     FPCDR_REQUIRE(p->B > 0 && p->V > 0 && p->T > 0 && p->H > 0 && p->W > 0 && p->Ht > 0 && p->Wt > 0 && p->C > 0,
                   "sizes must be positive");
     FPCDR_REQUIRE(p->H <= 32767 && p->W <= 32767 && p->B <= 65535, "resolution / batch too large");
+    FPCDR_REQUIRE(p->T < (1 << 24), "more than 2^24 triangles (rast stores triangle index + 1 as a float)");
     FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C <= 0x7fffffffLL, "texture too large");
     hipStream_t st = (hipStream_t)stream;
@@ -1334,17 +1345,18 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
                     l->sil, l->ref, l->grad_aa, cmask, (unsigned long long *)(cm + q.cm_edges), l->loss_sum, l->bg, l->color_scale,
                     l->grad_scale};
     // hinted single-shot launch + strided sweep of the rest (l->cap_bins <= 0: no hint, one workgroup per possible entry)
+    const fpcdr_bin_decode dc = fpcdr_make_bin_decode(OX, OY);
     const int cap_bins = (l->cap_bins > 0 && (size_t)l->cap_bins < nbins) ? l->cap_bins : (int)nbins;
     if (p->C == 1 && p->boundary_mode == FPCDR_BOUNDARY_WRAP)     // the reference's case, with both as compile-time constants
-        hipLaunchKernelGGL((k_bins_list<false, true, true, 1, FPCDR_BOUNDARY_WRAP>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY,
+        hipLaunchKernelGGL((k_bins_list<false, true, true, 1, FPCDR_BOUNDARY_WRAP>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY, dc,
                        (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
                        (float4 *)nullptr, sh);
     else
-        hipLaunchKernelGGL((k_bins_list<false, true, true>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY,
+        hipLaunchKernelGGL((k_bins_list<false, true, true>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY, dc,
                        (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
                        (float4 *)nullptr, sh);
     if ((size_t)cap_bins < nbins)
-        hipLaunchKernelGGL((k_bins_queue<false, true, true>), dim3(FPCDR_SWEEP_WGS), dim3(256), 0, st, bin_list, n_bins, cap_bins, OX, OY,
+        hipLaunchKernelGGL((k_bins_queue<false, true, true>), dim3(FPCDR_SWEEP_WGS), dim3(256), 0, st, bin_list, n_bins, cap_bins, OX, OY, dc,
                            (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
                            (float4 *)nullptr, sh);
     hipLaunchKernelGGL(k_list_count<true>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, p->occ,
