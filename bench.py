@@ -54,7 +54,21 @@ def algorithmic_bytes_per_px(C, with_db):
     }
 
 
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_counters_cfg3.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r03_counters_cfg3.json")
+
+
+def kernel_source_sha16():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile, include/fpcdr.h): the counters file records the one it was measured
+    on (scripts/make_counters_json.py), and counters of other sources are not paired with this run's times."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "fpc_diffrend_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "fpc_diffrend_amd", "csrc", "*.h"))
+                   + [os.path.join(ROOT, "fpc_diffrend_amd", "csrc", "Makefile"), os.path.join(ROOT, "include", "fpcdr.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 # kernels behind each C-ABI entry point (the PMC passes are per kernel)
 # kernels of each entry point, by name prefix (template arguments vary with the instantiation the launch picked)
 ENTRY_KERNELS = {
@@ -68,38 +82,54 @@ N_SIMD = 1024           # 256 CUs x 4 SIMDs
 F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X dense f32 matrix peak (MI355X_MICROARCH.md)
 
 
-def measured_counters(name, workload, n_images, C):
-    """Per-launch PMC figures of one entry point from the committed rocprofv3 passes (profiles/r02_counters_cfg3.json: separate
-    --pmc passes of scripts/prof_objective.py, scripts/measure_round.sh), or None when no pass exists for this configuration.
+def measured_counters(name, workload, n_images, C, t_ms=None):
+    """Per-launch PMC figures of one entry point from the committed rocprofv3 passes (COUNTERS_FILE: separate --pmc passes of
+    scripts/prof_objective.py, scripts/measure_round.sh).  Returns (figures, None) or (None, reason): the figures are used only
+    if the file describes this workload, was measured on THESE kernel sources (kernel_source_sha16) and -- t_ms given -- the
+    kernels' durations in the passes agree with this run's HIP-event time of the call to 10 %.
     HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE: on gfx950 FETCH_SIZE reports exactly half the bytes of a coalesced stream of ANY
     width per lane (1, 2, 4, 8, 16 B: profiles/r02_fetch_calibration.txt); the kernels' gathers (vertices, texels) hit L2 and do
     not reach the counter."""
     try:
         with open(COUNTERS_FILE) as f:
             t = json.load(f)
-        if t["workload"] != workload or t["images"] != n_images or t["channels"] != C:
-            return None
-        tot = {"fetch_kb": 0.0, "write_kb": 0.0, "valu_insts": 0.0, "gui_active": 0.0, "mfma_busy": 0.0, "lds_conflict": 0.0, "lds_active": 0.0}
-        for kname, entry in t["kernels"].items():
-            short = kname[5:] if kname.startswith("void ") else kname
-            c = entry.get("counters")
-            if not c or not any(short == pre or (pre.endswith(("<", "true", "false")) and short.startswith(pre)) for pre in ENTRY_KERNELS[name]):
-                continue
-            tot["fetch_kb"] += c.get("FETCH_SIZE", 0.0)
-            tot["write_kb"] += c.get("WRITE_SIZE", 0.0)
-            tot["valu_insts"] += c.get("SQ_INSTS_VALU", 0.0)
-            tot["gui_active"] += c.get("GRBM_GUI_ACTIVE", 0.0)
-            tot["mfma_busy"] += c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
-            tot["lds_conflict"] += c.get("SQ_LDS_BANK_CONFLICT", 0.0)
-            tot["lds_active"] += c.get("SQ_LDS_IDX_ACTIVE", 0.0)
-        tot["hbm_bytes"] = (2.0 * tot["fetch_kb"] + tot["write_kb"]) * 1024.0
-        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles of the launches = / 8; a VALU wave-instruction occupies its SIMD 4 cycles
-        cyc = tot["gui_active"] / 8.0
-        tot["valu_issue_frac"] = (tot["valu_insts"] * 4.0 / (N_SIMD * cyc)) if cyc else None
-        tot["mfma_busy_frac"] = (tot["mfma_busy"] / (N_SIMD * cyc)) if cyc else None
-        return tot
-    except Exception:
-        return None
+    except Exception as e:
+        return None, f"no counters file ({e!r})"
+    src = os.path.relpath(COUNTERS_FILE, ROOT)
+    if t.get("workload") != workload or t.get("images") != n_images or t.get("channels") != C:
+        return None, f"{src} describes {t.get('workload')} / {t.get('images')} images / C = {t.get('channels')}, not this run"
+    if t.get("kernel_source_sha16") != kernel_source_sha16():
+        return None, (f"{src} was measured on kernel sources {t.get('kernel_source_sha16')} (commit {t.get('git_head')}), this run's are "
+                      f"{kernel_source_sha16()}: counters of other kernels are not paired with these times")
+    tot = {"fetch_kb": 0.0, "write_kb": 0.0, "valu_insts": 0.0, "gui_active": 0.0, "mfma_busy": 0.0, "lds_conflict": 0.0, "lds_active": 0.0,
+           "thread_cycles_valu": 0.0, "pass_ms": 0.0}
+    for kname, entry in t["kernels"].items():
+        short = kname[5:] if kname.startswith("void ") else kname
+        c = entry.get("counters")
+        if not c or not any(short == pre or (pre.endswith(("<", "true", "false")) and short.startswith(pre)) for pre in ENTRY_KERNELS[name]):
+            continue
+        tot["fetch_kb"] += c.get("FETCH_SIZE", 0.0)
+        tot["write_kb"] += c.get("WRITE_SIZE", 0.0)
+        tot["valu_insts"] += c.get("SQ_INSTS_VALU", 0.0)
+        tot["thread_cycles_valu"] += c.get("SQ_THREAD_CYCLES_VALU", 0.0)
+        tot["gui_active"] += c.get("GRBM_GUI_ACTIVE", 0.0)
+        tot["mfma_busy"] += c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        tot["lds_conflict"] += c.get("SQ_LDS_BANK_CONFLICT", 0.0)
+        tot["lds_active"] += c.get("SQ_LDS_IDX_ACTIVE", 0.0)
+        d = list(entry.get("duration_us", {}).values())
+        tot["pass_ms"] += (sum(d) / len(d) / 1e3) if d else 0.0
+    if t_ms is not None and tot["pass_ms"] > 0 and abs(tot["pass_ms"] - t_ms) > 0.10 * t_ms:
+        return None, (f"{src}: the kernels of {name} took {tot['pass_ms']:.3f} ms in the PMC passes, {t_ms:.3f} ms in this run "
+                      "(> 10 % apart): counters not paired with these times")
+    tot["hbm_bytes"] = (2.0 * tot["fetch_kb"] + tot["write_kb"]) * 1024.0
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles of the launches = / 8; a VALU wave-instruction occupies its SIMD 4 cycles
+    # (measured: scripts/micro/valu_rate_bench.hip -- every f32 / i32 / f64 / conversion instruction alike, v_rcp_f32 8)
+    cyc = tot["gui_active"] / 8.0
+    tot["valu_issue_frac"] = (tot["valu_insts"] * 4.0 / (N_SIMD * cyc)) if cyc else None
+    tot["mfma_busy_frac"] = (tot["mfma_busy"] / (N_SIMD * cyc)) if cyc else None
+    tot["lane_utilisation"] = (tot["thread_cycles_valu"] / (64.0 * tot["valu_insts"])) if tot["valu_insts"] and tot["thread_cycles_valu"] else None
+    tot["source"] = {"file": src, "git_head": t.get("git_head"), "kernel_source_sha16": t.get("kernel_source_sha16")}
+    return tot, None
 
 
 def standalone_op_sweep(fitter, reps=3):
@@ -130,6 +160,60 @@ def standalone_op_sweep(fitter, reps=3):
     summ = timer.summary()
     _lib.TIMER = None
     return summ
+
+
+def count_launches(step_fn, steps=3):
+    """GPU kernel launches per step (torch profiler over `steps` eager steps)."""
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(steps):
+            step_fn()
+        torch.cuda.synchronize()
+    n = 0
+    for e in prof.events():
+        if str(getattr(e, "device_type", "")).endswith("CUDA") and not e.name.startswith(("Memcpy", "Memset")):
+            n += 1
+    return n / steps
+
+
+def reference_shaped_step(device, steps=40, frames=8):
+    """The reference's OWN run shape (main.py:28-30, fit.py:525-526): ONE random (camera, frame) image of 1600 x 1200 per
+    iteration, a 1024^2 x 1 texture, 30k triangles -- what a user who only switches the import gets.  Two surfaces:
+      drop_in    rasterize / interpolate / texture / antialias as four operators + the reference's torch.where / mean loss
+      objective  ops.pixel_objective (the fused two-call path), eager and replayed as HIP graphs
+    Wall-clock ms per step between synchronisations, images/s, and GPU launches per step of the eager form."""
+    from fpc_diffrend_amd import fit, scene
+    sc = scene.cfg("ref", n_frames=frames)
+    out = {"resolution": list(sc.resolution), "texture": list(sc.texture.shape), "triangles": int(sc.pos_idx.shape[0]),
+           "frames_in_take": frames, "cameras": 9, "images_per_step": 1,
+           "what": "one random (camera, frame) image per Adam step as reference fit.py:525-526; wall clock over %d steps" % steps}
+    targets = None
+    surfaces = (("drop_in", dict(fused_objective=False, fused_render=False, fused_loss=False), False),
+                ("objective", {}, False), ("objective_hip_graph", {}, True))
+    for name, kw, graph in surfaces:
+        try:
+            cfg = fit.FitConfig(max_iter=80000, frames_per_step=1, views_per_step=1, init_texture="random", hip_graph=graph, **kw)
+            ft = fit.Fitter(sc, cfg, device=device, targets=targets)
+            targets = ft.targets
+            for _ in range(fit.Fitter.GRAPH_WARMUP + 3):
+                ft.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ft.step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            row = {"ms": 1e3 * dt, "images_per_s": 1.0 / dt}
+            if not graph:
+                row["launches_per_step"] = count_launches(ft.step)
+            else:
+                row["launches_per_step"] = "two graph replays (forward + backward, Adam) + the per-step index copies"
+            out[name] = row
+            del ft
+        except Exception as e:   # never take the measurement down
+            out[name] = {"error": repr(e)}
+    return out
 
 
 def cpu_baseline(sc, seconds_budget=30.0):
@@ -192,7 +276,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg5", "ref"],
+                    help="ref: the reference's own run shape -- ONE random (camera, frame) image of 1600 x 1200 per step (main.py:28-30, "
+                         "fit.py:525-526), replayed as HIP graphs")
+    ap.add_argument("--early-tex-reduce", action="store_true",
+                    help="all-reduce the texture gradient on its own as soon as the backward kernel has produced it (dist.EarlyReduce), "
+                         "beside the rest of the backward pass; eager steps only")
+    ap.add_argument("--no-reference-shaped-step", action="store_true", help="skip the reference_shaped_step extra of the default run")
     ap.add_argument("--frames-per-gpu", type=int, default=0)
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--mip", action="store_true")
@@ -214,7 +304,7 @@ def main():
     torch.cuda.set_device(device)
     _lib.load()
 
-    fpg = args.frames_per_gpu or {"cfg1": 4, "cfg2": 1, "cfg3": 32, "cfg5": 4}[args.workload]
+    fpg = args.frames_per_gpu or {"cfg1": 4, "cfg2": 1, "cfg3": 32, "cfg5": 4, "ref": 8}[args.workload]
     n_frames = fpg * world
     sc = scene.cfg(args.workload, n_frames=n_frames)
     if args.fill:
@@ -226,14 +316,18 @@ def main():
     if args.workload == "cfg2":       # BASELINE configs[1]: single frame, rasterize + interpolate only, no texture
         cfg.optimize_texture = False
         cfg.shading = "vertex"
+    if args.workload == "ref":        # the reference's loop: one random (camera, frame) image per iteration
+        cfg.frames_per_step = 1
+        cfg.views_per_step = 1
     if args.workload == "cfg5":       # BASELINE configs[4]: 4K, per-vertex free-form offsets on top of the blendshapes
         cfg.mode = "combined"
         cfg.max_iter = 2              # the reference enables the free-form basis after max_iter / 2 (fit.py:603-608)
-    use_graph = bool(args.graph) if args.graph >= 0 else args.workload == "cfg2"
+    use_graph = bool(args.graph) if args.graph >= 0 else args.workload in ("cfg2", "ref")
     cfg.hip_graph = use_graph
     bucket = None
     fitter = fit.Fitter(sc, cfg, device=device, rank=rank, world=world)
-    bucket = fdist.GradBucket(fitter.params, device)
+    early = [fitter.tex_opt] if (args.early_tex_reduce and world > 1 and not use_graph) else ()
+    bucket = fdist.GradBucket(fitter.params, device, timed=True, early=early)     # HIP events around the collective alone
     fitter.reduce_fn = bucket if world > 1 else None
     H, W = fitter.resolution
     n_cam = len(fitter.cam_idxs)
@@ -283,15 +377,21 @@ def main():
     _lib.TIMER = None
     elapsed = fdist.max_over_ranks(elapsed, device)
 
-    frames_total = fpg * world * args.steps
+    # a "frame" = all views of one time-frame; the ref workload renders ONE image (one view of one frame) per step and rank
+    frames_step = 1 if args.workload == "ref" else fpg
+    n_views_step = 1 if args.workload == "ref" else n_cam
+    frames_total = frames_step * world * args.steps
     value = frames_total / elapsed
+    allreduce_ms = bucket.reduce_ms() if world > 1 else None
     out = {
-        "metric": "fit-loop frames/sec (9-view 1080p)" if args.workload in ("cfg2", "cfg3") else f"fit-loop frames/sec ({args.workload})",
-        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": "fit-loop frames/sec (9-view 1080p)" if args.workload in ("cfg2", "cfg3") else
+                  ("fit-loop images/sec (reference run shape: 1 view x 1 frame of 1600x1200 per step)" if args.workload == "ref"
+                   else f"fit-loop frames/sec ({args.workload})"),
+        "value": value, "unit": "images/s" if args.workload == "ref" else "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {n_cam}-view {W}x{H}, K={sc.blendshapes.shape[1]} blendshapes, "
-                               f"T={sc.pos_idx.shape[0]} triangles, {fpg} frames/GPU/step ({fpg * n_cam} images), "
+                               f"T={sc.pos_idx.shape[0]} triangles, {frames_step} frames/GPU/step ({frames_step * n_views_step} images), "
                                + ("rasterize + interpolate only (per-vertex grey), Adam on weights+pose"
                                   if args.workload == "cfg2" else
                                   f"textured C={C} + antialias fwd/bwd{' + mip' if args.mip else ''}, Adam on weights+pose+texture"
@@ -299,12 +399,18 @@ def main():
                    "coverage": coverage, "frames_per_gpu": fpg, "views": n_cam, "resolution": [H, W], "triangles": int(sc.pos_idx.shape[0]),
                    "blendshapes": int(sc.blendshapes.shape[1]), "texture": list(sc.texture.shape),
                    "parallelism": f"dp{world} (frames sharded, one RCCL all-reduce of {bucket.nbytes / 1e6:.1f} MB per step)"},
+        # the data-parallel exchange of one step: HIP-event time of the RCCL all-reduce of the flat gradient bucket on this rank
+        # (mean over the timed steps; includes waiting for the slowest rank) and the bucket's size; null on one GPU
+        "allreduce_ms": allreduce_ms,
+        "allreduce_ms_max_over_ranks": fdist.max_over_ranks(allreduce_ms, device) if allreduce_ms is not None else None,
+        "bucket_bytes": bucket.nbytes,
+        "early_tex_reduce_bytes": sum(p.numel() * 4 for p in early) if early else 0,
         "final_loss": float(loss) if loss is not None else None,
         "hbm_allocated_peak_GB": torch.cuda.max_memory_allocated(device) / 1e9,
     }
     if rank == 0 and timer is not None:
         bpp = algorithmic_bytes_per_px(C, args.mip)
-        npix = fpg * n_cam * H * W
+        npix = frames_step * n_views_step * H * W
 
         def table_of(summ):
             table = {}
@@ -336,51 +442,80 @@ def main():
         if px_ops:
             dom = max(px_ops, key=lambda k: px_ops[k]["avg_ms"] * px_ops[k]["calls"])
             t_s = px_ops[dom]["avg_ms"] * 1e-3
-            pmc = measured_counters(dom, args.workload, fpg * n_cam, C)
+            pmc, why = measured_counters(dom, args.workload, fpg * n_cam, C, t_ms=px_ops[dom]["avg_ms"])
             alg_bytes = bpp[dom] * sparse_px.get(dom, npix)
             a = alg_bytes / t_s / 1e9
-            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            valu_bound = bool(pmc and pmc.get("valu_issue_frac") and pmc["valu_issue_frac"] > (pmc["hbm_bytes"] / t_s / 1e9 / HBM_PEAK_GBS))
+            out["roofline"] = {"kernel": dom,
+                               # what the counters say limits the call; achieved / peak / frac below are the HBM figures the
+                               # metric asks for (algorithmic bytes against the 8 TB/s peak), whatever the bound
+                               "bound": "valu-issue" if valu_bound else "hbm",
+                               "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": a / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
                                "traffic": pmc["hbm_bytes"] if pmc else None,
                                "traffic_GBps": (pmc["hbm_bytes"] / t_s / 1e9) if pmc else None,
                                "traffic_frac": (pmc["hbm_bytes"] / t_s / 1e9 / HBM_PEAK_GBS) if pmc else None,
+                               "traffic_source": pmc["source"] if pmc else None,
+                               "traffic_unavailable": why,
                                "dense_equivalent_GBps": px_ops[dom]["algorithmic_GBps"],
                                "note": "achieved = algorithmic bytes of the SPARSE call (B/px x 1024 px x the bins on its list, counted "
                                        "live) / HIP-event time inside the timed region; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the "
-                                       "call's kernels from the committed PMC passes (profiles/r02_counters_cfg3.json); "
-                                       "dense_equivalent counts every pixel of the batch although 80 % are never touched. The "
-                                       "kernel is bound by vector-ALU issue, not HBM: see roofline_valu"}
+                                       "call's kernels from the committed PMC passes named in traffic_source (null, with the reason in "
+                                       "traffic_unavailable, when they were measured on other kernel sources or their durations differ "
+                                       "from this run's by more than 10 %); dense_equivalent counts every pixel of the batch although "
+                                       "80 % are never touched"}
             if pmc and pmc.get("valu_issue_frac") is not None:
                 out["roofline_valu"] = {"kernel": dom, "bound": "valu-issue", "achieved": pmc["valu_insts"] / t_s / 1e9,
                                         "unit": "G wave-instructions/s", "peak": N_SIMD * (pmc["gui_active"] / 8.0) / 4.0 / t_s / 1e9 if t_s else None,
-                                        "frac": pmc["valu_issue_frac"], "lds_bank_conflict_share": (pmc["lds_conflict"] / pmc["lds_active"]) if pmc["lds_active"] else None,
-                                        "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) from the committed PMC "
-                                                "passes: share of the chip's vector issue slots (a 64-wide f32 instruction holds its "
-                                                "SIMD16 for 4 cycles; f64 / transcendental / integer-multiply instructions longer, so the "
-                                                "true busy share is higher)"}
-        if "fpcdr_blend_fwd" in table or True:
-            bl = measured_counters("fpcdr_blend_fwd", args.workload, fpg * n_cam, C)
-            if bl and bl.get("mfma_busy_frac") is not None:
-                Mrows, Kb = 3 * (sc.v_base.shape[0] // 3), sc.blendshapes.shape[1]
-                cyc = bl["gui_active"] / 8.0
-                t_blend = cyc / 2.4e9       # (launch duration from the pass's own clock count at 2.4 GHz is only indicative)
-                out["roofline_blend_mfma"] = {"kernel": "k_blend_fwd_lds (V = v_base + W B^T, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
-                                              "flops": 2.0 * Mrows * Kb * fpg, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                              "mfma_busy_frac": bl["mfma_busy_frac"],
-                                              "hbm_bytes": bl["hbm_bytes"],
-                                              "note": "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) from "
-                                                      "the committed PMC pass; the contraction is 0.43 GFLOP against one 27 MB read of the "
-                                                      "blendshape basis: it is bounded by that read and by per-tile latency, not by the "
-                                                      "matrix cores"}
+                                        "frac": pmc["valu_issue_frac"], "lane_utilisation": pmc.get("lane_utilisation"),
+                                        "lds_bank_conflict_share": (pmc["lds_conflict"] / pmc["lds_active"]) if pmc["lds_active"] else None,
+                                        "source": pmc["source"],
+                                        "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): share of the chip's vector "
+                                                "issue slots (every VALU instruction holds its SIMD for 4 cycles on gfx950 -- f32, i32 "
+                                                "multiplies, f64, conversions alike; v_rcp_f32 8; packed f32 4.6 for two results: "
+                                                "profiles/r03_valu_rate_bench.txt); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x "
+                                                "SQ_INSTS_VALU), the share of lanes doing work in an issued instruction"}
+            # vector wave-instructions per 64 pixels of the two objective calls (the figure an HBM-bound kernel could afford ~120 of)
+            vpp = {}
+            for name_ in ("fpcdr_render_loss_fwd", "fpcdr_render_aa_bwd"):
+                if name_ in table and sparse_px.get(name_):
+                    pm, _ = measured_counters(name_, args.workload, fpg * n_cam, C, t_ms=table[name_]["avg_ms"])
+                    if pm and pm["valu_insts"]:
+                        vpp[name_] = pm["valu_insts"] / (sparse_px[name_] / 64.0)
+            if vpp:
+                out["valu_insts_per_px"] = dict(vpp, note="SQ_INSTS_VALU of the call's kernels / (pixels on its bin list / 64): vector "
+                                                          "wave-instructions issued per 64 pixels")
+        bl, _ = measured_counters("fpcdr_blend_fwd", args.workload, fpg * n_cam, C)
+        if bl and bl.get("mfma_busy_frac") is not None:
+            Mrows, Kb = 3 * (sc.v_base.shape[0] // 3), sc.blendshapes.shape[1]
+            out["roofline_blend_mfma"] = {"kernel": "k_blend_fwd_lds (V = v_base + W B^T, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                                          "flops": 2.0 * Mrows * Kb * fpg, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "mfma_busy_frac": bl["mfma_busy_frac"],
+                                          "hbm_bytes": bl["hbm_bytes"], "source": bl["source"],
+                                          "note": "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) from "
+                                                  "the committed PMC pass; the contraction is 0.43 GFLOP against one 27 MB read of the "
+                                                  "blendshape basis: it is bounded by that read and by per-tile latency, not by the "
+                                                  "matrix cores"}
         if not args.mip and args.workload in ("cfg1", "cfg3") and world == 1:   # (scaling runs: all ranks leave together)
             try:
                 st = table_of(standalone_op_sweep(fitter))
+                # with region hints (include/fpcdr.h) the operators skip the READS of empty bins: bytes/px x every pixel of the batch
+                # is then a dense-EQUIVALENT rate, not traffic, and may exceed the HBM peak.  Only the calls that really move those
+                # bytes keep the name algorithmic_GBps: rasterize forward (writes every pixel), antialias backward (a full copy), the
+                # pixel loss.
+                moves_all = ("fpcdr_rasterize_fwd", "fpcdr_antialias_bwd", "fpcdr_pixel_loss")
+                for name_, row in st.items():
+                    if "algorithmic_GBps" in row and name_ not in moves_all:
+                        row["dense_equivalent_GBps"] = row.pop("algorithmic_GBps")
+                        row["note"] = "region hints skip the reads of empty bins: not a roofline figure"
                 out["kernels_standalone_ops"] = st
                 if "fpcdr_antialias_bwd" in st:
                     a = st["fpcdr_antialias_bwd"]["algorithmic_GBps"]
+                    ab, ab_why = measured_counters("fpcdr_antialias_bwd", args.workload, fpg * n_cam, C, t_ms=st["fpcdr_antialias_bwd"]["avg_ms"])
                     out["roofline_antialias_bwd"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                      "frac": a / HBM_PEAK_GBS,
-                                                     "traffic": (measured_counters("fpcdr_antialias_bwd", args.workload, fpg * n_cam, C) or {}).get("hbm_bytes") or None,
+                                                     "traffic": ab["hbm_bytes"] if ab else None, "traffic_source": ab["source"] if ab else None,
+                                                     "traffic_unavailable": ab_why,
                                                      "note": "stand-alone dr.antialias backward at the same batch, outside the timed region"}
             except Exception as e:   # the sweep must never take the measurement down
                 out["kernels_standalone_ops"] = {"error": repr(e)}
@@ -406,6 +541,10 @@ def main():
                     del ft_d
                 except Exception as e:
                     out["drop_in_path"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and args.workload in ("cfg3", "ref") and not args.no_reference_shaped_step:
+        del fitter
+        torch.cuda.empty_cache()
+        out["reference_shaped_step"] = reference_shaped_step(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(sc)

@@ -401,6 +401,9 @@ class FitConfig:
     regularize_prior: bool = False
     # build-side additions
     frames_per_step: int = 0        # 0 = every frame of this rank's shard, each step
+    views_per_step: int = 0         # 0 = every camera of cam_idxs; k = a random subset of k cameras per step.  frames_per_step = 1 with
+                                    # views_per_step = 1 is the reference's own run shape: ONE random (camera, frame) image per
+                                    # iteration (fit.py:525-526)
     seed: int = 0
     optimize_texture: bool = True
     init_texture: str = "truth"     # 'truth' | 'random' (reference: np.random.uniform when no texpath, fit.py:438)
@@ -511,8 +514,9 @@ class Fitter:
         else:
             self.optimizer = GroupedAdam(groups, lr=cfg.lr_base, renorm=(self.q_opt, self.per_frame_q)) if cfg.grouped_adam \
                 else torch.optim.Adam(groups, lr=cfg.lr_base, fused=True)
-        self._graphs, self._graph_key, self._frame_idx = None, None, None
+        self._graphs, self._graph_key, self._frame_idx, self._view_idx = None, None, None, None
         self._side_stream = torch.cuda.Stream(device=dev)
+        self._background = torch.tensor(BACKGROUND, device=dev)     # (a device scalar made once: no host copy inside a HIP-graph capture)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lr_lambda=lambda x: cfg.lr_ramp ** (float(x) / float(cfg.max_iter)))
         self.params = [g["params"][0] for g in self.optimizer.param_groups]
@@ -549,8 +553,13 @@ class Fitter:
     def _n(frame_ids):
         return frame_ids.stop - frame_ids.start if isinstance(frame_ids, slice) else len(frame_ids)
 
-    def mvp(self, frame_ids):
-        """mvp[f,c] = P_c . Rt(q_f,t_f) . Rt(q_c,t_c) . MV_c . T(0,170,0)   (fit.py:541-553), [Fb*Nc,4,4]."""
+    def mvp(self, frame_ids, view_ids=None):
+        """mvp[f,c] = P_c . Rt(q_f,t_f) . Rt(q_c,t_c) . MV_c . T(0,170,0)   (fit.py:541-553), [Fb*Nc,4,4].
+        view_ids: positions in cam_idxs of the cameras of this step (a device index tensor; None = all of them)."""
+        if view_ids is not None:
+            cams = self.cam_sel.index_select(0, view_ids)
+            return _mvp_func.apply(self.q_opt.index_select(0, cams), self.t_opt.index_select(0, cams), self.per_frame_q[frame_ids],
+                                   self.per_frame_t[frame_ids], self.proj.index_select(0, view_ids), self.t_mv.index_select(0, view_ids))
         all_cams = self.cam_idxs == list(range(self.q_opt.shape[0]))    # no gather (and no sort in its backward) then
         q_c, t_c = (self.q_opt, self.t_opt) if all_cams else (self.q_opt[self.cam_sel], self.t_opt[self.cam_sel])
         return _mvp_func.apply(q_c, t_c, self.per_frame_q[frame_ids], self.per_frame_t[frame_ids], self.proj, self.t_mv)
@@ -617,8 +626,21 @@ class Fitter:
         self._frame_idx.copy_(sel)
         return self._frame_idx
 
-    def loss_and_backward(self, frame_ids):
-        """Forward + backward of fit.py:556-611 for a batch of frames x all cameras.  Returns the loss (tensor)."""
+    def pick_views(self):
+        """The cameras of this step: None = all of cam_idxs, else a device tensor of k random positions in cam_idxs."""
+        k = self.cfg.views_per_step
+        if not k or k >= len(self.cam_idxs):
+            return None
+        sel = torch.tensor(np.sort(self.rng.choice(len(self.cam_idxs), size=k, replace=False)), dtype=torch.long)
+        if not self.use_graph:
+            return sel.to(self.device)
+        if self._view_idx is None:      # graphs read the step's camera numbers from one fixed buffer
+            self._view_idx = torch.empty(k, dtype=torch.long, device=self.device)
+        self._view_idx.copy_(sel)
+        return self._view_idx
+
+    def loss_and_backward(self, frame_ids, view_ids=None):
+        """Forward + backward of fit.py:556-611 for a batch of frames x cameras (view_ids: see mvp).  Returns the loss (tensor)."""
         cfg = self.cfg
         i = self.iteration
         # fit.py:603-608 switches the learned basis on AFTER the forward pass of the first iteration i > max_iter / 2, so
@@ -626,15 +648,16 @@ class Fitter:
         if cfg.mode == 'combined' and (i - 1) > cfg.max_iter / 2:
             for m in (self.m1, self.m2, self.m3):
                 m.requires_grad = True
-        Fb, Nc = self._n(frame_ids), len(self.cam_idxs)
+        Fb, Nc = self._n(frame_ids), (len(self.cam_idxs) if view_ids is None else int(view_ids.shape[0]))
         vtx_pos = self.vertices(frame_ids)                            # [Fb,3V]
         vtx_pos_split = vtx_pos.reshape(Fb, -1, 3)
-        mvp = self.mvp(frame_ids)
+        mvp = self.mvp(frame_ids, view_ids)
         ref = None
         n_img_global = Fb * Nc * self.world
         local = slice(frame_ids.start - self.frame_lo, frame_ids.stop - self.frame_lo) if isinstance(frame_ids, slice) \
             else frame_ids - self.frame_lo
-        ref = self.targets[local].reshape(Fb * Nc, *self.resolution)
+        ref = self.targets[local] if view_ids is None else self.targets[local].index_select(1, view_ids)
+        ref = ref.reshape(Fb * Nc, *self.resolution)
         C = self.tex_opt.shape[2]
         n_total = n_img_global * self.resolution[0] * self.resolution[1] * C
         one_shot = (cfg.fused_objective and cfg.fused_render and cfg.fused_loss and not cfg.enable_mip and C in (1, 3, 4)
@@ -674,7 +697,10 @@ class Fitter:
             vtx_pos_split.record_stream(side)
         self.optimizer.zero_grad(set_to_none=True)
         if one_shot:
-            bg_sum = self.target_bg_sumsq[local].sum() if cfg.sparse_objective else None
+            bg_sum = None
+            if cfg.sparse_objective:
+                bg = self.target_bg_sumsq[local]
+                bg_sum = (bg if view_ids is None else bg.index_select(1, view_ids)).sum()
             pix = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
                                      n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum)
             if side is not None:
@@ -693,11 +719,12 @@ class Fitter:
             torch.autograd.backward(roots, seeds)
             loss = sum_sq[0].to(torch.float32) / n_total + reg.detach()
         else:
-            col = torch.where(rast_out[..., 3:] > 0, colour, torch.tensor(BACKGROUND, device=self.device))
+            col = torch.where(rast_out[..., 3:] > 0, colour, self._background)
             # the reference holds its target image as float32 on the GPU (fit.py:531-532); the 8-bit batch is converted once
             if getattr(self, "_targets_f32", None) is None:
                 self._targets_f32 = self.targets.to(torch.float32)
-            ref_f = self._targets_f32[local].reshape(Fb * Nc, *self.resolution, 1)
+            ref_f = self._targets_f32[local] if view_ids is None else self._targets_f32[local].index_select(1, view_ids)
+            ref_f = ref_f.reshape(Fb * Nc, *self.resolution, 1)
             loss = torch.mean((ref_f - col * 255) ** 2) / self.world + reg
             loss.backward()
         self.result[frame_ids] = vtx_pos.detach()
@@ -714,10 +741,11 @@ class Fitter:
     def step(self):
         """One Adam step (fit.py:524-618): forward, backward, gradient all-reduce, update, schedule, renormalise."""
         frame_ids = self.pick_frames()
+        view_ids = self.pick_views()
         if self.use_graph and self.iteration >= self.GRAPH_WARMUP:
-            loss = self._step_graphed(frame_ids)
+            loss = self._step_graphed(frame_ids, view_ids)
         else:
-            loss = self.loss_and_backward(frame_ids)
+            loss = self.loss_and_backward(frame_ids, view_ids)
             if self.reduce_fn is not None:
                 self.reduce_fn(self.params)
             self._update()
@@ -763,7 +791,7 @@ class Fitter:
 
     GRAPH_WARMUP = 3    # eager steps before capture (allocator, Adam state, scratch and topology caches settle)
 
-    def _step_graphed(self, frame_ids):
+    def _step_graphed(self, frame_ids, view_ids=None):
         """Replay (capturing first if needed) graph A = forward + backward into fixed gradient buffers and graph B =
         Adam + quaternion renormalisation; the gradient all-reduce runs between them, outside any graph.  The set of
         trainable tensors is part of the key: 'combined' mode switches the free-form basis on half way (fit.py:603-608)."""
@@ -772,7 +800,7 @@ class Fitter:
         if self._graph_key != key:
             # new set of trainable tensors: one eager step first, so that Adam creates their state outside a capture
             self._graph_key, self._graphs = key, None
-            loss = self.loss_and_backward(frame_ids)
+            loss = self.loss_and_backward(frame_ids, view_ids)
             if self.reduce_fn is not None:
                 self.reduce_fn(self.params)
             self._update()
@@ -784,7 +812,7 @@ class Fitter:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             self.optimizer.zero_grad(set_to_none=True)
             with torch.cuda.graph(ga):
-                loss = self.loss_and_backward(frame_ids)
+                loss = self.loss_and_backward(frame_ids, view_ids)
             with torch.cuda.graph(gb, pool=ga.pool()):
                 self._update()
             self._graphs = (ga, gb, loss)      # capture does not execute: fall through to the first replay

@@ -15,7 +15,12 @@
  *
  * Rules (all arithmetic IEEE-754, no fused multiply-add: build with
  * -ffp-contract=off):
- *   R1  a triangle is dropped unless all three w > 0 (no near-plane clipping);
+ *   R1  a triangle whose three w are > 0 is rasterised as it is.  Any other triangle is CLIPPED against the near plane
+ *       z + w >= 0 (Sutherland-Hodgman in double; a crossing is always computed from the vertex inside to the one outside:
+ *       t = d_in / (d_in - d_out), p = in + t (out - in) for x, y, z, w, so the two triangles of a shared edge get the same
+ *       point).  The polygon left (3 or 4 vertices, fanned from its first vertex into 1 or 2 pieces) is rasterised piece by
+ *       piece under the triangle's OWN index if every polygon vertex has w > 0; otherwise (and for NaNs) the triangle is
+ *       dropped.  Float outputs (barycentrics, z/w) always come from the three original vertices;
  *   R2  vertex -> fixed point, 8 sub-pixel bits, in double:
  *         X = floor((x/w * 0.5 + 0.5) * (W*256) + 0.5), same for Y with H;
  *       dropped if any |X|,|Y| > 2^24 (guard band);
@@ -56,23 +61,60 @@ static int64_t floordiv(int64_t a, int64_t b) { /* b > 0 */
     return q;
 }
 
-/* returns 0 if the triangle is dropped */
-static int setup_triangle(const float *v0, const float *v1, const float *v2, int H, int W,
-                          tri_setup_t *ts) {
+/* R1: the pieces of a triangle (vertices in double).  Returns their number (0 = dropped, 1, or 2). */
+static int clip_pieces(const float *v0, const float *v1, const float *v2, double pc[2][3][4]) {
     const float *v[3] = {v0, v1, v2};
+    if (v0[3] > 0.0f && v1[3] > 0.0f && v2[3] > 0.0f) {
+        for (int i = 0; i < 3; ++i)
+            for (int c = 0; c < 4; ++c) pc[0][i][c] = (double)v[i][c];
+        return 1;
+    }
+    double d[3], poly[4][4];
+    int n = 0;
+    for (int i = 0; i < 3; ++i) {
+        d[i] = (double)v[i][2] + (double)v[i][3];
+        if (!(d[i] == d[i])) return 0; /* NaN */
+    }
+    for (int i = 0; i < 3; ++i) {
+        int j = (i + 1) % 3;
+        int in_i = d[i] >= 0.0, in_j = d[j] >= 0.0;
+        if (in_i) {
+            for (int c = 0; c < 4; ++c) poly[n][c] = (double)v[i][c];
+            ++n;
+        }
+        if (in_i != in_j) { /* the edge crosses the plane: from the inside vertex to the outside one */
+            int a = in_i ? i : j, b = in_i ? j : i;
+            double t = d[a] / (d[a] - d[b]);
+            for (int c = 0; c < 4; ++c) poly[n][c] = (double)v[a][c] + t * ((double)v[b][c] - (double)v[a][c]);
+            ++n;
+        }
+    }
+    if (n < 3) return 0;
+    for (int i = 0; i < n; ++i)
+        if (!(poly[i][3] > 0.0)) return 0;
+    for (int k = 0; k + 2 < n; ++k) { /* fan */
+        memcpy(pc[k][0], poly[0], sizeof(double) * 4);
+        memcpy(pc[k][1], poly[k + 1], sizeof(double) * 4);
+        memcpy(pc[k][2], poly[k + 2], sizeof(double) * 4);
+    }
+    return n - 2;
+}
+
+/* returns 0 if the piece is dropped */
+static int setup_triangle(double v[3][4], int H, int W, tri_setup_t *ts) {
     int64_t X[3], Y[3];
     double zw[3];
     for (int i = 0; i < 3; ++i) {
-        float w = v[i][3];
-        if (!(w > 0.0f)) return 0; /* R1 (also rejects NaN) */
-        double xs = (double)v[i][0] / (double)w;
-        double ys = (double)v[i][1] / (double)w;
+        double w = v[i][3];
+        if (!(w > 0.0)) return 0; /* (also rejects NaN) */
+        double xs = v[i][0] / w;
+        double ys = v[i][1] / w;
         double fx = floor((xs * 0.5 + 0.5) * (double)(W * SUBPIX) + 0.5);
         double fy = floor((ys * 0.5 + 0.5) * (double)(H * SUBPIX) + 0.5);
         if (!(fabs(fx) <= GUARD) || !(fabs(fy) <= GUARD)) return 0; /* R2 */
         X[i] = (int64_t)fx;
         Y[i] = (int64_t)fy;
-        zw[i] = (double)v[i][2] / (double)w;
+        zw[i] = v[i][2] / w;
     }
     int64_t D = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
     if (D == 0) return 0; /* R3 */
@@ -135,8 +177,11 @@ int fpcdr_oracle_rasterize_ids(const float *pos, const int32_t *tri, int B, int 
         for (int t = 0; t < T; ++t) {
             int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
             if (i0 < 0 || i0 >= V || i1 < 0 || i1 >= V || i2 < 0 || i2 >= V) continue;
+            double pc[2][3][4];
+            const int npieces = clip_pieces(p + 4 * (size_t)i0, p + 4 * (size_t)i1, p + 4 * (size_t)i2, pc);
+            for (int piece = 0; piece < npieces; ++piece) {
             tri_setup_t ts;
-            if (!setup_triangle(p + 4 * (size_t)i0, p + 4 * (size_t)i1, p + 4 * (size_t)i2, H, W, &ts))
+            if (!setup_triangle(pc[piece], H, W, &ts))
                 continue;
             for (int py = ts.py0; py <= ts.py1; ++py) {
                 int64_t Py = (int64_t)py * SUBPIX + HALFPIX;
@@ -157,6 +202,7 @@ int fpcdr_oracle_rasterize_ids(const float *pos, const int32_t *tri, int B, int 
                         ids[o] = t + 1;
                     }
                 }
+            }
             }
         }
         if (out_depth) memcpy(out_depth + (size_t)b * npix, zbuf, npix * sizeof(float));

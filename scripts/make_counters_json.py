@@ -7,7 +7,13 @@ largest grid of each kernel are averaged (the list kernels' grids follow the hin
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-META = {"workload": "cfg3", "images": 288, "channels": 1}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_sha16      # the hash bench.py compares before it pairs these counters with its own timings
+
+# git_head: the commit the passes ran on (the GPU box has no .git: scripts/measure_round.sh passes git_head=... through)
+META = {"workload": "cfg3", "images": 288, "channels": 1, "git_head": os.environ.get("FPCDR_GIT_HEAD", "unknown"),
+        "kernel_source_sha16": kernel_source_sha16()}
 ARGS = [a for a in sys.argv[1:] if "=" not in a]
 for a in sys.argv[1:]:
     if "=" in a:

@@ -16,15 +16,16 @@ if [ "$2" != quick ]; then
   echo "stats done"
 fi
 # PMC passes over scripts/prof_objective.py (seven fit steps at cfg3, nothing else): one counter set per pass
-pass() {   # name, counters...
+pass() {   # name, counters...   (a failed pass ends the script: no partial counters file for bench.py to trust)
   local name=$1; shift
-  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_$name -- python3 scripts/prof_objective.py > /dev/null 2> gpurun_out/pmc_$name.err || echo "pass $name FAILED"
+  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_$name -- python3 scripts/prof_objective.py > /dev/null 2> gpurun_out/pmc_$name.err || { echo "pass $name FAILED"; exit 1; }
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE
+pass sq3 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU GRBM_GUI_ACTIVE
 pass sq2 SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE
-python scripts/summarize_rocprof.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 > gpurun_out/${TAG}_rocprof_pmc_cfg3.txt
-python scripts/make_counters_json.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 > gpurun_out/${TAG}_counters.json
-rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2
+python scripts/summarize_rocprof.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_sq3 > gpurun_out/${TAG}_rocprof_pmc_cfg3.txt
+python scripts/make_counters_json.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_sq3 > gpurun_out/${TAG}_counters.json
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_sq3
 echo "pmc done"

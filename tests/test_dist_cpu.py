@@ -30,8 +30,9 @@ def _worker(rank, world, port, ret):
     tex = torch.rand(4, 4).requires_grad_(True)
     frozen = torch.zeros(3, 3)                 # requires_grad False: must not travel
     params = [frozen, M1, M2, tex]
-    bucket = fdist.GradBucket(params, "cpu")
-    assert bucket.nbytes == 4 * (F * F + K * F + 16)
+    early = bool(int(os.environ.get("FPCDR_TEST_EARLY", "0")))       # the texture's gradient reduced on its own, from an autograd hook
+    bucket = fdist.GradBucket(params, "cpu", early=[tex] if early else ())
+    assert bucket.nbytes == 4 * (F * F + K * F + (0 if early else 16))
     opt = torch.optim.Adam([M1, M2, tex], lr=1e-2)
     target = torch.linspace(0, 1, F * K).reshape(F, K)
     lo, hi = rank * F // world, (rank + 1) * F // world        # contiguous frame shard
@@ -43,7 +44,7 @@ def _worker(rank, world, port, ret):
         loss.backward()
         bucket(params)
         opt.step()
-    assert bucket.calls == 3
+    assert bucket.calls == 3 and (not early or bucket.early[0].fired == 3)
     ret[rank] = torch.cat([p.detach().reshape(-1) for p in (M1, M2, tex)])
     fdist.barrier()
     assert fdist.max_over_ranks(float(rank), "cpu") == world - 1
@@ -67,7 +68,11 @@ def _single(F=8, K=5):
     return torch.cat([p.detach().reshape(-1) for p in (M1, M2, tex)])
 
 
-def test_two_rank_data_parallel_equals_single_process():
+@pytest.mark.parametrize("early", [False, True])
+def test_two_rank_data_parallel_equals_single_process(early, monkeypatch):
+    """early: the texture's gradient travels in its own all-reduce, launched from an autograd hook as soon as it exists
+    (dist.EarlyReduce), the rest in the bucket -- same replicas, same result."""
+    monkeypatch.setenv("FPCDR_TEST_EARLY", "1" if early else "0")
     world = 2
     port = _free_port()
     mgr = mp.Manager()

@@ -29,14 +29,15 @@ cfg = fit.FitConfig(max_iter=30, cam_idxs=(0, 3, 6), lr_base=5e-3, lr_t=5e-3, lr
                     weight_meshedge=0.3, init_texture='truth', hip_graph={graph})
 ft = fit.Fitter(sc, cfg, device=dev, rank=rank, world=world)
 ft.init_near_truth(0.8)
-bucket = fdist.GradBucket(ft.params, dev)
+bucket = fdist.GradBucket(ft.params, dev, early=[ft.tex_opt] if {early} else ())      # early: dist.EarlyReduce for the texture
 ft.reduce_fn = bucket if world > 1 else None
 losses = [float(ft.step()) for _ in range({steps})]
 if world > 1:
     losses = [fdist.sum_over_ranks(l, dev) for l in losses]       # each rank reports its share of the global mean
 res = ft.gather_result()
 ft.save({out!r} + f"/save_w{{world}}")
-torch.save({{"losses": losses, "params": [p.detach().cpu() for p in ft.params], "result": res.cpu(), "calls": bucket.calls}},
+torch.save({{"losses": losses, "params": [p.detach().cpu() for p in ft.params], "result": res.cpu(), "calls": bucket.calls,
+            "early_fired": [e.fired for e in bucket.early]}},
            {out!r} + f"/w{{world}}_r{{rank}}.pt")
 if world > 1:
     import torch.distributed as tdist
@@ -53,10 +54,10 @@ def _free_port():
     return p
 
 
-def _run(tmp_path, world, graph, steps):
+def _run(tmp_path, world, graph, steps, early=False):
     import subprocess
     script = tmp_path / f"child_w{world}.py"
-    script.write_text(CHILD.format(root=ROOT, out=str(tmp_path), graph=graph, steps=steps))
+    script.write_text(CHILD.format(root=ROOT, out=str(tmp_path), graph=graph, steps=steps, early=early))
     procs = []
     port = _free_port()
     for r in range(world):
@@ -80,15 +81,18 @@ def _run(tmp_path, world, graph, steps):
         assert p.returncode == 0, o[-3000:]
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_two_rank_fitter_equals_single_process(tmp_path, graph):
+@pytest.mark.parametrize("graph,early", [(False, False), (True, False), (False, True)])
+def test_two_rank_fitter_equals_single_process(tmp_path, graph, early):
+    """early: the texture gradient is all-reduced on its own from an autograd hook, beside the rest of the backward pass
+    (dist.EarlyReduce; eager steps only), everything else in the flat bucket."""
     import torch      # imported here; nothing in this test process touches the GPU
     steps = 6 if graph else 3       # graph path: three eager steps, one that fixes the parameter set, then capture + replay
-    _run(tmp_path, 2, graph, steps)
+    _run(tmp_path, 2, graph, steps, early)
     _run(tmp_path, 1, graph, steps)
     a, b = (torch.load(tmp_path / f"w2_r{r}.pt") for r in (0, 1))
     one = torch.load(tmp_path / "w1_r0.pt")
-    assert a["calls"] == steps and b["calls"] == steps      # exactly one all-reduce per step
+    assert a["calls"] == steps and b["calls"] == steps      # exactly one bucket all-reduce per step
+    assert a["early_fired"] == ([steps] if early else [])   # ... plus the texture's own, once per step
     for p, q in zip(a["params"], b["params"]):
         assert torch.equal(p, q), "replicas diverged"
     assert torch.equal(a["result"], b["result"])

@@ -604,3 +604,50 @@ def test_fit_recovers_hidden_weights_and_pose():
     assert l < 0.15 * l0, (l0, l)
     assert w_err() < 0.25 * w0, (w0, w_err())
     assert t_err() < 0.7 * t0, (t0, t_err())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_reference_run_shape_one_random_view_per_step(fused):
+    """frames_per_step = 1 with views_per_step = 1 is the reference's loop shape: ONE random (camera, frame) image per
+    iteration (fit.py:525-526).  The step then equals a hand-made step on exactly that image (same camera, same frame, the
+    four operators + the reference's torch loss), the camera / frame pairs vary from step to step, eager and HIP-graph
+    replay give the same trajectory, and only the drawn camera's and frame's pose rows receive a gradient."""
+    from fpc_diffrend_amd import fit, scene
+    import fpc_diffrend_amd.ops as dr
+    kw = dict(max_iter=12, cam_idxs=(0, 2, 3, 7), lr_base=5e-3, lr_t=5e-3, lr_q=1e-5, frames_per_step=1, views_per_step=1,
+              weight_laplacian=0.0, init_texture='truth')
+    if not fused:
+        kw.update(fused_objective=False, fused_render=False, fused_loss=False)
+    traj, picks = {}, []
+    for graph in (False, True):
+        sc = scene.cfg('cfg1', n_frames=4)
+        sc.q_gt[:] = (0.0, 0.0, 0.0, 1.0)
+        ft = fit.Fitter(sc, fit.FitConfig(hip_graph=graph, **kw), device='cuda')
+        ft.init_near_truth(0.8)
+        losses = []
+        for it in range(12):
+            if not graph and it == 0:
+                # the same draw, by hand: peek at the generator's next picks without consuming them
+                state = ft.rng.bit_generator.state
+                f = int(ft.pick_frames()[0])
+                v = int(ft.pick_views()[0])
+                ft.rng.bit_generator.state = state
+                cam = ft.cam_idxs[v]
+                verts = ft.vertices(torch.tensor([f], device='cuda')).reshape(1, -1, 3)
+                mvp = ft.mvp(torch.tensor([f], device='cuda'), torch.tensor([v], device='cuda'))
+                col = fit.render(ft.glctx, mvp, verts, ft.pos_idx, ft.uv, ft.uv_idx, ft.tex_opt, ft.resolution, False, 0)
+                want = torch.mean((ft.targets[f, v].float()[..., None] - col[0] * 255) ** 2)
+                picks.append((f, cam))
+            losses.append(float(ft.step()))
+            if not graph and it == 0:
+                assert abs(losses[0] - float(want)) < 1e-4 * float(want), (losses[0], float(want))
+                rows_q = (ft.q_opt.grad.abs().sum(dim=1) > 0).nonzero().flatten().tolist()
+                rows_f = (ft.per_frame_t.grad.abs().sum(dim=1) > 0).nonzero().flatten().tolist()
+                assert rows_q == [cam] and rows_f == [f], (rows_q, rows_f, cam, f)
+        traj[graph] = losses
+        if graph:
+            assert ft._graphs is not None
+    a, b = np.asarray(traj[False]), np.asarray(traj[True])
+    assert np.isfinite(b).all() and len(set(np.round(a, 3))) > 6          # different images from step to step
+    assert np.allclose(a, b, rtol=2e-3), (a, b)
