@@ -51,12 +51,19 @@ static_assert(TILES_PER_WAVE >= 1, "a bin needs at least one tile per wave");
 struct __attribute__((aligned(8))) TriRec {  // 40 bytes
     int32_t X0, Y0, X1, Y1, X2, Y2;   // snapped vertices (R2)
     float zA, zB, z0;                 // depth plane anchored at vertex 0 (R6)
-    int32_t pad;
+    int32_t tid;                      // the triangle this record is (a piece of): its slot, except for the second piece of a clipped one
 };
 struct __attribute__((aligned(8))) TriBox {  // inclusive pixel bbox; x0 > x1 = dropped
     int16_t x0, y0, x1, y1;
 };
-struct ImgBox { int32_t x0, y0, x1, y1; };  // folded with atomicMin/atomicMax
+struct ImgBox { int32_t x0, y0, x1, y1, n_over, pad0, pad1, pad2; };  // box folded with atomicMin/atomicMax; n_over: overflow records (below)
+
+// Per-image record slots.  A triangle that crosses the near plane is clipped into one or two pieces (rule R1): the first takes the
+// triangle's own slot t, the second is appended to the image's OVERFLOW region -- slots [Tp, Tp + n_over), Tp = T rounded up to whole
+// 256-slot chunks -- with an atomic counter.  The region has room for every triangle (it is only ever touched where clipping
+// happens: none of it in the fit loop), so the scratch buffer holds 2 Tp slots per image.  Overflow chunks carry no chunk box: a bin
+// scans all of them.
+__host__ __device__ inline int padded_slots(int T) { return (T + 255) / 256 * 256; }
 
 struct __attribute__((aligned(16))) EdgeRec {  // LDS, 80 bytes
     int32_t A0, B0, A1, B1, A2, B2;
@@ -105,6 +112,78 @@ constexpr unsigned long long Z_EMPTY = ~0ull;
 __device__ __forceinline__ long long floordiv256(long long a) { return a >> 8; }  // arithmetic shift = floor
 
 // ---------------------------------------------------------------------------------------------
+// One piece (a triangle, or a piece of a clipped one) in double clip coordinates -> record + pixel box: rules R2, R3, R6.
+__device__ __forceinline__ bool setup_piece(const double (&v)[3][4], int H, int W, int tid, TriRec &r, TriBox &box) {
+    long long X[3], Y[3];
+    double zw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double dw = v[i][3];
+        if (!(dw > 0.0)) return false;
+        const double xs = v[i][0] / dw;
+        const double ys = v[i][1] / dw;
+        const double fx = floor((xs * 0.5 + 0.5) * (double)(W * SUBPIX) + 0.5);
+        const double fy = floor((ys * 0.5 + 0.5) * (double)(H * SUBPIX) + 0.5);
+        if (!(fabs(fx) <= GUARD) || !(fabs(fy) <= GUARD)) return false;
+        X[i] = (long long)fx;
+        Y[i] = (long long)fy;
+        zw[i] = v[i][2] / dw;
+    }
+    const long long D = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
+    if (D == 0) return false;
+    const double Dd = (double)D;
+    const long long xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
+    const long long ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
+    long long px0 = floordiv256(xmin - HALFPIX + SUBPIX - 1), px1 = floordiv256(xmax - HALFPIX);
+    long long py0 = floordiv256(ymin - HALFPIX + SUBPIX - 1), py1 = floordiv256(ymax - HALFPIX);
+    px0 = max(px0, 0ll); py0 = max(py0, 0ll);
+    px1 = min(px1, (long long)W - 1); py1 = min(py1, (long long)H - 1);
+    if (px0 > px1 || py0 > py1) return false;
+    box = {(int16_t)px0, (int16_t)py0, (int16_t)px1, (int16_t)py1};
+    r.X0 = (int32_t)X[0]; r.Y0 = (int32_t)Y[0];
+    r.X1 = (int32_t)X[1]; r.Y1 = (int32_t)Y[1];
+    r.X2 = (int32_t)X[2]; r.Y2 = (int32_t)Y[2];
+    const double dz1 = zw[1] - zw[0], dz2 = zw[2] - zw[0];
+    r.zA = (float)((dz1 * (double)(Y[2] - Y[0]) - dz2 * (double)(Y[1] - Y[0])) / Dd);
+    r.zB = (float)((dz2 * (double)(X[1] - X[0]) - dz1 * (double)(X[2] - X[0])) / Dd);
+    r.z0 = (float)zw[0];
+    r.tid = tid;
+    return true;
+}
+
+// Rule R1 for a triangle with some w <= 0: Sutherland-Hodgman against the near plane z + w >= 0, in double, every crossing computed
+// from the vertex inside to the one outside (the same arithmetic, in the same order, as oracle/raster_ref.c clip_pieces).  Returns the
+// number of pieces (0 = dropped) and their vertices.
+__device__ __noinline__ int clip_pieces(const float4 (&v)[3], double (&pc)[2][3][4]) {
+    double d[3], poly[4][4], vd[3][4];
+    for (int i = 0; i < 3; ++i) {
+        vd[i][0] = (double)v[i].x; vd[i][1] = (double)v[i].y; vd[i][2] = (double)v[i].z; vd[i][3] = (double)v[i].w;
+        d[i] = vd[i][2] + vd[i][3];
+        if (!(d[i] == d[i])) return 0;
+    }
+    int n = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int j = (i + 1) % 3;
+        const bool in_i = d[i] >= 0.0, in_j = d[j] >= 0.0;
+        if (in_i) {
+            for (int c = 0; c < 4; ++c) poly[n][c] = vd[i][c];
+            ++n;
+        }
+        if (in_i != in_j) {
+            const int a = in_i ? i : j, bb = in_i ? j : i;
+            const double t = d[a] / (d[a] - d[bb]);
+            for (int c = 0; c < 4; ++c) poly[n][c] = vd[a][c] + t * (vd[bb][c] - vd[a][c]);
+            ++n;
+        }
+    }
+    if (n < 3) return 0;
+    for (int i = 0; i < n; ++i)
+        if (!(poly[i][3] > 0.0)) return 0;
+    for (int k = 0; k + 2 < n; ++k)
+        for (int c = 0; c < 4; ++c) { pc[k][0][c] = poly[0][c]; pc[k][1][c] = poly[k + 1][c]; pc[k][2][c] = poly[k + 2][c]; }
+    return n - 2;
+}
+
 __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                 int B, int V, int T, int H, int W, TriRec *__restrict__ recs,
                                                 TriBox *__restrict__ boxes, TriBox *__restrict__ cboxes,
@@ -117,9 +196,12 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
     __shared__ int s_box[4][4];
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Tp = padded_slots(T);
+    const size_t img_slot = (size_t)b * 2 * Tp;
+    const int OX = (W + BIN - 1) / BIN, OY = (H + BIN - 1) / BIN;
     int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
     if (t < T) {
-        const size_t gid = (size_t)b * T + t;
+        const size_t gid = img_slot + t;
         TriBox box = {1, 1, 0, 0};
         int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
         bool ok = !(i0 < 0 || i0 >= V || i1 < 0 || i1 >= V || i2 < 0 || i2 >= V);
@@ -127,51 +209,42 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
             const long long first = ranges[2 * b], count = ranges[2 * b + 1];
             ok = ok && t >= first && t < first + count;
         }
-        long long X[3], Y[3];
-        double zw[3];
         if (ok) {
             const float4 *p = pos + (size_t)b * V;
-            float4 v[3] = {p[i0], p[i1], p[i2]};
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float w = v[i].w;
-                if (!(w > 0.0f)) { ok = false; }
-                double dw = (double)(ok ? w : 1.0f);
-                double xs = (double)v[i].x / dw;
-                double ys = (double)v[i].y / dw;
-                double fx = floor((xs * 0.5 + 0.5) * (double)(W * SUBPIX) + 0.5);
-                double fy = floor((ys * 0.5 + 0.5) * (double)(H * SUBPIX) + 0.5);
-                if (!(fabs(fx) <= GUARD) || !(fabs(fy) <= GUARD)) { ok = false; fx = 0.0; fy = 0.0; }
-                X[i] = (long long)fx;
-                Y[i] = (long long)fy;
-                zw[i] = (double)v[i].z / dw;
-            }
-        }
-        if (ok) {
-            long long D = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
-            if (D == 0) ok = false;
-            if (ok) {
-                const double Dd = (double)D;
-                long long xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
-                long long ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
-                long long px0 = floordiv256(xmin - HALFPIX + SUBPIX - 1), px1 = floordiv256(xmax - HALFPIX);
-                long long py0 = floordiv256(ymin - HALFPIX + SUBPIX - 1), py1 = floordiv256(ymax - HALFPIX);
-                px0 = max(px0, 0ll); py0 = max(py0, 0ll);
-                px1 = min(px1, (long long)W - 1); py1 = min(py1, (long long)H - 1);
-                if (px0 > px1 || py0 > py1) ok = false;
-                if (ok) {
-                    box = {(int16_t)px0, (int16_t)py0, (int16_t)px1, (int16_t)py1};
-                    TriRec r;
-                    r.X0 = (int32_t)X[0]; r.Y0 = (int32_t)Y[0];
-                    r.X1 = (int32_t)X[1]; r.Y1 = (int32_t)Y[1];
-                    r.X2 = (int32_t)X[2]; r.Y2 = (int32_t)Y[2];
-                    const double dz1 = zw[1] - zw[0], dz2 = zw[2] - zw[0];
-                    r.zA = (float)((dz1 * (double)(Y[2] - Y[0]) - dz2 * (double)(Y[1] - Y[0])) / Dd);
-                    r.zB = (float)((dz2 * (double)(X[1] - X[0]) - dz1 * (double)(X[2] - X[0])) / Dd);
-                    r.z0 = (float)zw[0];
-                    r.pad = 0;
+            const float4 v0 = p[i0], v1 = p[i1], v2 = p[i2];      // (kept as scalars: an array handed to the out-of-line clipper would
+            TriRec r;                                             // live in scratch memory on the common path too)
+            if (v0.w > 0.0f && v1.w > 0.0f && v2.w > 0.0f) {      // (R1) the usual case: the triangle as it is
+                const double vd[3][4] = {{(double)v0.x, (double)v0.y, (double)v0.z, (double)v0.w},
+                                         {(double)v1.x, (double)v1.y, (double)v1.z, (double)v1.w},
+                                         {(double)v2.x, (double)v2.y, (double)v2.z, (double)v2.w}};
+                if (setup_piece(vd, H, W, t, r, box)) {
                     recs[gid] = r;
-                    bx0 = (int)px0; by0 = (int)py0; bx1 = (int)px1; by1 = (int)py1;
+                    bx0 = box.x0; by0 = box.y0; bx1 = box.x1; by1 = box.y1;
+                } else {
+                    box = {1, 1, 0, 0};
+                }
+            } else {      // a vertex at or behind w = 0: clip against the near plane, one or two pieces
+                double pc[2][3][4];
+                const float4 vv[3] = {v0, v1, v2};
+                const int np = clip_pieces(vv, pc);
+                if (np >= 1 && setup_piece(pc[0], H, W, t, r, box)) {
+                    recs[gid] = r;
+                    bx0 = box.x0; by0 = box.y0; bx1 = box.x1; by1 = box.y1;
+                } else {
+                    box = {1, 1, 0, 0};
+                }
+                TriBox box2;
+                if (np == 2 && setup_piece(pc[1], H, W, t, r, box2)) {
+                    // second piece: appended to the image's overflow slots (no chunk box there: bins scan every overflow chunk);
+                    // it folds itself into the image box and marks the bins it touches
+                    const int k = atomicAdd(&ibox[b].n_over, 1);
+                    recs[img_slot + Tp + k] = r;
+                    boxes[img_slot + Tp + k] = box2;
+                    atomicMin(&ibox[b].x0, (int)box2.x0); atomicMin(&ibox[b].y0, (int)box2.y0);
+                    atomicMax(&ibox[b].x1, (int)box2.x1); atomicMax(&ibox[b].y1, (int)box2.y1);
+                    if (live)
+                        for (int gy = box2.y0 / BIN; gy <= box2.y1 / BIN; ++gy)
+                            for (int gx = box2.x0 / BIN; gx <= box2.x1 / BIN; ++gx) live[((size_t)b * OY + gy) * OX + gx] = 1;
                 }
             }
         }
@@ -206,7 +279,6 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
         __syncthreads();
         const int cx0 = s_box[0][0], cy0 = s_box[0][1], cx1 = s_box[0][2], cy1 = s_box[0][3];
         if (cx1 >= 0) {
-            const int OX = (W + BIN - 1) / BIN, OY = (H + BIN - 1) / BIN;
             const int gx0 = cx0 / BIN, gy0 = cy0 / BIN, nx = cx1 / BIN - gx0 + 1, ny = cy1 / BIN - gy0 + 1;
             for (int k = threadIdx.x; k < nx * ny; k += blockDim.x)
                 live[((size_t)b * OY + gy0 + k / nx) * OX + gx0 + k % nx] = 1;
@@ -216,7 +288,7 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
 
 __global__ void k_init_ibox(ImgBox *ibox, int B) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) ibox[i] = {0x7fffffff, 0x7fffffff, -1, -1};
+    if (i < B) ibox[i] = {0x7fffffff, 0x7fffffff, -1, -1, 0, 0, 0, 0};
 }
 
 // work-queue mode: image boxes + zeroed live map, raw occupancy map and queue header (grid-stride)
@@ -224,7 +296,7 @@ __global__ void __launch_bounds__(256) k_init_queue(ImgBox *ibox, int B, uint32_
                                                     uint32_t *__restrict__ occ_words, long long n_occ_words, int32_t *__restrict__ hdr,
                                                     int32_t *__restrict__ hdr_bwd) {
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
-    if (i0 < B) ibox[i0] = {0x7fffffff, 0x7fffffff, -1, -1};
+    if (i0 < B) ibox[i0] = {0x7fffffff, 0x7fffffff, -1, -1, 0, 0, 0, 0};
     if (i0 < 16) { hdr[i0] = 0; hdr_bwd[i0] = 0; }
     for (long long i = i0; i < n_live_words; i += stride) live_words[i] = 0u;
     for (long long i = i0; i < n_occ_words; i += stride) occ_words[i] = 0u;
@@ -485,10 +557,13 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         for (int k = tid; k < 4 * NTILES * (BIGB / 64); k += 256) (&s_mask[0][0][0][0])[k] = 0ull;
         if (tid == 0) { s_nbig = 0; s_pending = 0; s_nlive = 0; }
         __syncthreads();
-        const TriBox *bx = boxes + (size_t)b * T;
-        const TriRec *rc = recs + (size_t)b * T;
-        const int n_chunks = (T + 255) / 256;
-        const TriBox *cbx = cboxes + (size_t)b * n_chunks;
+        // record slots of the image: [0, T) one per triangle, [Tp, Tp + n_over) the second pieces of clipped triangles (k_setup); slot =
+        // chunk * 256 + lane in both regions (Tp is chunk-aligned), and the overflow chunks, which carry no chunk box, are all scanned
+        const int Tp = padded_slots(T), n_over = ib.n_over, slot_end = Tp + n_over;
+        const TriBox *bx = boxes + (size_t)b * 2 * Tp;
+        const TriRec *rc = recs + (size_t)b * 2 * Tp;
+        const int n_prim = Tp / 256, n_chunks = n_prim + (n_over + 255) / 256;
+        const TriBox *cbx = cboxes + (size_t)b * n_prim;
         const unsigned long long below = (1ull << lane) - 1ull;
         int pending = 0;  // block-uniform copy of s_pending: entries waiting in s_list
         int round_no = 0; // block-uniform: tile-path rounds done (parity selects the mask buffer)
@@ -544,7 +619,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                         for (int c = 0; c < bw; ++c) {
                             if ((E0 | E1 | E2) >= 0) {
                                 const float d = __fmaf_rn(r.zA, (float)rx, dzr);
-                                if (d >= -1.0f && d <= 1.0f) atomicMin(&zrow[c], zpack(d, t));
+                                if (d >= -1.0f && d <= 1.0f) atomicMin(&zrow[c], zpack(d, r.tid));
                             }
                             E0 += A0s; E1 += A1s; E2 += A2s; rx += SUBPIX;
                         }
@@ -568,7 +643,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                     const TriRec r = rc[t];
                     const TriBox q = bx[t];
                     EdgeRec e;
-                    e.id = t;
+                    e.id = r.tid;
                     e.zA = r.zA; e.zB = r.zB; e.z0 = r.z0;
                     e.X0 = r.X0; e.Y0 = r.Y0;
                     const int ext_x = max(r.X0, max(r.X1, r.X2)) - min(r.X0, min(r.X1, r.X2));
@@ -633,9 +708,11 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
             {
                 const int c = seg + tid;
                 bool live = false;
-                if (c < n_chunks) {
+                if (c < n_prim) {
                     const TriBox q = cbx[c];
                     live = (q.x0 <= q.x1) && !(q.x1 < bin_x0 || q.x0 > bin_x1 || q.y1 < bin_y0 || q.y0 > bin_y1);
+                } else if (c < n_chunks) {
+                    live = true;
                 }
                 const unsigned long long bal = __ballot(live);
                 int base = 0;
@@ -652,17 +729,18 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
 #pragma unroll
                 for (int k = 0; k < SCAN_K; ++k) {
                     hit[k] = false;
-                    tt[k] = (ci + k < n_live) ? s_clist[ci + k] * 256 + tid : T;
+                    tt[k] = (ci + k < n_live) ? s_clist[ci + k] * 256 + tid : slot_end;
+                    if (tt[k] >= T && tt[k] < Tp) tt[k] = slot_end;      // (padding of the last triangle chunk)
                 }
                 TriBox qk[SCAN_K];
 #pragma unroll
-                for (int k = 0; k < SCAN_K; ++k) qk[k] = bx[min(tt[k], T - 1)];
+                for (int k = 0; k < SCAN_K; ++k) qk[k] = bx[min(tt[k], slot_end - 1)];
                 unsigned long long bal[SCAN_K];
                 int total = 0;
 #pragma unroll
                 for (int k = 0; k < SCAN_K; ++k) {
                     const TriBox q = qk[k];
-                    hit[k] = tt[k] < T && (q.x0 <= q.x1) && !(q.x1 < bin_x0 || q.x0 > bin_x1 || q.y1 < bin_y0 || q.y0 > bin_y1);
+                    hit[k] = tt[k] < slot_end && (q.x0 <= q.x1) && !(q.x1 < bin_x0 || q.x0 > bin_x1 || q.y1 < bin_y0 || q.y0 > bin_y1);
                     bal[k] = __ballot(hit[k]);
                     total += __popcll(bal[k]);
                 }
@@ -1176,14 +1254,25 @@ __global__ void __launch_bounds__(256) k_render_bwd(const float4 *__restrict__ p
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// layout of the caller's scratch buffer: records and boxes (2 Tp slots per image: triangles + overflow), chunk boxes, image boxes
+struct RasterScratch { TriRec *recs; TriBox *boxes, *cboxes; ImgBox *ibox; size_t bytes; };
+static RasterScratch raster_scratch(void *base, int B, int T) {
+    const size_t n = (size_t)B * 2 * (size_t)padded_slots(T), nc = (size_t)B * (size_t)(padded_slots(T) / 256);
+    char *s = (char *)base;
+    RasterScratch r;
+    r.recs = (TriRec *)s;
+    r.boxes = (TriBox *)(s + align_up(n * sizeof(TriRec), 256));
+    r.cboxes = (TriBox *)((char *)r.boxes + align_up(n * sizeof(TriBox), 256));
+    r.ibox = (ImgBox *)((char *)r.cboxes + align_up(nc * sizeof(TriBox), 256));
+    r.bytes = (size_t)((char *)r.ibox - s) + align_up((size_t)B * sizeof(ImgBox), 256);
+    return r;
+}
+
 }  // namespace
 
 extern "C" size_t fpcdr_rasterize_scratch_bytes(int32_t B, int32_t T) {
     if (B <= 0 || T <= 0) return 0;
-    size_t n = (size_t)B * (size_t)T;
-    size_t nc = (size_t)B * (size_t)((T + 255) / 256);
-    return align_up(n * sizeof(TriRec), 256) + align_up(n * sizeof(TriBox), 256) + align_up(nc * sizeof(TriBox), 256) +
-           align_up((size_t)B * sizeof(ImgBox), 256);
+    return raster_scratch(nullptr, B, T).bytes;
 }
 
 extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *stream) {
@@ -1194,13 +1283,10 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
     FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
     FPCDR_REQUIRE(p->T < (1 << 24), "more than 2^24 triangles (rast stores triangle index + 1 as a float)");
     hipStream_t st = (hipStream_t)stream;
-    size_t n = (size_t)p->B * p->T;
-    char *s = (char *)p->scratch;
-    TriRec *recs = (TriRec *)s;
-    TriBox *boxes = (TriBox *)(s + align_up(n * sizeof(TriRec), 256));
-    TriBox *cboxes = (TriBox *)((char *)boxes + align_up(n * sizeof(TriBox), 256));
-    const size_t nc = (size_t)p->B * (size_t)fpcdr_cdiv(p->T, 256);
-    ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
+    const RasterScratch rs = raster_scratch(p->scratch, p->B, p->T);
+    TriRec *recs = rs.recs;
+    TriBox *boxes = rs.boxes, *cboxes = rs.cboxes;
+    ImgBox *ibox = rs.ibox;
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, p->ranges);
@@ -1249,13 +1335,10 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
     FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C <= 0x7fffffffLL, "texture too large");
     hipStream_t st = (hipStream_t)stream;
-    size_t n = (size_t)p->B * p->T;
-    char *s = (char *)p->scratch;
-    TriRec *recs = (TriRec *)s;
-    TriBox *boxes = (TriBox *)(s + align_up(n * sizeof(TriRec), 256));
-    TriBox *cboxes = (TriBox *)((char *)boxes + align_up(n * sizeof(TriBox), 256));
-    const size_t nc = (size_t)p->B * (size_t)fpcdr_cdiv(p->T, 256);
-    ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
+    const RasterScratch rs = raster_scratch(p->scratch, p->B, p->T);
+    TriRec *recs = rs.recs;
+    TriBox *boxes = rs.boxes, *cboxes = rs.cboxes;
+    ImgBox *ibox = rs.ibox;
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, (const int32_t *)nullptr);
@@ -1312,13 +1395,10 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     hipStream_t st = (hipStream_t)stream;
     int rc = fpcdr_launch_sil(p->pos, p->tri, l->adj, p->B, p->V, p->T, p->H, p->W, l->sil, st);
     if (rc) return rc;
-    size_t n = (size_t)p->B * p->T;
-    char *s = (char *)p->scratch;
-    TriRec *recs = (TriRec *)s;
-    TriBox *boxes = (TriBox *)(s + align_up(n * sizeof(TriRec), 256));
-    TriBox *cboxes = (TriBox *)((char *)boxes + align_up(n * sizeof(TriBox), 256));
-    const size_t nc = (size_t)p->B * (size_t)fpcdr_cdiv(p->T, 256);
-    ImgBox *ibox = (ImgBox *)((char *)cboxes + align_up(nc * sizeof(TriBox), 256));
+    const RasterScratch rs = raster_scratch(p->scratch, p->B, p->T);
+    TriRec *recs = rs.recs;
+    TriBox *boxes = rs.boxes, *cboxes = rs.cboxes;
+    ImgBox *ibox = rs.ibox;
     const int OX = fpcdr_cdiv(p->W, BIN), OY = fpcdr_cdiv(p->H, BIN);
     const size_t nbins = (size_t)p->B * OY * OX;
     FPCDR_REQUIRE(nbins < 0x7fffffffULL, "too many bins for one call");

@@ -69,3 +69,20 @@ def decode_aa_flags(flags, B, H, W):
     shifts = torch.arange(64, dtype=torch.int64)
     bits = ((words[..., None] >> shifts) & 1).reshape(2, B, H, Wq * 64)[..., :W].to(torch.uint8)
     return bits[0] | (bits[1] << 1)
+
+
+def near_crossing_soup(B, T, seed, frac=0.4):
+    """Triangles in front of a perspective-like camera, a share of them with one or two vertices pushed through the near plane
+    (z + w < 0, mostly w < 0 as well): clip-space z = a * w_eye + b with the near plane at w = 1."""
+    g = torch.Generator().manual_seed(seed)
+    c = (torch.rand(B, T, 1, 3, generator=g) * 2 - 1) * torch.tensor([1.5, 1.5, 0.0]) + torch.tensor([0.0, 0.0, 4.0])
+    v = c + (torch.rand(B, T, 3, 3, generator=g) * 2 - 1) * torch.tensor([0.9, 0.9, 1.2])       # eye space, depth along +z
+    push = torch.rand(B, T, 3, generator=g) < frac * 0.6
+    push[:, ::3] = False                                                                  # a third of the triangles untouched
+    v[..., 2] = torch.where(push, -torch.rand(B, T, 3, generator=g) * 3.0 + 0.5, v[..., 2])     # depth in (-2.5, 0.5): behind / near
+    n, f = 1.0, 20.0
+    w = v[..., 2:3]
+    z = (f + n) / (f - n) * w - 2 * f * n / (f - n)
+    pos = torch.cat([v[..., :2] * 1.2, z, w], dim=-1).reshape(B, T * 3, 4).contiguous()
+    tri = torch.arange(T * 3, dtype=torch.int32).reshape(T, 3)
+    return pos, tri

@@ -300,3 +300,48 @@ def test_rccl_backend_reduces_the_gradient_bucket(tmp_path):
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and "RCCL_OK" in out, out[-3000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# near-plane clipping (rule R1): triangles with vertices behind the camera
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("res,T,seed", [((96, 128), 60, 3), ((160, 200), 400, 4), ((75, 101), 900, 5)])
+def test_near_plane_clipping_matches_oracle(dr, oracle_ops, res, T, seed):
+    """Triangles crossing the near plane are clipped against it and their one or two pieces drawn under the triangle's own index
+    (the second piece through the overflow slots of the raster scratch): ids bit-exact, rast / rast_db floats from the ORIGINAL
+    vertices to 1e-4, and the gradient of the rasterize -> interpolate -> antialias chain to the clip-space positions."""
+    from helpers import near_crossing_soup
+    pos, tri = near_crossing_soup(2, T, seed)
+    behind = (pos[..., 3].reshape(2, -1, 3) <= 0).any(dim=2)
+    ids_ref = oracle_ops.rasterize_ids(pos, tri, res)
+    shown = torch.zeros_like(behind)
+    for b in range(2):
+        shown[b, (ids_ref[b][ids_ref[b] > 0] - 1).long().unique()] = True
+    assert int((shown & behind).sum()) >= 5, "clipped triangles must be visible"
+    ctx = dr.RasterizeGLContext(device='cuda')
+    g = torch.Generator().manual_seed(seed)
+    attr = torch.rand(1, pos.shape[1], 3, generator=g)
+    gy = torch.randn(2, res[0], res[1], 3, generator=g)
+    gdb = torch.randn(2, res[0], res[1], 4, generator=g) * 0.05
+    p_ref = pos.clone().requires_grad_(True)
+    r_o, db_o = oracle_ops.rasterize(p_ref, tri, res)
+    c_o, _ = oracle_ops.interpolate(attr, r_o, tri)
+    aa_o = oracle_ops.antialias(c_o, r_o, p_ref, tri)
+    ((aa_o * gy).sum() + (db_o * gdb).sum()).backward()
+    p_gpu = pos.cuda().requires_grad_(True)
+    rast, db = dr.rasterize(ctx, p_gpu, tri.cuda(), res)
+    col, _ = dr.interpolate(attr.cuda(), rast, tri.cuda())
+    aa = dr.antialias(col, rast, p_gpu, tri.cuda())
+    ((aa * gy.cuda()).sum() + (db * gdb.cuda()).sum()).backward()
+    assert torch.equal(rast[..., 3].int().cpu(), ids_ref)
+    assert rel_l2(rast, r_o) < TOL and rel_l2(db, db_o) < TOL and rel_l2(aa, aa_o) < TOL
+    assert rel_l2(p_gpu.grad, p_ref.grad) < TOL, rel_l2(p_gpu.grad, p_ref.grad)
+    # the fused forward carries the same rasteriser in its list form
+    uv = torch.rand(pos.shape[1], 2, generator=g).cuda()
+    tex = torch.rand(16, 16, 1, generator=g).cuda()
+    _, rast2 = dr.render_textured(ctx, pos.cuda(), tri.cuda(), uv, tri.cuda(), tex, res)
+    assert torch.equal(rast2[..., 3].int().cpu(), ids_ref)
+    ref_img = torch.randint(0, 141, (2,) + tuple(res), generator=g, dtype=torch.uint8).cuda()
+    loss = dr.pixel_objective(ctx, pos.cuda().requires_grad_(True), tri.cuda(), uv, tri.cuda(), tex.requires_grad_(True), ref_img, res)
+    assert torch.isfinite(loss)

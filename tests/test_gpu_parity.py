@@ -219,7 +219,8 @@ def test_rasterize_small_triangle_soup_ids_bit_exact(dr, ctx, oracle_ops, res, T
 
 def test_rasterize_depth_ties_go_to_the_smaller_index(dr, ctx, oracle_ops):
     """Every triangle twice (identical vertices, so identical depth planes): rule R6 gives the pixel to the smaller index
-    although triangles reach a bin in no particular order; plus triangles with w <= 0 and NaN vertices, which are dropped."""
+    although triangles reach a bin in no particular order; plus a triangle with a vertex at w <= 0 (clipped against the near
+    plane or dropped, rule R1) and one with a NaN vertex (dropped)."""
     pos, tri = random_soup(1, 600, 7, size=0.2)
     T = tri.shape[0]
     perm = torch.randperm(2 * T, generator=torch.Generator().manual_seed(0))
@@ -354,7 +355,7 @@ def test_range_mode_matches_oracle(dr, oracle_ops):
 def test_rasterize_fuzz_bin_population(dr, ctx, oracle_ops, seed):
     """Ids bit-exact for soups built to exercise every batch shape of the bin kernel: a few / ~100 / several hundred tiny
     triangles inside one 32 x 32-pixel bin (the lane path's 4-, 2- and 1-thread-per-triangle forms and more than one batch),
-    mixed with large ones (tile path), depth ties (z quantised to 1/8), back faces and vertices behind the camera; odd
+    mixed with large ones (tile path), depth ties (z quantised to 1/8), back faces and vertices behind the camera (clipped); odd
     resolutions; through the operator and through the fused forward (which carries the same rasteriser in its list form)."""
     import fpc_diffrend_amd.ops as ops
     g = torch.Generator().manual_seed(100 + seed)
@@ -376,7 +377,7 @@ def test_rasterize_fuzz_bin_population(dr, ctx, oracle_ops, seed):
     z = torch.round((torch.rand(B, T, 3, 1, generator=g) * 2 - 1) * 0.9 * 8) / 8            # many exact depth ties
     z[:, ::7] = z[:, ::7, :1]                                                             # whole triangles at one depth
     w = torch.rand(B, T, 3, 1, generator=g) * 2.5 + 0.5
-    w[:, 5::31, 0] = -0.3                                                                 # a vertex behind the camera: dropped (R1)
+    w[:, 5::31, 0] = -0.3                                                                 # a vertex behind the camera: near-plane clipping (R1)
     pos = torch.cat([xy * w, z * w, w], dim=-1).reshape(B, T * 3, 4).contiguous()
     tri = torch.arange(T * 3, dtype=torch.int32).reshape(T, 3)
     ids_ref = oracle_ops.rasterize_ids(pos, tri, res)

@@ -293,3 +293,59 @@ def test_texture_custom_mip_stack(oracle_ops):
     assert not torch.allclose(a, c)
     c.sum().backward()
     assert all(float(m.grad.abs().sum()) > 0 for m in own[:2])
+
+
+def test_near_plane_clipping_rule(oracle_ops):
+    """Rule R1: a triangle with a vertex at w <= 0 is clipped against the near plane z + w >= 0 and its pieces are drawn under its
+    own index.  (1) triangles with all w > 0 are untouched by the rule; (2) a straddling triangle covers exactly what its
+    hand-clipped pieces cover (same arithmetic written out here in float64 numpy; the pieces' vertices are rounded to float32 to
+    be drawn, hence a tolerance of a thin line of pixels); (3) float outputs come from the ORIGINAL vertices: barycentrics stay
+    inside the triangle and the gradient of a clipped, visible triangle reaches all three of its vertices."""
+    from helpers import near_crossing_soup
+    pos, tri = near_crossing_soup(2, 60, 3)
+    res = (96, 128)
+    ids = oracle_ops.rasterize_ids(pos, tri, res)
+    w = pos[..., 3].reshape(2, -1, 3)
+    behind = (w <= 0).any(dim=2)
+    assert int(behind.sum()) > 20 and int((~behind).sum()) > 20
+    shown = torch.zeros_like(behind)
+    for b in range(2):
+        shown[b, (ids[b][ids[b] > 0] - 1).long().unique()] = True
+    assert int((shown & behind).sum()) > 5, "clipped triangles must be visible in the test scene"
+    # (2) hand-clipped pieces of each straddling triangle, rendered as ordinary triangles one at a time
+    p = pos[0].double().numpy().reshape(-1, 3, 4)
+    checked = 0
+    for t in torch.nonzero(behind[0]).flatten().tolist()[:12]:
+        d = p[t, :, 2] + p[t, :, 3]
+        poly = []
+        for i in range(3):
+            j = (i + 1) % 3
+            if d[i] >= 0:
+                poly.append(p[t, i])
+            if (d[i] >= 0) != (d[j] >= 0):
+                a, bb = (i, j) if d[i] >= 0 else (j, i)
+                tt = d[a] / (d[a] - d[bb])
+                poly.append(p[t, a] + tt * (p[t, bb] - p[t, a]))
+        alone = oracle_ops.rasterize_ids(pos[:1, 3 * t:3 * t + 3], torch.tensor([[0, 1, 2]], dtype=torch.int32), res)[0] > 0
+        if len(poly) < 3 or not all(q[3] > 0 for q in poly):
+            assert not alone.any()
+            continue
+        cover = torch.zeros(res, dtype=torch.bool)
+        for k in range(len(poly) - 2):
+            piece = torch.tensor(np.stack([poly[0], poly[k + 1], poly[k + 2]]), dtype=torch.float64)
+            # (the pieces' vertices are not float32 numbers: rasterize_ids would round them, so compare up to the rounding)
+            cover |= oracle_ops.rasterize_ids(piece[None].float(), torch.tensor([[0, 1, 2]], dtype=torch.int32), res)[0] > 0
+        diff = int((cover ^ alone).sum())
+        assert diff <= 0.02 * max(int(alone.sum()), 1) + 3, (t, diff, int(alone.sum()))
+        checked += int(alone.sum()) > 0
+    assert checked >= 3
+    # (3) floats from the original vertices
+    pos_g = pos.clone().requires_grad_(True)
+    rast, _ = oracle_ops.rasterize(pos_g, tri, res)
+    (rast[..., :2] ** 2).sum().backward()
+    g = pos_g.grad.reshape(2, -1, 3, 4)
+    vis_clipped = torch.nonzero(shown & behind)
+    b0, t0 = vis_clipped[0].tolist()
+    assert (g[b0, t0].abs().sum(dim=1) > 0).all(), "every original vertex of a clipped, visible triangle receives a gradient"
+    u, v = rast[..., 0], rast[..., 1]
+    assert float(u.min()) >= 0 and float((u + v).max()) <= 1 + 1e-6
