@@ -99,9 +99,10 @@ __global__ void k_topo_resolve(const int32_t *__restrict__ tri, int T, const uns
 __global__ void __launch_bounds__(256) k_sil(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                              const int32_t *__restrict__ adj, int B, int V, int T, float hw, float hh,
                                              uint8_t *__restrict__ sil) {
-    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)B * T) return;
-    const int b = (int)(gid / T), t = (int)(gid - (long long)b * T);
+    // grid (triangle chunks, images): a flat thread index would cost every thread a 64-bit division
+    const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const size_t gid = (size_t)b * T + t;
     const float4 *p = pos + (size_t)b * V;
     int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
     unsigned int bits = 0;
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(256) k_aa_fwd(const float *__restrict__ color,
                 c4 = (int)pair_candidate(silb, T, me, nR) | (int)pair_candidate(silb, T, me, nU) | (int)pair_candidate(silb, T, nL, me) |
                      (int)pair_candidate(silb, T, nD, me);
             if (c4) cand |= 1u << r;
-            else { for (int c = 0; c < C; ++c) out[off * C + c] = color[off * C + c]; }
+            else if (filled < 2) { for (int c = 0; c < C; ++c) out[off * C + c] = color[off * C + c]; }      // (2: the fill kernel copied it)
         }
     }
     unsigned int rows = 0;
@@ -267,17 +268,17 @@ __global__ void __launch_bounds__(256) k_aa_fwd(const float *__restrict__ color,
     }
 }
 
-// C = 1, W % 4 == 0, with a region hint: the bins that (with their eight neighbours) are empty -- three quarters of a face-rig
-// frame -- are written here with one 16-byte store per lane, one workgroup per 32 x 32-pixel bin (4-byte-per-lane stores
-// reach ~1 TB/s, 16-byte ones 5); k_aa_fwd then leaves them alone.
+// C = 1, W % 4 == 0, with a region hint: EVERY pixel's un-antialiased value is written here with one 16-byte store per lane, one
+// workgroup per 32 x 32-pixel bin (4-byte-per-lane stores reach ~1 TB/s, 16-byte ones 5): the bins that (with their eight neighbours)
+// are empty -- three quarters of a face-rig frame -- get their known constant without a read, the others a copy of colour.  k_aa_fwd
+// then only overwrites the pixels it blends (~1 % of a frame) and issues no bulk stores at all.
 __global__ void __launch_bounds__(256) k_aa_fill_bin1(const float4 *__restrict__ color4, int B, int H, int W, float4 *__restrict__ out4,
                                                       const uint8_t *__restrict__ hint, const float *__restrict__ empty_color) {
     const int tid = threadIdx.x, b = blockIdx.z;
     const int px = blockIdx.x * 32 + (tid & 7) * 4, py = blockIdx.y * 32 + (tid >> 3);
     if (px >= W || py >= H) return;
-    if (fpcdr_hint_on(hint, 1, B, H, W, b, py, px)) return;
     const size_t i4 = (((size_t)b * H + py) * W + px) / 4;
-    if (empty_color) { const float e = empty_color[0]; out4[i4] = make_float4(e, e, e, e); }
+    if (!fpcdr_hint_on(hint, 1, B, H, W, b, py, px) && empty_color) { const float e = empty_color[0]; out4[i4] = make_float4(e, e, e, e); }
     else out4[i4] = color4[i4];
 }
 
@@ -439,7 +440,7 @@ extern "C" int fpcdr_antialias_fwd(const fpcdr_antialias_fwd_params *p, void *st
     FPCDR_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->C > 0 && p->V > 0 && p->T > 0, "sizes must be positive");
     FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 4) <= 65535, "image batch / height too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sil, dim3(fpcdr_cdiv((long long)p->B * p->T, 256)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+    hipLaunchKernelGGL(k_sil, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil);
     dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 4 * AROWS), p->B);
     int filled = 0, flags_zeroed = 0;
@@ -450,7 +451,7 @@ extern "C" int fpcdr_antialias_fwd(const fpcdr_antialias_fwd_params *p, void *st
     if (p->hint && p->C == 1 && (p->W & 3) == 0 && (((size_t)p->color | (size_t)p->out) & 15) == 0) {
         hipLaunchKernelGGL(k_aa_fill_bin1, dim3(fpcdr_cdiv(p->W, 32), fpcdr_cdiv(p->H, 32), p->B), dim3(256), 0, st, (const float4 *)p->color,
                            p->B, p->H, p->W, (float4 *)p->out, p->hint, p->empty_color);
-        filled = 1;
+        filled = 2;      // every pixel holds its un-antialiased value: k_aa_fwd writes the blended ones only
     }
 #define LAUNCH_FWD(CS)                                                                                                   \
     hipLaunchKernelGGL(k_aa_fwd<CS>, grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, \
