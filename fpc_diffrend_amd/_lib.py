@@ -14,7 +14,7 @@ MAX_ATTR = 32
 MAX_MIP = 16
 LOSS_SLOTS = 256
 OCC_BIN = 32         # FPCDR_OCC_BIN
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
 BOUNDARY = {'wrap': 0, 'clamp': 1, 'zero': 2}    # 'zero': dr.texture only (the fused render paths take wrap / clamp)
@@ -131,6 +131,7 @@ SYMBOLS = {
     "fpcdr_occ_bytes": (_sz, [_i, _i, _i]),
     "fpcdr_cmask_bytes": (_sz, [_i, _i, _i]),
     "fpcdr_ref_bg_sumsq": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, _p, _p]),
+    "fpcdr_objective_value": (_int, [_p, _i, _p, ctypes.c_double, ctypes.c_double, _p, _p]),
     "fpcdr_render_aa_bwd": (_int, [ctypes.POINTER(RenderAaBwd), _p]),
     "fpcdr_interpolate_fwd": (_int, [ctypes.POINTER(InterpolateFwd), _p]),
     "fpcdr_interpolate_bwd": (_int, [ctypes.POINTER(InterpolateBwd), _p]),

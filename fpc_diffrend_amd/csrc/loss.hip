@@ -33,7 +33,30 @@ __global__ void __launch_bounds__(256) k_pixel_loss(const float *__restrict__ co
     if (threadIdx.x == 0) atomicAdd(loss_sum, (double)s_part[0] + (double)s_part[1] + (double)s_part[2] + (double)s_part[3]);
 }
 
+// value of the pixel objective from the loss slots of fpcdr_render_loss_fwd / fpcdr_aa_loss_fwd: one wave, one launch (the same
+// arithmetic as five eager torch kernels -- sum, scale, add, divide, cast -- took 30 us between the forward and the backward call)
+__global__ void __launch_bounds__(64) k_objective_value(const double *__restrict__ slots, int n, const double *__restrict__ bg_sumsq,
+                                                        double bg_coeff, double n_total, float *__restrict__ out) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) acc += slots[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (threadIdx.x == 0) {
+        if (bg_sumsq) acc = acc + bg_coeff * bg_sumsq[0];
+        out[0] = (float)(acc / n_total);
+    }
+}
+
 }  // namespace
+
+extern "C" int fpcdr_objective_value(const double *loss_slots, int32_t n_slots, const double *bg_sumsq, double bg_coeff,
+                                     double n_total, float *out, void *stream) {
+    FPCDR_REQUIRE(loss_slots && out, "null pointer");
+    FPCDR_REQUIRE(n_slots > 0 && n_total > 0.0, "bad sizes");
+    hipLaunchKernelGGL(k_objective_value, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_slots, n_slots, bg_sumsq, bg_coeff, n_total, out);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
 
 extern "C" int fpcdr_pixel_loss(const fpcdr_pixel_loss_params *p, void *stream) {
     FPCDR_REQUIRE(p != nullptr, "null params");

@@ -516,6 +516,7 @@ class Fitter:
                 else torch.optim.Adam(groups, lr=cfg.lr_base, fused=True)
         self._graphs, self._graph_key, self._frame_idx, self._view_idx = None, None, None, None
         self._side_stream = torch.cuda.Stream(device=dev)
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
         self._background = torch.tensor(BACKGROUND, device=dev)     # (a device scalar made once: no host copy inside a HIP-graph capture)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lr_lambda=lambda x: cfg.lr_ramp ** (float(x) / float(cfg.max_iter)))
@@ -706,8 +707,14 @@ class Fitter:
             if side is not None:
                 main_stream.wait_stream(side)
                 reg.record_stream(main_stream)
-            loss = pix + reg
-            loss.backward()
+            # d loss / d pix = d loss / d reg = 1, handed over as a cached device scalar: `(pix + reg).backward()` would put an add and
+            # a fill between the forward and the backward kernel; the sum is formed after the backward pass has been enqueued
+            roots, seeds = [pix], [self._one]
+            if reg.requires_grad:
+                roots.append(reg)
+                seeds.append(self._one)
+            torch.autograd.backward(roots, seeds)
+            loss = pix.detach() + reg.detach()
             if side is not None:
                 main_stream.wait_stream(side)    # the regularisers' backward ran on the side stream
         elif cfg.fused_loss:

@@ -327,6 +327,7 @@ class _pixel_objective_func(torch.autograd.Function):
                            H=H, W=W, C=C, V=V, T=T, bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
                            flags=_ptr(flags), grad_aa=_ptr(g_aa), occ=_ptr(occ), empty_color=_ptr(ecol), loss_sum=_ptr(acc))
         ctx.cap_bwd = 0
+        ctx.hint_update = None
         if sparse:
             # one call: the rasteriser settles every pixel antialiasing cannot touch, a second kernel the candidates it marks
             cmask = torch.empty(lib.fpcdr_cmask_bytes(B, H, W), dtype=torch.uint8, device=dev)
@@ -335,9 +336,11 @@ class _pixel_objective_func(torch.autograd.Function):
                 q.cap_bins, q.cap_fix, ctx.cap_bwd = hints.poll()
             _lib.call("fpcdr_render_loss_fwd", ctypes.byref(p), ctypes.byref(q), _ptr(cmask), _stream())
             if hints is not None:
+                # (the counts are read back after the BACKWARD call has been enqueued: the copy would otherwise sit between the
+                # two large kernels on the stream)
                 nb = B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN)
                 off = (4 * nb + 3) // 4 * 4                       # FPCDR_OCC_COUNTS_OFFSET
-                hints.update(occ[off:off + 16].view(torch.int32))
+                ctx.hint_update = (hints, occ[off:off + 16].view(torch.int32))
         else:
             _lib.call("fpcdr_render_fwd", ctypes.byref(p), _stream())
             _lib.call("fpcdr_aa_loss_fwd", ctypes.byref(q), _stream())
@@ -349,13 +352,16 @@ class _pixel_objective_func(torch.autograd.Function):
         # the default and the list form stays selectable
         ctx.queued = 1 if (sparse and queued_backward) else 0
         # (sparse => the one-call forward, which also leaves the per-bin summary of the antialias flags in `occ`)
-        total = acc.sum()
+        bg_sum = None
         if sparse:
             # the kernel summed only the difference to an all-background image; the rest depends on ref alone
-            if ref_bg_sumsq is None:
-                ref_bg_sumsq = reference_background_sumsq(ref, bg).sum()
-            total = total + C * ref_bg_sumsq
-        return (total / n_total).to(torch.float32)
+            bg_sum = (reference_background_sumsq(ref, bg).sum() if ref_bg_sumsq is None else ref_bg_sumsq).to(torch.float64).contiguous()
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.call("fpcdr_objective_value", _ptr(acc), _lib.LOSS_SLOTS, _ptr(bg_sum), float(C), float(n_total), _ptr(out), _stream())
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and ctx.hint_update is not None:      # forward only: read the counts back now
+            ctx.hint_update[0].update(ctx.hint_update[1])
+            ctx.hint_update = None
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -373,6 +379,9 @@ class _pixel_objective_func(torch.autograd.Function):
                              grad_tex=_ptr(g_tex), tri_uv=_ptr(tri_uv), upstream=_ptr(g),    # g: applied inside the kernel
                              queued=ctx.queued, cap_bwd=ctx.cap_bwd, binflags=1 if occ is not None else 0)
         _lib.call("fpcdr_render_aa_bwd", ctypes.byref(p), _stream())
+        if ctx.hint_update is not None:
+            ctx.hint_update[0].update(ctx.hint_update[1])
+            ctx.hint_update = None
         if not ctx.needs_input_grad[0]:
             g_pos = None
         return (g_pos, g_tex) + (None,) * 14

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FPCDR_ABI_VERSION 5
+#define FPCDR_ABI_VERSION 6
 
 enum {
     FPCDR_OK = 0,
@@ -52,7 +52,8 @@ const char *fpcdr_last_error(void);
  * valid only for the very tensor it was produced with (the Python binding drops it when the tensor was modified). */
 #define FPCDR_HINT_BYTES(B, H, W) ((size_t)2 * (B) * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W))
 
-/* bytes of scratch fpcdr_rasterize_fwd needs for B images of T triangles */
+/* bytes of scratch fpcdr_rasterize_fwd needs for B images of T triangles: per image two record slots per triangle (one for the
+ * triangle, one for the second piece of a triangle clipped against the near plane), their pixel boxes, chunk and image boxes */
 size_t fpcdr_rasterize_scratch_bytes(int32_t B, int32_t T);
 
 typedef struct {
@@ -186,6 +187,11 @@ int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *r, const fpcdr_aa_loss_
  * uint8, out f64 (zero-filled by the caller).  The part of the pixel loss (fit.py:579) that a sparse fpcdr_aa_loss_fwd
  * leaves to the caller: it depends on the reference images only, so a fit loop computes it once. */
 int fpcdr_ref_bg_sumsq(const uint8_t *ref, int64_t n_images, int64_t px_per_image, float bg_scaled, double *out, void *stream);
+
+/* Value of the pixel objective: out[0] = float((sum of the n_slots loss slots + bg_coeff * bg_sumsq[0]) / n_total), one launch.
+ * bg_sumsq: device scalar (the all-background share of the sparse mode, fpcdr_ref_bg_sumsq summed over the call's images), or NULL. */
+int fpcdr_objective_value(const double *loss_slots, int32_t n_slots, const double *bg_sumsq, double bg_coeff, double n_total,
+                          float *out, void *stream);
 
 /* Backward of antialias + texture + interpolate + rasterize in one pass: reads grad_aa (4C B/px), rast (16 B/px) and
  * the flag planes; scatters into grad_pos and grad_tex; writes nothing dense.                                 */
