@@ -440,30 +440,39 @@ def main():
                 out["config"]["occupied_bins"] = {"rasteriser": n_bins, "antialias_fix": n_fix, "backward": n_bwd,
                                                   "of": fpg * n_cam * ((H + 31) // 32) * ((W + 31) // 32)}
         if px_ops:
+            def hbm_roofline(name_):
+                """HBM roofline of one per-pixel entry point: algorithmic bytes / HIP-event time against the 8 TB/s peak, the PMC
+                traffic of its kernels beside it, and what the counters say bounds it."""
+                t_s_ = px_ops[name_]["avg_ms"] * 1e-3
+                pmc_, why_ = measured_counters(name_, args.workload, fpg * n_cam, C, t_ms=px_ops[name_]["avg_ms"])
+                alg_ = bpp[name_] * sparse_px.get(name_, npix)
+                a_ = alg_ / t_s_ / 1e9
+                valu_bound = bool(pmc_ and pmc_.get("valu_issue_frac") and pmc_["valu_issue_frac"] > (pmc_["hbm_bytes"] / t_s_ / 1e9 / HBM_PEAK_GBS))
+                return {"kernel": name_,
+                        # what the counters say limits the call; achieved / peak / frac are the HBM figures the metric asks for
+                        # (algorithmic bytes against the 8 TB/s peak), whatever the bound
+                        "bound": "valu-issue" if valu_bound else "hbm",
+                        "achieved": a_, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_ / HBM_PEAK_GBS, "ms": px_ops[name_]["avg_ms"],
+                        "algorithmic_bytes": alg_,
+                        "traffic": pmc_["hbm_bytes"] if pmc_ else None,
+                        "traffic_GBps": (pmc_["hbm_bytes"] / t_s_ / 1e9) if pmc_ else None,
+                        "traffic_frac": (pmc_["hbm_bytes"] / t_s_ / 1e9 / HBM_PEAK_GBS) if pmc_ else None,
+                        "valu_issue_frac": pmc_.get("valu_issue_frac") if pmc_ else None,
+                        "traffic_source": pmc_["source"] if pmc_ else None,
+                        "traffic_unavailable": why_,
+                        "dense_equivalent_GBps": px_ops[name_]["algorithmic_GBps"]}, pmc_
+
             dom = max(px_ops, key=lambda k: px_ops[k]["avg_ms"] * px_ops[k]["calls"])
             t_s = px_ops[dom]["avg_ms"] * 1e-3
-            pmc, why = measured_counters(dom, args.workload, fpg * n_cam, C, t_ms=px_ops[dom]["avg_ms"])
-            alg_bytes = bpp[dom] * sparse_px.get(dom, npix)
-            a = alg_bytes / t_s / 1e9
-            valu_bound = bool(pmc and pmc.get("valu_issue_frac") and pmc["valu_issue_frac"] > (pmc["hbm_bytes"] / t_s / 1e9 / HBM_PEAK_GBS))
-            out["roofline"] = {"kernel": dom,
-                               # what the counters say limits the call; achieved / peak / frac below are the HBM figures the
-                               # metric asks for (algorithmic bytes against the 8 TB/s peak), whatever the bound
-                               "bound": "valu-issue" if valu_bound else "hbm",
-                               "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": a / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
-                               "traffic": pmc["hbm_bytes"] if pmc else None,
-                               "traffic_GBps": (pmc["hbm_bytes"] / t_s / 1e9) if pmc else None,
-                               "traffic_frac": (pmc["hbm_bytes"] / t_s / 1e9 / HBM_PEAK_GBS) if pmc else None,
-                               "traffic_source": pmc["source"] if pmc else None,
-                               "traffic_unavailable": why,
-                               "dense_equivalent_GBps": px_ops[dom]["algorithmic_GBps"],
-                               "note": "achieved = algorithmic bytes of the SPARSE call (B/px x 1024 px x the bins on its list, counted "
+            out["roofline"], pmc = hbm_roofline(dom)
+            out["roofline"]["note"] = ("achieved = algorithmic bytes of the SPARSE call (B/px x 1024 px x the bins on its list, counted "
                                        "live) / HIP-event time inside the timed region; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the "
                                        "call's kernels from the committed PMC passes named in traffic_source (null, with the reason in "
                                        "traffic_unavailable, when they were measured on other kernel sources or their durations differ "
                                        "from this run's by more than 10 %); dense_equivalent counts every pixel of the batch although "
-                                       "80 % are never touched"}
+                                       "80 % are never touched")
+            # the two calls of the objective take nearly the same time and swap places from run to run: both are reported
+            out["roofline_objective_calls"] = {n_: hbm_roofline(n_)[0] for n_ in ("fpcdr_render_loss_fwd", "fpcdr_render_aa_bwd") if n_ in px_ops}
             if pmc and pmc.get("valu_issue_frac") is not None:
                 out["roofline_valu"] = {"kernel": dom, "bound": "valu-issue", "achieved": pmc["valu_insts"] / t_s / 1e9,
                                         "unit": "G wave-instructions/s", "peak": N_SIMD * (pmc["gui_active"] / 8.0) / 4.0 / t_s / 1e9 if t_s else None,

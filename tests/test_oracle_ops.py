@@ -349,3 +349,51 @@ def test_near_plane_clipping_rule(oracle_ops):
     assert (g[b0, t0].abs().sum(dim=1) > 0).all(), "every original vertex of a clipped, visible triangle receives a gradient"
     u, v = rast[..., 0], rast[..., 1]
     assert float(u.min()) >= 0 and float((u + v).max()) <= 1 + 1e-6
+
+
+def test_gradient_sensitivity_to_last_bit_of_barycentrics(oracle_ops):
+    """How much of the 1e-4 gradient budget a last-bit change of (u, v) costs: the barycentrics of every covered pixel of one
+    256 x 256 image moved by -1 / 0 / +1 ulp at random (values only; the backward pass is unchanged).  A texture coordinate that
+    crosses a texel border picks the neighbouring cell's slope, so the gradients move by a few 1e-5 relative L2 -- within the
+    bar, but a third of it: the HIP kernels therefore keep the oracle's float arithmetic bit for bit (Accuracy bars)."""
+    from fpc_diffrend_amd import scene
+    from helpers import clip_positions, rel_l2
+    from oracle import fit as ofit
+    sc = scene.cfg('cfg1', n_frames=2)
+    cam = 4
+    pos, _ = clip_positions(sc, [cam], frames=[1])
+    H, W = sc.resolution
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    targets = (70 + 60 * torch.sin(0.05 * xx + 0.3) * torch.cos(0.07 * yy)).clamp(0, 140).reshape(1, H, W, 1).float()
+    st = ofit.State(sc, (cam,))
+
+    class Nudge(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, rast):
+            r = rast.clone()
+            bits = r[..., :2].contiguous().view(torch.int32)
+            d = torch.randint(-1, 2, bits.shape, generator=torch.Generator().manual_seed(1), dtype=torch.int32)
+            bits = torch.where((r[..., 3:] > 0) & (r[..., :2] > 0), bits + d, bits)
+            r[..., :2] = bits.view(torch.float32)
+            return r
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    def run(nudge):
+        p = pos.clone().requires_grad_(True)
+        st.tex.grad = None
+        rast, _ = oracle_ops.rasterize(p, st.pos_idx, (H, W))
+        if nudge:
+            rast = Nudge.apply(rast)
+        texc, _ = oracle_ops.interpolate(st.uv[None], rast, st.uv_idx)
+        colour = oracle_ops.antialias(oracle_ops.texture(st.tex[None], texc, filter_mode='linear'), rast, p, st.pos_idx)
+        image = torch.where(rast[..., 3:] > 0, colour, torch.tensor(45 / 255.))
+        torch.mean((targets - image * 255) ** 2).backward()
+        return image.detach(), p.grad.clone(), st.tex.grad.clone()
+
+    a, b = run(False), run(True)
+    assert rel_l2(b[0], a[0]) < 5e-6                       # the image itself barely moves
+    e_pos, e_tex = rel_l2(b[1], a[1]), rel_l2(b[2], a[2])
+    assert 1e-7 < e_pos < 1e-4 and 1e-7 < e_tex < 1e-4, (e_pos, e_tex)
