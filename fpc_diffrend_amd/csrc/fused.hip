@@ -264,6 +264,13 @@ constexpr int BBIN = 32;
 constexpr int BWD_NT = FPCDR_BWD_NT;          // threads per bin workgroup (measured: 128 -> 3.08 ms, 256 -> 2.61, 512 -> 3.28)
 constexpr int BWD_NPX = BBIN * BBIN / BWD_NT;  // pixels per thread
 
+// texture coordinates of triangle t through the index buffer (callers that did not pre-gather uv[uv_tri]); out of line: merged with
+// the pre-gathered branch, its loads would drag 64-bit address arithmetic into the common path
+__device__ __noinline__ void uv_indirect(const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri, int t, float2 &q0, float2 &q1,
+                                         float2 &q2) {
+    q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]];
+}
+
 template <int CS, int BMODE = -1>      // BMODE >= 0: the texture boundary mode as a compile-time constant
 __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, const int byi,
                                                        const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
@@ -306,6 +313,15 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
     }
     const bool v_me = ow.bin(0, 0);
     const size_t img = (size_t)b * H * W;
+    // every gather of the hot path goes through a 32-bit byte offset from a wave-uniform base (common.h ld32): the bin's own pixels
+    // at bin_off + r * W + col, its flag words at flag_base + r * Wq, per-image vertex / triangle arrays
+    struct I3 { int a, b, c; };
+    struct UV3 { float2 q0, q1, q2; };
+    const size_t bin_off = img + (size_t)by0 * W + bx0;
+    const int Wq = FPCDR_AA_ROW_WORDS(W);
+    const size_t flag_plane = (size_t)B * H * Wq;
+    const unsigned long long *const flags_bin = flags + ((size_t)b * H + by0) * Wq + (bx0 >> 6);
+    const float4 *const pos_img = pos + (size_t)b * V;
     const float up = upstream ? upstream[0] : 1.0f;   // d(final loss)/d(this objective), a device scalar
     // flag words are loaded only where this bin, its left or its lower neighbour holds a blended pair (binflag: per-bin summary
     // written by k_aa_fix; null = unknown, load everywhere)
@@ -333,20 +349,22 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
 #pragma unroll
         for (int c = 0; c < CS; ++c) go[k][c] = 0.0f;
         if (x < W && y < H) {
-            const int Wq = FPCDR_AA_ROW_WORDS(W);
-            const size_t plane = (size_t)B * H * Wq;
+            const unsigned int rk = (unsigned int)(rowk0 + 2 * k);      // the pixel's row inside the bin
+            const size_t plane = flag_plane;
             const size_t wi = ((size_t)b * H + y) * Wq + (x >> 6);
             const int bit = x & 63;
             bool own_x = false, own_y = false, left_x = false, down_y = false;
             if (flags_here) {
-                const unsigned long long fxw = flags[wi], fyw = flags[plane + wi];
+                const unsigned int wo = rk * (unsigned int)Wq;
+                const unsigned long long fxw = ld32(flags_bin, wo), fyw = ld32(flags_bin + flag_plane, wo);
                 own_x = (fxw >> bit) & 1ull; own_y = (fyw >> bit) & 1ull;
                 left_x = bit > 0 ? ((fxw >> (bit - 1)) & 1ull) : (x > 0 ? ((flags[wi - 1] >> 63) & 1ull) : false);
                 down_y = y > 0 ? ((flags[plane + wi - Wq] >> bit) & 1ull) : false;
             }
-            const size_t off = img + (size_t)y * W + x;
+            const unsigned int poff = rk * (unsigned int)W + (unsigned int)col;
+            const size_t off = bin_off + poff;
 #pragma unroll
-            for (int c = 0; c < CS; ++c) { go[k][c] = v_me ? g_aa[off * CS + c] * up : 0.0f; any[k] |= (go[k][c] != 0.0f); }
+            for (int c = 0; c < CS; ++c) { go[k][c] = v_me ? ld32(g_aa + bin_off * CS, poff * CS + c) * up : 0.0f; any[k] |= (go[k][c] != 0.0f); }
             if (own_x | own_y | left_x | down_y) {
                 // antialias backward for this pixel (see k_aa_bwd_fix in antialias.hip); sparse: plain global atomics
                 AAGeom geo = {pos + (size_t)b * V, tri, sil + (size_t)b * T, T, W, H, 0.5f * (float)W, 0.5f * (float)H};
@@ -429,13 +447,13 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
         for (int k = 0; k < BWD_NPX; ++k) {
             pt[k] = -1; tu[k] = 0.f; tv[k] = 0.f;
             if (any[k] && v_me) {
-                const float4 r = rast[img + (size_t)(by0 + rowk0 + 2 * k) * W + x];
+                const float4 r = ld32(rast + bin_off, (unsigned int)(rowk0 + 2 * k) * (unsigned int)W + (unsigned int)col);
                 int t = (int)r.w - 1;
                 if (t >= T) t = -1;
                 if (t >= 0) {
                     float2 q0, q1, q2;
-                    if (tri_uv) { q0 = tri_uv[3 * t]; q1 = tri_uv[3 * t + 1]; q2 = tri_uv[3 * t + 2]; }
-                    else { q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]]; }
+                    if (tri_uv) { const UV3 tq = ld32(reinterpret_cast<const UV3 *>(tri_uv), t); q0 = tq.q0; q1 = tq.q1; q2 = tq.q2; }
+                    else uv_indirect(uv, uv_tri, t, q0, q1, q2);
                     const float w = 1.0f - r.x - r.y;
                     tu[k] = r.x * q0.x + r.y * q1.x + w * q2.x;
                     tv[k] = r.x * q0.y + r.y * q1.y + w * q2.y;
@@ -484,7 +502,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
             for (int c = 0; c < CS; ++c) {
                 const float gc = go[k][c];
                 float t00, t10, t01, t11;
-                load_taps(tex, tp, c, CS, t00, t10, t01, t11);
+                load_taps<true>(tex, tp, c, CS, t00, t10, t01, t11);      // (the entry point requires < 2^30 texel values)
                 gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
                 gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
 #ifdef FPCDR_ABL_NOTEX
@@ -509,8 +527,8 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
             }
             if (t >= 0) {
                 float2 q0, q1, q2;
-                if (tri_uv) { q0 = tri_uv[3 * t]; q1 = tri_uv[3 * t + 1]; q2 = tri_uv[3 * t + 2]; }
-                else { q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]]; }
+                if (tri_uv) { const UV3 tq = ld32(reinterpret_cast<const UV3 *>(tri_uv), t); q0 = tq.q0; q1 = tq.q1; q2 = tq.q2; }
+                else uv_indirect(uv, uv_tri, t, q0, q1, q2);
                 const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu[k] >= 0.0f && tu[k] <= 1.0f)) ? 0.0f : 1.0f;
                 const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv[k] >= 0.0f && tv[k] <= 1.0f)) ? 0.0f : 1.0f;
                 const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
@@ -523,18 +541,17 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
         float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         int vk[3] = {0, 0, 0};   // the triangle's vertex ids: the run's last lane emits with them
         if (tkey >= 0) {
-            vk[0] = tri[3 * tkey]; vk[1] = tri[3 * tkey + 1]; vk[2] = tri[3 * tkey + 2];
+            { const I3 ti = ld32(reinterpret_cast<const I3 *>(tri), tkey); vk[0] = ti.a; vk[1] = ti.b; vk[2] = ti.c; }
 #ifdef FPCDR_ABL_NOSHADEBWD
             gv9[0] = gu; gv9[4] = gvv;
             if (false) {
 #else
             {
 #endif
-            const float4 *p = pos + (size_t)b * V;
             const float fx = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
             const float fy = (2.0f * (float)(by0 + rowk0 + 2 * k) + 1.0f) / (float)H - 1.0f;
             float g0[3], g1[3], g2[3];
-            shade_pixel_bwd<false>(p[vk[0]], p[vk[1]], p[vk[2]], fx, fy, 2.0f / (float)W, 2.0f / (float)H,
+            shade_pixel_bwd<false>(ld32(pos_img, vk[0]), ld32(pos_img, vk[1]), ld32(pos_img, vk[2]), fx, fy, 2.0f / (float)W, 2.0f / (float)H,
                                    make_float4(gu, gvv, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), g0, g1, g2);
             gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
             gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
@@ -967,6 +984,8 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
                   "sizes must be positive");
     FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
     FPCDR_REQUIRE(p->B <= 65535, "more than 65535 images per call");
+    FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30) && p->H <= 32767 && p->W <= 32767 && p->T < (1 << 24),
+                  "texture / resolution / mesh too large for the fused backward (32-bit gather offsets)");
     FPCDR_REQUIRE(!p->occ || p->empty_color, "sparse mode needs empty_color");
     hipStream_t st = (hipStream_t)stream;
     FPCDR_REQUIRE(!(p->queued || p->binflags) || p->occ != nullptr, "queued / binflags need the occupancy buffer of fpcdr_render_loss_fwd");

@@ -502,6 +502,12 @@ struct ShadeArgs {
     uint8_t *op_hint;        // operator form (fpcdr_rasterize_fwd): out, plane 0 of the region hint, or null
 };
 
+// texture coordinates of triangle t through the index buffer (callers that did not pre-gather uv[uv_tri])
+__device__ __noinline__ void uv_indirect(const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri, int t, float2 &q0, float2 &q1,
+                                         float2 &q2) {
+    q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]];
+}
+
 // One 32x32 bin (bxi, byi) of image b; OX x OY bins per image.  Every branch that leaves is uniform over the workgroup.
 // CS / BMODE: channel count and texture boundary mode as compile-time constants (0 / -1 = read them from ShadeArgs); the list
 // kernels of the objective are instantiated for the reference's case (one channel, 'wrap'), which strips the channel loops, the
@@ -578,8 +584,8 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
             if (tid < n * split) {
                 const int part = (tid >= n) + (tid >= 2 * n) + (tid >= 3 * n);
                 const int t = s_list[pending - n + (tid - part * n)];
-                const TriRec r = rc[t];
-                const TriBox q = bx[t];
+                const TriRec r = ld32(rc, t);
+                const TriBox q = ld32(bx, t);
                 const int ext_x = max(r.X0, max(r.X1, r.X2)) - min(r.X0, min(r.X1, r.X2));
                 const int ext_y = max(r.Y0, max(r.Y1, r.Y2)) - min(r.Y0, min(r.Y1, r.Y2));
                 const int x0 = max((int)q.x0, bin_x0), x1 = min((int)q.x1, bin_x1);
@@ -640,8 +646,8 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                 bool any_large = false;
                 if (tid < m) {
                     const int t = s_big[base + tid];
-                    const TriRec r = rc[t];
-                    const TriBox q = bx[t];
+                    const TriRec r = ld32(rc, t);
+                    const TriBox q = ld32(bx, t);
                     EdgeRec e;
                     e.id = r.tid;
                     e.zA = r.zA; e.zB = r.zB; e.z0 = r.z0;
@@ -709,7 +715,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                 const int c = seg + tid;
                 bool live = false;
                 if (c < n_prim) {
-                    const TriBox q = cbx[c];
+                    const TriBox q = ld32(cbx, c);
                     live = (q.x0 <= q.x1) && !(q.x1 < bin_x0 || q.x0 > bin_x1 || q.y1 < bin_y0 || q.y0 > bin_y1);
                 } else if (c < n_chunks) {
                     live = true;
@@ -734,7 +740,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                 }
                 TriBox qk[SCAN_K];
 #pragma unroll
-                for (int k = 0; k < SCAN_K; ++k) qk[k] = bx[min(tt[k], slot_end - 1)];
+                for (int k = 0; k < SCAN_K; ++k) qk[k] = ld32(bx, min(tt[k], slot_end - 1));
                 unsigned long long bal[SCAN_K];
                 int total = 0;
 #pragma unroll
@@ -846,6 +852,13 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         for (int c = 0; c < min(C, 4); ++c) empty_col[c] = bilerp(sh.tex, empty_tp, c, C);
     }
     const int px = bin_x0 + zx;
+    // Every gather below goes through a 32-bit byte offset from a wave-uniform base (common.h ld32 / at32): per-image vertex, index
+    // and silhouette arrays, and the bin's own pixels at bin_off + zy * W + zx.
+    struct I3 { int a, b, c; };
+    struct UV3 { float2 q0, q1, q2; };
+    const size_t bin_off = ((size_t)b * H + bin_y0) * W + bin_x0;
+    float4 *const rast_bin = rast + bin_off;
+    const uint8_t *const sil_img = LOSS ? sh.sil + (size_t)b * T : nullptr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int zy = zy0 + 8 * k, py = bin_y0 + zy;
@@ -858,19 +871,20 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         const int t = win[k];
 #endif
         if (t >= 0) {
-            const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+            const I3 ti = ld32(reinterpret_cast<const I3 *>(tri), t);
             const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
             const float fy = s_fy[zy];
-            Shade sd = shade_pixel(p[i0], p[i1], p[i2], fx, fy, sx, sy);
+            Shade sd = shade_pixel(ld32(p, ti.a), ld32(p, ti.b), ld32(p, ti.c), fx, fy, sx, sy);
             o = make_float4(sd.u, sd.v, sd.zw, (float)(t + 1));
             d = make_float4(sd.dudx, sd.dudy, sd.dvdx, sd.dvdy);
         }
-        const size_t off = ((size_t)b * H + py) * W + px;
-        rast[off] = o;
+        const unsigned int poff = (unsigned int)(zy * W + zx);      // pixel offset inside the bin's window of the image
+        const size_t off = bin_off + poff;
+        at32(rast_bin, poff) = o;
         if (WRITE_DB) rast_db[off] = d;
         if (LOSS) {   // (z/w, id) of the bin's pixels for the neighbour tests below; this thread owns the entry
             // id + 1 in 24 bits (ids are exact in rast's float anyway), the triangle's silhouette bits above them
-            const unsigned int sb = t >= 0 ? (unsigned int)sh.sil[(size_t)b * T + t] : 0u;
+            const unsigned int sb = t >= 0 ? (unsigned int)ld32(sil_img, t) : 0u;
             any_sil |= sb;
             s_z[zy * BIN + zx] = ((unsigned long long)__float_as_uint(o.z) << 32) | (sb << 24) | (unsigned int)(t + 1);
         }
@@ -879,14 +893,15 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
             // kernels; an empty pixel samples uv = (0,0) exactly as they do (one tap set, hoisted out of the loops)
             if (t >= 0) {
                 float2 q0, q1, q2;
-                if (sh.tri_uv) { q0 = sh.tri_uv[3 * t]; q1 = sh.tri_uv[3 * t + 1]; q2 = sh.tri_uv[3 * t + 2]; }
-                else { q0 = sh.uv[sh.uv_tri[3 * t]]; q1 = sh.uv[sh.uv_tri[3 * t + 1]]; q2 = sh.uv[sh.uv_tri[3 * t + 2]]; }
+                if (sh.tri_uv) { const UV3 tq = ld32(reinterpret_cast<const UV3 *>(sh.tri_uv), t); q0 = tq.q0; q1 = tq.q1; q2 = tq.q2; }
+                else uv_indirect(sh.uv, sh.uv_tri, t, q0, q1, q2);      // (out of line: merged with the branch above, its loads would drag
+                                                                       //  64-bit address arithmetic into the common path)
                 const float w = 1.0f - o.x - o.y;
                 const float tu = o.x * q0.x + o.y * q1.x + w * q2.x;
                 const float tv = o.x * q0.y + o.y * q1.y + w * q2.y;
                 const Taps tp = make_taps(tu, tv, sh.Ht, sh.Wt, C, boundary);
                 for (int c = 0; c < C; ++c) {
-                    const float v = bilerp(sh.tex, tp, c, C);
+                    const float v = bilerp<true>(sh.tex, tp, c, C);      // (the fused entry points require < 2^30 texel values)
                     if (stage) s_col[zy * BIN + zx] = v;
                     else sh.color[off * C + c] = v;
                     if (LOSS && c == 0) col0[k] = v;
@@ -903,13 +918,14 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         const int r = tid >> 3, c4 = (tid & 7) * 4;
         const int fx0 = bin_x0 + c4, fy = bin_y0 + r;
         if (fy >= H || fx0 >= W) return;
-        const size_t off = ((size_t)b * H + fy) * W + fx0;
+        float *const dst_bin = dst + bin_off;      // (uniform)
+        const unsigned int poff = (unsigned int)(r * W + c4);
         const float4 v = *reinterpret_cast<const float4 *>(s_plane + r * BIN + c4);
-        if ((W & 3) == 0 && (((size_t)dst) & 15) == 0) *reinterpret_cast<float4 *>(dst + off) = v;
+        if ((W & 3) == 0 && (((size_t)dst) & 15) == 0) *reinterpret_cast<float4 *>(&at32(dst_bin, poff)) = v;
         else {
             const float e[4] = {v.x, v.y, v.z, v.w};
             for (int j = 0; j < 4; ++j)
-                if (fx0 + j < W) dst[off + j] = e[j];
+                if (fx0 + j < W) at32(dst_bin, poff + j) = e[j];
         }
     };
 #ifdef FPCDR_ABL_NOLOSSPASS
@@ -982,9 +998,10 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                 }
             }
             if (cand) atomicOr(&s_cmask[zy], 1u << zx);
-            const size_t off = ((size_t)b * H + py) * W + px;
+            const unsigned int poff = (unsigned int)(zy * W + zx);
+            const size_t off = bin_off + poff;
             if (id > 0) {
-                const float rf = (float)sh.ref[off];
+                const float rf = (float)ld32(sh.ref + bin_off, poff);
                 const float d0 = rf - sh.bg * sh.color_scale;
                 for (int c = 0; c < C; ++c) {
                     const float cv = c == 0 ? col0[k] : sh.color[off * C + c];   // this thread wrote it above
@@ -1335,7 +1352,7 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
     FPCDR_REQUIRE(p->H <= 32767 && p->W <= 32767 && p->B <= 65535, "resolution / batch too large");
     FPCDR_REQUIRE(p->T < (1 << 24), "more than 2^24 triangles (rast stores triangle index + 1 as a float)");
     FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
-    FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C <= 0x7fffffffLL, "texture too large");
+    FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30), "texture too large (the fused paths take < 2^30 texel values)");
     hipStream_t st = (hipStream_t)stream;
     const RasterScratch rs = raster_scratch(p->scratch, p->B, p->T);
     TriRec *recs = rs.recs;
@@ -1393,7 +1410,7 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     FPCDR_REQUIRE(p->H <= 32767 && p->W <= 32767 && p->B <= 65535, "resolution / batch too large");
     FPCDR_REQUIRE(p->T < (1 << 24), "more than 2^24 triangles");
     FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
-    FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C <= 0x7fffffffLL, "texture too large");
+    FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30), "texture too large (the fused paths take < 2^30 texel values)");
     hipStream_t st = (hipStream_t)stream;
     int rc = fpcdr_launch_sil(p->pos, p->tri, l->adj, p->B, p->V, p->T, p->H, p->W, l->sil, st);
     if (rc) return rc;

@@ -58,12 +58,24 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int Ht, int Wt, int 
 // the texture kernels, so halving the number of gather instructions matters
 typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));
 
+// OFF32: the texel offsets go through 32-bit byte offsets from the (uniform) texture base (common.h ld32; the caller guarantees
+// Ht * Wt * C < 2^30 values)
+template <bool OFF32 = false>
 __device__ __forceinline__ void load_taps(const float *tx, const Taps &t, int c, int C, float &t00, float &t10, float &t01,
                                           float &t11) {
     if (C == 1 && t.i10 == t.i00 + 1) {   // no wrap between the two columns
-        const float2_u a = *reinterpret_cast<const float2_u *>(tx + t.i00);
-        const float2_u b = *reinterpret_cast<const float2_u *>(tx + t.i01);
-        t00 = a.x; t10 = a.y; t01 = b.x; t11 = b.y;
+        float2_u va, vb;
+        if (OFF32) {
+            va = *reinterpret_cast<const float2_u *>(reinterpret_cast<const char *>(tx) + ((unsigned int)t.i00 << 2));
+            vb = *reinterpret_cast<const float2_u *>(reinterpret_cast<const char *>(tx) + ((unsigned int)t.i01 << 2));
+        } else {
+            va = *reinterpret_cast<const float2_u *>(tx + t.i00);
+            vb = *reinterpret_cast<const float2_u *>(tx + t.i01);
+        }
+        t00 = va.x; t10 = va.y; t01 = vb.x; t11 = vb.y;
+    } else if (OFF32) {
+        t00 = ld32(tx, (unsigned int)(t.i00 + c)); t10 = ld32(tx, (unsigned int)(t.i10 + c));
+        t01 = ld32(tx, (unsigned int)(t.i01 + c)); t11 = ld32(tx, (unsigned int)(t.i11 + c));
     } else {
         t00 = tx[t.i00 + c]; t10 = tx[t.i10 + c]; t01 = tx[t.i01 + c]; t11 = tx[t.i11 + c];
     }
@@ -79,9 +91,10 @@ __device__ __forceinline__ void mask_taps(const Taps &t, float &t00, float &t10,
     }
 }
 
+template <bool OFF32 = false>
 __device__ __forceinline__ float bilerp(const float *tx, const Taps &t, int c, int C) {
     float t00, t10, t01, t11;
-    load_taps(tx, t, c, C, t00, t10, t01, t11);
+    load_taps<OFF32>(tx, t, c, C, t00, t10, t01, t11);
     mask_taps(t, t00, t10, t01, t11);
     const float top = t00 + (t10 - t00) * t.fx;
     const float bot = t01 + (t11 - t01) * t.fx;
