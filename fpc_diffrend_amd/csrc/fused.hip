@@ -487,7 +487,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
             for (int c = 0; c < CS; ++c) esum[c] += go[k][c];
         } else if (any[k]) {
             const int t = pt[k];
-            const Taps tp = make_taps(tu[k], tv[k], Ht, Wt, CS, boundary);
+            const Taps tp = make_taps_fast(tu[k], tv[k], Ht, Wt, CS, boundary);      // (wrap / clamp only here)
             const float w00 = (1.0f - tp.fx) * (1.0f - tp.fy), w10 = tp.fx * (1.0f - tp.fy);
             const float w01 = (1.0f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
             bool in_win = false;
@@ -518,10 +518,10 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                         lds_add_f64(w + TEXW * CS, gc * w01);
                         lds_add_f64(w + TEXW * CS + CS, gc * w11);
                     } else {
-                        atomicAdd(grad_tex + tp.i00 + c, gc * w00);
-                        atomicAdd(grad_tex + tp.i10 + c, gc * w10);
-                        atomicAdd(grad_tex + tp.i01 + c, gc * w01);
-                        atomicAdd(grad_tex + tp.i11 + c, gc * w11);
+                        atomicAdd(&at32(grad_tex, (unsigned int)(tp.i00 + c)), gc * w00);
+                        atomicAdd(&at32(grad_tex, (unsigned int)(tp.i10 + c)), gc * w10);
+                        atomicAdd(&at32(grad_tex, (unsigned int)(tp.i01 + c)), gc * w01);
+                        atomicAdd(&at32(grad_tex, (unsigned int)(tp.i11 + c)), gc * w11);
                     }
                 }
             }
@@ -589,8 +589,8 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                     lds_add_f64(&s_vacc[slot[kk]][1], sm[3 * kk + 1]);
                     lds_add_f64(&s_vacc[slot[kk]][2], sm[3 * kk + 2]);
                 } else {   // table full: straight to memory
-                    atomicAdd(gp + 4 * (size_t)key + 0, sm[3 * kk]); atomicAdd(gp + 4 * (size_t)key + 1, sm[3 * kk + 1]);
-                    atomicAdd(gp + 4 * (size_t)key + 3, sm[3 * kk + 2]);
+                    atomicAdd(&at32(gp, 4u * (unsigned int)key + 0u), sm[3 * kk]); atomicAdd(&at32(gp, 4u * (unsigned int)key + 1u), sm[3 * kk + 1]);
+                    atomicAdd(&at32(gp, 4u * (unsigned int)key + 3u), sm[3 * kk + 2]);
                 }
             }
         });
@@ -615,7 +615,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
         const int key = s_vkey[slot];
         if (key >= 0 && comp != 2) {      // (x, y, -, w): z receives no gradient
             const float v = (float)s_vacc[slot][comp == 3 ? 2 : comp];
-            if (v != 0.0f) atomicAdd(gp + 4 * (size_t)key + comp, v);
+            if (v != 0.0f) atomicAdd(&at32(gp, 4u * (unsigned int)key + (unsigned int)comp), v);
         }
     }
     if (grad_tex && ox != 0x7fffffff) {
@@ -625,7 +625,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                 const int c = k % CS, cell = k / CS;
                 const int colx = cell % TEXW, row = cell / TEXW;
                 const int gx = wrap_near(ox + colx, Wt, boundary), gy = wrap_near(oy + row, Ht, boundary);   // no division
-                atomicAdd(grad_tex + ((size_t)gy * Wt + gx) * CS + c, v);
+                atomicAdd(&at32(grad_tex, (unsigned int)((gy * Wt + gx) * CS + c)), v);
             }
         }
     }
@@ -987,6 +987,7 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30) && p->H <= 32767 && p->W <= 32767 && p->T < (1 << 24),
                   "texture / resolution / mesh too large for the fused backward (32-bit gather offsets)");
     FPCDR_REQUIRE(!p->occ || p->empty_color, "sparse mode needs empty_color");
+    FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
     hipStream_t st = (hipStream_t)stream;
     FPCDR_REQUIRE(!(p->queued || p->binflags) || p->occ != nullptr, "queued / binflags need the occupancy buffer of fpcdr_render_loss_fwd");
     const uint8_t *binflag = p->binflags ? (const uint8_t *)p->occ + fpcdr_queue_layout_of(p->B, p->H, p->W).occ_binflag : nullptr;

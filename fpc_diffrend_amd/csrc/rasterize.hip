@@ -899,7 +899,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                 const float w = 1.0f - o.x - o.y;
                 const float tu = o.x * q0.x + o.y * q1.x + w * q2.x;
                 const float tv = o.x * q0.y + o.y * q1.y + w * q2.y;
-                const Taps tp = make_taps(tu, tv, sh.Ht, sh.Wt, C, boundary);
+                const Taps tp = make_taps_fast(tu, tv, sh.Ht, sh.Wt, C, boundary);      // (fused paths: wrap / clamp only)
                 for (int c = 0; c < C; ++c) {
                     const float v = bilerp<true>(sh.tex, tp, c, C);      // (the fused entry points require < 2^30 texel values)
                     if (stage) s_col[zy * BIN + zx] = v;
