@@ -290,6 +290,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
     __shared__ double s_tex[TEXH * TEXW * CS];
     __shared__ int s_org[2];            // smallest tap x, y of the bin (unwrapped texel coordinates)
     __shared__ float s_esum[CS];        // gradient arriving at EMPTY pixels' colour (they all sample uv = (0,0))
+    __shared__ float s_fy[BBIN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // pixel k of this thread: row 8 wave + 2 k + (lane >> 5) of the bin; the odd row runs right to left, so that lane 31
     // and lane 32 are vertical neighbours and a triangle's run continues from one row into the next
@@ -336,6 +337,8 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
     }
     if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
     if (tid < CS) s_esum[tid] = 0.0f;
+    // NDC y of the bin's 32 rows: one IEEE division per row instead of one per pixel (and the column's fx once per thread, below)
+    if (tid < BBIN) s_fy[tid] = (2.0f * (float)(by0 + tid) + 1.0f) / (float)H - 1.0f;
     // (both are read only behind the barriers below; in the work-queue form the pop's barriers separate one bin's reads from
     // the next bin's initialisation)
 
@@ -472,6 +475,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
     const int ox = s_org[0], oy = s_org[1];
 
     // ---- pixel phase B: texture backward; (dL/du, dL/dv) of the barycentrics into LDS; triangle set ----
+    const float fx_col = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
     float esum[CS];
 #pragma unroll
     for (int c = 0; c < CS; ++c) esum[c] = 0.0f;
@@ -548,8 +552,8 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
 #else
             {
 #endif
-            const float fx = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
-            const float fy = (2.0f * (float)(by0 + rowk0 + 2 * k) + 1.0f) / (float)H - 1.0f;
+            const float fx = fx_col;
+            const float fy = s_fy[rowk0 + 2 * k];
             float g0[3], g1[3], g2[3];
             shade_pixel_bwd<false>(ld32(pos_img, vk[0]), ld32(pos_img, vk[1]), ld32(pos_img, vk[2]), fx, fy, 2.0f / (float)W, 2.0f / (float)H,
                                    make_float4(gu, gvv, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), g0, g1, g2);
