@@ -847,7 +847,11 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
     const float4 *p = pos + (size_t)b * V;
     Taps empty_tp = {};
     float empty_col[4] = {0.f, 0.f, 0.f, 0.f};
-    if (SHADE) {
+    if (SHADE && QUEUE && C <= 4) {
+        // list form: the colour of an empty pixel was computed once for the call (k_list_count, block 0) -- four scalar loads
+        // instead of a tap set and four texel loads in front of every bin's shading
+        for (int c = 0; c < C; ++c) empty_col[c] = sh.empty_out[c];
+    } else if (SHADE) {
         empty_tp = make_taps(0.0f, 0.0f, sh.Ht, sh.Wt, C, boundary);
         for (int c = 0; c < min(C, 4); ++c) empty_col[c] = bilerp(sh.tex, empty_tp, c, C);
     }
