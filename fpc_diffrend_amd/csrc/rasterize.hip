@@ -120,14 +120,15 @@ __device__ __forceinline__ bool setup_piece(const double (&v)[3][4], int H, int 
     for (int i = 0; i < 3; ++i) {
         const double dw = v[i][3];
         if (!(dw > 0.0)) return false;
-        const double xs = v[i][0] / dw;
-        const double ys = v[i][1] / dw;
+        const double rw = 1.0 / dw;      // (R2: one double division per vertex, not three: k_setup is bound by vector issue)
+        const double xs = v[i][0] * rw;
+        const double ys = v[i][1] * rw;
         const double fx = floor((xs * 0.5 + 0.5) * (double)(W * SUBPIX) + 0.5);
         const double fy = floor((ys * 0.5 + 0.5) * (double)(H * SUBPIX) + 0.5);
         if (!(fabs(fx) <= GUARD) || !(fabs(fy) <= GUARD)) return false;
         X[i] = (long long)fx;
         Y[i] = (long long)fy;
-        zw[i] = v[i][2] / dw;
+        zw[i] = v[i][2] * rw;
     }
     const long long D = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
     if (D == 0) return false;

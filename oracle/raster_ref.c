@@ -21,8 +21,8 @@
  *       point).  The polygon left (3 or 4 vertices, fanned from its first vertex into 1 or 2 pieces) is rasterised piece by
  *       piece under the triangle's OWN index if every polygon vertex has w > 0; otherwise (and for NaNs) the triangle is
  *       dropped.  Float outputs (barycentrics, z/w) always come from the three original vertices;
- *   R2  vertex -> fixed point, 8 sub-pixel bits, in double:
- *         X = floor((x/w * 0.5 + 0.5) * (W*256) + 0.5), same for Y with H;
+ *   R2  vertex -> fixed point, 8 sub-pixel bits, in double, with r = 1.0 / w (one division per vertex):
+ *         X = floor(((x * r) * 0.5 + 0.5) * (W*256) + 0.5), same for Y with H;
  *       dropped if any |X|,|Y| > 2^24 (guard band);
  *   R3  D = (X1-X0)(Y2-Y0) - (Y1-Y0)(X2-X0); D == 0 dropped; back faces are kept
  *       (edge functions are multiplied by sign(D));
@@ -32,7 +32,7 @@
  *       covered iff every E >= 0, where an edge with E == 0 counts only if its
  *       normalised direction (dx,dy) has dy > 0, or dy == 0 and dx < 0;
  *   R6  depth is a float32 plane through the snapped vertices, anchored at vertex 0 (like a
- *       24-bit hardware depth buffer): with zw_i = z_i/w_i in double,
+ *       24-bit hardware depth buffer): with zw_i = z_i * r_i in double,
  *         zA = ((zw1-zw0)(Y2-Y0) - (zw2-zw0)(Y1-Y0)) / D,  zB = ((zw2-zw0)(X1-X0) - (zw1-zw0)(X2-X0)) / D
  *       rounded to float, depth(P) = fmaf(zA, (float)(Px-X0), fmaf(zB, (float)(Py-Y0), (float)zw0));
  *       fragments with depth outside [-1,1] are discarded; the smaller depth wins, ties
@@ -107,14 +107,15 @@ static int setup_triangle(double v[3][4], int H, int W, tri_setup_t *ts) {
     for (int i = 0; i < 3; ++i) {
         double w = v[i][3];
         if (!(w > 0.0)) return 0; /* (also rejects NaN) */
-        double xs = v[i][0] / w;
-        double ys = v[i][1] / w;
+        double rw = 1.0 / w; /* R2: ONE division per vertex; x, y and z are multiplied by the reciprocal */
+        double xs = v[i][0] * rw;
+        double ys = v[i][1] * rw;
         double fx = floor((xs * 0.5 + 0.5) * (double)(W * SUBPIX) + 0.5);
         double fy = floor((ys * 0.5 + 0.5) * (double)(H * SUBPIX) + 0.5);
         if (!(fabs(fx) <= GUARD) || !(fabs(fy) <= GUARD)) return 0; /* R2 */
         X[i] = (int64_t)fx;
         Y[i] = (int64_t)fy;
-        zw[i] = v[i][2] / w;
+        zw[i] = v[i][2] * rw;
     }
     int64_t D = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
     if (D == 0) return 0; /* R3 */
