@@ -33,7 +33,11 @@ __device__ __forceinline__ Shade shade_pixel(float4 v0, float4 v1, float4 v2, fl
     // u = uc / max(uc + vc, 1): the division is by exactly 1 unless rounding pushed the sum past it -- waves without such a
     // pixel skip it (x * (1 / 1) == x, so the values are the same)
     float sc = 1.0f;
-    if (uc + vc > 1.0f) sc = 1.0f / (uc + vc);
+    if (__builtin_amdgcn_ballot_w64(uc + vc > 1.0f) != 0) {      // (a wave vote and an asm the compiler cannot hoist: a plain
+        float sum = uc + vc;                                      //  `if` is if-converted, and every pixel pays the division)
+        asm volatile("; renormalise" : "+v"(sum));
+        if (sum > 1.0f) sc = 1.0f / sum;
+    }
     s.u = uc * sc;
     s.v = vc * sc;
     return s;
@@ -60,8 +64,10 @@ __device__ __forceinline__ void shade_pixel_bwd(float4 v0, float4 v1, float4 v2,
     const float uc = fminf(fmaxf(b0, 0.0f), 1.0f), vc = fminf(fmaxf(b1, 0.0f), 1.0f);
     float guc = g.x, gvc = g.y;
     const float sum = uc + vc;
-    if (sum > 1.0f) {
-        const float s = 1.0f / sum;
+    if (__builtin_amdgcn_ballot_w64(sum > 1.0f) != 0 && sum > 1.0f) {      // (wave vote first: see shade_pixel)
+        float sum_ = sum;
+        asm volatile("; renormalise" : "+v"(sum_));
+        const float s = 1.0f / sum_;
         const float dot = (uc * g.x + vc * g.y) * s * s;
         guc = g.x * s - dot;
         gvc = g.y * s - dot;
