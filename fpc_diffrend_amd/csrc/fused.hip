@@ -869,40 +869,60 @@ __global__ void __launch_bounds__(FIX_NT) k_aa_fix_queue(const int32_t *__restri
     }
 }
 
-// per-image silhouette classification (same arithmetic as k_sil in antialias.hip)
+// per-image silhouette classification (same arithmetic as k_sil in antialias.hip).  The kernel is a chain of gathers with two dozen
+// instructions behind them -- latency, not issue, is its cost -- so a thread classifies its triangle in SIL_NI images: the six
+// indices (own vertices, vertices across the three edges) are loaded once, and the 6 x SIL_NI position gathers are all in flight
+// before the first is used (the vertex across an edge used to be fetched only after the edge's line had been computed).
+#ifndef FPCDR_SIL_NI
+#define FPCDR_SIL_NI 2
+#endif
+constexpr int SIL_NI = FPCDR_SIL_NI;
 __global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               const int32_t *__restrict__ adj, int B, int V, int T, float hw, float hh,
                                               uint8_t *__restrict__ sil) {
-    // grid (triangle chunks, images): a flat thread index would cost every thread a 64-bit division
-    const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    // grid (triangle chunks, groups of SIL_NI images): a flat thread index would cost every thread a 64-bit division
+    const int b0 = blockIdx.y * SIL_NI, t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    const size_t gid = (size_t)b * T + t;
-    const float4 *p = pos + (size_t)b * V;
-    int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
-    unsigned int bits = 0;
+    const int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    const int ad[3] = {adj[3 * t], adj[3 * t + 1], adj[3 * t + 2]};
     bool ok = true;
     for (int k = 0; k < 3; ++k) ok &= (vi[k] >= 0 && vi[k] < V);
-    if (ok) {
-        float qx[3], qy[3], qw[3];
-        for (int k = 0; k < 3; ++k) {
-            const float4 c = p[vi[k]];
-            qx[k] = c.x * hw; qy[k] = c.y * hh; qw[k] = c.w;
-        }
-        for (int e = 0; e < 3; ++e) {
-            const int ad = adj[3 * t + e];
-            if (ad == -1) { bits |= 1u << e; continue; }
-            if (ad < 0 || ad >= V) continue;
-            const int a = (e + 1) % 3, bb = (e + 2) % 3;
-            const float Lx = qy[a] * qw[bb] - qw[a] * qy[bb];
-            const float Ly = qw[a] * qx[bb] - qx[a] * qw[bb];
-            const float Lz = qx[a] * qy[bb] - qy[a] * qx[bb];
-            const float so = Lx * qx[e] + Ly * qy[e] + Lz * qw[e];
-            const float4 c = p[ad];
-            const float sp = Lx * (c.x * hw) + Ly * (c.y * hh) + Lz * c.w;
-            if ((so > 0.0f && sp > 0.0f) || (so < 0.0f && sp < 0.0f)) bits |= 1u << e;
-        }
+    unsigned int idx[6];      // (an index that is not used reads vertex 0)
+    for (int k = 0; k < 3; ++k) {
+        idx[k] = ok ? (unsigned int)vi[k] : 0u;
+        idx[3 + k] = (ad[k] >= 0 && ad[k] < V) ? (unsigned int)ad[k] : 0u;
     }
-    sil[gid] = (uint8_t)bits;
+    float4 c[SIL_NI][6];
+#pragma unroll
+    for (int i = 0; i < SIL_NI; ++i) {
+        const float4 *p = pos + (size_t)min(b0 + i, B - 1) * V;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c[i][k] = ld32(p, idx[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < SIL_NI; ++i) {
+        if (b0 + i >= B) break;
+        unsigned int bits = 0;
+        if (ok) {
+            float qx[3], qy[3], qw[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { qx[k] = c[i][k].x * hw; qy[k] = c[i][k].y * hh; qw[k] = c[i][k].w; }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                if (ad[e] == -1) { bits |= 1u << e; continue; }
+                if (ad[e] < 0 || ad[e] >= V) continue;
+                const int a = (e + 1) % 3, bb = (e + 2) % 3;
+                const float Lx = qy[a] * qw[bb] - qw[a] * qy[bb];
+                const float Ly = qw[a] * qx[bb] - qx[a] * qw[bb];
+                const float Lz = qx[a] * qy[bb] - qy[a] * qx[bb];
+                const float so = Lx * qx[e] + Ly * qy[e] + Lz * qw[e];
+                const float4 o = c[i][3 + e];
+                const float sp = Lx * (o.x * hw) + Ly * (o.y * hh) + Lz * o.w;
+                if ((so > 0.0f && sp > 0.0f) || (so < 0.0f && sp < 0.0f)) bits |= 1u << e;
+            }
+        }
+        sil[(size_t)(b0 + i) * T + t] = (uint8_t)bits;
+    }
 }
 
 }  // namespace
@@ -910,7 +930,7 @@ __global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, co
 // ---- pieces of fpcdr_render_loss_fwd (rasterize.hip) that live in this file; not part of the C ABI ----
 int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, int B, int V, int T, int H, int W, uint8_t *sil,
                      hipStream_t st) {
-    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv(T, 256), B), dim3(256), 0, st, (const float4 *)pos, tri, adj, B, V, T,
+    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv(T, 256), fpcdr_cdiv(B, SIL_NI)), dim3(256), 0, st, (const float4 *)pos, tri, adj, B, V, T,
                        0.5f * (float)W, 0.5f * (float)H, sil);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
@@ -946,7 +966,7 @@ extern "C" int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream
     FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
     FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 32) <= 65535, "image batch / height too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv(p->T, 256), fpcdr_cdiv(p->B, SIL_NI)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil);
     dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 32), p->B);
 #define LAUNCH(CS, SP)                                                                                                         \

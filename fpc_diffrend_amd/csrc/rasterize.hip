@@ -1314,7 +1314,9 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
     const size_t nbins = (size_t)p->B * grid.y * grid.x;
     // (Tried: the empty result of the bins no chunk box touches streamed by a row-wise fill kernel, k_bins on the rest -- 1.5 ms of
     // fill + 1.3 ms for the occupied fifth of the bins, one after the other, against 2.33 ms here: in ONE kernel the memory-bound
-    // empty bins overlap the compute-bound occupied ones.)
+    // empty bins overlap the compute-bound occupied ones.  r3: a stride permutation of each image's bins in dispatch order, so that
+    // occupied and empty bins are in flight together at every moment, changes nothing -- 2.25 ms for strides 0 / n/55 / n/7 / n/1.6:
+    // the long-lived occupied workgroups pile up on the CUs by themselves and the fill shares their 7 slots per CU.)
     hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, p->ranges);
     ShadeArgs sh = {};
