@@ -166,7 +166,19 @@ __global__ void __launch_bounds__(256) k_aa_fwd(const float *__restrict__ color,
     // region hint (plane 1): the pixel's bin and its eight neighbours are empty, so neither the pixel nor any of its four
     // neighbours is covered -- no pair to blend: out = colour, without reading rast (nor colour, when its value there is known)
     const bool skip = x < W && hint && !fpcdr_hint_on(hint, 1, B, H, W, b, ybase, x);
-    const bool live = x < W && !skip;
+    bool live = x < W && !skip;
+    if (live && hint && !fpcdr_hint_on(hint, 0, B, H, W, b, ybase, x)) {
+        // an empty bin beside an occupied one: a pair needs a covered pixel, and pairs are horizontal or vertical, so only the pixels on
+        // a side that FACES an occupied bin can be blended -- a column of the bin, or the wave's rows if they hold the facing row (a
+        // third of the bins whose rast the kernel reads are of this kind)
+        const int cx = x & 31;
+        bool face = false;
+        if (cx == 0 && x > 0) face |= fpcdr_hint_on(hint, 0, B, H, W, b, ybase, x - 1);
+        if (cx == 31 && x + 1 < W) face |= fpcdr_hint_on(hint, 0, B, H, W, b, ybase, x + 1);
+        if ((ybase & 31) == 0 && ybase > 0) face |= fpcdr_hint_on(hint, 0, B, H, W, b, ybase - 1, x);
+        if (((ybase + AROWS) & 31) == 0 && ybase + AROWS < H) face |= fpcdr_hint_on(hint, 0, B, H, W, b, ybase + AROWS, x);
+        live = face;
+    }
     if (filled && flags_zeroed && !__builtin_amdgcn_readfirstlane(__ballot(live) != 0ull)) return;   // nothing left to do for this wave
     float2 mer[AROWS + 2];
 #pragma unroll
@@ -190,6 +202,8 @@ __global__ void __launch_bounds__(256) k_aa_fwd(const float *__restrict__ color,
                 if (empty_color) { for (int c = 0; c < C; ++c) out[off * C + c] = empty_color[c]; }
                 else { for (int c = 0; c < C; ++c) out[off * C + c] = color[off * C + c]; }
             }
+        } else if (x < W && !live) {      // (an empty bin's pixel that no pair can reach)
+            if (filled < 2) { for (int c = 0; c < C; ++c) out[off * C + c] = color[off * C + c]; }
         } else if (x < W) {
             const float2 me = mer[r + 1];
             const int id = (int)me.y;
