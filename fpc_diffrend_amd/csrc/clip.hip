@@ -108,13 +108,20 @@ __global__ void __launch_bounds__(256) k_lap_gather(const float *__restrict__ x,
     }
 #pragma unroll
     for (int d = 0; d < U; ++d) { sx += wgt[d] * gx[d]; sy += wgt[d] * gy[d]; sz += wgt[d] * gz[d]; }
-    if (D > U && nb[U - 1] < V) {
-        for (int d = U; d < D; ++d) {
-            const int n = nbr[(size_t)d * V + v];
-            if (n >= V) break;
-            const float w = mode ? inv_deg[n] : 1.0f;
-            sx += w * xf[3 * n]; sy += w * xf[3 * n + 1]; sz += w * xf[3 * n + 2];
+    // (the rest of a long ring -- the poles -- eight slots at a time as well: one slot per trip is ~100 dependent round trips for the
+    //  two pole threads, 40 us of a launch whose other threads are done after 3)
+    for (int d0 = U; d0 < D && nb[U - 1] < V; d0 += U) {
+#pragma unroll
+        for (int d = 0; d < U; ++d) nb[d] = d0 + d < D ? nbr[(size_t)(d0 + d) * V + v] : V;
+#pragma unroll
+        for (int d = 0; d < U; ++d) {
+            const bool ok = nb[d] < V;
+            const int n = ok ? nb[d] : v;
+            wgt[d] = ok ? (mode ? inv_deg[n] : 1.0f) : 0.0f;
+            gx[d] = xf[3 * n]; gy[d] = xf[3 * n + 1]; gz[d] = xf[3 * n + 2];
         }
+#pragma unroll
+        for (int d = 0; d < U; ++d) { sx += wgt[d] * gx[d]; sy += wgt[d] * gy[d]; sz += wgt[d] * gz[d]; }
     }
     const float s = mode ? 1.0f : inv_deg[v];
     float *o = out + ((size_t)f * V + v) * 3;
