@@ -228,6 +228,60 @@ def test_1080p_sweep_kernels_equal_the_hinted_launch():
         dr._list_hints.clear()
 
 
+def test_cfg3_batch_of_288_images_equals_its_chunks():
+    """The headline batch itself (32 frames x 9 views of 1920 x 1080: 587 520 bins on the lists, launch hints, 17 GB of buffers)
+    against the same images in 8 calls of 36: an image's pixels and vertices are its own, so the loss is the sum of the chunks'
+    (same n_total), the position gradients are those of the chunks (up to the order of the float atomics), and the texture
+    gradient is their sum.  The first
+    288-image call runs without hints (full grids), the second with the counts the first left behind."""
+    import fpc_diffrend_amd.ops as dr
+    from fpc_diffrend_amd import scene
+    nf = 32
+    sc = scene.cfg('cfg3', n_frames=nf)
+    pos, _ = clip_positions(sc, list(range(9)), frames=list(range(nf)))
+    dev = 'cuda'
+    pos = pos.to(dev)
+    B = pos.shape[0]
+    assert B == 288
+    tri, uv, uv_idx = (torch.tensor(a, device=dev) for a in (sc.pos_idx, sc.uv, sc.uv_idx))
+    H, W = sc.resolution
+    g = torch.Generator(device=dev).manual_seed(23)
+    ref = torch.randint(0, 141, (B, H, W), generator=g, dtype=torch.uint8, device=dev)
+    tex0 = torch.tensor(sc.texture, device=dev)
+    n_total = B * H * W * tex0.shape[2]
+    ctx = dr.RasterizeGLContext(device=dev)
+
+    def run(sl):
+        p = pos[sl].clone().requires_grad_(True)
+        t = tex0.clone().requires_grad_(True)
+        loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref[sl], sc.resolution, n_total=n_total)
+        loss.backward()
+        return loss.detach().double(), p.grad, t.grad.double()
+
+    dr._list_hints.clear()
+    try:
+        whole_first = run(slice(0, B))                 # no hints yet: every list kernel at its full grid
+        whole = run(slice(0, B))                       # sized from the first call's counts
+        torch.cuda.synchronize()
+        # (gradients are sums of float atomics: equal up to the order of the additions)
+        assert abs(float(whole[0]) - float(whole_first[0])) <= 1e-9 * abs(float(whole[0]))
+        assert rel_l2(whole[1].double().cpu(), whole_first[1].double().cpu()) < 1e-6
+        assert rel_l2(whole[2].cpu(), whole_first[2].cpu()) < 1e-6
+        loss = torch.zeros((), dtype=torch.float64, device=dev)
+        gtex = torch.zeros_like(whole[2])
+        for c in range(0, B, 36):
+            l, gp, gt = run(slice(c, c + 36))
+            loss += l
+            gtex += gt
+            assert rel_l2(gp.double().cpu(), whole[1][c:c + 36].double().cpu()) < 1e-6, c      # an image's vertices see only its own pixels
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(whole[0])) <= 2e-6 * abs(float(whole[0]))
+        assert rel_l2(gtex.cpu(), whole[2].cpu()) < 1e-5
+        assert torch.isfinite(whole[1]).all() and float(whole[1].abs().max()) > 0
+    finally:
+        dr._list_hints.clear()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # bin-shaped interpolate backward: last bin row with H % 32 in 1..7 (ADVICE r2: rows past the image were read)
 # ---------------------------------------------------------------------------------------------------------------------
