@@ -17,7 +17,7 @@ OCC_BIN = 32         # FPCDR_OCC_BIN
 ABI_VERSION = 6
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
-BOUNDARY = {'wrap': 0, 'clamp': 1, 'zero': 2}    # 'zero': dr.texture only (the fused render paths take wrap / clamp)
+BOUNDARY = {'wrap': 0, 'clamp': 1, 'zero': 2}
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int32

@@ -491,9 +491,12 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
             for (int c = 0; c < CS; ++c) esum[c] += go[k][c];
         } else if (any[k]) {
             const int t = pt[k];
-            const Taps tp = make_taps_fast(tu[k], tv[k], Ht, Wt, CS, boundary);      // (wrap / clamp only here)
-            const float w00 = (1.0f - tp.fx) * (1.0f - tp.fy), w10 = tp.fx * (1.0f - tp.fy);
-            const float w01 = (1.0f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
+            // ('zero': the general tap routine with validity bits; a tap in the padding reads 0 and receives nothing -- its weight is
+            //  zeroed, so the window cell or the clamped address it maps to gets + 0)
+            const Taps tp = boundary == FPCDR_BOUNDARY_ZERO ? make_taps(tu[k], tv[k], Ht, Wt, CS, boundary)
+                                                            : make_taps_fast(tu[k], tv[k], Ht, Wt, CS, boundary);
+            const float w00 = (tp.valid & 1u) ? (1.0f - tp.fx) * (1.0f - tp.fy) : 0.0f, w10 = (tp.valid & 2u) ? tp.fx * (1.0f - tp.fy) : 0.0f;
+            const float w01 = (tp.valid & 4u) ? (1.0f - tp.fx) * tp.fy : 0.0f, w11 = (tp.valid & 8u) ? tp.fx * tp.fy : 0.0f;
             bool in_win = false;
             int lx = 0, ly = 0;
             if (t >= 0 && grad_tex) {
@@ -507,6 +510,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                 const float gc = go[k][c];
                 float t00, t10, t01, t11;
                 load_taps<true>(tex, tp, c, CS, t00, t10, t01, t11);      // (the entry point requires < 2^30 texel values)
+                mask_taps(tp, t00, t10, t01, t11);
                 gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
                 gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
 #ifdef FPCDR_ABL_NOTEX
@@ -608,10 +612,10 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
     if (grad_tex && tid < CS && s_esum[tid] != 0.0f) {   // the empty pixels' share, once per workgroup
         const Taps tp0 = make_taps(0.0f, 0.0f, Ht, Wt, CS, boundary);
         const float e = s_esum[tid];
-        atomicAdd(grad_tex + tp0.i00 + tid, e * ((1.0f - tp0.fx) * (1.0f - tp0.fy)));
-        atomicAdd(grad_tex + tp0.i10 + tid, e * (tp0.fx * (1.0f - tp0.fy)));
-        atomicAdd(grad_tex + tp0.i01 + tid, e * ((1.0f - tp0.fx) * tp0.fy));
-        atomicAdd(grad_tex + tp0.i11 + tid, e * (tp0.fx * tp0.fy));
+        if (tp0.valid & 1u) atomicAdd(grad_tex + tp0.i00 + tid, e * ((1.0f - tp0.fx) * (1.0f - tp0.fy)));
+        if (tp0.valid & 2u) atomicAdd(grad_tex + tp0.i10 + tid, e * (tp0.fx * (1.0f - tp0.fy)));
+        if (tp0.valid & 4u) atomicAdd(grad_tex + tp0.i01 + tid, e * ((1.0f - tp0.fx) * tp0.fy));
+        if (tp0.valid & 8u) atomicAdd(grad_tex + tp0.i11 + tid, e * (tp0.fx * tp0.fy));
     }
     // ---- flush: lane = (slot, component), so the four dwords of a vertex are one contiguous 16-byte access ----
     for (int k = tid; k < VSLOTS * 4; k += BWD_NT) {
@@ -1011,7 +1015,8 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30) && p->H <= 32767 && p->W <= 32767 && p->T < (1 << 24),
                   "texture / resolution / mesh too large for the fused backward (32-bit gather offsets)");
     FPCDR_REQUIRE(!p->occ || p->empty_color, "sparse mode needs empty_color");
-    FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
+    FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP || p->boundary_mode == FPCDR_BOUNDARY_ZERO,
+                  "bad boundary mode");
     hipStream_t st = (hipStream_t)stream;
     FPCDR_REQUIRE(!(p->queued || p->binflags) || p->occ != nullptr, "queued / binflags need the occupancy buffer of fpcdr_render_loss_fwd");
     const uint8_t *binflag = p->binflags ? (const uint8_t *)p->occ + fpcdr_queue_layout_of(p->B, p->H, p->W).occ_binflag : nullptr;

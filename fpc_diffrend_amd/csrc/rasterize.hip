@@ -904,7 +904,9 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                 const float w = 1.0f - o.x - o.y;
                 const float tu = o.x * q0.x + o.y * q1.x + w * q2.x;
                 const float tv = o.x * q0.y + o.y * q1.y + w * q2.y;
-                const Taps tp = make_taps_fast(tu, tv, sh.Ht, sh.Wt, C, boundary);      // (fused paths: wrap / clamp only)
+                // ('zero' takes the general tap routine: its taps carry validity bits, which bilerp masks by)
+                const Taps tp = boundary == FPCDR_BOUNDARY_ZERO ? make_taps(tu, tv, sh.Ht, sh.Wt, C, boundary)
+                                                                : make_taps_fast(tu, tv, sh.Ht, sh.Wt, C, boundary);
                 for (int c = 0; c < C; ++c) {
                     const float v = bilerp<true>(sh.tex, tp, c, C);      // (the fused entry points require < 2^30 texel values)
                     if (stage) s_col[zy * BIN + zx] = v;
@@ -1230,13 +1232,14 @@ __global__ void __launch_bounds__(256) k_render_bwd(const float4 *__restrict__ p
                 const float gc = g[c];
                 float t00, t10, t01, t11;
                 load_taps(tex, tp, c, C, t00, t10, t01, t11);
+                mask_taps(tp, t00, t10, t01, t11);
                 gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
                 gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
-                if (grad_tex && gc != 0.0f) {
-                    atomicAdd(grad_tex + tp.i00 + c, gc * w00);
-                    atomicAdd(grad_tex + tp.i10 + c, gc * w10);
-                    atomicAdd(grad_tex + tp.i01 + c, gc * w01);
-                    atomicAdd(grad_tex + tp.i11 + c, gc * w11);
+                if (grad_tex && gc != 0.0f) {      // (boundary mode 'zero': the padding receives no gradient)
+                    if (tp.valid & 1u) atomicAdd(grad_tex + tp.i00 + c, gc * w00);
+                    if (tp.valid & 2u) atomicAdd(grad_tex + tp.i10 + c, gc * w10);
+                    if (tp.valid & 4u) atomicAdd(grad_tex + tp.i01 + c, gc * w01);
+                    if (tp.valid & 8u) atomicAdd(grad_tex + tp.i11 + c, gc * w11);
                 }
             }
             if (t >= 0 && grad_pos) {
@@ -1358,7 +1361,8 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
                   "sizes must be positive");
     FPCDR_REQUIRE(p->H <= 32767 && p->W <= 32767 && p->B <= 65535, "resolution / batch too large");
     FPCDR_REQUIRE(p->T < (1 << 24), "more than 2^24 triangles (rast stores triangle index + 1 as a float)");
-    FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
+    FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP || p->boundary_mode == FPCDR_BOUNDARY_ZERO,
+                  "bad boundary mode");
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30), "texture too large (the fused paths take < 2^30 texel values)");
     hipStream_t st = (hipStream_t)stream;
     const RasterScratch rs = raster_scratch(p->scratch, p->B, p->T);
@@ -1416,7 +1420,8 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
     FPCDR_REQUIRE(p->H <= 32767 && p->W <= 32767 && p->B <= 65535, "resolution / batch too large");
     FPCDR_REQUIRE(p->T < (1 << 24), "more than 2^24 triangles");
-    FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP, "bad boundary mode");
+    FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP || p->boundary_mode == FPCDR_BOUNDARY_ZERO,
+                  "bad boundary mode");
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30), "texture too large (the fused paths take < 2^30 texel values)");
     hipStream_t st = (hipStream_t)stream;
     int rc = fpcdr_launch_sil(p->pos, p->tri, l->adj, p->B, p->V, p->T, p->H, p->W, l->sil, st);

@@ -257,8 +257,6 @@ def render_textured(glctx, pos, tri, uv, uv_tri, tex, resolution, boundary_mode=
     _check_tensor('tex', tex, torch.float32, 3)
     if uv.shape[1] != 2 or uv_tri.shape != tri.shape or pos.shape[2] != 4 or tri.shape[1] != 3:
         raise ValueError("shapes: pos [B,V,4], tri [T,3], uv [Vt,2], uv_tri [T,3], tex [Ht,Wt,C]")
-    if boundary_mode == 'zero':
-        raise NotImplementedError("the fused render paths take boundary_mode 'wrap' or 'clamp'")
     if boundary_mode not in _lib.BOUNDARY:
         raise ValueError(f"unknown boundary_mode '{boundary_mode}'")
     H, W = int(resolution[0]), int(resolution[1])
@@ -423,8 +421,8 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
         raise ValueError("pixel_objective supports 1, 3 or 4 colour channels")
     if ref_u8.shape != (pos.shape[0], H, W):
         raise ValueError("ref_u8 must have shape [B,H,W]")
-    if boundary_mode not in ('wrap', 'clamp'):
-        raise NotImplementedError("pixel_objective takes boundary_mode 'wrap' or 'clamp'")
+    if boundary_mode not in _lib.BOUNDARY:
+        raise ValueError(f"unknown boundary_mode '{boundary_mode}'")
     tri = tri.contiguous()
     adj = _cached_topology(tri)
     n_total = n_total or pos.shape[0] * H * W * tex.shape[2]

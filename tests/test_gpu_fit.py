@@ -145,7 +145,7 @@ def test_fit_reduces_loss(fused):
     assert np.abs(ft.weights().cpu().numpy() - sc.weights_gt)[act].mean() < w0
 
 
-@pytest.mark.parametrize("C,boundary", [(1, 'wrap'), (3, 'clamp')])
+@pytest.mark.parametrize("C,boundary", [(1, 'wrap'), (3, 'clamp'), (1, 'zero'), (4, 'zero')])
 def test_fused_render_equals_separate_ops(C, boundary):
     """ops.render_textured == rasterize -> interpolate -> texture('linear'): bitwise forward, gradients to tolerance."""
     import fpc_diffrend_amd.ops as dr
@@ -350,7 +350,8 @@ def test_rerender_of_saved_result_matches_the_fit_images(tmp_path):
 
 
 @pytest.mark.parametrize("C,res,boundary,geom", [(1, (150, 200), 'wrap', 'mesh'), (3, (97, 131), 'clamp', 'mesh'), (4, (64, 320), 'wrap', 'mesh'),
-                                                 (1, (97, 131), 'wrap', 'few'), (3, (33, 65), 'wrap', 'few')])
+                                                 (1, (97, 131), 'wrap', 'few'), (3, (33, 65), 'wrap', 'few'),
+                                                 (1, (97, 131), 'zero', 'mesh'), (3, (70, 96), 'zero', 'few')])
 def test_objective_sparse_dense_chain_agree_at_odd_sizes(C, res, boundary, geom):
     """pixel_objective (candidate-based sparse forward, dense forward) == the operator chain + pixel loss when neither
     image side is a multiple of the 32-pixel bin or the 64-pixel flag word, for every channel count it supports.
