@@ -413,8 +413,11 @@ class FitConfig:
     grouped_adam: bool = True       # all ten Adam groups + the quaternion division as one launch (False: torch.optim.Adam(fused=True))
     sparse_objective: bool = True   # the three kernels skip image regions far from any geometry (same result)
     overlap_regularisers: bool = True   # fused path: mesh regularisers on a second stream beside the pixel objective
-    hip_graph: bool = False         # capture forward+backward and the Adam update as two HIP graphs (launch-bound
-                                    # small batches: cfg2 3.2 -> 1.8 ms / step; no gain once a step is GPU-bound)
+    hip_graph: object = False       # capture forward+backward and the Adam update as two HIP graphs (launch-bound
+                                    # small batches: cfg2 3.2 -> 1.8 ms / step; no gain once a step is GPU-bound: the graph
+                                    # cannot use the launch hints).  'auto': graphs when a step draws few enough images for the
+                                    # ~100 launches to cost more than the kernels (images x 32-pixel bins <= GRAPH_AUTO_BINS:
+                                    # the reference's one-image steps, 1.6 -> 0.9 ms; not the 288-image batch)
     shading: str = "texture"        # 'texture' = reference render(); 'vertex' = rasterize + interpolate of a per-vertex
                                     # grey only (BASELINE.json configs[1]: "raster+interp only, no texture")
     log_interval: int = 0           # every n steps one JSON line {it, loss, lr, frames_per_s} (reference print, fit.py:621-623)
@@ -506,7 +509,11 @@ class Fitter:
                   {"params": self.maps_intermediate['local'], 'lr': cfg.lr_base}, {"params": self.t_opt, 'lr': cfg.lr_t},
                   {"params": self.q_opt, 'lr': cfg.lr_q}, {"params": self.per_frame_t, 'lr': cfg.lr_t},
                   {"params": self.per_frame_q, 'lr': cfg.lr_q}, {"params": self.tex_opt, 'lr': cfg.lr_base * cfg.lr_tex_coef}]
-        self.use_graph = bool(cfg.hip_graph)
+        if cfg.hip_graph == 'auto':
+            self.use_graph = self.auto_graph((cfg.frames_per_step or (self.frame_hi - self.frame_lo)) * (cfg.views_per_step or len(self.cam_idxs)),
+                                             self.resolution)
+        else:
+            self.use_graph = bool(cfg.hip_graph)
         if self.use_graph:      # replayed updates read the learning rates from device memory
             for g in groups:
                 g['lr'] = torch.tensor(float(g['lr']), dtype=torch.float32, device=dev)
@@ -797,6 +804,13 @@ class Fitter:
             print(line, flush=True)
 
     GRAPH_WARMUP = 3    # eager steps before capture (allocator, Adam state, scratch and topology caches settle)
+    GRAPH_AUTO_BINS = 40960   # hip_graph='auto': graphs up to this many 32 x 32-pixel bins per step (~20 images of 1920 x 1080)
+
+    @classmethod
+    def auto_graph(cls, images_per_step, resolution):
+        """The rule of FitConfig.hip_graph='auto'."""
+        H, W = resolution
+        return images_per_step * ((H + 31) // 32) * ((W + 31) // 32) <= cls.GRAPH_AUTO_BINS
 
     def _step_graphed(self, frame_ids, view_ids=None):
         """Replay (capturing first if needed) graph A = forward + backward into fixed gradient buffers and graph B =

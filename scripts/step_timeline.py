@@ -16,6 +16,6 @@ busy_end = t0
 print("step: %.3f ms between two k_setup launches, %d dispatches" % ((rows[b][0] - t0) / 1e6, b - a))
 for s, e, n, q in rows[a:b]:
     gap = (s - busy_end) / 1e3
-    if (e - s) > 3000 or gap > 5:
+    if (e - s) > 3000 or gap > 5 or "--all" in sys.argv:
         print("%9.1f us  +%8.1f us  gap %7.1f  q%-3s %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap, q, n))
     busy_end = max(busy_end, e)

@@ -649,6 +649,10 @@ def test_reference_run_shape_one_random_view_per_step(fused):
         traj[graph] = losses
         if graph:
             assert ft._graphs is not None
+            # hip_graph='auto' picks graphs for a one-image step and eager launches for a batch of many large images
+            assert fit.Fitter(sc, fit.FitConfig(hip_graph='auto', **kw), device='cuda').use_graph
+            assert fit.Fitter.auto_graph(1, (1600, 1200)) and fit.Fitter.auto_graph(9, (1080, 1920))
+            assert not fit.Fitter.auto_graph(288, (1080, 1920))
     a, b = np.asarray(traj[False]), np.asarray(traj[True])
     assert np.isfinite(b).all() and len(set(np.round(a, 3))) > 6          # different images from step to step
     assert np.allclose(a, b, rtol=2e-3), (a, b)
