@@ -566,22 +566,30 @@ class Fitter:
         view_ids: positions in cam_idxs of the cameras of this step (a device index tensor; None = all of them)."""
         if view_ids is not None:
             cams = self.cam_sel.index_select(0, view_ids)
-            return _mvp_func.apply(self.q_opt.index_select(0, cams), self.t_opt.index_select(0, cams), self.per_frame_q[frame_ids],
-                                   self.per_frame_t[frame_ids], self.proj.index_select(0, view_ids), self.t_mv.index_select(0, view_ids))
+            return _mvp_func.apply(self.q_opt.index_select(0, cams), self.t_opt.index_select(0, cams), self._take(self.per_frame_q, 0, frame_ids),
+                                   self._take(self.per_frame_t, 0, frame_ids), self.proj.index_select(0, view_ids), self.t_mv.index_select(0, view_ids))
         all_cams = self.cam_idxs == list(range(self.q_opt.shape[0]))    # no gather (and no sort in its backward) then
         q_c, t_c = (self.q_opt, self.t_opt) if all_cams else (self.q_opt[self.cam_sel], self.t_opt[self.cam_sel])
-        return _mvp_func.apply(q_c, t_c, self.per_frame_q[frame_ids], self.per_frame_t[frame_ids], self.proj, self.t_mv)
+        return _mvp_func.apply(q_c, t_c, self._take(self.per_frame_q, 0, frame_ids), self._take(self.per_frame_t, 0, frame_ids), self.proj, self.t_mv)
+
+    @staticmethod
+    def _take(t, dim, ids):
+        """t[ids] / t[:, ids] for a slice or an index tensor.  A tensor goes through index_select: its backward is ONE index_add
+        launch where advanced indexing sorts the indices first (seven launches) -- a fifth of a one-image step's launches."""
+        if isinstance(ids, slice):
+            return t[ids] if dim == 0 else t[:, ids]
+        return t.index_select(dim, ids)
 
     def vertices(self, frame_ids, iteration=None):
         """Blended vertex buffers [Fb,3V] for a batch of frames (fit.py:555-562).  The reference multiplies by a
         one-hot frame vector (fit.py:536, 115-116); M e_f is column f of M, so the batch selects columns
         (a slice -- no copy -- when the frames are a contiguous range)."""
         if self.cfg.mode in ('prior', 'combined'):
-            mapped = torch.matmul(self.maps_intermediate['local'], self.maps['local'][:, frame_ids])     # [K,Fb]
+            mapped = torch.matmul(self.maps_intermediate['local'], self._take(self.maps['local'], 1, frame_ids))     # [K,Fb]
             out = blend_batched(self.v_base, self.datasets['local'], mapped.t())
             if self.cfg.mode == 'prior':
                 return out
-        basis = torch.matmul(self.m2, self.m1[:, frame_ids])                                             # [F,Fb]
+        basis = torch.matmul(self.m2, self._take(self.m1, 1, frame_ids))                                             # [F,Fb]
         if self.cfg.mode == 'free':
             return blend_batched(self.v_base, self.m3, basis.t())
         return out + 0.5 * blend_batched(None, self.m3, basis.t())    # learned_coefficient=0.5, fit.py:562
@@ -694,10 +702,10 @@ class Fitter:
         if cfg.weight_normalconsistency:
             reg = reg + cfg.weight_normalconsistency * mesh_normal_consistency(vtx_pos_split, self.topo)
         if cfg.regularize_correctives and cfg.mode == 'combined' and i > cfg.max_iter / 2:
-            basis = torch.matmul(self.m2, self.m1[:, frame_ids])
+            basis = torch.matmul(self.m2, self._take(self.m1, 1, frame_ids))
             reg = reg + torch.mean(torch.matmul(self.m3, basis) ** 2)
         if cfg.regularize_prior and cfg.mode == 'prior':
-            mi = torch.matmul(self.maps_intermediate['local'], self.maps['local'][:, frame_ids])
+            mi = torch.matmul(self.maps_intermediate['local'], self._take(self.maps['local'], 1, frame_ids))
             reg = reg + torch.mean(mi ** 2)
         reg = reg / self.world
         if side is not None:
