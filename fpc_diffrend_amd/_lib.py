@@ -14,7 +14,7 @@ MAX_ATTR = 32
 MAX_MIP = 16
 LOSS_SLOTS = 256
 OCC_BIN = 32         # FPCDR_OCC_BIN
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
 BOUNDARY = {'wrap': 0, 'clamp': 1, 'zero': 2}
@@ -149,6 +149,8 @@ SYMBOLS = {
     "fpcdr_mvp_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "fpcdr_mvp_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "fpcdr_laplacian_gather": (_int, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "fpcdr_laplacian_penalty_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, ctypes.c_float, _i, _i, _i, _p]),
+    "fpcdr_laplacian_penalty_bwd": (_int, [_p, _p, _p, _p, _p, _p, ctypes.c_float, _i, _i, _i, _p]),
     "fpcdr_blend_fwd": (_int, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_blend_bwd_w": (_int, [_p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_blend_bwd_basis": (_int, [_p, _p, _p, _i, _i, _i, _p]),

@@ -83,6 +83,34 @@ __global__ void __launch_bounds__(256) k_clip_bwd_mvp(const float *__restrict__ 
 //   mode 0 (forward):   out[f][v] = inv_deg[v] * sum_n x[f][n] - x[f][v]            (L x,   L = D^-1 A - I)
 //   mode 1 (backward):  out[f][v] = sum_n inv_deg[n] * x[f][n] - x[f][v]            (L^T x, L^T = A D^-1 - I)
 // nbr [V,D] holds neighbour indices, entries >= V are padding.  Both directions are gathers: no atomics.
+// One vertex's ring sum: sum over the ring of w_n * fetch(n), w_n = inv_deg[n] (mode 1) or 1 (mode 0).
+// slot-major table: consecutive threads read consecutive entries; a vertex's ring is stored front to back, so the
+// first pad ends it (a UV sphere has two poles of degree ~100 among vertices of degree 6).  Eight slots are
+// fetched together and their neighbours gathered together: the kernel is a chain of dependent loads otherwise
+// (one slot per trip is ~100 dependent round trips for the two pole threads, 40 us of a launch whose other threads are done after 3).
+template <typename Fetch>
+__device__ __forceinline__ void ring_sum(const int32_t *__restrict__ nbr, const float *__restrict__ inv_deg, int V, int D, int mode, int v,
+                                         Fetch fetch, float &sx, float &sy, float &sz) {
+    constexpr int U = 8;
+    sx = 0.f; sy = 0.f; sz = 0.f;
+    int nb[U];
+    nb[U - 1] = 0;
+    for (int d0 = 0; d0 < D && (d0 == 0 || nb[U - 1] < V); d0 += U) {
+#pragma unroll
+        for (int d = 0; d < U; ++d) nb[d] = d0 + d < D ? nbr[(size_t)(d0 + d) * V + v] : V;
+        float wgt[U], gx[U], gy[U], gz[U];
+#pragma unroll
+        for (int d = 0; d < U; ++d) {
+            const bool ok = nb[d] < V;
+            const int n = ok ? nb[d] : v;
+            wgt[d] = ok ? (mode ? inv_deg[n] : 1.0f) : 0.0f;
+            fetch(n, gx[d], gy[d], gz[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < U; ++d) { sx += wgt[d] * gx[d]; sy += wgt[d] * gy[d]; sz += wgt[d] * gz[d]; }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_lap_gather(const float *__restrict__ x, const int32_t *__restrict__ nbr,
                                                     const float *__restrict__ inv_deg, int V, int D, int mode,
                                                     float *__restrict__ out) {
@@ -90,42 +118,90 @@ __global__ void __launch_bounds__(256) k_lap_gather(const float *__restrict__ x,
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     const float *xf = x + (size_t)f * V * 3;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    // slot-major table: consecutive threads read consecutive entries; a vertex's ring is stored front to back, so the
-    // first pad ends it (a UV sphere has two poles of degree ~100 among vertices of degree 6).  The first eight slots
-    // are fetched together and their neighbours gathered together: the kernel is a chain of dependent loads otherwise.
-    constexpr int U = 8;
-    int nb[U];
-#pragma unroll
-    for (int d = 0; d < U; ++d) nb[d] = d < D ? nbr[(size_t)d * V + v] : V;
-    float wgt[U], gx[U], gy[U], gz[U];
-#pragma unroll
-    for (int d = 0; d < U; ++d) {
-        const bool ok = nb[d] < V;
-        const int n = ok ? nb[d] : v;
-        wgt[d] = ok ? (mode ? inv_deg[n] : 1.0f) : 0.0f;
-        gx[d] = xf[3 * n]; gy[d] = xf[3 * n + 1]; gz[d] = xf[3 * n + 2];
-    }
-#pragma unroll
-    for (int d = 0; d < U; ++d) { sx += wgt[d] * gx[d]; sy += wgt[d] * gy[d]; sz += wgt[d] * gz[d]; }
-    // (the rest of a long ring -- the poles -- eight slots at a time as well: one slot per trip is ~100 dependent round trips for the
-    //  two pole threads, 40 us of a launch whose other threads are done after 3)
-    for (int d0 = U; d0 < D && nb[U - 1] < V; d0 += U) {
-#pragma unroll
-        for (int d = 0; d < U; ++d) nb[d] = d0 + d < D ? nbr[(size_t)(d0 + d) * V + v] : V;
-#pragma unroll
-        for (int d = 0; d < U; ++d) {
-            const bool ok = nb[d] < V;
-            const int n = ok ? nb[d] : v;
-            wgt[d] = ok ? (mode ? inv_deg[n] : 1.0f) : 0.0f;
-            gx[d] = xf[3 * n]; gy[d] = xf[3 * n + 1]; gz[d] = xf[3 * n + 2];
-        }
-#pragma unroll
-        for (int d = 0; d < U; ++d) { sx += wgt[d] * gx[d]; sy += wgt[d] * gy[d]; sz += wgt[d] * gz[d]; }
-    }
+    float sx, sy, sz;
+    ring_sum(nbr, inv_deg, V, D, mode, v, [&](int n, float &a, float &b, float &c) { a = xf[3 * n]; b = xf[3 * n + 1]; c = xf[3 * n + 2]; },
+             sx, sy, sz);
     const float s = mode ? 1.0f : inv_deg[v];
     float *o = out + ((size_t)f * V + v) * 3;
     o[0] = s * sx - xf[3 * v]; o[1] = s * sy - xf[3 * v + 1]; o[2] = s * sz - xf[3 * v + 2];
+}
+
+// The Laplacian term of the reference's objective (fit.py:581: weight * mesh_laplacian_smoothing(mesh)^2, one mesh per step; a batch
+// takes the mean of the squares) as ONE launch each way instead of a gather and a dozen torch kernels:
+//   per_f = mean_v || (L x_f)_v ||,   value = weight / F * sum_f per_f^2.
+// Forward: every workgroup adds its vertices' norms to its mesh's double accumulator; the LAST workgroup to finish (a ticket
+// counter behind a fence) forms the value, stores per_f for the backward and zeroes accumulators and ticket for the next call.
+__global__ void __launch_bounds__(256) k_lap_penalty_fwd(const float *__restrict__ x, const int32_t *__restrict__ nbr,
+                                                         const float *__restrict__ inv_deg, int F, int V, int D, float weight,
+                                                         float *__restrict__ lap, double *__restrict__ acc, unsigned int *__restrict__ ticket,
+                                                         float *__restrict__ per, float *__restrict__ out) {
+    __shared__ double s_part[4];
+    __shared__ unsigned int s_ticket;
+    const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    float nrm = 0.0f;
+    if (v < V) {
+        const float *xf = x + (size_t)f * V * 3;
+        float sx, sy, sz;
+        ring_sum(nbr, inv_deg, V, D, 0, v, [&](int n, float &a, float &b, float &c) { a = xf[3 * n]; b = xf[3 * n + 1]; c = xf[3 * n + 2]; },
+                 sx, sy, sz);
+        const float s = inv_deg[v];
+        const float lx = s * sx - xf[3 * v], ly = s * sy - xf[3 * v + 1], lz = s * sz - xf[3 * v + 2];
+        float *o = lap + ((size_t)f * V + v) * 3;
+        o[0] = lx; o[1] = ly; o[2] = lz;
+        nrm = sqrtf(lx * lx + ly * ly + lz * lz);
+    }
+    const float ws = wave_sum_dpp(nrm);
+    if (lane == 0) s_part[wave] = (double)ws;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[f], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+        __threadfence();
+        s_ticket = atomicAdd(ticket, 1u);
+    }
+    __syncthreads();
+    if (s_ticket != gridDim.x * gridDim.y - 1) return;
+    __threadfence();
+    double tot = 0.0;
+    for (int i = threadIdx.x; i < F; i += blockDim.x) {
+        const double p = __hip_atomic_load(&acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (double)V;
+        per[i] = (float)p;
+        tot += p * p;
+        acc[i] = 0.0;
+    }
+    // block sum of doubles: through LDS (F is small)
+    __shared__ double s_tot[256];
+    s_tot[threadIdx.x] = tot;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) s_tot[threadIdx.x] += s_tot[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = (float)((double)weight * s_tot[0] / (double)F); *ticket = 0u; }
+}
+
+// Backward: d value / d x = L^T y,  y_v = c_f * lap_v / ||lap_v||,  c_f = upstream * weight * 2 per_f / (F V)  (0 where lap_v = 0,
+// as torch's norm does); y is formed on the fly from the saved Laplacian inside the transposed gather.
+__global__ void __launch_bounds__(256) k_lap_penalty_bwd(const float *__restrict__ lap, const int32_t *__restrict__ nbr,
+                                                         const float *__restrict__ inv_deg, const float *__restrict__ per,
+                                                         const float *__restrict__ upstream, int F, int V, int D, float weight,
+                                                         float *__restrict__ grad_x) {
+    const int f = blockIdx.y;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float *lf = lap + (size_t)f * V * 3;
+    const float cf = upstream[0] * weight * 2.0f * per[f] / ((float)F * (float)V);
+    auto y = [&](int n, float &a, float &b, float &c) {
+        const float lx = lf[3 * n], ly = lf[3 * n + 1], lz = lf[3 * n + 2];
+        const float nr = sqrtf(lx * lx + ly * ly + lz * lz);
+        const float s = nr > 0.0f ? cf / nr : 0.0f;
+        a = s * lx; b = s * ly; c = s * lz;
+    };
+    float sx, sy, sz, yx, yy, yz;
+    ring_sum(nbr, inv_deg, V, D, 1, v, y, sx, sy, sz);
+    y(v, yx, yy, yz);
+    float *o = grad_x + ((size_t)f * V + v) * 3;
+    o[0] = sx - yx; o[1] = sy - yy; o[2] = sz - yz;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -267,6 +343,29 @@ extern "C" int fpcdr_laplacian_gather(const float *x, const int32_t *nbr, const 
     FPCDR_REQUIRE(F > 0 && V > 0 && D > 0 && F <= 65535, "bad sizes");
     hipLaunchKernelGGL(k_lap_gather, dim3(fpcdr_cdiv(V, 256), F), dim3(256), 0, (hipStream_t)stream, x, nbr, inv_deg, V, D,
                        transpose ? 1 : 0, out);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_laplacian_penalty_fwd(const float *x, const int32_t *nbr, const float *inv_deg, float *lap, void *acc, float *per,
+                                           float *out, float weight, int32_t F, int32_t V, int32_t D, void *stream) {
+    FPCDR_REQUIRE(x && nbr && inv_deg && lap && acc && per && out, "null pointer");
+    FPCDR_REQUIRE(F > 0 && V > 0 && D > 0 && F <= 65535, "bad sizes");
+    FPCDR_REQUIRE(((size_t)acc & 7) == 0, "acc must be 8-byte aligned");
+    // acc: F doubles + one 8-byte slot for the ticket, zero on entry and zero again when the call has run
+    hipLaunchKernelGGL(k_lap_penalty_fwd, dim3(fpcdr_cdiv(V, 256), F), dim3(256), 0, (hipStream_t)stream, x, nbr, inv_deg, F, V, D, weight,
+                       lap, (double *)acc, (unsigned int *)((double *)acc + F), per, out);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_laplacian_penalty_bwd(const float *lap, const int32_t *nbr, const float *inv_deg, const float *per,
+                                           const float *upstream, float *grad_x, float weight, int32_t F, int32_t V, int32_t D,
+                                           void *stream) {
+    FPCDR_REQUIRE(lap && nbr && inv_deg && per && upstream && grad_x, "null pointer");
+    FPCDR_REQUIRE(F > 0 && V > 0 && D > 0 && F <= 65535, "bad sizes");
+    hipLaunchKernelGGL(k_lap_penalty_bwd, dim3(fpcdr_cdiv(V, 256), F), dim3(256), 0, (hipStream_t)stream, lap, nbr, inv_deg, per, upstream,
+                       F, V, D, weight, grad_x);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }

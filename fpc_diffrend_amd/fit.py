@@ -299,6 +299,41 @@ def mesh_laplacian_smoothing(verts, topo, per_mesh=False):
     return per if per_mesh else per.mean()
 
 
+class _laplacian_penalty(torch.autograd.Function):
+    """weight * mean_f (mean_v ||(L x_f)_v||)^2 in one launch each way (fpcdr_laplacian_penalty_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, verts, nbr32, inv_deg, weight):
+        if not verts.is_cuda:
+            raise RuntimeError("the mesh regularisers run on the GPU only (fpcdr_laplacian_penalty_fwd); there is no CPU fallback")
+        x = verts.contiguous()
+        F, V, _ = x.shape
+        lap = torch.empty_like(x)
+        acc = torch.zeros(F + 1, dtype=torch.float64, device=x.device)      # (the call leaves it zero; a fresh one keeps calls independent)
+        per = torch.empty(F, dtype=torch.float32, device=x.device)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        _lib.call("fpcdr_laplacian_penalty_fwd", _ptr(x), _ptr(nbr32), _ptr(inv_deg), _ptr(lap), _ptr(acc), _ptr(per), _ptr(out),
+                  float(weight), F, V, nbr32.shape[0], _stream())
+        ctx.save_for_backward(lap, nbr32, inv_deg, per)
+        ctx.weight = float(weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lap, nbr32, inv_deg, per = ctx.saved_tensors
+        F, V, _ = lap.shape
+        gx = torch.empty_like(lap)
+        _lib.call("fpcdr_laplacian_penalty_bwd", _ptr(lap), _ptr(nbr32), _ptr(inv_deg), _ptr(per), _ptr(g.to(torch.float32).contiguous()),
+                  _ptr(gx), ctx.weight, F, V, nbr32.shape[0], _stream())
+        return gx, None, None, None
+
+
+def laplacian_penalty(verts, topo, weight):
+    """weight * mean over the meshes of verts [F,V,3] of mesh_laplacian_smoothing(mesh)^2 -- the reference's term (fit.py:581 squares
+    the value of the ONE mesh of its step) -- as two launches per step instead of a gather and fifteen torch kernels."""
+    return _laplacian_penalty.apply(verts, topo.nbr32, topo.inv_deg, weight)
+
+
 def mesh_normal_consistency(verts, topo):
     """pytorch3d.loss.mesh_normal_consistency restated (reference fit.py:582; weight 0 in main.py:40): for every edge
     shared by exactly two faces, 1 - cos of the angle between the two face normals (oriented by the faces' own vertex
@@ -698,7 +733,8 @@ class Fitter:
             reg = reg + cfg.weight_meshedge * mesh_edge_loss(vtx_pos_split, self.topo, 0.1)
         if cfg.weight_laplacian:
             # the reference squares the value of ONE mesh per step (fit.py:581): a batch is the mean of the squares
-            reg = reg + cfg.weight_laplacian * (mesh_laplacian_smoothing(vtx_pos_split, self.topo, per_mesh=True) ** 2).mean()
+            reg = reg + (laplacian_penalty(vtx_pos_split, self.topo, cfg.weight_laplacian) if cfg.fused_loss else
+                         cfg.weight_laplacian * (mesh_laplacian_smoothing(vtx_pos_split, self.topo, per_mesh=True) ** 2).mean())
         if cfg.weight_normalconsistency:
             reg = reg + cfg.weight_normalconsistency * mesh_normal_consistency(vtx_pos_split, self.topo)
         if cfg.regularize_correctives and cfg.mode == 'combined' and i > cfg.max_iter / 2:

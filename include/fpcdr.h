@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FPCDR_ABI_VERSION 6
+#define FPCDR_ABI_VERSION 7
 
 enum {
     FPCDR_OK = 0,
@@ -375,6 +375,16 @@ int fpcdr_mvp_bwd(const float *proj, const float *t_mv, const float *q_cam, cons
  * back and padded with indices >= V; inv_deg [V].                                                              */
 int fpcdr_laplacian_gather(const float *x, const int32_t *nbr, const float *inv_deg, float *out, int32_t F, int32_t V, int32_t D,
                            int32_t transpose, void *stream);
+
+/* The Laplacian term of the objective in one launch each way (reference fit.py:581 squares pytorch3d's mesh_laplacian_smoothing of
+ * the ONE mesh of its step; a batch takes the mean of the squares):
+ *   per[f] = mean_v || (L x_f)_v ||,   out[0] = weight / F * sum_f per[f]^2,   L = D^-1 A - I as in fpcdr_laplacian_gather.
+ * lap [F,V,3] and per [F] are saved for the backward call.  acc: (F + 1) * 8 bytes, 8-byte aligned, ZERO on entry; the call leaves
+ * it zero again.  Backward: grad_x [F,V,3] = upstream[0] * d out / d x (overwritten, not accumulated). */
+int fpcdr_laplacian_penalty_fwd(const float *x, const int32_t *nbr, const float *inv_deg, float *lap, void *acc, float *per, float *out,
+                                float weight, int32_t F, int32_t V, int32_t D, void *stream);
+int fpcdr_laplacian_penalty_bwd(const float *lap, const int32_t *nbr, const float *inv_deg, const float *per, const float *upstream,
+                                float *grad_x, float weight, int32_t F, int32_t V, int32_t D, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* blend -- V = v_base + Bmat . w     reference fit.py:115-122 (prior), :58-62 (free)            */

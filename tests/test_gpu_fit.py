@@ -226,6 +226,48 @@ def test_laplacian_gather_form_matches_dense():
     assert rel_l2(v1.grad, v2.grad) < 1e-5
 
 
+def test_laplacian_penalty_one_launch_matches_the_torch_chain():
+    """fit.laplacian_penalty (fpcdr_laplacian_penalty_fwd / _bwd: value by the last workgroup, transposed gather of the normalised
+    Laplacian) == weight * mean_f mesh_laplacian_smoothing(mesh f)^2 through the gather kernel and torch, value and gradient; with
+    an upstream factor, with vertices whose Laplacian is exactly zero (a flat regular patch: torch's norm passes 0 there), for one
+    mesh and for several, and twice in a row (the call leaves its accumulators zeroed)."""
+    from fpc_diffrend_amd import fit, scene
+    sc = scene.cfg('cfg1', n_frames=3)
+    topo = fit.MeshTopology(sc.pos_idx, sc.n_vertices, 'cuda')
+    g = torch.Generator().manual_seed(5)
+    for F in (1, 3):
+        verts = (torch.tensor(sc.v_base).reshape(1, -1, 3) + 0.1 * torch.randn(F, sc.n_vertices, 3, generator=g)).cuda()
+        for rep in range(2):
+            v1 = verts.clone().requires_grad_(True)
+            l1 = fit.laplacian_penalty(v1, topo, 7.5)
+            (l1 * 0.3).backward()
+            v2 = verts.clone().requires_grad_(True)
+            l2 = 7.5 * (fit.mesh_laplacian_smoothing(v2, topo, per_mesh=True) ** 2).mean()
+            (l2 * 0.3).backward()
+            assert abs(float(l1) - float(l2)) < 2e-6 * abs(float(l2)), (F, rep, float(l1), float(l2))
+            assert rel_l2(v1.grad, v2.grad) < 1e-5, (F, rep)
+    # a flat 5 x 5 grid: the interior vertices' uniform Laplacian is exactly zero
+    n = 5
+    idx = lambda i, j: i * n + j
+    faces = [[idx(i, j), idx(i + 1, j), idx(i, j + 1)] for i in range(n - 1) for j in range(n - 1)] + \
+            [[idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)] for i in range(n - 1) for j in range(n - 1)]
+    topo2 = fit.MeshTopology(np.asarray(faces, dtype=np.int32), n * n, 'cuda')
+    # (a symmetric neighbourhood is needed for a zero: shear the grid so that the six-ring of an interior vertex is centred)
+    xy = torch.tensor([[float(i) + 0.5 * j, float(j), 0.0] for i in range(n) for j in range(n)])[None].cuda()
+    deg = torch.tensor([int((topo2.nbr[v] < n * n).sum()) for v in range(n * n)])
+    v1 = xy.clone().requires_grad_(True)
+    l1 = fit.laplacian_penalty(v1, topo2, 2.0)
+    l1.backward()
+    v2 = xy.clone().requires_grad_(True)
+    l2 = 2.0 * (fit.mesh_laplacian_smoothing(v2, topo2, per_mesh=True) ** 2).mean()
+    l2.backward()
+    lap = fit._uniform_laplacian.apply(xy, topo2.nbr, topo2.nbr32, topo2.inv_deg)
+    assert int((lap.norm(dim=2) == 0).sum()) >= 1 and int(deg.max()) == 6
+    assert torch.isfinite(v1.grad).all()
+    assert abs(float(l1) - float(l2)) < 2e-6 * abs(float(l2))
+    assert rel_l2(v1.grad, v2.grad) < 1e-5
+
+
 def test_transform_clip_kernel_matches_torch():
     from fpc_diffrend_amd import camera, fit
     g = torch.Generator().manual_seed(0)
