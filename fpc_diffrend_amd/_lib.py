@@ -36,7 +36,8 @@ class RasterizeBwd(ctypes.Structure):
 class RenderFwd(ctypes.Structure):
     _fields_ = [("pos", _p), ("tri", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i), ("scratch", _p),
                 ("uv", _p), ("uv_tri", _p), ("Vt", _i), ("tex", _p), ("Ht", _i), ("Wt", _i), ("C", _i),
-                ("boundary_mode", _i), ("rast", _p), ("color", _p), ("tri_uv", _p), ("occ", _p), ("empty_color", _p)]
+                ("boundary_mode", _i), ("rast", _p), ("color", _p), ("tri_uv", _p), ("occ", _p), ("empty_color", _p),
+                ("mip", _i), ("n_levels", _i), ("tex_mip", _p * MAX_MIP)]
 
 
 class RenderBwd(ctypes.Structure):
@@ -57,7 +58,8 @@ class RenderAaBwd(ctypes.Structure):
                 ("grad_aa", _p), ("sil", _p), ("flags", _p), ("occ", _p), ("empty_color", _p), ("B", _i), ("V", _i), ("T", _i),
                 ("H", _i), ("W", _i),
                 ("Vt", _i), ("Ht", _i), ("Wt", _i), ("C", _i), ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p),
-                ("tri_uv", _p), ("upstream", _p), ("queued", _i), ("cap_bwd", _i), ("binflags", _i)]
+                ("tri_uv", _p), ("upstream", _p), ("queued", _i), ("cap_bwd", _i), ("binflags", _i),
+                ("mip", _i), ("n_levels", _i), ("tex_mip", _p * MAX_MIP), ("grad_tex_mip", _p * MAX_MIP)]
 
 
 class InterpolateFwd(ctypes.Structure):

@@ -271,7 +271,18 @@ __device__ __noinline__ void uv_indirect(const float2 *__restrict__ uv, const in
     q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]];
 }
 
-template <int CS, int BMODE = -1>      // BMODE >= 0: the texture boundary mode as a compile-time constant
+// mip levels of the MIP instantiation (the reference's enable_mip branch): level l = tex[l - 1] / grad[l - 1], level 0 = tex / grad_tex
+struct MipArgs {
+    const float *tex[FPCDR_MAX_MIP];
+    float *grad[FPCDR_MAX_MIP];
+    int n_levels;
+};
+
+// BMODE >= 0: the texture boundary mode as a compile-time constant.  MIP: the texture lookup was 'linear-mipmap-linear' with the
+// footprint from the barycentrics' screen derivatives (bins_body<MIP>, rasterize.hip): texel gradients go to every level's buffer
+// with global atomics (no LDS window), and the footprint's gradient flows through the derivative outputs of the rasteriser
+// (shade_pixel_bwd<true>), as in the chain interpolate(diff_attrs='all') -> texture(uv_da) of the separate operators.
+template <int CS, int BMODE = -1, bool MIP = false>
 __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, const int byi,
                                                        const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
@@ -283,7 +294,8 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                                                        int B, int V, int T, int H,
                                                        int W, int Ht, int Wt, int boundary_arg, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
-                                                       const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
+                                                       const float *__restrict__ upstream, const uint8_t *__restrict__ binflag,
+                                                       const MipArgs *ma = nullptr) {
     const int boundary = BMODE >= 0 ? BMODE : boundary_arg;
     __shared__ int s_vkey[VSLOTS];
     __shared__ double s_vacc[VSLOTS][3];           // (x, y, w) sums per vertex slot, in double: ds_add_f64 (common.h lds_add_f64)
@@ -461,7 +473,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                     tu[k] = r.x * q0.x + r.y * q1.x + w * q2.x;
                     tv[k] = r.x * q0.y + r.y * q1.y + w * q2.y;
                     pt[k] = t;
-                    if (grad_tex) {
+                    if (grad_tex && !MIP) {
                         ux0 = min(ux0, (int)floorf(prep_coord(tu[k], boundary) * (float)Wt - 0.5f));
                         uy0 = min(uy0, (int)floorf(prep_coord(tv[k], boundary) * (float)Ht - 0.5f));
                     }
@@ -483,12 +495,54 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
     for (int k = 0; k < BWD_NPX; ++k) {
         int tkey = -1;
         float gu = 0.f, gvv = 0.f;
+        int mip_vk[3] = {0, 0, 0};
+        float mip_g9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (any[k] && pt[k] < 0) {
             // an empty pixel sampled uv = (0,0): same four texels, same weights for every one of them.  Scattering each
             // with global atomics made thousands of rim pixels per image queue on four addresses (0.6 ms); they are
             // summed per workgroup instead and scattered once, below.
 #pragma unroll
             for (int c = 0; c < CS; ++c) esum[c] += go[k][c];
+        } else if (MIP && any[k]) {
+            // ---- mip-mapped lookup: footprint from the rasteriser's derivatives (recomputed: rast_db is never stored), both levels'
+            // texels and the level's fraction; the footprint's gradient goes back through the derivatives ----
+            const int t = pt[k];
+            float2 q0, q1, q2;
+            if (tri_uv) { const UV3 tq = ld32(reinterpret_cast<const UV3 *>(tri_uv), t); q0 = tq.q0; q1 = tq.q1; q2 = tq.q2; }
+            else uv_indirect(uv, uv_tri, t, q0, q1, q2);
+            const I3 ti = ld32(reinterpret_cast<const I3 *>(tri), t);
+            const float4 p0 = ld32(pos_img, ti.a), p1 = ld32(pos_img, ti.b), p2 = ld32(pos_img, ti.c);
+            const float fx = fx_col, fy = s_fy[rowk0 + 2 * k];
+            const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
+            const Shade sd = shade_pixel(p0, p1, p2, fx, fy, sx, sy);
+            const float e0x = q0.x - q2.x, e0y = q0.y - q2.y, e1x = q1.x - q2.x, e1y = q1.y - q2.y;
+            const float4 da = make_float4(sd.dudx * e0x + sd.dvdx * e1x, sd.dudy * e0x + sd.dvdy * e1x,
+                                          sd.dudx * e0y + sd.dvdx * e1y, sd.dudy * e0y + sd.dvdy * e1y);
+            TexLevels lv;
+            lv.tex[0] = tex; lv.grad[0] = grad_tex;
+            for (int l = 1; l <= FPCDR_MAX_MIP; ++l) { lv.tex[l] = ma->tex[l - 1]; lv.grad[l] = ma->grad[l - 1]; }
+            float gch[CS];
+#pragma unroll
+            for (int c = 0; c < CS; ++c) gch[c] = go[k][c];
+            float gtu = 0.f, gtv = 0.f, gbias = 0.f;
+            float4 gda = make_float4(0.f, 0.f, 0.f, 0.f);
+            mip_sample_bwd(lv, 0, ma->n_levels, make_float2(tu[k], tv[k]), true, da, 0.0f, Ht, Wt, CS, true, boundary, gch, gtu, gtv, gda, gbias);
+            const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu[k] >= 0.0f && tu[k] <= 1.0f)) ? 0.0f : 1.0f;
+            const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv[k] >= 0.0f && tv[k] <= 1.0f)) ? 0.0f : 1.0f;
+            gtu *= mu; gtv *= mv;
+            gu = gtu * e0x + gtv * e0y;
+            gvv = gtu * e1x + gtv * e1y;
+            // interpolate backward of the derivative outputs: d (uv_da) / d (rast_db)
+            const float4 gdb = make_float4(gda.x * e0x + gda.z * e0y, gda.y * e0x + gda.w * e0y, gda.x * e1x + gda.z * e1y, gda.y * e1x + gda.w * e1y);
+            if (gu != 0.0f || gvv != 0.0f || gdb.x != 0.0f || gdb.y != 0.0f || gdb.z != 0.0f || gdb.w != 0.0f) {
+                tkey = t;
+                mip_vk[0] = ti.a; mip_vk[1] = ti.b; mip_vk[2] = ti.c;
+                float g0[3], g1[3], g2[3];
+                shade_pixel_bwd<true>(p0, p1, p2, fx, fy, sx, sy, make_float4(gu, gvv, 0.f, 0.f), gdb, g0, g1, g2);
+                mip_g9[0] = g0[0]; mip_g9[1] = g0[1]; mip_g9[2] = g0[2];
+                mip_g9[3] = g1[0]; mip_g9[4] = g1[1]; mip_g9[5] = g1[2];
+                mip_g9[6] = g2[0]; mip_g9[7] = g2[1]; mip_g9[8] = g2[2];
+            }
         } else if (any[k]) {
             const int t = pt[k];
             // ('zero': the general tap routine with validity bits; a tap in the padding reads 0 and receives nothing -- its weight is
@@ -548,7 +602,11 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
         // ---- vertices: chain through the barycentrics, sum per run of equal triangle, tails add into the LDS table ----
         float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         int vk[3] = {0, 0, 0};   // the triangle's vertex ids: the run's last lane emits with them
-        if (tkey >= 0) {
+        if (MIP) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) gv9[q] = mip_g9[q];
+            vk[0] = mip_vk[0]; vk[1] = mip_vk[1]; vk[2] = mip_vk[2];
+        } else if (tkey >= 0) {
             { const I3 ti = ld32(reinterpret_cast<const I3 *>(tri), tkey); vk[0] = ti.a; vk[1] = ti.b; vk[2] = ti.c; }
 #ifdef FPCDR_ABL_NOSHADEBWD
             gv9[0] = gu; gv9[4] = gvv;
@@ -654,6 +712,22 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
                                                        const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
     render_aa_bwd_body<CS, BMODE>(blockIdx.z, blockIdx.x, blockIdx.y, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ, empty_color,
                            B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag);
+}
+
+// grid form of the MIP instantiation (one colour channel, boundary mode at run time)
+__global__ void __launch_bounds__(BWD_NT) k_render_aa_bwd_mip(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                       const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
+                                                       const float *__restrict__ tex, const float4 *__restrict__ rast,
+                                                       const float *__restrict__ color, const float *__restrict__ g_aa,
+                                                       const uint8_t *__restrict__ sil,
+                                                       const unsigned long long *__restrict__ flags,
+                                                       const uint16_t *__restrict__ occ, const float *__restrict__ empty_color,
+                                                       int B, int V, int T, int H,
+                                                       int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
+                                                       float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
+                                                       const float *__restrict__ upstream, const uint8_t *__restrict__ binflag, MipArgs ma) {
+    render_aa_bwd_body<1, -1, true>(blockIdx.z, blockIdx.x, blockIdx.y, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ, empty_color,
+                                    B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag, &ma);
 }
 
 // list form (after fpcdr_render_loss_fwd): one workgroup per entry of the list k_occ_window built (own or a 4-neighbour bin
@@ -1020,6 +1094,24 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
     hipStream_t st = (hipStream_t)stream;
     FPCDR_REQUIRE(!(p->queued || p->binflags) || p->occ != nullptr, "queued / binflags need the occupancy buffer of fpcdr_render_loss_fwd");
     const uint8_t *binflag = p->binflags ? (const uint8_t *)p->occ + fpcdr_queue_layout_of(p->B, p->H, p->W).occ_binflag : nullptr;
+    if (p->mip) {      // the reference's enable_mip branch: one colour channel, one workgroup per bin
+        FPCDR_REQUIRE(p->C == 1, "the mip-mapped fused objective takes one colour channel");
+        FPCDR_REQUIRE(p->n_levels >= 0 && p->n_levels <= FPCDR_MAX_MIP, "bad n_levels");
+        MipArgs ma;
+        for (int lvl = 0; lvl < FPCDR_MAX_MIP; ++lvl) {
+            ma.tex[lvl] = lvl < p->n_levels ? p->tex_mip[lvl] : nullptr;
+            ma.grad[lvl] = (lvl < p->n_levels && p->grad_tex) ? p->grad_tex_mip[lvl] : nullptr;
+            FPCDR_REQUIRE(lvl >= p->n_levels || (ma.tex[lvl] && (!p->grad_tex || ma.grad[lvl])), "missing mip level");
+        }
+        ma.n_levels = p->n_levels;
+        dim3 grid(fpcdr_cdiv(p->W, BBIN), fpcdr_cdiv(p->H, BBIN), p->B);
+        hipLaunchKernelGGL(k_render_aa_bwd_mip, grid, dim3(BWD_NT), 0, st, (const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, p->tex,
+                           (const float4 *)p->rast, p->color, p->grad_aa, p->sil, (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B,
+                           p->V, p->T, p->H, p->W, p->Ht, p->Wt, p->boundary_mode, p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream,
+                           binflag, ma);
+        FPCDR_CHECK_LAUNCH();
+        return FPCDR_OK;
+    }
     if (p->queued) {
         const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W);
         const int32_t *hdr = (const int32_t *)((const char *)p->occ + q.occ_hdr);      // [0] = number of listed bins

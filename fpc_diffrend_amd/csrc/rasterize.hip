@@ -501,6 +501,9 @@ struct ShadeArgs {
     double *loss_sum;        // [FPCDR_LOSS_SLOTS]
     float bg, color_scale, grad_scale;
     uint8_t *op_hint;        // operator form (fpcdr_rasterize_fwd): out, plane 0 of the region hint, or null
+    // MIP instantiations (the reference's enable_mip branch, fit.py:153-155): tex = level 0, mip[l - 1] = level l of the chain
+    const float *mip[FPCDR_MAX_MIP];
+    int n_levels;
 };
 
 // texture coordinates of triangle t through the index buffer (callers that did not pre-gather uv[uv_tri])
@@ -513,7 +516,7 @@ __device__ __noinline__ void uv_indirect(const float2 *__restrict__ uv, const in
 // CS / BMODE: channel count and texture boundary mode as compile-time constants (0 / -1 = read them from ShadeArgs); the list
 // kernels of the objective are instantiated for the reference's case (one channel, 'wrap'), which strips the channel loops, the
 // index scaling and the mode branches from the ~200 instructions a shaded pixel costs
-template <bool WRITE_DB, bool SHADE, bool LOSS, bool QUEUE, int CS = 0, int BMODE = -1>
+template <bool WRITE_DB, bool SHADE, bool LOSS, bool QUEUE, int CS = 0, int BMODE = -1, bool MIP = false>
 __device__ __forceinline__ void bins_body(const int b, const int bxi, const int byi, const int OX, const int OY,
                                           const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                           int V, int T, int H, int W, const TriRec *__restrict__ recs,
@@ -904,14 +907,25 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                 const float w = 1.0f - o.x - o.y;
                 const float tu = o.x * q0.x + o.y * q1.x + w * q2.x;
                 const float tv = o.x * q0.y + o.y * q1.y + w * q2.y;
-                // ('zero' takes the general tap routine: its taps carry validity bits, which bilerp masks by)
-                const Taps tp = boundary == FPCDR_BOUNDARY_ZERO ? make_taps(tu, tv, sh.Ht, sh.Wt, C, boundary)
-                                                                : make_taps_fast(tu, tv, sh.Ht, sh.Wt, C, boundary);
-                for (int c = 0; c < C; ++c) {
-                    const float v = bilerp<true>(sh.tex, tp, c, C);      // (the fused entry points require < 2^30 texel values)
+                auto put = [&](int c, float v) {
                     if (stage) s_col[zy * BIN + zx] = v;
                     else sh.color[off * C + c] = v;
                     if (LOSS && c == 0) col0[k] = v;
+                };
+                if (MIP) {
+                    // interpolate(..., rast_db, diff_attrs='all') + texture('linear-mipmap-linear') (fit.py:153-155), same arithmetic as
+                    // the stand-alone kernels: the footprint of the texture coordinate from the barycentrics' screen derivatives
+                    const float e0x = q0.x - q2.x, e0y = q0.y - q2.y, e1x = q1.x - q2.x, e1y = q1.y - q2.y;
+                    const float4 da = make_float4(d.x * e0x + d.z * e1x, d.y * e0x + d.w * e1x, d.x * e0y + d.z * e1y, d.y * e0y + d.w * e1y);
+                    TexLevels lv;
+                    lv.tex[0] = sh.tex;
+                    for (int l = 1; l <= FPCDR_MAX_MIP; ++l) lv.tex[l] = sh.mip[l - 1];
+                    mip_sample_fwd(lv, 0, sh.n_levels, make_float2(tu, tv), true, da, 0.0f, sh.Ht, sh.Wt, C, true, boundary, put);
+                } else {
+                // ('zero' takes the general tap routine: its taps carry validity bits, which bilerp masks by)
+                const Taps tp = boundary == FPCDR_BOUNDARY_ZERO ? make_taps(tu, tv, sh.Ht, sh.Wt, C, boundary)
+                                                                : make_taps_fast(tu, tv, sh.Ht, sh.Wt, C, boundary);
+                for (int c = 0; c < C; ++c) put(c, bilerp<true>(sh.tex, tp, c, C));      // (the fused entry points require < 2^30 texel values)
                 }
             } else if (stage) {
                 s_col[zy * BIN + zx] = empty_col[0];
@@ -1058,7 +1072,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
 #ifndef FPCDR_BINSQ_WPE
 #define FPCDR_BINSQ_WPE
 #endif
-template <bool WRITE_DB, bool SHADE, bool LOSS, int CS = 0, int BMODE = -1>
+template <bool WRITE_DB, bool SHADE, bool LOSS, int CS = 0, int BMODE = -1, bool MIP = false>
 __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
                                               int OX, int OY, fpcdr_bin_decode dc,
                                               const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
@@ -1071,7 +1085,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t 
     const int lin = __builtin_amdgcn_readfirstlane(list[item]);
     int b, byi, bxi;
     fpcdr_decode_bin(lin, dc, b, byi, bxi);
-    bins_body<WRITE_DB, SHADE, LOSS, true, CS, BMODE>(b, bxi, byi, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox, rast, rast_db, sh);
+    bins_body<WRITE_DB, SHADE, LOSS, true, CS, BMODE, MIP>(b, bxi, byi, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox, rast, rast_db, sh);
 }
 
 // strided form: entries first, first + gridDim.x, ... of the list.  The loop variable is scalar by construction, so the loop
@@ -1079,7 +1093,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t 
 // between two barriers -- made LLVM's structurizer wrap the barrier pair in a second loop level, and waves repeated
 // barriers out of step; and the body inlined into a loop runs ~25 % slower than stand-alone -- 150 spilled SGPRs --, which
 // is why this form only sweeps up what the hinted launch above did not reach.)
-template <bool WRITE_DB, bool SHADE, bool LOSS>
+template <bool WRITE_DB, bool SHADE, bool LOSS, bool MIP = false>
 __global__ void __launch_bounds__(256) FPCDR_BINSQ_WPE k_bins_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
                                               int first, int OX, int OY, fpcdr_bin_decode dc,
                                               const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
@@ -1092,7 +1106,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINSQ_WPE k_bins_queue(const int32_
         const int lin = __builtin_amdgcn_readfirstlane(list[item]);
         int b, byi, bxi;
         fpcdr_decode_bin(lin, dc, b, byi, bxi);
-        bins_body<WRITE_DB, SHADE, LOSS, true>(b, bxi, byi, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox, rast, rast_db, sh);
+        bins_body<WRITE_DB, SHADE, LOSS, true, 0, -1, MIP>(b, bxi, byi, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox, rast, rast_db, sh);
         __syncthreads();     // the next bin's first LDS writes must not overtake this bin's last LDS reads
     }
 }
@@ -1364,6 +1378,7 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
     FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP || p->boundary_mode == FPCDR_BOUNDARY_ZERO,
                   "bad boundary mode");
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30), "texture too large (the fused paths take < 2^30 texel values)");
+    FPCDR_REQUIRE(!p->mip, "the mip-mapped lookup is part of fpcdr_render_loss_fwd only");
     hipStream_t st = (hipStream_t)stream;
     const RasterScratch rs = raster_scratch(p->scratch, p->B, p->T);
     TriRec *recs = rs.recs;
@@ -1423,6 +1438,14 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP || p->boundary_mode == FPCDR_BOUNDARY_ZERO,
                   "bad boundary mode");
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30), "texture too large (the fused paths take < 2^30 texel values)");
+    if (p->mip) {
+        FPCDR_REQUIRE(p->C == 1, "the mip-mapped fused objective takes one colour channel");
+        FPCDR_REQUIRE(p->n_levels >= 0 && p->n_levels <= FPCDR_MAX_MIP, "bad n_levels");
+        for (int lvl = 1; lvl <= p->n_levels; ++lvl) {
+            FPCDR_REQUIRE(p->tex_mip[lvl - 1] != nullptr, "missing mip level");
+            FPCDR_REQUIRE(!((p->Ht >> (lvl - 1)) & 1) && !((p->Wt >> (lvl - 1)) & 1), "mip levels need even sizes");
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     int rc = fpcdr_launch_sil(p->pos, p->tri, l->adj, p->B, p->V, p->T, p->H, p->W, l->sil, st);
     if (rc) return rc;
@@ -1455,10 +1478,18 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
                     occ_raw, p->empty_color, (const float2 *)p->tri_uv,
                     l->sil, l->ref, l->grad_aa, cmask, (unsigned long long *)(cm + q.cm_edges), l->loss_sum, l->bg, l->color_scale,
                     l->grad_scale};
+    if (p->mip) {
+        for (int lvl = 0; lvl < FPCDR_MAX_MIP; ++lvl) sh.mip[lvl] = lvl < p->n_levels ? p->tex_mip[lvl] : nullptr;
+        sh.n_levels = p->n_levels;
+    }
     // hinted single-shot launch + strided sweep of the rest (l->cap_bins <= 0: no hint, one workgroup per possible entry)
     const fpcdr_bin_decode dc = fpcdr_make_bin_decode(OX, OY);
     const int cap_bins = (l->cap_bins > 0 && (size_t)l->cap_bins < nbins) ? l->cap_bins : (int)nbins;
-    if (p->C == 1 && p->boundary_mode == FPCDR_BOUNDARY_WRAP)     // the reference's case, with both as compile-time constants
+    if (p->mip)
+        hipLaunchKernelGGL((k_bins_list<false, true, true, 1, -1, true>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY, dc,
+                       (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
+                       (float4 *)nullptr, sh);
+    else if (p->C == 1 && p->boundary_mode == FPCDR_BOUNDARY_WRAP)     // the reference's case, with both as compile-time constants
         hipLaunchKernelGGL((k_bins_list<false, true, true, 1, FPCDR_BOUNDARY_WRAP>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY, dc,
                        (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
                        (float4 *)nullptr, sh);
@@ -1466,10 +1497,16 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
         hipLaunchKernelGGL((k_bins_list<false, true, true>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY, dc,
                        (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
                        (float4 *)nullptr, sh);
-    if ((size_t)cap_bins < nbins)
-        hipLaunchKernelGGL((k_bins_queue<false, true, true>), dim3(FPCDR_SWEEP_WGS), dim3(256), 0, st, bin_list, n_bins, cap_bins, OX, OY, dc,
-                           (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
-                           (float4 *)nullptr, sh);
+    if ((size_t)cap_bins < nbins) {
+        if (p->mip)
+            hipLaunchKernelGGL((k_bins_queue<false, true, true, true>), dim3(FPCDR_SWEEP_WGS), dim3(256), 0, st, bin_list, n_bins, cap_bins, OX, OY, dc,
+                               (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
+                               (float4 *)nullptr, sh);
+        else
+            hipLaunchKernelGGL((k_bins_queue<false, true, true>), dim3(FPCDR_SWEEP_WGS), dim3(256), 0, st, bin_list, n_bins, cap_bins, OX, OY, dc,
+                               (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
+                               (float4 *)nullptr, sh);
+    }
     hipLaunchKernelGGL(k_list_count<true>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, p->occ,
                        (const float *)nullptr, 0, 0, 0, 0, (float *)nullptr);
     hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, n_fix, hdr_bwd);

@@ -17,29 +17,6 @@ namespace {
 
 constexpr int TROWS = 8;   // rows per thread of the forward kernel (divides the 32-row hint bin)
 
-struct TexLevels {
-    const float *tex[FPCDR_MAX_MIP + 1];
-    float *grad[FPCDR_MAX_MIP + 1];
-};
-
-// level of detail from the uv footprint; returns the unclamped level, outputs the pieces the backward needs
-struct Lod { float level, l2, rt, df, bq, dudx, dudy, dvdx, dvdy; };
-
-__device__ __forceinline__ Lod compute_lod(float4 d, int Ht, int Wt, float bias) {
-    Lod L;
-    L.dudx = d.x * (float)Wt; L.dudy = d.y * (float)Wt; L.dvdx = d.z * (float)Ht; L.dvdy = d.w * (float)Ht;
-    const float A = L.dudx * L.dudx + L.dudy * L.dudy;
-    const float Bq = L.dudx * L.dvdx + L.dudy * L.dvdy;
-    const float Cc = L.dvdx * L.dvdx + L.dvdy * L.dvdy;
-    const float tr = 0.5f * (A + Cc);
-    L.df = 0.5f * (A - Cc);
-    L.bq = Bq;
-    L.rt = sqrtf(L.df * L.df + Bq * Bq + 1e-30f);
-    L.l2 = tr + L.rt;
-    L.level = 0.5f * log2f(fmaxf(L.l2, 1e-30f)) + bias;
-    return L;
-}
-
 // the texture's value at uv = (0,0) (what every empty pixel of the fit loop samples): out [C]
 __global__ void k_tex_empty(TexLevels lv, int Ht, int Wt, int C, int filter, int boundary, float *__restrict__ out) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -97,32 +74,9 @@ __global__ void __launch_bounds__(256) k_tex_fwd(TexLevels lv, int n_levels, con
             const float *tx = lv.tex[0] + (size_t)b * Ht * Wt * C;
             for (int c = 0; c < C; ++c) o[c] = bilerp(tx, t, c, C);
         } else {
-            float level = bias ? bias[i] : 0.0f;
-            if (uv_da) level = compute_lod(uv_da[i], Ht, Wt, level).level;
-            level = fminf(fmaxf(level, 0.0f), (float)n_levels);
-            int l0;
-            float fl = 0.0f;
-            if (filter == FPCDR_FILTER_LINEAR_MIPMAP_NEAREST) {
-                l0 = min((int)floorf(level + 0.5f), n_levels);
-            } else {
-                l0 = min((int)floorf(level), n_levels);
-                fl = level - (float)l0;
-            }
-            const int h0 = Ht >> l0, w0 = Wt >> l0;
-            const Taps t0 = make_taps(q.x, q.y, h0, w0, C, boundary);
-            const float *tx0 = lv.tex[l0] + (size_t)b * h0 * w0 * C;
-            if (filter == FPCDR_FILTER_LINEAR_MIPMAP_NEAREST) {
-                for (int c = 0; c < C; ++c) o[c] = bilerp(tx0, t0, c, C);
-            } else {
-                const int l1 = min(l0 + 1, n_levels);
-                const int h1 = Ht >> l1, w1 = Wt >> l1;
-                const Taps t1 = make_taps(q.x, q.y, h1, w1, C, boundary);
-                const float *tx1 = lv.tex[l1] + (size_t)b * h1 * w1 * C;
-                for (int c = 0; c < C; ++c) {
-                    const float c0 = bilerp(tx0, t0, c, C), c1 = bilerp(tx1, t1, c, C);
-                    o[c] = c0 + (c1 - c0) * fl;
-                }
-            }
+            const float4 da = uv_da ? uv_da[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            mip_sample_fwd(lv, (size_t)b, n_levels, q, uv_da != nullptr, da, bias ? bias[i] : 0.0f, Ht, Wt, C,
+                           filter == FPCDR_FILTER_LINEAR_MIPMAP_LINEAR, boundary, [&](int c, float v) { o[c] = v; });
         }
     }
 }
@@ -149,26 +103,6 @@ __global__ void __launch_bounds__(256) k_tex_fwd_bin1(const float *__restrict__ 
     o.z = bilerp(tex, make_taps(c.x, c.y, Ht, Wt, 1, boundary), 0, 1);
     o.w = bilerp(tex, make_taps(c.z, c.w, Ht, Wt, 1, boundary), 0, 1);
     out4[i / 4] = o;
-}
-
-// scatter dy * weight into the four taps of one level and return (d out / d fx, d out / d fy) summed over channels
-__device__ __forceinline__ void taps_bwd(const float *tx, float *gtx, const Taps &t, const float *g, float scale, int C,
-                                         float &gfx, float &gfy) {
-    const float w00 = (1.0f - t.fx) * (1.0f - t.fy), w10 = t.fx * (1.0f - t.fy), w01 = (1.0f - t.fx) * t.fy, w11 = t.fx * t.fy;
-    for (int c = 0; c < C; ++c) {
-        const float gc = g[c] * scale;
-        float t00, t10, t01, t11;
-        load_taps(tx, t, c, C, t00, t10, t01, t11);
-        mask_taps(t, t00, t10, t01, t11);
-        gfx += gc * ((t10 - t00) * (1.0f - t.fy) + (t11 - t01) * t.fy);
-        gfy += gc * ((t01 + (t11 - t01) * t.fx) - (t00 + (t10 - t00) * t.fx));
-        if (gtx && gc != 0.0f) {      // (boundary mode 'zero': the padding receives no gradient)
-            if (t.valid & 1u) atomicAdd(gtx + t.i00 + c, gc * w00);
-            if (t.valid & 2u) atomicAdd(gtx + t.i10 + c, gc * w10);
-            if (t.valid & 4u) atomicAdd(gtx + t.i01 + c, gc * w01);
-            if (t.valid & 8u) atomicAdd(gtx + t.i11 + c, gc * w11);
-        }
-    }
 }
 
 __global__ void __launch_bounds__(256) k_tex_bwd(TexLevels lv, int n_levels, const float2 *__restrict__ uv,
@@ -211,51 +145,10 @@ __global__ void __launch_bounds__(256) k_tex_bwd(TexLevels lv, int n_levels, con
                 taps_bwd(lv.tex[0] + img, lv.grad[0] ? lv.grad[0] + img : nullptr, t, g, 1.0f, C, gfx, gfy);
                 guv = make_float2(gfx * (float)Wt * mu, gfy * (float)Ht * mv);
             } else {
-                float raw = bias ? bias[i] : 0.0f;
-                Lod L;
-                if (uv_da) { L = compute_lod(uv_da[i], Ht, Wt, raw); raw = L.level; }
-                const float level = fminf(fmaxf(raw, 0.0f), (float)n_levels);
-                int l0;
-                float fl = 0.0f;
-                const bool trilinear = (filter == FPCDR_FILTER_LINEAR_MIPMAP_LINEAR);
-                if (!trilinear) {
-                    l0 = min((int)floorf(level + 0.5f), n_levels);
-                } else {
-                    l0 = min((int)floorf(level), n_levels);
-                    fl = level - (float)l0;
-                }
-                const int h0 = Ht >> l0, w0 = Wt >> l0;
-                const Taps t0 = make_taps(q.x, q.y, h0, w0, C, boundary);
-                const size_t img0 = (size_t)b * h0 * w0 * C;
-                float gfx = 0.f, gfy = 0.f;
-                taps_bwd(lv.tex[l0] + img0, lv.grad[l0] ? lv.grad[l0] + img0 : nullptr, t0, g, 1.0f - fl, C, gfx, gfy);
-                float gu = gfx * (float)w0, gv = gfy * (float)h0;
-                if (trilinear) {
-                    const int l1 = min(l0 + 1, n_levels);
-                    const int h1 = Ht >> l1, w1 = Wt >> l1;
-                    const Taps t1 = make_taps(q.x, q.y, h1, w1, C, boundary);
-                    const size_t img1 = (size_t)b * h1 * w1 * C;
-                    float gfx1 = 0.f, gfy1 = 0.f;
-                    taps_bwd(lv.tex[l1] + img1, lv.grad[l1] ? lv.grad[l1] + img1 : nullptr, t1, g, fl, C, gfx1, gfy1);
-                    gu += gfx1 * (float)w1;
-                    gv += gfy1 * (float)h1;
-                    // d out / d fl = sum_c g_c (c1 - c0);  level clamp passes gradient inside [0, n_levels]
-                    float gfl = 0.f;
-                    for (int c = 0; c < C; ++c) gfl += g[c] * (bilerp(lv.tex[l1] + img1, t1, c, C) - bilerp(lv.tex[l0] + img0, t0, c, C));
-                    const float glevel = (raw >= 0.0f && raw <= (float)n_levels) ? gfl : 0.0f;
-                    gbias = glevel;
-                    if (uv_da) {
-                        // level = 0.5 log2(max(l2, eps)) + bias ; l2 = tr + rt ; rt = sqrt(df^2 + bq^2 + eps)
-                        const float gl2 = (L.l2 >= 1e-30f) ? glevel * 0.5f / (L.l2 * 0.6931471805599453f) : 0.0f;
-                        const float gdf = gl2 * L.df / L.rt, gbq = gl2 * L.bq / L.rt;
-                        const float gA = 0.5f * gl2 + 0.5f * gdf, gC = 0.5f * gl2 - 0.5f * gdf;
-                        const float g_dudx = 2.0f * L.dudx * gA + L.dvdx * gbq;
-                        const float g_dudy = 2.0f * L.dudy * gA + L.dvdy * gbq;
-                        const float g_dvdx = 2.0f * L.dvdx * gC + L.dudx * gbq;
-                        const float g_dvdy = 2.0f * L.dvdy * gC + L.dudy * gbq;
-                        gda = make_float4(g_dudx * (float)Wt, g_dudy * (float)Wt, g_dvdx * (float)Ht, g_dvdy * (float)Ht);
-                    }
-                }
+                const float4 da = uv_da ? uv_da[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float gu, gv;
+                mip_sample_bwd(lv, (size_t)b, n_levels, q, uv_da != nullptr, da, bias ? bias[i] : 0.0f, Ht, Wt, C,
+                               filter == FPCDR_FILTER_LINEAR_MIPMAP_LINEAR, boundary, g, gu, gv, gda, gbias);
                 guv = make_float2(gu * mu, gv * mv);
             }
         }

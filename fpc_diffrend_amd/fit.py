@@ -711,8 +711,9 @@ class Fitter:
         ref = ref.reshape(Fb * Nc, *self.resolution)
         C = self.tex_opt.shape[2]
         n_total = n_img_global * self.resolution[0] * self.resolution[1] * C
-        one_shot = (cfg.fused_objective and cfg.fused_render and cfg.fused_loss and not cfg.enable_mip and C in (1, 3, 4)
-                    and cfg.shading == 'texture')
+        # (the mip branch of the reference's render(), fit.py:153-155, runs inside the same kernels for one colour channel)
+        one_shot = (cfg.fused_objective and cfg.fused_render and cfg.fused_loss and C in (1, 3, 4) and cfg.shading == 'texture'
+                    and (not cfg.enable_mip or (C == 1 and cfg.sparse_objective)))
         pos_clip = transform_clip_batched(mvp, vtx_pos_split)        # camera.transform_clip (camera.py:11-23), batched
         if cfg.shading == 'vertex':
             colour, rast_out = self.render_vertex(self.glctx, pos_clip)
@@ -754,7 +755,8 @@ class Fitter:
                 bg = self.target_bg_sumsq[local]
                 bg_sum = (bg if view_ids is None else bg.index_select(1, view_ids)).sum()
             pix = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
-                                     n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum)
+                                     n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum,
+                                     enable_mip=cfg.enable_mip, max_mip_level=cfg.max_mip_level)
             if side is not None:
                 main_stream.wait_stream(side)
                 reg.record_stream(main_stream)

@@ -299,7 +299,7 @@ class _pixel_objective_func(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, sparse, ref_bg_sumsq, use_hints,
-                queued_backward):
+                queued_backward, mip_levels=None):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -316,6 +316,12 @@ class _pixel_objective_func(torch.autograd.Function):
         p = _lib.RenderFwd(pos=_ptr(pos), tri=_ptr(tri), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
                            uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C, boundary_mode=boundary,
                            rast=_ptr(rast), color=_ptr(color), tri_uv=_ptr(tri_uv), occ=_ptr(occ), empty_color=_ptr(ecol))
+        # mip_levels = n: the reference's enable_mip branch inside the same kernels (the chain is built here, box filter as texture())
+        chain = _build_mips(tex[None], mip_levels)[1:] if mip_levels is not None else []
+        if mip_levels is not None:
+            p.mip, p.n_levels = 1, len(chain)
+            for l, t in enumerate(chain):
+                p.tex_mip[l] = _ptr(t)
         g_aa = torch.empty_like(color)
         sil = torch.empty(B, T, dtype=torch.uint8, device=dev)
         nflag = lib.fpcdr_antialias_flags_bytes(B, H, W) // 8
@@ -343,7 +349,8 @@ class _pixel_objective_func(torch.autograd.Function):
             _lib.call("fpcdr_render_fwd", ctypes.byref(p), _stream())
             _lib.call("fpcdr_aa_loss_fwd", ctypes.byref(q), _stream())
         del scratch
-        ctx.save_for_backward(pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, occ, ecol, tri_uv)
+        ctx.save_for_backward(pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, occ, ecol, tri_uv, *chain)
+        ctx.mip = mip_levels is not None
         ctx.boundary = boundary
         # the one-call sparse forward leaves the list of bins the backward visits in `occ`; measured at cfg3 the backward gains
         # nothing from it (2.69 vs 2.64 ms: its dead workgroups' dispatch hides behind the live ones' work), so the grid form is
@@ -363,12 +370,14 @@ class _pixel_objective_func(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, occ, ecol, tri_uv = ctx.saved_tensors
+        pos, tex, tri, uv, uv_tri, rast, color, g_aa, sil, flags, occ, ecol, tri_uv = ctx.saved_tensors[:13]
+        chain = ctx.saved_tensors[13:]
         B, V, _ = pos.shape
         _, H, W, _ = rast.shape
         Ht, Wt, C = tex.shape
         g_pos = torch.zeros_like(pos)
         g_tex = torch.zeros_like(tex) if ctx.needs_input_grad[1] else None
+        g_chain = [torch.zeros_like(t) for t in chain] if g_tex is not None else []
         g = g.to(torch.float32).contiguous()
         p = _lib.RenderAaBwd(pos=_ptr(pos), tri=_ptr(tri), uv=_ptr(uv), uv_tri=_ptr(uv_tri), tex=_ptr(tex), rast=_ptr(rast),
                              color=_ptr(color), grad_aa=_ptr(g_aa), sil=_ptr(sil), flags=_ptr(flags), occ=_ptr(occ), empty_color=_ptr(ecol), B=B, V=V,
@@ -376,13 +385,24 @@ class _pixel_objective_func(torch.autograd.Function):
                              H=H, W=W, Vt=uv.shape[0], Ht=Ht, Wt=Wt, C=C, boundary_mode=ctx.boundary, grad_pos=_ptr(g_pos),
                              grad_tex=_ptr(g_tex), tri_uv=_ptr(tri_uv), upstream=_ptr(g),    # g: applied inside the kernel
                              queued=ctx.queued, cap_bwd=ctx.cap_bwd, binflags=1 if occ is not None else 0)
+        if ctx.mip:
+            p.mip, p.n_levels = 1, len(chain)
+            for l, t in enumerate(chain):
+                p.tex_mip[l] = _ptr(t)
+                if g_chain:
+                    p.grad_tex_mip[l] = _ptr(g_chain[l])
         _lib.call("fpcdr_render_aa_bwd", ctypes.byref(p), _stream())
+        if g_chain:      # fold the levels' gradients into the texture's (the box filter's backward, coarse to fine)
+            g_all = [g_tex[None]] + g_chain
+            for l in range(len(chain), 0, -1):
+                _, h, w, _ = g_all[l - 1].shape
+                _lib.call("fpcdr_mip_downsample_bwd", _ptr(g_all[l]), _ptr(g_all[l - 1]), 1, h, w, C, _stream())
         if ctx.hint_update is not None:
             ctx.hint_update[0].update(ctx.hint_update[1])
             ctx.hint_update = None
         if not ctx.needs_input_grad[0]:
             g_pos = None
-        return (g_pos, g_tex) + (None,) * 14
+        return (g_pos, g_tex) + (None,) * 15
 
 
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
@@ -398,7 +418,8 @@ def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
 
 
 def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_total=None, background=45.0 / 255.0,
-                    boundary_mode='wrap', sparse=True, ref_bg_sumsq=None, launch_hints=True, queued_backward=False):
+                    boundary_mode='wrap', sparse=True, ref_bg_sumsq=None, launch_hints=True, queued_backward=False,
+                    enable_mip=False, max_mip_level=None):
     """The whole pixel term of the reference's loss (fit.py:151-161 + the first term of :579) for a minibatch,
     as three kernels:  mean((ref - 255 * where(rast.w > 0, antialias(texture(interpolate(rasterize(pos)))), bg))^2)
     over n_total elements (default: all of this call's).  pos [B,V,4], tex [Ht,Wt,C] (C in 1,3,4), ref_u8 [B,H,W] uint8.
@@ -408,7 +429,10 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     reference_background_sumsq(ref_u8, background) over this call's images; computed here when None); same result.
     launch_hints: size the sparse kernels' launches from the bin counts of the previous call on the same batch shape
     (read back asynchronously, never waited for; the result does not depend on them).  queued_backward: the backward
-    kernel also runs over the compact list of occupied bins instead of one workgroup per bin (same result)."""
+    kernel also runs over the compact list of occupied bins instead of one workgroup per bin (same result).
+    enable_mip (one colour channel, sparse mode): the reference's other branch (fit.py:153-155) -- interpolate with the rasteriser's
+    screen-space derivatives and texture 'linear-mipmap-linear' with max_mip_level -- inside the same three kernels; equals the
+    chain rasterize(output_db) -> interpolate(diff_attrs='all') -> texture(texd) -> antialias + pixel loss."""
     assert isinstance(glctx, RasterizeHipContext)
     _check_tensor('pos', pos, torch.float32, 3)
     _check_tensor('tri', tri, torch.int32, 2)
@@ -426,9 +450,14 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     tri = tri.contiguous()
     adj = _cached_topology(tri)
     n_total = n_total or pos.shape[0] * H * W * tex.shape[2]
+    mip_levels = None
+    if enable_mip:
+        if tex.shape[2] != 1 or not sparse:
+            raise NotImplementedError("pixel_objective(enable_mip=True) takes one colour channel in sparse mode (use the separate operators otherwise)")
+        mip_levels = _num_mip_levels(tex.shape[0], tex.shape[1], max_mip_level)
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                        ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq,
-                                       bool(launch_hints), bool(queued_backward))
+                                       bool(launch_hints), bool(queued_backward), mip_levels)
 
 
 # ----------------------------------------------------------------------------------------------

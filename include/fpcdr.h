@@ -85,6 +85,8 @@ int fpcdr_rasterize_bwd(const fpcdr_rasterize_bwd_params *p, void *stream);
 /* render -- rasterize + interpolate(uv) + texture('linear') fused   reference fit.py:151,157,158 */
 /* ------------------------------------------------------------------------------------------ */
 
+#define FPCDR_MAX_MIP 16
+
 /* The non-mip branch of the reference's render() up to the antialias call, in one pass: the wave that resolves
  * a pixel also interpolates its texture coordinate and taps the texture, so texc never exists in HBM
  * (20 B/px written instead of 52 read+written).  Results are identical to the three separate calls.
@@ -111,6 +113,11 @@ typedef struct {
                                occupied, dx in -1..2, dy in -1..1; the rest of the buffer belongs to the library (raw map, and the
                                list of bins the backward call visits with its work cursor). */
     float *empty_color;     /* sparse mode: out [4], the colour of an empty pixel (the texture at uv = (0,0), fit.py:157-158) */
+    /* ABI v7, fpcdr_render_loss_fwd only: the reference's enable_mip branch (fit.py:153-155) -- interpolate with the rasteriser's
+     * screen-space derivatives (diff_attrs='all') and texture 'linear-mipmap-linear' -- inside the same kernels.  C = 1 only. */
+    int32_t mip;            /* 1 = mip-mapped lookup (0: the 'linear' lookup above) */
+    int32_t n_levels;       /* levels below tex in the chain, 0 .. FPCDR_MAX_MIP (nvdiffrast's max_mip_level, already clamped) */
+    const float *tex_mip[FPCDR_MAX_MIP];   /* tex_mip[l - 1] = level l, [Ht >> l, Wt >> l, C] (fpcdr_mip_downsample) */
 } fpcdr_render_fwd_params;
 int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream);
 
@@ -217,6 +224,10 @@ typedef struct {
     int32_t cap_bwd;       /* queued = 1: launch-size hint for the list kernel, as cap_bins above (0 = none) */
     int32_t binflags;      /* 1: occ was filled by fpcdr_render_loss_fwd, which also left a per-bin summary of the flag planes:
                               flag words are then loaded only near bins that hold a blended pair */
+    /* ABI v7: backward of the mip-mapped forward (fpcdr_render_fwd_params.mip; C = 1, one workgroup per bin) */
+    int32_t mip, n_levels;
+    const float *tex_mip[FPCDR_MAX_MIP];        /* as in the forward call */
+    float *grad_tex_mip[FPCDR_MAX_MIP];         /* per level, accumulated (the caller folds them into grad_tex: fpcdr_mip_downsample_bwd) */
 } fpcdr_render_aa_bwd_params;
 int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *stream);
 
@@ -263,8 +274,7 @@ int fpcdr_interpolate_bwd(const fpcdr_interpolate_bwd_params *p, void *stream);
 
 enum { FPCDR_FILTER_NEAREST = 0, FPCDR_FILTER_LINEAR = 1, FPCDR_FILTER_LINEAR_MIPMAP_NEAREST = 2,
        FPCDR_FILTER_LINEAR_MIPMAP_LINEAR = 3 };
-enum { FPCDR_BOUNDARY_WRAP = 0, FPCDR_BOUNDARY_CLAMP = 1, FPCDR_BOUNDARY_ZERO = 2 };   /* ZERO: texture padded with zeros (texture op only) */
-#define FPCDR_MAX_MIP 16
+enum { FPCDR_BOUNDARY_WRAP = 0, FPCDR_BOUNDARY_CLAMP = 1, FPCDR_BOUNDARY_ZERO = 2 };   /* ZERO: texture padded with zeros */
 
 /* level l+1 [N,Ht/2,Wt/2,C] = 2x2 box filter of level l [N,Ht,Wt,C] (Ht, Wt even) */
 int fpcdr_mip_downsample(const float *src, float *dst, int32_t N, int32_t Ht, int32_t Wt, int32_t C, void *stream);

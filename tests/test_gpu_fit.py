@@ -180,10 +180,11 @@ def test_fused_render_equals_separate_ops(C, boundary):
     assert rel_l2(p2.grad, p1.grad) < 1e-4
 
 
-@pytest.mark.parametrize("C", [1, 3])
-def test_fitter_fused_and_unfused_paths_agree(C):
+@pytest.mark.parametrize("C,mip", [(1, False), (3, False), (1, True)])
+def test_fitter_fused_and_unfused_paths_agree(C, mip):
     """The three execution paths of the pixel term -- one-shot objective (3 kernels), fused render + separate
-    antialias / loss, and the four nvdiffrast-style ops + reference loss chain -- give the same loss and gradients."""
+    antialias / loss, and the four nvdiffrast-style ops + reference loss chain -- give the same loss and gradients; with
+    enable_mip (the reference's other render() branch) the one-shot objective runs the mip-mapped lookup itself."""
     from fpc_diffrend_amd import fit, scene
     sc = scene.cfg('cfg1', n_frames=2)
     if C != 1:
@@ -191,7 +192,7 @@ def test_fitter_fused_and_unfused_paths_agree(C):
     results = []
     for kw in (dict(), dict(sparse_objective=False), dict(fused_objective=False),
                dict(fused_objective=False, fused_render=False, fused_loss=False)):
-        cfg = fit.FitConfig(max_iter=10, cam_idxs=(0, 5), weight_laplacian=10.0, **kw)
+        cfg = fit.FitConfig(max_iter=10, cam_idxs=(0, 5), weight_laplacian=10.0, enable_mip=mip, max_mip_level=3, **kw)
         ft = fit.Fitter(sc, cfg, device='cuda')
         ft.init_near_truth(0.7)
         loss = ft.loss_and_backward(torch.arange(0, 2, device='cuda'))

@@ -170,6 +170,60 @@ def test_mip_chain_end_to_end_matches_oracle(dr, oracle_ops):
     assert rel_l2(tex.grad, st.tex.grad) < TOL, rel_l2(tex.grad, st.tex.grad)
 
 
+@pytest.mark.parametrize("res,max_mip,boundary", [(None, 4, 'wrap'), ((97, 131), None, 'wrap'), ((150, 200), 2, 'clamp'), ((64, 96), 0, 'wrap')])
+def test_fused_objective_with_mip_equals_the_operator_chain_and_the_oracle(dr, oracle_ops, res, max_mip, boundary):
+    """pixel_objective(enable_mip=True) -- the reference's enable_mip branch (fit.py:153-155) inside the three fused kernels: the
+    footprint from the barycentrics' screen derivatives recomputed per pixel, 'linear-mipmap-linear' over the box-filtered chain,
+    gradients to every level folded back into the texture and through the derivative outputs of the rasteriser into the
+    vertices -- equals the chain rasterize(output_db) -> interpolate(diff_attrs='all') -> texture(texd, max_mip_level) ->
+    antialias -> background -> pixel loss (loss, d/d pos, d/d tex), and at the scene's own size the oracle's."""
+    from fpc_diffrend_amd import fit, scene
+    sc = scene.cfg('cfg1', n_frames=2)
+    if res is not None:
+        sc.resolution = res
+    cams = (0, 4, 7)
+    pos, _ = clip_positions(sc, list(cams), frames=[1])
+    H, W = sc.resolution
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(3)
+    ref8 = torch.randint(0, 141, (len(cams), H, W), generator=g, dtype=torch.uint8)
+    ctx = dr.RasterizeGLContext(device=dev)
+    tri, uv, uv_idx = (torch.tensor(a, device=dev) for a in (sc.pos_idx, sc.uv, sc.uv_idx))
+    if boundary == 'clamp':
+        uv = uv * 1.2 - 0.1
+    # the chain of separate operators + the reference's torch loss
+    p1 = pos.to(dev).requires_grad_(True)
+    t1 = torch.tensor(sc.texture, device=dev).requires_grad_(True)
+    rast, rast_db = dr.rasterize(ctx, p1, tri, sc.resolution)
+    texc, texd = dr.interpolate(uv[None], rast, uv_idx, rast_db=rast_db, diff_attrs='all')
+    col = dr.texture(t1[None], texc, texd, filter_mode='linear-mipmap-linear', boundary_mode=boundary, max_mip_level=max_mip)
+    col = dr.antialias(col, rast, p1, tri)
+    img = torch.where(rast[..., 3:] > 0, col, torch.tensor(fit.BACKGROUND, device=dev))
+    l1 = torch.mean((ref8.to(dev).float()[..., None] - img * 255) ** 2)
+    l1.backward()
+    # the fused objective
+    p2 = pos.to(dev).requires_grad_(True)
+    t2 = torch.tensor(sc.texture, device=dev).requires_grad_(True)
+    l2 = dr.pixel_objective(ctx, p2, tri, uv, uv_idx, t2, ref8.to(dev), sc.resolution, boundary_mode=boundary, enable_mip=True,
+                            max_mip_level=max_mip)
+    l2.backward()
+    assert abs(float(l2) - float(l1)) <= 2e-6 * abs(float(l1)), (float(l2), float(l1))
+    assert rel_l2(p2.grad, p1.grad) < TOL, rel_l2(p2.grad, p1.grad)
+    assert rel_l2(t2.grad, t1.grad) < TOL, rel_l2(t2.grad, t1.grad)
+    assert float(t1.grad.abs().max()) > 0 and float(p1.grad.abs().max()) > 0
+    if res is None and boundary == 'wrap':
+        from oracle import fit as ofit
+        st = ofit.State(sc, cams)
+        p_ref = pos.clone().requires_grad_(True)
+        loss_o, _, _ = ofit.forward_from_clip(st, p_ref, ref8.reshape(1, len(cams), H, W), enable_mip=True, max_mip_level=max_mip)
+        loss_o.backward()
+        assert abs(float(l2) - float(loss_o)) < TOL * float(loss_o)
+        assert rel_l2(p2.grad, p_ref.grad) < TOL and rel_l2(t2.grad, st.tex.grad) < TOL
+    # more than one channel: refused, not silently something else
+    with pytest.raises(NotImplementedError):
+        dr.pixel_objective(ctx, p2.detach(), tri, uv, uv_idx, t2.detach().repeat(1, 1, 3), ref8.to(dev), sc.resolution, enable_mip=True)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the reference's own run shape: ONE 1600 x 1200 image, 1024^2 x 1 texture (main.py:28-30, fit.py:525-526)
 # ---------------------------------------------------------------------------------------------------------------------
