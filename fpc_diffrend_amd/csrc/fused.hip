@@ -301,6 +301,11 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
     __shared__ double s_vacc[VSLOTS][3];           // (x, y, w) sums per vertex slot, in double: ds_add_f64 (common.h lds_add_f64)
     __shared__ double s_tex[TEXH * TEXW * CS];
     __shared__ int s_org[2];            // smallest tap x, y of the bin (unwrapped texel coordinates)
+    // MIP: a second window for level 1 of the chain (a bin's footprint there is a quarter of its level-0 one); taps of coarser
+    // levels, and taps outside the windows, go to memory
+    constexpr int TEX1 = 24;
+    __shared__ double s_tex1[MIP ? TEX1 * TEX1 * CS : 1];
+    __shared__ int s_org1[2];
     __shared__ float s_esum[CS];        // gradient arriving at EMPTY pixels' colour (they all sample uv = (0,0))
     __shared__ float s_fy[BBIN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -347,7 +352,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
         if (byi > 0) f |= binflag[bl - OX];
         flags_here = __builtin_amdgcn_readfirstlane((int)f) != 0;
     }
-    if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
+    if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; s_org1[0] = 0x7fffffff; s_org1[1] = 0x7fffffff; }
     if (tid < CS) s_esum[tid] = 0.0f;
     // NDC y of the bin's 32 rows: one IEEE division per row instead of one per pixel (and the column's fx once per thread, below)
     if (tid < BBIN) s_fy[tid] = (2.0f * (float)(by0 + tid) + 1.0f) / (float)H - 1.0f;
@@ -454,10 +459,11 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
         s_vacc[k][0] = 0.0; s_vacc[k][1] = 0.0; s_vacc[k][2] = 0.0;
     }
     for (int k = tid; k < TEXH * TEXW * CS; k += BWD_NT) s_tex[k] = 0.0;
+    if (MIP) for (int k = tid; k < TEX1 * TEX1 * CS; k += BWD_NT) s_tex1[k] = 0.0;
     int pt[BWD_NPX];
     float tu[BWD_NPX], tv[BWD_NPX];
     {
-        int ux0 = 0x7fffffff, uy0 = 0x7fffffff;
+        int ux0 = 0x7fffffff, uy0 = 0x7fffffff, vx0 = 0x7fffffff, vy0 = 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < BWD_NPX; ++k) {
             pt[k] = -1; tu[k] = 0.f; tv[k] = 0.f;
@@ -473,18 +479,27 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                     tu[k] = r.x * q0.x + r.y * q1.x + w * q2.x;
                     tv[k] = r.x * q0.y + r.y * q1.y + w * q2.y;
                     pt[k] = t;
-                    if (grad_tex && !MIP) {
+                    if (grad_tex) {
                         ux0 = min(ux0, (int)floorf(prep_coord(tu[k], boundary) * (float)Wt - 0.5f));
                         uy0 = min(uy0, (int)floorf(prep_coord(tv[k], boundary) * (float)Ht - 0.5f));
+                        if (MIP) {
+                            vx0 = min(vx0, (int)floorf(prep_coord(tu[k], boundary) * (float)(Wt >> 1) - 0.5f));
+                            vy0 = min(vy0, (int)floorf(prep_coord(tv[k], boundary) * (float)(Ht >> 1) - 0.5f));
+                        }
                     }
                 }
             }
         }
         const int mx = wave_min_dpp(ux0), my = wave_min_dpp(uy0);
         if (lane == 0 && mx != 0x7fffffff) { atomicMin(&s_org[0], mx); atomicMin(&s_org[1], my); }
+        if (MIP) {
+            const int m1x = wave_min_dpp(vx0), m1y = wave_min_dpp(vy0);
+            if (lane == 0 && m1x != 0x7fffffff) { atomicMin(&s_org1[0], m1x); atomicMin(&s_org1[1], m1y); }
+        }
     }
     __syncthreads();
     const int ox = s_org[0], oy = s_org[1];
+    const int ox1 = s_org1[0], oy1 = s_org1[1];
 
     // ---- pixel phase B: texture backward; (dL/du, dL/dv) of the barycentrics into LDS; triangle set ----
     const float fx_col = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
@@ -526,7 +541,20 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
             for (int c = 0; c < CS; ++c) gch[c] = go[k][c];
             float gtu = 0.f, gtv = 0.f, gbias = 0.f;
             float4 gda = make_float4(0.f, 0.f, 0.f, 0.f);
-            mip_sample_bwd(lv, 0, ma->n_levels, make_float2(tu[k], tv[k]), true, da, 0.0f, Ht, Wt, CS, true, boundary, gch, gtu, gtv, gda, gbias);
+            // texel gradients: level 0 and level 1 through their LDS windows (flushed once per bin), anything else straight to memory
+            const int lx0 = (int)floorf(prep_coord(tu[k], boundary) * (float)Wt - 0.5f) - ox;
+            const int ly0 = (int)floorf(prep_coord(tv[k], boundary) * (float)Ht - 0.5f) - oy;
+            const bool in0 = lx0 >= 0 && ly0 >= 0 && lx0 + 1 < TEXW && ly0 + 1 < TEXH;
+            const int lx1 = (int)floorf(prep_coord(tu[k], boundary) * (float)(Wt >> 1) - 0.5f) - ox1;
+            const int ly1 = (int)floorf(prep_coord(tv[k], boundary) * (float)(Ht >> 1) - 0.5f) - oy1;
+            const bool in1 = lx1 >= 0 && ly1 >= 0 && lx1 + 1 < TEX1 && ly1 + 1 < TEX1;
+            mip_sample_bwd_to(lv, 0, ma->n_levels, make_float2(tu[k], tv[k]), true, da, 0.0f, Ht, Wt, CS, true, boundary, gch, gtu, gtv, gda, gbias,
+                              [&](int level, int tap, size_t off, int c, float v) {
+                                  const int dx = tap & 1, dy = tap >> 1;
+                                  if (level == 0 && in0) lds_add_f64(&s_tex[((ly0 + dy) * TEXW + lx0 + dx) * CS + c], v);
+                                  else if (level == 1 && in1) lds_add_f64(&s_tex1[((ly1 + dy) * TEX1 + lx1 + dx) * CS + c], v);
+                                  else atomicAdd(lv.grad[level] + off + c, v);
+                              });
             const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu[k] >= 0.0f && tu[k] <= 1.0f)) ? 0.0f : 1.0f;
             const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv[k] >= 0.0f && tv[k] <= 1.0f)) ? 0.0f : 1.0f;
             gtu *= mu; gtv *= mv;
@@ -684,6 +712,17 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
             if (v != 0.0f) atomicAdd(&at32(gp, 4u * (unsigned int)key + (unsigned int)comp), v);
         }
     }
+    if (MIP && grad_tex && ox1 != 0x7fffffff && ma->n_levels >= 1) {
+        const int Wt1 = Wt >> 1, Ht1 = Ht >> 1;
+        for (int k = tid; k < TEX1 * TEX1 * CS; k += BWD_NT) {
+            const float v = (float)s_tex1[k];
+            if (v != 0.0f) {
+                const int c = k % CS, cell = k / CS;
+                const int gx = wrap_near(ox1 + cell % TEX1, Wt1, boundary), gy = wrap_near(oy1 + cell / TEX1, Ht1, boundary);
+                atomicAdd(ma->grad[0] + (size_t)(gy * Wt1 + gx) * CS + c, v);
+            }
+        }
+    }
     if (grad_tex && ox != 0x7fffffff) {
         for (int k = tid; k < TEXH * TEXW * CS; k += BWD_NT) {
             const float v = (float)s_tex[k];
@@ -715,7 +754,12 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
 }
 
 // grid form of the MIP instantiation (one colour channel, boundary mode at run time)
-__global__ void __launch_bounds__(BWD_NT) k_render_aa_bwd_mip(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+#ifdef FPCDR_MIPBWD_WAVES
+#define FPCDR_MIPBWD_WPE __attribute__((amdgpu_waves_per_eu(FPCDR_MIPBWD_WAVES, 8)))
+#else
+#define FPCDR_MIPBWD_WPE
+#endif
+__global__ void __launch_bounds__(BWD_NT) FPCDR_MIPBWD_WPE k_render_aa_bwd_mip(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
                                                        const float *__restrict__ tex, const float4 *__restrict__ rast,
                                                        const float *__restrict__ color, const float *__restrict__ g_aa,

@@ -155,9 +155,12 @@ __device__ __forceinline__ Lod compute_lod(float4 d, int Ht, int Wt, float bias)
     return L;
 }
 
-// scatter dy * weight into the four taps of one level and return (d out / d fx, d out / d fy) summed over channels
-__device__ __forceinline__ void taps_bwd(const float *tx, float *gtx, const Taps &t, const float *g, float scale, int C,
-                                         float &gfx, float &gfy) {
+// the four taps of one level: hand dy * weight to scatter(tap 0..3 = (00, 10, 01, 11), element offset, channel, value) for every tap
+// that lies in the texture (boundary mode 'zero': the padding receives no gradient) and return (d out / d fx, d out / d fy) summed over
+// channels
+template <typename Scatter>
+__device__ __forceinline__ void taps_bwd_to(const float *tx, bool want_tex, const Taps &t, const float *g, float scale, int C,
+                                            float &gfx, float &gfy, Scatter &&scatter) {
     const float w00 = (1.0f - t.fx) * (1.0f - t.fy), w10 = t.fx * (1.0f - t.fy), w01 = (1.0f - t.fx) * t.fy, w11 = t.fx * t.fy;
     for (int c = 0; c < C; ++c) {
         const float gc = g[c] * scale;
@@ -166,13 +169,18 @@ __device__ __forceinline__ void taps_bwd(const float *tx, float *gtx, const Taps
         mask_taps(t, t00, t10, t01, t11);
         gfx += gc * ((t10 - t00) * (1.0f - t.fy) + (t11 - t01) * t.fy);
         gfy += gc * ((t01 + (t11 - t01) * t.fx) - (t00 + (t10 - t00) * t.fx));
-        if (gtx && gc != 0.0f) {      // (boundary mode 'zero': the padding receives no gradient)
-            if (t.valid & 1u) atomicAdd(gtx + t.i00 + c, gc * w00);
-            if (t.valid & 2u) atomicAdd(gtx + t.i10 + c, gc * w10);
-            if (t.valid & 4u) atomicAdd(gtx + t.i01 + c, gc * w01);
-            if (t.valid & 8u) atomicAdd(gtx + t.i11 + c, gc * w11);
+        if (want_tex && gc != 0.0f) {
+            if (t.valid & 1u) scatter(0, t.i00, c, gc * w00);
+            if (t.valid & 2u) scatter(1, t.i10, c, gc * w10);
+            if (t.valid & 4u) scatter(2, t.i01, c, gc * w01);
+            if (t.valid & 8u) scatter(3, t.i11, c, gc * w11);
         }
     }
+}
+// ... with global atomics into gtx (null: no texel gradient wanted)
+__device__ __forceinline__ void taps_bwd(const float *tx, float *gtx, const Taps &t, const float *g, float scale, int C,
+                                         float &gfx, float &gfy) {
+    taps_bwd_to(tx, gtx != nullptr, t, g, scale, C, gfx, gfy, [&](int, int off, int c, float v) { atomicAdd(gtx + off + c, v); });
 }
 
 // One pixel of a mip-mapped lookup at texture coordinate q: level from the footprint da (has_da) plus bias, clamped to
@@ -211,9 +219,11 @@ __device__ __forceinline__ void mip_sample_fwd(const TexLevels &lv, size_t b, in
 
 // Backward of mip_sample_fwd for the incoming gradient g[C]: scatters into lv.grad[level] (where non-null) and returns the gradient
 // of the texture coordinate (gu, gv: the caller applies the clamp-mode mask), of the footprint (gda, has_da) and of the bias.
-__device__ __forceinline__ void mip_sample_bwd(const TexLevels &lv, size_t b, int n_levels, float2 q, bool has_da, float4 da, float bias,
-                                               int Ht, int Wt, int C, bool trilinear, int boundary, const float *g, float &gu, float &gv,
-                                               float4 &gda, float &gbias) {
+// scatter(level, tap, element offset inside the level's image, channel, value) receives the texel gradients.
+template <typename Scatter>
+__device__ __forceinline__ void mip_sample_bwd_to(const TexLevels &lv, size_t b, int n_levels, float2 q, bool has_da, float4 da, float bias,
+                                                  int Ht, int Wt, int C, bool trilinear, int boundary, const float *g, float &gu, float &gv,
+                                                  float4 &gda, float &gbias, Scatter &&scatter) {
     float raw = bias;
     Lod L;
     if (has_da) { L = compute_lod(da, Ht, Wt, raw); raw = L.level; }
@@ -230,7 +240,8 @@ __device__ __forceinline__ void mip_sample_bwd(const TexLevels &lv, size_t b, in
     const Taps t0 = make_taps(q.x, q.y, h0, w0, C, boundary);
     const size_t img0 = b * h0 * w0 * C;
     float gfx = 0.f, gfy = 0.f;
-    taps_bwd(lv.tex[l0] + img0, lv.grad[l0] ? lv.grad[l0] + img0 : nullptr, t0, g, 1.0f - fl, C, gfx, gfy);
+    taps_bwd_to(lv.tex[l0] + img0, lv.grad[l0] != nullptr, t0, g, 1.0f - fl, C, gfx, gfy,
+                [&](int tap, int off, int c, float v) { scatter(l0, tap, img0 + off, c, v); });
     gu = gfx * (float)w0; gv = gfy * (float)h0;
     if (trilinear) {
         const int l1 = min(l0 + 1, n_levels);
@@ -238,7 +249,8 @@ __device__ __forceinline__ void mip_sample_bwd(const TexLevels &lv, size_t b, in
         const Taps t1 = make_taps(q.x, q.y, h1, w1, C, boundary);
         const size_t img1 = b * h1 * w1 * C;
         float gfx1 = 0.f, gfy1 = 0.f;
-        taps_bwd(lv.tex[l1] + img1, lv.grad[l1] ? lv.grad[l1] + img1 : nullptr, t1, g, fl, C, gfx1, gfy1);
+        taps_bwd_to(lv.tex[l1] + img1, lv.grad[l1] != nullptr, t1, g, fl, C, gfx1, gfy1,
+                    [&](int tap, int off, int c, float v) { scatter(l1, tap, img1 + off, c, v); });
         gu += gfx1 * (float)w1;
         gv += gfy1 * (float)h1;
         // d out / d fl = sum_c g_c (c1 - c0);  level clamp passes gradient inside [0, n_levels]
@@ -258,4 +270,12 @@ __device__ __forceinline__ void mip_sample_bwd(const TexLevels &lv, size_t b, in
             gda = make_float4(g_dudx * (float)Wt, g_dudy * (float)Wt, g_dvdx * (float)Ht, g_dvdy * (float)Ht);
         }
     }
+}
+
+// ... with global atomics into lv.grad[level]
+__device__ __forceinline__ void mip_sample_bwd(const TexLevels &lv, size_t b, int n_levels, float2 q, bool has_da, float4 da, float bias,
+                                               int Ht, int Wt, int C, bool trilinear, int boundary, const float *g, float &gu, float &gv,
+                                               float4 &gda, float &gbias) {
+    mip_sample_bwd_to(lv, b, n_levels, q, has_da, da, bias, Ht, Wt, C, trilinear, boundary, g, gu, gv, gda, gbias,
+                      [&](int level, int, size_t off, int c, float v) { atomicAdd(lv.grad[level] + off + c, v); });
 }
