@@ -161,6 +161,13 @@ __global__ void __launch_bounds__(256) k_blend_fwd_lds(const float *__restrict__
         if (f0 > 0) {
             __syncthreads();                          // previous frame tile (and its s_red) consumed
             load_tile(w + (size_t)f0 * K, (long long)(F - f0) * K, vw4);
+            // s_red overwrote the pad columns of s_w with partial sums: zero them again (they meet the zero pads of s_b, but
+            // 0 * x is 0 only for finite x)
+            const int np = KP - K;
+            for (int e = tid; e < 32 * np; e += 256) {
+                const int r = e / np;
+                s_w[r * KP + K + e - r * np] = 0.0f;
+            }
         }
         store_tile(s_w, vw4);
         __syncthreads();

@@ -279,6 +279,9 @@ __device__ __forceinline__ void wave_segment_reduce(int key, const float (&val)[
 // 6 x 10 instructions instead of ~250 through update_dpp + select + add: the backward kernel is vector-issue bound
 // (profiles/r02: 80 % of the issue slots) and a quarter of its instructions were this scan.  Lanes without a DPP source are
 // disabled for that instruction (no bound_ctrl), which leaves value and mask unchanged -- the neutral element of both.
+// Finite values only: the mask is a FACTOR (0 / 1), so a NaN or infinite value of one run reaches the sums of the runs after it in the
+// wave (0 * NaN), where the select-based wave_segment_reduce keeps it inside its own run.  The callers' values are gradients of a
+// finite loss; a step whose gradients are not finite is lost either way (Adam's moments keep the NaN).
 template <typename Emit>
 __device__ __forceinline__ void wave_segment_reduce9(int key, const float (&val)[9], Emit &&emit) {
     const int l = lane_id();

@@ -402,6 +402,8 @@ class GroupedAdam(torch.optim.Optimizer):
                         st['step'] = torch.zeros((), dtype=torch.float32)
                         st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                         st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    if st['step'].is_cuda:      # (a checkpoint written by torch.optim.Adam(fused=True) keeps its counters on the GPU:
+                        st['step'] = st['step'].cpu()      # one copy here instead of a host sync per tensor and step)
                     st['step'] += 1
                     n_step = float(st['step'])
                     grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
