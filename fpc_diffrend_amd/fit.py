@@ -369,7 +369,9 @@ class GroupedAdam(torch.optim.Optimizer):
     fit.py:493-505 ten groups with their own learning rates, :610-618 step + division).  torch's fused Adam launches twice
     per group, and the two divisions are four small launches each: two dozen ~5 us launches in the serial tail of a 5 ms
     step.  State layout and names are torch.optim.Adam's ('step', 'exp_avg', 'exp_avg_sq'), so LambdaLR, state_dict() and
-    checkpoints work unchanged.  `renorm` = the parameters divided by their whole-tensor norm after every step."""
+    checkpoints work unchanged (the update is the same formula evaluated in a slightly different order -- step_size * (m / denom) --
+    so a run with grouped_adam on and one with it off agree to a few ulps per step, not bit for bit).  `renorm` = the parameters
+    divided by their whole-tensor norm after every step."""
 
     def __init__(self, groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, renorm=()):
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps))
