@@ -74,7 +74,7 @@ def kernel_source_sha16():
 ENTRY_KERNELS = {
     "fpcdr_render_loss_fwd": ["k_sil2", "k_init_queue", "k_setup", "k_list_count<", "k_list_scan", "k_list_write<",
                               "k_bins_list<false, true, true", "k_bins_queue<false, true, true", "k_aa_fix_list<", "k_aa_fix_queue<"],
-    "fpcdr_render_aa_bwd": ["k_render_aa_bwd<"],
+    "fpcdr_render_aa_bwd": ["k_render_aa_bwd<", "k_render_aa_bwd_list<", "k_render_aa_bwd_queue<"],
     "fpcdr_antialias_bwd": ["k_copy_f4_chunk", "k_aa_bwd_fix<"],
     "fpcdr_blend_fwd": ["k_blend_fwd_lds"],
 }

@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_MIPBWD_WPE k_render_aa_bwd_mip(c
 
 // list form (after fpcdr_render_loss_fwd): one workgroup per entry of the list k_occ_window built (own or a 4-neighbour bin
 // occupied); the launch is sized by the caller's hint, the strided form sweeps up the rest (see k_bins_list, rasterize.hip)
-template <int CS>
+template <int CS, int BMODE = -1>
 __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
                                                        fpcdr_bin_decode dc, const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
@@ -794,8 +794,8 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd_list(con
     const int lin = __builtin_amdgcn_readfirstlane(list[item]);
     int b, byi, bxi;
     fpcdr_decode_bin(lin, dc, b, byi, bxi);
-    render_aa_bwd_body<CS>(b, bxi, byi, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ,
-                           empty_color, B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag);
+    render_aa_bwd_body<CS, BMODE>(b, bxi, byi, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ,
+                                  empty_color, B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag);
 }
 
 #ifndef FPCDR_BWDQ_WPE
@@ -1173,7 +1173,11 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
             if (cap < nbins)                                                                                                \
                 hipLaunchKernelGGL(k_render_aa_bwd_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(BWD_NT), 0, st, list, hdr, cap, dc, ARGSQ); \
         } while (0)
-        if (p->C == 1) LAUNCHQ(1);
+        if (p->C == 1 && p->boundary_mode == FPCDR_BOUNDARY_WRAP) {     // the reference's case
+            hipLaunchKernelGGL((k_render_aa_bwd_list<1, FPCDR_BOUNDARY_WRAP>), dim3(cap), dim3(BWD_NT), 0, st, list, hdr, dc, ARGSQ);
+            if (cap < nbins)
+                hipLaunchKernelGGL(k_render_aa_bwd_queue<1>, dim3(FPCDR_SWEEP_WGS), dim3(BWD_NT), 0, st, list, hdr, cap, dc, ARGSQ);
+        } else if (p->C == 1) LAUNCHQ(1);
         else if (p->C == 3) LAUNCHQ(3);
         else LAUNCHQ(4);
 #undef LAUNCHQ
