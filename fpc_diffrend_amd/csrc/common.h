@@ -118,6 +118,24 @@ template <typename T> __device__ __forceinline__ T &at32(T *base, unsigned int i
     return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + i * (unsigned int)sizeof(T));
 }
 
+// ---- list kernels: which entry a workgroup takes ------------------------------------------------
+// Workgroup i of a launch runs on XCD i mod 8 (scripts/micro/atomic_scope_bench.hip), and each XCD has its own L2.  Taking entry i
+// would deal NEIGHBOURING bins -- which share vertices, triangle records and texels -- to eight different L2s; instead XCD x takes
+// the x-th eighth of the entries [0, m), m = min(entries, launch size), in order.  The launch is rounded up to a multiple of 8
+// workgroups (fpcdr_list_grid) so that every entry below m has a workgroup.  Returns -1 for a workgroup without an entry.
+#ifndef FPCDR_XCD_LISTS
+#define FPCDR_XCD_LISTS 1
+#endif
+__host__ __device__ inline int fpcdr_list_grid(int cap) { return FPCDR_XCD_LISTS ? (cap + 7) / 8 * 8 : cap; }
+__device__ __forceinline__ int fpcdr_list_item(int n_entries, int cap) {
+    const int m = min(n_entries, cap);
+    if (!FPCDR_XCD_LISTS) return (int)blockIdx.x < m ? (int)blockIdx.x : -1;
+    const int chunk = (m + 7) >> 3;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int idx = x * chunk + j;
+    return (j < chunk && idx < m) ? idx : -1;
+}
+
 // ---- region hints (include/fpcdr.h) ----------------------------------------------------------
 // plane: 0 = the bin itself is occupied, 1 = the bin or one of its eight neighbours is
 __device__ __forceinline__ bool fpcdr_hint_on(const uint8_t *__restrict__ hint, int plane, int B, int H, int W, int b, int y, int x) {

@@ -778,7 +778,7 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_MIPBWD_WPE k_render_aa_bwd_mip(c
 // occupied); the launch is sized by the caller's hint, the strided form sweeps up the rest (see k_bins_list, rasterize.hip)
 template <int CS, int BMODE = -1>
 __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
-                                                       fpcdr_bin_decode dc, const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                                       int cap, fpcdr_bin_decode dc, const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
                                                        const float *__restrict__ tex, const float4 *__restrict__ rast,
                                                        const float *__restrict__ color, const float *__restrict__ g_aa,
@@ -789,8 +789,8 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd_list(con
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
                                                        const float *__restrict__ upstream, const uint8_t *__restrict__ binflag) {
-    const int item = blockIdx.x;
-    if (item >= *count) return;
+    const int item = fpcdr_list_item(*count, cap);      // (XCD x takes the x-th eighth of the entries: common.h)
+    if (item < 0) return;
     const int lin = __builtin_amdgcn_readfirstlane(list[item]);
     int b, byi, bxi;
     fpcdr_decode_bin(lin, dc, b, byi, bxi);
@@ -967,10 +967,10 @@ __device__ __forceinline__ void aa_fix_body(const int b, const int bxi, const in
 #define FPCDR_AA_FIX_PASS                                                                                                       \
     color, rast, pos, tri, sil, ref, B, H, W, V, T, bg, color_scale, grad_scale, flags, g_aa, occ, empty_color, cmask, edges, loss_sum, binflag
 template <int CS>
-__global__ void __launch_bounds__(FIX_NT) k_aa_fix_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, fpcdr_bin_decode dc,
-                                                        FPCDR_AA_FIX_ARGS) {
-    const int item = blockIdx.x;
-    if (item >= *count) return;
+__global__ void __launch_bounds__(FIX_NT) k_aa_fix_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int cap,
+                                                        fpcdr_bin_decode dc, FPCDR_AA_FIX_ARGS) {
+    const int item = fpcdr_list_item(*count, cap);
+    if (item < 0) return;
     const int OX = FPCDR_OCC_DIM(W), OY = FPCDR_OCC_DIM(H);
     const int lin = __builtin_amdgcn_readfirstlane(list[item]);
     int b, byi, bxi;
@@ -1068,7 +1068,7 @@ int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask
     (uint8_t *)p->occ + fpcdr_queue_layout_of(p->B, p->H, p->W).occ_binflag
 #define LAUNCH(CS)                                                                                                             \
     do {                                                                                                                       \
-        hipLaunchKernelGGL(k_aa_fix_list<CS>, dim3(cap), dim3(FIX_NT), 0, st, fix_list, fix_count, dc, ARGS);                    \
+        hipLaunchKernelGGL(k_aa_fix_list<CS>, dim3(fpcdr_list_grid(cap)), dim3(FIX_NT), 0, st, fix_list, fix_count, cap, dc, ARGS); \
         if (cap < nbins) hipLaunchKernelGGL(k_aa_fix_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(FIX_NT), 0, st, fix_list, fix_count, cap, dc, ARGS); \
     } while (0)
     if (p->C == 1) LAUNCH(1);
@@ -1169,12 +1169,12 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
         p->boundary_mode, p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream, binflag
 #define LAUNCHQ(CS)                                                                                                         \
         do {                                                                                                                \
-            hipLaunchKernelGGL(k_render_aa_bwd_list<CS>, dim3(cap), dim3(BWD_NT), 0, st, list, hdr, dc, ARGSQ);              \
+            hipLaunchKernelGGL(k_render_aa_bwd_list<CS>, dim3(fpcdr_list_grid(cap)), dim3(BWD_NT), 0, st, list, hdr, cap, dc, ARGSQ);  \
             if (cap < nbins)                                                                                                \
                 hipLaunchKernelGGL(k_render_aa_bwd_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(BWD_NT), 0, st, list, hdr, cap, dc, ARGSQ); \
         } while (0)
         if (p->C == 1 && p->boundary_mode == FPCDR_BOUNDARY_WRAP) {     // the reference's case
-            hipLaunchKernelGGL((k_render_aa_bwd_list<1, FPCDR_BOUNDARY_WRAP>), dim3(cap), dim3(BWD_NT), 0, st, list, hdr, dc, ARGSQ);
+            hipLaunchKernelGGL((k_render_aa_bwd_list<1, FPCDR_BOUNDARY_WRAP>), dim3(fpcdr_list_grid(cap)), dim3(BWD_NT), 0, st, list, hdr, cap, dc, ARGSQ);
             if (cap < nbins)
                 hipLaunchKernelGGL(k_render_aa_bwd_queue<1>, dim3(FPCDR_SWEEP_WGS), dim3(BWD_NT), 0, st, list, hdr, cap, dc, ARGSQ);
         } else if (p->C == 1) LAUNCHQ(1);

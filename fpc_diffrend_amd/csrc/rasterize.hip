@@ -1074,14 +1074,14 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
 #endif
 template <bool WRITE_DB, bool SHADE, bool LOSS, int CS = 0, int BMODE = -1, bool MIP = false>
 __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
-                                              int OX, int OY, fpcdr_bin_decode dc,
+                                              int cap, int OX, int OY, fpcdr_bin_decode dc,
                                               const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               int V, int T, int H, int W, const TriRec *__restrict__ recs,
                                               const TriBox *__restrict__ boxes, const TriBox *__restrict__ cboxes,
                                               const ImgBox *__restrict__ ibox, float4 *__restrict__ rast,
                                               float4 *__restrict__ rast_db, ShadeArgs sh) {
-    const int item = blockIdx.x;
-    if (item >= *count) return;
+    const int item = fpcdr_list_item(*count, cap);      // (XCD x takes the x-th eighth of the entries: common.h)
+    if (item < 0) return;
     const int lin = __builtin_amdgcn_readfirstlane(list[item]);
     int b, byi, bxi;
     fpcdr_decode_bin(lin, dc, b, byi, bxi);
@@ -1486,15 +1486,15 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     const fpcdr_bin_decode dc = fpcdr_make_bin_decode(OX, OY);
     const int cap_bins = (l->cap_bins > 0 && (size_t)l->cap_bins < nbins) ? l->cap_bins : (int)nbins;
     if (p->mip)
-        hipLaunchKernelGGL((k_bins_list<false, true, true, 1, -1, true>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY, dc,
+        hipLaunchKernelGGL((k_bins_list<false, true, true, 1, -1, true>), dim3(fpcdr_list_grid(cap_bins)), dim3(256), 0, st, bin_list, n_bins, cap_bins, OX, OY, dc,
                        (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
                        (float4 *)nullptr, sh);
     else if (p->C == 1 && p->boundary_mode == FPCDR_BOUNDARY_WRAP)     // the reference's case, with both as compile-time constants
-        hipLaunchKernelGGL((k_bins_list<false, true, true, 1, FPCDR_BOUNDARY_WRAP>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY, dc,
+        hipLaunchKernelGGL((k_bins_list<false, true, true, 1, FPCDR_BOUNDARY_WRAP>), dim3(fpcdr_list_grid(cap_bins)), dim3(256), 0, st, bin_list, n_bins, cap_bins, OX, OY, dc,
                        (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
                        (float4 *)nullptr, sh);
     else
-        hipLaunchKernelGGL((k_bins_list<false, true, true>), dim3(cap_bins), dim3(256), 0, st, bin_list, n_bins, OX, OY, dc,
+        hipLaunchKernelGGL((k_bins_list<false, true, true>), dim3(fpcdr_list_grid(cap_bins)), dim3(256), 0, st, bin_list, n_bins, cap_bins, OX, OY, dc,
                        (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
                        (float4 *)nullptr, sh);
     if ((size_t)cap_bins < nbins) {
