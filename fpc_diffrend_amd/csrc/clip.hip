@@ -155,19 +155,23 @@ __global__ void __launch_bounds__(256) k_lap_penalty_fwd(const float *__restrict
     if (lane == 0) s_part[wave] = (double)ws;
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&acc[f], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
-        __threadfence();
-        s_ticket = atomicAdd(ticket, 1u);
+        // No __threadfence here: on gfx950 a device-scope release writes the XCD's whole L2 back, and with ~2 000 workgroups doing it
+        // a concurrent store stream (the flag planes' zero-fill of the next forward call, on the other queue) ran 4x slower.  Both
+        // operations are device-scope read-modify-writes performed at the memory side; the ticket is taken only after the sum's
+        // atomic has RETURNED (the asm consumes its result), and the last workgroup reads the sums with device-scope atomic loads.
+        const double before = __hip_atomic_fetch_add(&acc[f], s_part[0] + s_part[1] + s_part[2] + s_part[3], __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(before));
+        s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (s_ticket != gridDim.x * gridDim.y - 1) return;
-    __threadfence();
     double tot = 0.0;
     for (int i = threadIdx.x; i < F; i += blockDim.x) {
         const double p = __hip_atomic_load(&acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (double)V;
         per[i] = (float)p;
         tot += p * p;
-        acc[i] = 0.0;
+        __hip_atomic_store(&acc[i], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // block sum of doubles: through LDS (F is small)
     __shared__ double s_tot[256];
@@ -177,7 +181,10 @@ __global__ void __launch_bounds__(256) k_lap_penalty_fwd(const float *__restrict
         if ((int)threadIdx.x < o) s_tot[threadIdx.x] += s_tot[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out[0] = (float)((double)weight * s_tot[0] / (double)F); *ticket = 0u; }
+    if (threadIdx.x == 0) {
+        out[0] = (float)((double)weight * s_tot[0] / (double)F);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Backward: d value / d x = L^T y,  y_v = c_f * lap_v / ||lap_v||,  c_f = upstream * weight * 2 per_f / (F V)  (0 where lap_v = 0,
