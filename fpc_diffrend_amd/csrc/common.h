@@ -32,7 +32,7 @@ static inline int fpcdr_cdiv(long long a, long long b) { return (int)((a + b - 1
 
 // internal cross-file launchers (fused.hip), used by fpcdr_render_loss_fwd (rasterize.hip)
 int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, int B, int V, int T, int H, int W, uint8_t *sil,
-                     hipStream_t st);
+                     void *zero_dst, size_t zero_bytes, hipStream_t st);
 int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask, const unsigned long long *edges,
                         const int32_t *fix_list, const int32_t *fix_count, int nbins, hipStream_t st);
 

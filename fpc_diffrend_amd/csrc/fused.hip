@@ -1001,9 +1001,16 @@ __global__ void __launch_bounds__(FIX_NT) k_aa_fix_queue(const int32_t *__restri
 constexpr int SIL_NI = FPCDR_SIL_NI;
 __global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                               const int32_t *__restrict__ adj, int B, int V, int T, float hw, float hh,
-                                              uint8_t *__restrict__ sil) {
+                                              uint8_t *__restrict__ sil, uint4 *__restrict__ zero_dst, unsigned long long zero_n16) {
     // grid (triangle chunks, groups of SIL_NI images): a flat thread index would cost every thread a 64-bit division
     const int b0 = blockIdx.y * SIL_NI, t = blockIdx.x * blockDim.x + threadIdx.x;
+    // fpcdr_render_loss_fwd: the antialias flag planes of the call (149 MB at cfg3) are zeroed HERE, by stores that cost this
+    // latency-bound kernel next to nothing, instead of by a 32-50 us fill of the caller's in front of the call
+    if (zero_dst) {
+        const unsigned long long stride = (unsigned long long)gridDim.x * gridDim.y * blockDim.x;
+        for (unsigned long long i = ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < zero_n16; i += stride)
+            zero_dst[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (t >= T) return;
     const int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
     const int ad[3] = {adj[3 * t], adj[3 * t + 1], adj[3 * t + 2]};
@@ -1051,9 +1058,13 @@ __global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, co
 
 // ---- pieces of fpcdr_render_loss_fwd (rasterize.hip) that live in this file; not part of the C ABI ----
 int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, int B, int V, int T, int H, int W, uint8_t *sil,
-                     hipStream_t st) {
+                     void *zero_dst, size_t zero_bytes, hipStream_t st) {
+    if (zero_dst && (((size_t)zero_dst | zero_bytes) & 15)) {      // (not 16-byte shaped: a plain memset)
+        FPCDR_REQUIRE(hipMemsetAsync(zero_dst, 0, zero_bytes, st) == hipSuccess, "memset of the flag planes failed");
+        zero_dst = nullptr;
+    }
     hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv(T, 256), fpcdr_cdiv(B, SIL_NI)), dim3(256), 0, st, (const float4 *)pos, tri, adj, B, V, T,
-                       0.5f * (float)W, 0.5f * (float)H, sil);
+                       0.5f * (float)W, 0.5f * (float)H, sil, (uint4 *)zero_dst, (unsigned long long)(zero_bytes / 16));
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }
@@ -1089,7 +1100,7 @@ extern "C" int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream
     FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 32) <= 65535, "image batch / height too large for one launch");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv(p->T, 256), fpcdr_cdiv(p->B, SIL_NI)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil);
+                       p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil, (uint4 *)nullptr, 0ull);
     dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 32), p->B);
 #define LAUNCH(CS, SP)                                                                                                         \
     hipLaunchKernelGGL((k_aa_loss<CS, SP>), grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, \

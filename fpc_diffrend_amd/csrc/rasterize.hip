@@ -1447,7 +1447,9 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    int rc = fpcdr_launch_sil(p->pos, p->tri, l->adj, p->B, p->V, p->T, p->H, p->W, l->sil, st);
+    // (the silhouette kernel also zeroes the call's flag planes: the caller need not)
+    int rc = fpcdr_launch_sil(p->pos, p->tri, l->adj, p->B, p->V, p->T, p->H, p->W, l->sil, l->flags,
+                              (size_t)2 * p->B * p->H * FPCDR_AA_ROW_WORDS(p->W) * sizeof(uint64_t), st);
     if (rc) return rc;
     const RasterScratch rs = raster_scratch(p->scratch, p->B, p->T);
     TriRec *recs = rs.recs;

@@ -325,7 +325,7 @@ class _pixel_objective_func(torch.autograd.Function):
         g_aa = torch.empty_like(color)
         sil = torch.empty(B, T, dtype=torch.uint8, device=dev)
         nflag = lib.fpcdr_antialias_flags_bytes(B, H, W) // 8
-        flags = (torch.zeros if sparse else torch.empty)(nflag, dtype=torch.int64, device=dev)
+        flags = torch.empty(nflag, dtype=torch.int64, device=dev)     # (sparse: zeroed by fpcdr_render_loss_fwd itself, inside its first kernel)
         acc = torch.zeros(_lib.LOSS_SLOTS, dtype=torch.float64, device=dev)
         q = _lib.AaLossFwd(color=_ptr(color), rast=_ptr(rast), pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), ref=_ptr(ref), B=B,
                            H=H, W=W, C=C, V=V, T=T, bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),

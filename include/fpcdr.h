@@ -185,7 +185,7 @@ int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream);
  * different ids at a silhouette edge) its loss term and gradient straight away and leaves a bit mask of the others
  * (bin-border pixels included); a second kernel runs antialias + loss on those candidates only.  Same outputs as the
  * two calls.  r->occ, r->empty_color must be set (sparse mode only); l->color / rast / pos / tri / occ / empty_color
- * must equal r's; flags zero-filled by the caller; cmask: scratch of fpcdr_cmask_bytes(B,H,W) bytes, 8-byte aligned
+ * must equal r's; l->flags is zeroed by the call itself (ABI v7; fpcdr_aa_loss_fwd still wants it zero-filled); cmask: scratch of fpcdr_cmask_bytes(B,H,W) bytes, 8-byte aligned
  * (per bin 32 row masks of candidate pixels and the bin's four border lines; the work lists of the call's kernels).
  * The rasteriser and the antialias pass run over compact LISTS of the occupied bins (l->cap_bins, l->cap_fix).      */
 int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *r, const fpcdr_aa_loss_fwd_params *l, uint32_t *cmask, void *stream);
