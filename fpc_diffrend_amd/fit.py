@@ -619,6 +619,8 @@ class Fitter:
         """t[ids] / t[:, ids] for a slice or an index tensor.  A tensor goes through index_select: its backward is ONE index_add
         launch where advanced indexing sorts the indices first (seven launches) -- a fifth of a one-image step's launches."""
         if isinstance(ids, slice):
+            if ids.step in (None, 1) and (ids.start or 0) == 0 and ids.stop is not None and ids.stop >= t.shape[dim]:
+                return t      # every frame (one rank, frames_per_step = 0): no slice node, whose backward is a zero-fill and a copy
             return t[ids] if dim == 0 else t[:, ids]
         return t.index_select(dim, ids)
 
