@@ -597,6 +597,7 @@ class Fitter:
         # the pixel loss of an all-background image, per (frame, camera): depends on the targets only (sparse objective)
         t = self.targets
         self.target_bg_sumsq = dr.reference_background_sumsq(t.reshape(-1, *self.resolution), BACKGROUND).reshape(t.shape[:2])
+        self._bg_sum_key = None      # (the cached sum over the whole shard, loss_and_backward)
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -761,8 +762,14 @@ class Fitter:
         if one_shot:
             bg_sum = None
             if cfg.sparse_objective:
-                bg = self.target_bg_sumsq[local]
-                bg_sum = (bg if view_ids is None else bg.index_select(1, view_ids)).sum()
+                if isinstance(local, slice) and view_ids is None:      # the whole shard, every view: the same number every step
+                    key = (local.start, local.stop)
+                    if getattr(self, "_bg_sum_key", None) != key:
+                        self._bg_sum_key, self._bg_sum_all = key, self.target_bg_sumsq[local].sum()
+                    bg_sum = self._bg_sum_all
+                else:
+                    bg = self.target_bg_sumsq[local]
+                    bg_sum = (bg if view_ids is None else bg.index_select(1, view_ids)).sum()
             pix = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
                                      n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum,
                                      enable_mip=cfg.enable_mip, max_mip_level=cfg.max_mip_level,
