@@ -2,7 +2,7 @@
 """frames/s of the cfg3 bench at several coverages (share of the frame the head covers): the sparse objective skips empty
 regions, so its speed is a function of coverage.  The synthetic rig's default framing (head = 60 % of the image height) covers
 11.5 % of a 1080p frame; the reference's own rig (f ~ 9.8 deg FOV, head filling a 1600 x 1200 frame) is the
-40 % + case.   python scripts/coverage_sweep.py > profiles/r02_coverage_sweep.json"""
+40 % + case.   python scripts/coverage_sweep.py > profiles/rNN_coverage_sweep.json"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 points = []
