@@ -194,3 +194,22 @@ def test_meshdata_matches_reference_golden(tmp_path):
     cp.write_text(json.dumps(cal))
     look = data.load_calibration(str(cp), ["x_pod1primary", "x_pod2primary"])
     assert look[1]['cam'] == "x_pod2primary" and look[1]['intr'].shape == (3, 3) and look[1]['trans_calib'].shape == (3, 1)
+
+
+def test_fitter_host_rules_graph_choice_and_frame_selection():
+    """Host-side rules of the fit loop that need no GPU: FitConfig.hip_graph='auto' (graphs for few images per step, eager launches
+    with launch hints for large batches) and the frame selection helper (a slice over every frame is the tensor itself, a slice of
+    some frames a view, an index tensor goes through index_select: same values either way)."""
+    from fpc_diffrend_amd import fit
+    assert fit.Fitter.auto_graph(1, (1600, 1200))              # the reference's one-image step
+    assert fit.Fitter.auto_graph(9, (1080, 1920))              # cfg2: nine views of one frame
+    assert not fit.Fitter.auto_graph(288, (1080, 1920))        # cfg3: the headline batch
+    assert fit.Fitter.auto_graph(288, (64, 64)) and not fit.Fitter.auto_graph(64, (2160, 3840))
+    t = torch.arange(24.0).reshape(6, 4)
+    assert fit.Fitter._take(t, 0, slice(0, 6)) is t and fit.Fitter._take(t, 1, slice(0, 4)) is t
+    assert torch.equal(fit.Fitter._take(t, 0, slice(2, 5)), t[2:5]) and torch.equal(fit.Fitter._take(t, 1, slice(1, 3)), t[:, 1:3])
+    ids = torch.tensor([4, 1])
+    assert torch.equal(fit.Fitter._take(t, 0, ids), t[ids]) and torch.equal(fit.Fitter._take(t, 1, ids), t[:, ids])
+    p = t.clone().requires_grad_(True)
+    fit.Fitter._take(p, 0, ids).sum().backward()
+    assert torch.equal(p.grad, torch.zeros(6, 4).index_fill_(0, ids, 1.0))
