@@ -209,7 +209,8 @@ def test_fitter_host_rules_graph_choice_and_frame_selection():
     assert fit.Fitter._take(t, 0, slice(0, 6)) is t and fit.Fitter._take(t, 1, slice(0, 4)) is t
     assert torch.equal(fit.Fitter._take(t, 0, slice(2, 5)), t[2:5]) and torch.equal(fit.Fitter._take(t, 1, slice(1, 3)), t[:, 1:3])
     ids = torch.tensor([4, 1])
-    assert torch.equal(fit.Fitter._take(t, 0, ids), t[ids]) and torch.equal(fit.Fitter._take(t, 1, ids), t[:, ids])
+    cols = torch.tensor([3, 0])
+    assert torch.equal(fit.Fitter._take(t, 0, ids), t[ids]) and torch.equal(fit.Fitter._take(t, 1, cols), t[:, cols])
     p = t.clone().requires_grad_(True)
     fit.Fitter._take(p, 0, ids).sum().backward()
     assert torch.equal(p.grad, torch.zeros(6, 4).index_fill_(0, ids, 1.0))
