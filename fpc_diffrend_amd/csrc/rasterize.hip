@@ -1457,7 +1457,7 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     ImgBox *ibox = rs.ibox;
     const int OX = fpcdr_cdiv(p->W, BIN), OY = fpcdr_cdiv(p->H, BIN);
     const size_t nbins = (size_t)p->B * OY * OX;
-    FPCDR_REQUIRE(nbins < 0x7fffffffULL, "too many bins for one call");
+    FPCDR_REQUIRE(nbins < 0x7ffffff0ULL, "too many bins for one call");      // (list launches are rounded up to a multiple of 8 workgroups)
     const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W);
     char *cm = (char *)cmask, *oc = (char *)p->occ;
     int32_t *hdr = (int32_t *)(cm + q.cm_hdr), *bin_list = (int32_t *)(cm + q.cm_bin_list), *fix_list = (int32_t *)(cm + q.cm_fix_list);
