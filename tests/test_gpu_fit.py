@@ -286,7 +286,7 @@ def test_transform_clip_kernel_matches_torch():
     assert rel_l2(mvp.grad, gm) < 1e-5 and rel_l2(verts.grad, gv) < 1e-6
 
 
-@pytest.mark.parametrize("mode,fps,shading", [("prior", 0, "texture"), ("combined", 2, "texture"), ("prior", 0, "vertex")])
+@pytest.mark.parametrize("mode,fps,shading", [("prior", 0, "texture"), ("combined", 2, "texture"), ("prior", 0, "vertex"), ("prior", 0, "mip")])
 def test_hip_graph_steps_equal_eager_steps(mode, fps, shading):
     """FitConfig.hip_graph replays forward+backward and the Adam update as two HIP graphs: the loss trajectory is the
     eager one (same kernels, same arguments; capturable Adam keeps its step count on the device, so allow rounding)."""
@@ -295,8 +295,10 @@ def test_hip_graph_steps_equal_eager_steps(mode, fps, shading):
     for graph in (False, True):
         sc = scene.cfg('cfg1', n_frames=4)
         sc.q_gt[:] = (0.0, 0.0, 0.0, 1.0)
+        mip = shading == "mip"      # the mip-mapped fused objective (its chain is rebuilt inside the captured forward)
         cfg = fit.FitConfig(max_iter=14, cam_idxs=(0, 3), lr_base=5e-3, lr_t=5e-3, lr_q=1e-5, mode=mode, frames_per_step=fps,
-                            shading=shading, optimize_texture=(shading == "texture"), hip_graph=graph, weight_laplacian=20.0)
+                            shading="texture" if mip else shading, optimize_texture=(shading != "vertex"), hip_graph=graph,
+                            weight_laplacian=20.0, enable_mip=mip, max_mip_level=3)
         ft = fit.Fitter(sc, cfg, device='cuda')
         if mode == "prior":
             ft.init_near_truth(0.8)
