@@ -170,7 +170,8 @@ def test_mip_chain_end_to_end_matches_oracle(dr, oracle_ops):
     assert rel_l2(tex.grad, st.tex.grad) < TOL, rel_l2(tex.grad, st.tex.grad)
 
 
-@pytest.mark.parametrize("res,max_mip,boundary", [(None, 4, 'wrap'), ((97, 131), None, 'wrap'), ((150, 200), 2, 'clamp'), ((64, 96), 0, 'wrap')])
+@pytest.mark.parametrize("res,max_mip,boundary", [(None, 4, 'wrap'), ((97, 131), None, 'wrap'), ((150, 200), 2, 'clamp'), ((64, 96), 0, 'wrap'),
+                                                  ((70, 96), 3, 'zero')])
 def test_fused_objective_with_mip_equals_the_operator_chain_and_the_oracle(dr, oracle_ops, res, max_mip, boundary):
     """pixel_objective(enable_mip=True) -- the reference's enable_mip branch (fit.py:153-155) inside the three fused kernels: the
     footprint from the barycentrics' screen derivatives recomputed per pixel, 'linear-mipmap-linear' over the box-filtered chain,
@@ -189,7 +190,7 @@ def test_fused_objective_with_mip_equals_the_operator_chain_and_the_oracle(dr, o
     ref8 = torch.randint(0, 141, (len(cams), H, W), generator=g, dtype=torch.uint8)
     ctx = dr.RasterizeGLContext(device=dev)
     tri, uv, uv_idx = (torch.tensor(a, device=dev) for a in (sc.pos_idx, sc.uv, sc.uv_idx))
-    if boundary == 'clamp':
+    if boundary != 'wrap':
         uv = uv * 1.2 - 0.1
     # the chain of separate operators + the reference's torch loss
     p1 = pos.to(dev).requires_grad_(True)
