@@ -608,10 +608,15 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                         lds_add_f64(w + TEXW * CS, gc * w01);
                         lds_add_f64(w + TEXW * CS + CS, gc * w11);
                     } else {
-                        atomicAdd(&at32(grad_tex, (unsigned int)(tp.i00 + c)), gc * w00);
-                        atomicAdd(&at32(grad_tex, (unsigned int)(tp.i10 + c)), gc * w10);
-                        atomicAdd(&at32(grad_tex, (unsigned int)(tp.i01 + c)), gc * w01);
-                        atomicAdd(&at32(grad_tex, (unsigned int)(tp.i11 + c)), gc * w11);
+                        // (the offsets go through an opaque copy: shared with the texel loads above, the compiler forms ONE 64-bit address
+                        //  per tap for both and the loads lose their scalar-base form -- 8 vector instructions per pixel)
+                        unsigned int o00 = (unsigned int)(tp.i00 + c), o10 = (unsigned int)(tp.i10 + c), o01 = (unsigned int)(tp.i01 + c),
+                                     o11 = (unsigned int)(tp.i11 + c);
+                        asm volatile("" : "+v"(o00), "+v"(o10), "+v"(o01), "+v"(o11));
+                        atomicAdd(&at32(grad_tex, o00), gc * w00);
+                        atomicAdd(&at32(grad_tex, o10), gc * w10);
+                        atomicAdd(&at32(grad_tex, o01), gc * w01);
+                        atomicAdd(&at32(grad_tex, o11), gc * w11);
                     }
                 }
             }
