@@ -96,39 +96,14 @@ __global__ void k_topo_resolve(const int32_t *__restrict__ tri, int T, const uns
 // ------------------------------------------------------------------------------------------------
 // per-image silhouette classification (uncentred pixel-scaled homogeneous coordinates)
 // ------------------------------------------------------------------------------------------------
+#include "sil_bits.h"
 __global__ void __launch_bounds__(256) k_sil(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                              const int32_t *__restrict__ adj, int B, int V, int T, float hw, float hh,
                                              uint8_t *__restrict__ sil) {
-    // grid (triangle chunks, images): a flat thread index would cost every thread a 64-bit division
-    const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    // grid (triangle chunks, groups of SIL_NI images): a flat thread index would cost every thread a 64-bit division
+    const int b0 = blockIdx.y * SIL_NI, t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    const size_t gid = (size_t)b * T + t;
-    const float4 *p = pos + (size_t)b * V;
-    int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
-    unsigned int bits = 0;
-    bool ok = true;
-    for (int k = 0; k < 3; ++k) ok &= (vi[k] >= 0 && vi[k] < V);
-    if (ok) {
-        float qx[3], qy[3], qw[3];
-        for (int k = 0; k < 3; ++k) {
-            const float4 c = p[vi[k]];
-            qx[k] = c.x * hw; qy[k] = c.y * hh; qw[k] = c.w;
-        }
-        for (int e = 0; e < 3; ++e) {
-            const int ad = adj[3 * t + e];
-            if (ad == -1) { bits |= 1u << e; continue; }
-            if (ad < 0 || ad >= V) continue;
-            const int a = (e + 1) % 3, bb = (e + 2) % 3;
-            const float Lx = qy[a] * qw[bb] - qw[a] * qy[bb];
-            const float Ly = qw[a] * qx[bb] - qx[a] * qw[bb];
-            const float Lz = qx[a] * qy[bb] - qy[a] * qx[bb];
-            const float so = Lx * qx[e] + Ly * qy[e] + Lz * qw[e];
-            const float4 c = p[ad];
-            const float sp = Lx * (c.x * hw) + Ly * (c.y * hh) + Lz * c.w;
-            if ((so > 0.0f && sp > 0.0f) || (so < 0.0f && sp < 0.0f)) bits |= 1u << e;
-        }
-    }
-    sil[gid] = (uint8_t)bits;
+    sil_classify(pos, tri, adj, B, V, T, hw, hh, sil, b0, t);
 }
 
 #include "aa_pairs.h"
@@ -454,7 +429,7 @@ extern "C" int fpcdr_antialias_fwd(const fpcdr_antialias_fwd_params *p, void *st
     FPCDR_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->C > 0 && p->V > 0 && p->T > 0, "sizes must be positive");
     FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 4) <= 65535, "image batch / height too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sil, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+    hipLaunchKernelGGL(k_sil, dim3(fpcdr_cdiv(p->T, 256), fpcdr_cdiv(p->B, SIL_NI)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                        p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil);
     dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 4 * AROWS), p->B);
     int filled = 0, flags_zeroed = 0;
