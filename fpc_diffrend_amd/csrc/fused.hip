@@ -759,12 +759,13 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_BWD_WPE k_render_aa_bwd(const fl
                            B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag);
 }
 
-// grid form of the MIP instantiation (one colour channel, boundary mode at run time)
+// grid form of the MIP instantiation (boundary mode at run time)
 #ifdef FPCDR_MIPBWD_WAVES
 #define FPCDR_MIPBWD_WPE __attribute__((amdgpu_waves_per_eu(FPCDR_MIPBWD_WAVES, 8)))
 #else
 #define FPCDR_MIPBWD_WPE
 #endif
+template <int CS>
 __global__ void __launch_bounds__(BWD_NT) FPCDR_MIPBWD_WPE k_render_aa_bwd_mip(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                        const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri,
                                                        const float *__restrict__ tex, const float4 *__restrict__ rast,
@@ -776,7 +777,7 @@ __global__ void __launch_bounds__(BWD_NT) FPCDR_MIPBWD_WPE k_render_aa_bwd_mip(c
                                                        int W, int Ht, int Wt, int boundary, float *__restrict__ grad_pos,
                                                        float *__restrict__ grad_tex, const float2 *__restrict__ tri_uv,
                                                        const float *__restrict__ upstream, const uint8_t *__restrict__ binflag, MipArgs ma) {
-    render_aa_bwd_body<1, -1, true>(blockIdx.z, blockIdx.x, blockIdx.y, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ, empty_color,
+    render_aa_bwd_body<CS, -1, true>(blockIdx.z, blockIdx.x, blockIdx.y, pos, tri, uv, uv_tri, tex, rast, color, g_aa, sil, flags, occ, empty_color,
                                     B, V, T, H, W, Ht, Wt, boundary, grad_pos, grad_tex, tri_uv, upstream, binflag, &ma);
 }
 
@@ -1112,8 +1113,7 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
     hipStream_t st = (hipStream_t)stream;
     FPCDR_REQUIRE(!(p->queued || p->binflags) || p->occ != nullptr, "queued / binflags need the occupancy buffer of fpcdr_render_loss_fwd");
     const uint8_t *binflag = p->binflags ? (const uint8_t *)p->occ + fpcdr_queue_layout_of(p->B, p->H, p->W).occ_binflag : nullptr;
-    if (p->mip) {      // the reference's enable_mip branch: one colour channel, one workgroup per bin
-        FPCDR_REQUIRE(p->C == 1, "the mip-mapped fused objective takes one colour channel");
+    if (p->mip) {      // the reference's enable_mip branch: one workgroup per bin
         FPCDR_REQUIRE(p->n_levels >= 0 && p->n_levels <= FPCDR_MAX_MIP, "bad n_levels");
         MipArgs ma;
         for (int lvl = 0; lvl < FPCDR_MAX_MIP; ++lvl) {
@@ -1123,10 +1123,15 @@ extern "C" int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *st
         }
         ma.n_levels = p->n_levels;
         dim3 grid(fpcdr_cdiv(p->W, BBIN), fpcdr_cdiv(p->H, BBIN), p->B);
-        hipLaunchKernelGGL(k_render_aa_bwd_mip, grid, dim3(BWD_NT), 0, st, (const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, p->tex,
-                           (const float4 *)p->rast, p->color, p->grad_aa, p->sil, (const unsigned long long *)p->flags, p->occ, p->empty_color, p->B,
-                           p->V, p->T, p->H, p->W, p->Ht, p->Wt, p->boundary_mode, p->grad_pos, p->grad_tex, (const float2 *)p->tri_uv, p->upstream,
-                           binflag, ma);
+#define LAUNCH_MIP(CS)                                                                                                                    \
+        hipLaunchKernelGGL(k_render_aa_bwd_mip<CS>, grid, dim3(BWD_NT), 0, st, (const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, \
+                           p->tex, (const float4 *)p->rast, p->color, p->grad_aa, p->sil, (const unsigned long long *)p->flags, p->occ,          \
+                           p->empty_color, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt, p->boundary_mode, p->grad_pos, p->grad_tex,               \
+                           (const float2 *)p->tri_uv, p->upstream, binflag, ma)
+        if (p->C == 1) LAUNCH_MIP(1);
+        else if (p->C == 3) LAUNCH_MIP(3);
+        else LAUNCH_MIP(4);
+#undef LAUNCH_MIP
         FPCDR_CHECK_LAUNCH();
         return FPCDR_OK;
     }

@@ -1439,7 +1439,6 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
                   "bad boundary mode");
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30), "texture too large (the fused paths take < 2^30 texel values)");
     if (p->mip) {
-        FPCDR_REQUIRE(p->C == 1, "the mip-mapped fused objective takes one colour channel");
         FPCDR_REQUIRE(p->n_levels >= 0 && p->n_levels <= FPCDR_MAX_MIP, "bad n_levels");
         for (int lvl = 1; lvl <= p->n_levels; ++lvl) {
             FPCDR_REQUIRE(p->tex_mip[lvl - 1] != nullptr, "missing mip level");
@@ -1487,7 +1486,11 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     // hinted single-shot launch + strided sweep of the rest (l->cap_bins <= 0: no hint, one workgroup per possible entry)
     const fpcdr_bin_decode dc = fpcdr_make_bin_decode(OX, OY);
     const int cap_bins = (l->cap_bins > 0 && (size_t)l->cap_bins < nbins) ? l->cap_bins : (int)nbins;
-    if (p->mip)
+    if (p->mip && p->C != 1)
+        hipLaunchKernelGGL((k_bins_list<false, true, true, 0, -1, true>), dim3(fpcdr_list_grid(cap_bins)), dim3(256), 0, st, bin_list, n_bins, cap_bins, OX, OY, dc,
+                       (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
+                       (float4 *)nullptr, sh);
+    else if (p->mip)
         hipLaunchKernelGGL((k_bins_list<false, true, true, 1, -1, true>), dim3(fpcdr_list_grid(cap_bins)), dim3(256), 0, st, bin_list, n_bins, cap_bins, OX, OY, dc,
                        (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
                        (float4 *)nullptr, sh);

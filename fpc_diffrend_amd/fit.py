@@ -721,9 +721,9 @@ class Fitter:
         ref = ref.reshape(Fb * Nc, *self.resolution)
         C = self.tex_opt.shape[2]
         n_total = n_img_global * self.resolution[0] * self.resolution[1] * C
-        # (the mip branch of the reference's render(), fit.py:153-155, runs inside the same kernels for one colour channel)
+        # (the mip branch of the reference's render(), fit.py:153-155, runs inside the same kernels)
         one_shot = (cfg.fused_objective and cfg.fused_render and cfg.fused_loss and C in (1, 3, 4) and cfg.shading == 'texture'
-                    and (not cfg.enable_mip or (C == 1 and cfg.sparse_objective)))
+                    and (not cfg.enable_mip or cfg.sparse_objective))
         pos_clip = transform_clip_batched(mvp, vtx_pos_split)        # camera.transform_clip (camera.py:11-23), batched
         if cfg.shading == 'vertex':
             colour, rast_out = self.render_vertex(self.glctx, pos_clip)

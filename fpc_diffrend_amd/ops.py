@@ -430,7 +430,7 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     launch_hints: size the sparse kernels' launches from the bin counts of the previous call on the same batch shape
     (read back asynchronously, never waited for; the result does not depend on them).  queued_backward: the backward
     kernel also runs over the compact list of occupied bins instead of one workgroup per bin (same result).
-    enable_mip (one colour channel, sparse mode): the reference's other branch (fit.py:153-155) -- interpolate with the rasteriser's
+    enable_mip (sparse mode): the reference's other branch (fit.py:153-155) -- interpolate with the rasteriser's
     screen-space derivatives and texture 'linear-mipmap-linear' with max_mip_level -- inside the same three kernels; equals the
     chain rasterize(output_db) -> interpolate(diff_attrs='all') -> texture(texd) -> antialias + pixel loss."""
     assert isinstance(glctx, RasterizeHipContext)
@@ -452,8 +452,8 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     n_total = n_total or pos.shape[0] * H * W * tex.shape[2]
     mip_levels = None
     if enable_mip:
-        if tex.shape[2] != 1 or not sparse:
-            raise NotImplementedError("pixel_objective(enable_mip=True) takes one colour channel in sparse mode (use the separate operators otherwise)")
+        if not sparse:
+            raise NotImplementedError("pixel_objective(enable_mip=True) runs in sparse mode (use the separate operators otherwise)")
         mip_levels = _num_mip_levels(tex.shape[0], tex.shape[1], max_mip_level)
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                        ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq,

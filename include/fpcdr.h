@@ -114,7 +114,7 @@ typedef struct {
                                list of bins the backward call visits with its work cursor). */
     float *empty_color;     /* sparse mode: out [4], the colour of an empty pixel (the texture at uv = (0,0), fit.py:157-158) */
     /* ABI v7, fpcdr_render_loss_fwd only: the reference's enable_mip branch (fit.py:153-155) -- interpolate with the rasteriser's
-     * screen-space derivatives (diff_attrs='all') and texture 'linear-mipmap-linear' -- inside the same kernels.  C = 1 only. */
+     * screen-space derivatives (diff_attrs='all') and texture 'linear-mipmap-linear' -- inside the same kernels (C = 1, 3, 4). */
     int32_t mip;            /* 1 = mip-mapped lookup (0: the 'linear' lookup above) */
     int32_t n_levels;       /* levels below tex in the chain, 0 .. FPCDR_MAX_MIP (nvdiffrast's max_mip_level, already clamped) */
     const float *tex_mip[FPCDR_MAX_MIP];   /* tex_mip[l - 1] = level l, [Ht >> l, Wt >> l, C] (fpcdr_mip_downsample) */
@@ -224,7 +224,7 @@ typedef struct {
     int32_t cap_bwd;       /* queued = 1: launch-size hint for the list kernel, as cap_bins above (0 = none) */
     int32_t binflags;      /* 1: occ was filled by fpcdr_render_loss_fwd, which also left a per-bin summary of the flag planes:
                               flag words are then loaded only near bins that hold a blended pair */
-    /* ABI v7: backward of the mip-mapped forward (fpcdr_render_fwd_params.mip; C = 1, one workgroup per bin) */
+    /* ABI v7: backward of the mip-mapped forward (fpcdr_render_fwd_params.mip; one workgroup per bin) */
     int32_t mip, n_levels;
     const float *tex_mip[FPCDR_MAX_MIP];        /* as in the forward call */
     float *grad_tex_mip[FPCDR_MAX_MIP];         /* per level, accumulated (the caller folds them into grad_tex: fpcdr_mip_downsample_bwd) */
