@@ -14,7 +14,7 @@ MAX_ATTR = 32
 MAX_MIP = 16
 LOSS_SLOTS = 256
 OCC_BIN = 32         # FPCDR_OCC_BIN
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
 BOUNDARY = {'wrap': 0, 'clamp': 1, 'zero': 2}
@@ -60,6 +60,15 @@ class RenderAaBwd(ctypes.Structure):
                 ("Vt", _i), ("Ht", _i), ("Wt", _i), ("C", _i), ("boundary_mode", _i), ("grad_pos", _p), ("grad_tex", _p),
                 ("tri_uv", _p), ("upstream", _p), ("queued", _i), ("cap_bwd", _i), ("binflags", _i),
                 ("mip", _i), ("n_levels", _i), ("tex_mip", _p * MAX_MIP), ("grad_tex_mip", _p * MAX_MIP)]
+
+
+class Objective(ctypes.Structure):
+    _fields_ = [("pos", _p), ("tri", _p), ("adj", _p), ("B", _i), ("V", _i), ("T", _i), ("H", _i), ("W", _i), ("scratch", _p),
+                ("uv", _p), ("uv_tri", _p), ("Vt", _i), ("tri_uv", _p), ("tex", _p), ("Ht", _i), ("Wt", _i), ("C", _i),
+                ("boundary_mode", _i), ("ref", _p), ("bg", ctypes.c_float), ("color_scale", ctypes.c_float),
+                ("grad_scale", ctypes.c_float), ("sil", _p), ("idp", _p), ("occ", _p), ("cmask", _p), ("rec", _p), ("color", _p),
+                ("grad_aa", _p), ("empty_color", _p), ("loss_sum", _p), ("grad_pos", _p), ("grad_tex", _p), ("cap_bins", _i),
+                ("cap_occ", _i)]
 
 
 class InterpolateFwd(ctypes.Structure):
@@ -135,6 +144,8 @@ SYMBOLS = {
     "fpcdr_ref_bg_sumsq": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, _p, _p]),
     "fpcdr_objective_value": (_int, [_p, _i, _p, ctypes.c_double, ctypes.c_double, _p, _p]),
     "fpcdr_render_aa_bwd": (_int, [ctypes.POINTER(RenderAaBwd), _p]),
+    "fpcdr_idplane_bytes": (_sz, [_i, _i, _i]),
+    "fpcdr_objective_fwd": (_int, [ctypes.POINTER(Objective), _p]),
     "fpcdr_interpolate_fwd": (_int, [ctypes.POINTER(InterpolateFwd), _p]),
     "fpcdr_interpolate_bwd": (_int, [ctypes.POINTER(InterpolateBwd), _p]),
     "fpcdr_mip_downsample": (_int, [_p, _p, _i, _i, _i, _i, _p]),

@@ -36,6 +36,8 @@ int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, i
 int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask, const unsigned long long *edges,
                         const int32_t *fix_list, const int32_t *fix_count, int nbins, hipStream_t st);
 
+int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, const int32_t **occ_list, const int32_t **n_occ_dev);
+
 // workgroups of the strided sweep behind a hinted single-shot launch (normally they find nothing to do)
 #define FPCDR_SWEEP_WGS 256
 

@@ -1,0 +1,658 @@
+// One-pass pixel objective for gfx950 (MI355X): value AND gradient of reference src/torch/fit.py:151-161 + the pixel term of :579 in
+// one call (include/fpcdr.h, fpcdr_objective_fwd).
+//
+// The two-call form (fpcdr_render_loss_fwd + fpcdr_render_aa_bwd, fused.hip) writes rast, colour and d loss / d colour -- 24 B/px --
+// so that the backward call can read them back and RE-DERIVE what the forward held in registers: 45 % of that backward's vector
+// instructions (profiles/r04_backward_ablation.txt).  The objective is a scalar, so its gradient is known the moment a pixel's loss
+// term is: here the thread that shades a pixel also chains its gradient back while barycentrics, taps, texels and vertices are live.
+//
+//   k_bins_list<IDS> (rasterize.hip)   coverage + depth only; leaves (triangle + 1) | silhouette bits << 24 per pixel, 4 KB per bin
+//   k_shade                            one workgroup per occupied bin: shade, texture, background + squared error, texture /
+//                                      interpolate / rasterize backward of the un-antialiased gradient into per-bin LDS accumulators
+//                                      (vertex table + texel window, doubles), one flush.  Pixels with a pixel pair of different ids
+//                                      at a triangle that owns a silhouette edge -- known exactly from the id planes, the neighbour
+//                                      bins' border lines included -- are DEFERRED: their record, colour and gradient are also stored
+//   k_fix<0>                           deferred pixels only: exact antialias blend, loss correction, final d loss / d colour
+//   k_fix<1>                           deferred pixels only: the DIFFERENCE between the gradient arriving at their colour through the
+//                                      antialias op and the un-antialiased one k_shade scattered (everything downstream is linear in
+//                                      it), and the antialias op's own d alpha / d pos
+//
+// The antialias pair analysis -- ~1 % of the covered pixels, 56 spilled VGPRs in the old backward -- lives in k_fix alone.
+#include "common.h"
+
+#include <stdlib.h>
+
+int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, int B, int V, int T, int H, int W, uint8_t *sil,
+                     void *zero_dst, size_t zero_bytes, hipStream_t st);
+
+namespace {
+
+#include "texsample.h"
+#include "raster_math.h"
+#include "aa_pairs.h"
+
+#ifndef FPCDR_OTEXWIN
+#define FPCDR_OTEXWIN 40          // texel window of a bin (see fused.hip: capacity swept 8 .. 64 at ~1 texel per pixel)
+#endif
+constexpr int OB = 32;            // pixels per bin side
+constexpr int OS = 36;            // LDS row stride of the id plane with its one-pixel apron (34 entries used)
+constexpr int OTW = FPCDR_OTEXWIN;
+constexpr int ONT = 256;          // threads of k_shade
+constexpr int FNT = 64;           // threads of k_fix: one wave per bin (a chain of dependent loads for a few dozen pixels)
+
+struct ObjArgs {
+    const float4 *pos; const int32_t *tri; const float2 *uv; const int32_t *uv_tri; const float2 *tri_uv;
+    const float *tex; const uint8_t *ref; const uint8_t *sil;
+    const uint32_t *idp; const uint16_t *occ; uint8_t *binflag; uint32_t *cmask;
+    float4 *rec; float *color; float *g_aa; const float *empty_color;
+    double *loss_sum; float *grad_pos; float *grad_tex;
+    int B, V, T, H, W, Ht, Wt, boundary;
+    float bg, color_scale, grad_scale;
+};
+
+// texture coordinates of triangle t through the index buffer (callers that did not pre-gather uv[uv_tri]); out of line, see fused.hip
+__device__ __noinline__ void uv_indirect(const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri, int t, float2 &q0, float2 &q1,
+                                         float2 &q2) {
+    q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]];
+}
+
+// d(grad_scale * sum of squares) / d colour for one channel: ONE expression for the three kernels, so that a deferred pixel no blend
+// touches gets a difference of exactly zero in k_fix<1>
+__device__ __forceinline__ float loss_grad(float dd, float color_scale, float grad_scale) { return (-2.0f * color_scale * grad_scale) * dd; }
+
+// a pixel pair can change under antialiasing only if the ids differ and one of the two triangles owns a silhouette edge
+__device__ __forceinline__ bool pair_maybe(unsigned int a, unsigned int b) { return ((a ^ b) & 0xffffffu) != 0u && ((a | b) >> 24) != 0u; }
+
+struct I3 { int a, b, c; };
+struct UV3 { float2 q0, q1, q2; };
+
+// ------------------------------------------------------------------------------------------------
+// k_shade: one 32 x 32 bin, 256 threads, four pixels per thread.  Pixel k of a thread: row 8 wave + 2 k + (lane >> 5), the odd row
+// right to left, so that the pixels of a triangle are neighbours in lane order and ONE segmented scan per pass sums the nine vertex
+// gradient components of every run (common.h wave_segment_reduce9).
+#ifndef FPCDR_SHADE_WPE
+#define FPCDR_SHADE_WPE
+#endif
+template <int CS, int BMODE>
+__device__ __forceinline__ void shade_body(const int b, const int bxi, const int byi, const int OX, const int OY, const ObjArgs &a) {
+    const int boundary = BMODE >= 0 ? BMODE : a.boundary;
+    __shared__ unsigned int s_id[(OB + 2) * OS];
+    __shared__ int s_vkey[FPCDR_VT_SLOTS];
+    __shared__ double s_vacc[FPCDR_VT_SLOTS][3];
+    __shared__ double s_tex[OTW * OTW * CS];
+    __shared__ int s_org[2];
+    __shared__ unsigned int s_cmask[OB];
+    __shared__ float s_fy[OB];
+    __shared__ float s_lpart[ONT / 64];
+    const VTable vt = {s_vkey, s_vacc};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = (lane & 32) ? 63 - lane : lane;
+    const int row0 = 8 * wave + (lane >> 5);
+    const int bx0 = bxi * OB, by0 = byi * OB;
+    const int x = bx0 + col;
+    const int H = a.H, W = a.W, Ht = a.Ht, Wt = a.Wt;
+    const size_t bin_lin = ((size_t)b * OY + byi) * OX + bxi;
+    const unsigned int wmask = (unsigned int)__builtin_amdgcn_readfirstlane((int)a.occ[bin_lin]);
+    const bool want_tex = a.grad_tex != nullptr, want_pos = a.grad_pos != nullptr, want_grad = want_tex || want_pos;   // (uniform)
+
+    // ---- phase 0: the bin's ids with a one-pixel apron from the neighbours' planes; tables ----
+    {
+        const uint4 v = reinterpret_cast<const uint4 *>(a.idp + bin_lin * (OB * OB))[tid];
+        unsigned int *d = &s_id[((tid >> 3) + 1) * OS + (tid & 7) * 4 + 1];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    if (tid < 4 * OB) {
+        const int side = tid >> 5, i = tid & 31;      // 0 left, 1 right, 2 below, 3 above
+        const int dx = side == 0 ? -1 : (side == 1 ? 1 : 0), dy = side == 2 ? -1 : (side == 3 ? 1 : 0);
+        unsigned int e = 0u;
+        if ((wmask >> ((dy + 1) * 4 + dx + 1)) & 1u) {      // (set only for bins inside the image that were rasterised)
+            const size_t nb = (size_t)((long long)bin_lin + dy * OX + dx);
+            const int sx = side == 0 ? OB - 1 : (side == 1 ? 0 : i), sy = side == 2 ? OB - 1 : (side == 3 ? 0 : i);
+            e = a.idp[nb * (OB * OB) + sy * OB + sx];
+        }
+        const int tx = side == 0 ? 0 : (side == 1 ? OB + 1 : i + 1), ty = side == 2 ? 0 : (side == 3 ? OB + 1 : i + 1);
+        s_id[ty * OS + tx] = e;
+    }
+    if (want_pos) vtable_init(vt, tid, ONT);
+    if (want_tex)
+        for (int k = tid; k < OTW * OTW * CS; k += ONT) s_tex[k] = 0.0;
+    if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
+    if (tid < OB) {
+        s_cmask[tid] = 0u;
+        s_fy[tid] = (2.0f * (float)(by0 + tid) + 1.0f) / (float)H - 1.0f;      // NDC y of the bin's rows: one IEEE division per row
+    }
+    __syncthreads();
+
+    const size_t img = (size_t)b * H * W;
+    const size_t bin_off = img + (size_t)by0 * W + bx0;
+    const float4 *const pos_img = a.pos + (size_t)b * a.V;
+    float *const gp = want_pos ? a.grad_pos + (size_t)b * a.V * 4 : nullptr;
+    const float fx_col = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
+    const float cs = a.color_scale, gs = a.grad_scale;
+    const float bgs = a.bg * cs;
+
+    // what a pixel keeps for the texel adds behind the barrier (the window's origin is the bin's smallest tap, known only then)
+    float k_gc[4][CS], k_fx[4], k_fy[4];
+    int k_x0[4], k_y0[4];
+    bool k_on[4];
+    int ux0 = 0x7fffffff, uy0 = 0x7fffffff;
+    float lsum = 0.0f;
+    bool any_def = false;
+
+    // ---- phase 1: shade, loss, chain back ----
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int zy = row0 + 2 * k, y = by0 + zy;
+        const unsigned int me = s_id[(zy + 1) * OS + col + 1];
+        const int id = (int)(me & 0xffffffu);      // (pixels beyond the image hold 0)
+        k_on[k] = false;
+        int tkey = -1;
+        int vk[3] = {0, 0, 0};
+        float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (id > 0) {
+            const unsigned int nR = s_id[(zy + 1) * OS + col + 2], nL = s_id[(zy + 1) * OS + col];
+            const unsigned int nU = s_id[(zy + 2) * OS + col + 1], nD = s_id[zy * OS + col + 1];
+            const bool deferred = (x + 1 < W && pair_maybe(me, nR)) || (y + 1 < H && pair_maybe(me, nU)) || (x > 0 && pair_maybe(me, nL)) ||
+                                  (y > 0 && pair_maybe(me, nD));
+            const int t = id - 1;
+            const I3 ti = ld32(reinterpret_cast<const I3 *>(a.tri), t);
+            const float4 v0 = ld32(pos_img, ti.a), v1 = ld32(pos_img, ti.b), v2 = ld32(pos_img, ti.c);
+            const float fy = s_fy[zy];
+            ShadeKeep K;
+            float u, v, zw;
+            shade_uvz(v0, v1, v2, fx_col, fy, K, u, v, zw);
+            // interpolate (fit.py:157) + texture 'linear' (fit.py:158): the arithmetic of the stand-alone kernels
+            float2 q0, q1, q2;
+            if (a.tri_uv) { const UV3 tq = ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t); q0 = tq.q0; q1 = tq.q1; q2 = tq.q2; }
+            else uv_indirect(a.uv, a.uv_tri, t, q0, q1, q2);
+            const float w = 1.0f - u - v;
+            const float tu = u * q0.x + v * q1.x + w * q2.x;
+            const float tv = u * q0.y + v * q1.y + w * q2.y;
+            const Taps tp = boundary == FPCDR_BOUNDARY_ZERO ? make_taps(tu, tv, Ht, Wt, CS, boundary) : make_taps_fast(tu, tv, Ht, Wt, CS, boundary);
+            const unsigned int poff = (unsigned int)(zy * W + col);
+            const size_t off = bin_off + poff;
+            const float rf = (float)ld32(a.ref + bin_off, poff);
+            const float d0 = rf - bgs;
+            float colv[CS], gq[CS];
+            float gfx = 0.f, gfy = 0.f;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                float t00, t10, t01, t11;
+                load_taps<true>(a.tex, tp, c, CS, t00, t10, t01, t11);      // (the entry point requires < 2^30 texel values)
+                mask_taps(tp, t00, t10, t01, t11);
+                const float top = t00 + (t10 - t00) * tp.fx;
+                const float bot = t01 + (t11 - t01) * tp.fx;
+                colv[c] = top + (bot - top) * tp.fy;
+                // background elsewhere (fit.py:161); squared error against the 8-bit reference (fit.py:579), as the difference to a
+                // background pixel (the all-background share of the loss depends on the references alone: fpcdr_ref_bg_sumsq)
+                const float dd = rf - colv[c] * cs;
+                lsum += dd * dd - d0 * d0;
+                gq[c] = loss_grad(dd, cs, gs);
+                gfx += gq[c] * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
+                gfy += gq[c] * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
+            }
+            if (deferred) {      // k_fix reads these back: a few per cent of the covered pixels
+                any_def = true;
+                atomicOr(&s_cmask[zy], 1u << col);
+                a.rec[off] = make_float4(u, v, zw, (float)id);
+#pragma unroll
+                for (int c = 0; c < CS; ++c) { a.color[off * CS + c] = colv[c]; a.g_aa[off * CS + c] = gq[c]; }
+            }
+            if (want_grad) {
+                bool nz = false;
+#pragma unroll
+                for (int c = 0; c < CS; ++c) { k_gc[k][c] = gq[c]; nz |= gq[c] != 0.0f; }
+                if (want_tex && nz) {
+                    k_on[k] = true;
+                    k_fx[k] = tp.fx; k_fy[k] = tp.fy;
+                    k_x0[k] = (int)floorf(prep_coord(tu, boundary) * (float)Wt - 0.5f);
+                    k_y0[k] = (int)floorf(prep_coord(tv, boundary) * (float)Ht - 0.5f);
+                    ux0 = min(ux0, k_x0[k]); uy0 = min(uy0, k_y0[k]);
+                }
+                if (want_pos) {
+                    const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
+                    const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv >= 0.0f && tv <= 1.0f)) ? 0.0f : 1.0f;
+                    const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
+                    const float gu = gtu * (q0.x - q2.x) + gtv * (q0.y - q2.y);
+                    const float gvv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
+                    if (gu != 0.0f || gvv != 0.0f) {
+                        tkey = t;
+                        vk[0] = ti.a; vk[1] = ti.b; vk[2] = ti.c;
+                        float g0[3], g1[3], g2[3];
+                        shade_uv_bwd(K, fx_col, fy, gu, gvv, g0, g1, g2);
+                        gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
+                        gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
+                        gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
+                    }
+                }
+            }
+        }
+        if (want_pos)      // (uniform)
+            wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) { vtable_add(vt, gp, vk, sm); });
+    }
+    if (want_tex) {
+        const int mx = wave_min_dpp(ux0), my = wave_min_dpp(uy0);
+        if (lane == 0 && mx != 0x7fffffff) { atomicMin(&s_org[0], mx); atomicMin(&s_org[1], my); }
+    }
+    lsum = wave_sum_dpp(lsum);
+    if (lane == 0) s_lpart[wave] = lsum;
+    const bool bin_def = __builtin_amdgcn_readfirstlane(__syncthreads_or(any_def ? 1 : 0)) != 0;
+
+    // ---- phase 2: the four texel adds of every pixel into the window (taps outside it -- uv seams -- go to memory) ----
+    if (want_tex) {
+        const int ox = s_org[0], oy = s_org[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!k_on[k]) continue;
+            const int x0 = k_x0[k], y0 = k_y0[k];
+            unsigned int valid = 0xFu;
+            if (boundary == FPCDR_BOUNDARY_ZERO) {
+                const bool vx0 = x0 >= 0 && x0 < Wt, vx1 = x0 >= -1 && x0 < Wt - 1, vy0 = y0 >= 0 && y0 < Ht, vy1 = y0 >= -1 && y0 < Ht - 1;
+                valid = (vx0 && vy0 ? 1u : 0u) | (vx1 && vy0 ? 2u : 0u) | (vx0 && vy1 ? 4u : 0u) | (vx1 && vy1 ? 8u : 0u);
+            }
+            const float fx = k_fx[k], fy = k_fy[k];
+            const float w00 = (valid & 1u) ? (1.0f - fx) * (1.0f - fy) : 0.0f, w10 = (valid & 2u) ? fx * (1.0f - fy) : 0.0f;
+            const float w01 = (valid & 4u) ? (1.0f - fx) * fy : 0.0f, w11 = (valid & 8u) ? fx * fy : 0.0f;
+            const int lx = x0 - ox, ly = y0 - oy;
+            if (lx >= 0 && ly >= 0 && lx + 1 < OTW && ly + 1 < OTW) {
+#pragma unroll
+                for (int c = 0; c < CS; ++c) {
+                    double *wp = s_tex + (ly * OTW + lx) * CS + c;
+                    const float gc = k_gc[k][c];
+                    lds_add_f64(wp, gc * w00);
+                    lds_add_f64(wp + CS, gc * w10);
+                    lds_add_f64(wp + OTW * CS, gc * w01);
+                    lds_add_f64(wp + OTW * CS + CS, gc * w11);
+                }
+            } else {
+                const int ix0 = wrap_near(x0, Wt, boundary), ix1 = wrap_near(x0 == 0x7fffffff ? x0 : x0 + 1, Wt, boundary);
+                const int iy0 = wrap_near(y0, Ht, boundary), iy1 = wrap_near(y0 == 0x7fffffff ? y0 : y0 + 1, Ht, boundary);
+#pragma unroll
+                for (int c = 0; c < CS; ++c) {
+                    const float gc = k_gc[k][c];
+                    atomicAdd(&at32(a.grad_tex, (unsigned int)((iy0 * Wt + ix0) * CS + c)), gc * w00);
+                    atomicAdd(&at32(a.grad_tex, (unsigned int)((iy0 * Wt + ix1) * CS + c)), gc * w10);
+                    atomicAdd(&at32(a.grad_tex, (unsigned int)((iy1 * Wt + ix0) * CS + c)), gc * w01);
+                    atomicAdd(&at32(a.grad_tex, (unsigned int)((iy1 * Wt + ix1) * CS + c)), gc * w11);
+                }
+            }
+        }
+    }
+    // ---- the bin's deferred pixels for k_fix; loss ----
+    if (tid < OB) a.cmask[bin_lin * OB + tid] = s_cmask[tid];
+    if (tid == 0) {
+        if (bin_def) a.binflag[bin_lin] = 1;      // (zero-filled by the call's first kernel)
+        const double tot = (double)s_lpart[0] + (double)s_lpart[1] + (double)s_lpart[2] + (double)s_lpart[3];
+        const unsigned int slot = ((unsigned int)bxi + 31u * (unsigned int)byi + 977u * (unsigned int)b) % FPCDR_LOSS_SLOTS;
+        if (tot != 0.0) atomicAdd(a.loss_sum + slot, tot);
+    }
+    if (!want_grad) return;
+    __syncthreads();
+    // ---- flush: every vertex slot and window cell once ----
+    if (want_pos) vtable_flush(vt, gp, tid, ONT);
+    if (want_tex && s_org[0] != 0x7fffffff) {
+        const int ox = s_org[0], oy = s_org[1];
+        for (int k = tid; k < OTW * OTW * CS; k += ONT) {
+            const float v = (float)s_tex[k];
+            if (v != 0.0f) {
+                const int c = k % CS, cell = k / CS;
+                const int gx = wrap_near(ox + cell % OTW, Wt, boundary), gy = wrap_near(oy + cell / OTW, Ht, boundary);
+                atomicAdd(&at32(a.grad_tex, (unsigned int)((gy * Wt + gx) * CS + c)), v);
+            }
+        }
+    }
+}
+
+template <int CS, int BMODE>
+__global__ void __launch_bounds__(ONT) FPCDR_SHADE_WPE k_shade_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int cap,
+                                                                    int OX, int OY, fpcdr_bin_decode dc, ObjArgs a) {
+    const int item = fpcdr_list_item(*count, cap);      // (XCD x takes the x-th eighth of the entries: common.h)
+    if (item < 0) return;
+    const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+    int b, byi, bxi;
+    fpcdr_decode_bin(lin, dc, b, byi, bxi);
+    shade_body<CS, BMODE>(b, bxi, byi, OX, OY, a);
+}
+
+// strided sweep of the entries beyond the hinted launch (normally none; scalar loop variable: see k_bins_queue in rasterize.hip)
+template <int CS>
+__global__ void __launch_bounds__(ONT) k_shade_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int first, int OX, int OY,
+                                                     fpcdr_bin_decode dc, ObjArgs a) {
+    const int n = *count;
+    for (int item = first + blockIdx.x; item < n; item += gridDim.x) {
+        const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+        int b, byi, bxi;
+        fpcdr_decode_bin(lin, dc, b, byi, bxi);
+        shade_body<CS, -1>(b, bxi, byi, OX, OY, a);
+        __syncthreads();     // the next bin's first LDS writes must not overtake this bin's last LDS reads
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fix: the deferred pixels of one bin, one wave per bin.
+//   PASS 0  antialias forward (gather form, the pair analysis of aa_pairs.h) for each deferred pixel: blended colour, correction of
+//           its loss term, final d loss / d colour.  Reads records / colours k_shade stored, writes grad_aa of its own pixels only.
+//   PASS 1  (separate launch: it reads the neighbours' FINAL grad_aa) gradient arriving at each deferred pixel's colour through the
+//           antialias op minus the un-antialiased one k_shade already scattered -> texture / interpolate / rasterize backward of the
+//           difference; the antialias op's d alpha / d pos; the share of empty pixels' colour (all sample uv = (0,0)).
+// Neighbour ids come from the id planes (own bin or a neighbour's), z/w and colour of a partner from the deferred records: both pixels
+// of a pair that passes pair_maybe are deferred.
+template <int CS, int PASS>
+__device__ __forceinline__ void fix_body(const int b, const int bxi, const int byi, const int OX, const int OY, const ObjArgs &a) {
+    __shared__ unsigned int s_mask[OB];
+    __shared__ int s_list[OB * OB];
+    __shared__ int s_n;
+    const size_t bin_lin = ((size_t)b * OY + byi) * OX + bxi;
+    if (!__builtin_amdgcn_readfirstlane((int)a.binflag[bin_lin])) return;      // no deferred pixel in this bin
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bx0 = bxi * OB, by0 = byi * OB;
+    const int H = a.H, W = a.W;
+    const unsigned int wmask = (unsigned int)__builtin_amdgcn_readfirstlane((int)a.occ[bin_lin]);
+    if (tid < OB) s_mask[tid] = a.cmask[bin_lin * OB + tid];
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < OB * OB / FNT; ++k) {
+        const int pix = k * FNT + tid;
+        const bool c = (s_mask[pix >> 5] >> (pix & 31)) & 1u;
+        const unsigned long long bal = __ballot(c);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (c) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = pix;
+    }
+    __syncthreads();
+    const int n = __builtin_amdgcn_readfirstlane(s_n);
+    if (n == 0) return;
+    float ecol[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) ecol[c] = a.empty_color[c];
+    const size_t img = (size_t)b * H * W;
+    const AAGeom g = {a.pos + (size_t)b * a.V, a.tri, a.sil + (size_t)b * a.T, a.T, W, H, 0.5f * (float)W, 0.5f * (float)H};
+    const float cs = a.color_scale, gs = a.grad_scale, bgs = a.bg * cs;
+    float *const gp = (PASS == 1 && a.grad_pos) ? a.grad_pos + (size_t)b * a.V * 4 : nullptr;
+    auto id_at = [&](int xx, int yy) -> unsigned int {      // entry of an in-image pixel of this bin or of one of its eight neighbours
+        const int dbx = (xx >> 5) - bxi, dby = (yy >> 5) - byi;
+        if (!((wmask >> ((dby + 1) * 4 + dbx + 1)) & 1u)) return 0u;      // a bin that was not rasterised holds empty pixels
+        return a.idp[(size_t)((long long)bin_lin + dby * OX + dbx) * (OB * OB) + (yy & 31) * OB + (xx & 31)];
+    };
+    float lsum = 0.0f;
+    float esum[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) esum[c] = 0.0f;
+    for (int base = 0; base < n; base += FNT) {      // (uniform trip count: the segmented scan of PASS 1 needs the whole wave)
+        const int i = base + tid;
+        const bool act = i < n;
+        const int pix = act ? s_list[i] : 0;
+        const int x = bx0 + (pix & 31), y = by0 + (pix >> 5);
+        int tkey = -1;
+        int vk[3] = {0, 0, 0};
+        float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (act) {
+            const size_t off = img + (size_t)y * W + x;
+            const unsigned int me = a.idp[bin_lin * (OB * OB) + pix];
+            const float4 rme = a.rec[off];
+            const float zX = rme.z;
+            float cme[CS], acc[CS], go[CS];
+#pragma unroll
+            for (int c = 0; c < CS; ++c) { cme[c] = a.color[off * CS + c]; acc[c] = cme[c]; go[c] = PASS == 1 ? a.g_aa[off * CS + c] : 0.0f; }
+            bool hit = false;
+            // pair (x0, y0) - (x0 + e_d): entries / depths in pair order; (ox, oy, eo) = the partner of X; first = X is the pair's first pixel
+            auto visit = [&](int x0, int y0, int d, unsigned int e0, float z0, unsigned int e1, float z1, int ox, int oy, unsigned int eo,
+                             bool first) {
+                for_active_edges(g, x0, y0, d, (int)(e0 & 0xffffffu), z0, (int)(e1 & 0xffffffu), z1,
+                    [&](float t, int Px, int Py, int Qx, int Qy, int va, int vb, const EdgeEval &ev, float s) {
+                        const bool far = t >= 0.5f;
+                        const int rx = far ? Qx : Px, ry = far ? Qy : Py;      // the pixel that is blended
+                        const float amt = far ? t - 0.5f : 0.5f - t;
+                        const bool rX = rx == x && ry == y;
+                        const bool o_cov = (eo & 0xffffffu) != 0u;
+                        const float *co = a.color + (img + (size_t)oy * W + ox) * CS;
+                        if (PASS == 0) {
+                            if (!rX) return;
+                            hit = true;
+#pragma unroll
+                            for (int c = 0; c < CS; ++c) acc[c] += amt * ((o_cov ? co[c] : ecol[c]) - cme[c]);
+                            return;
+                        }
+                        if (!rX && !o_cov) return;      // the blended pixel is an empty one: no gradient arrives
+                        float gr[CS];
+#pragma unroll
+                        for (int c = 0; c < CS; ++c) gr[c] = a.g_aa[(img + (size_t)ry * W + rx) * CS + c];
+                        if (rX) {
+#pragma unroll
+                            for (int c = 0; c < CS; ++c) { go[c] -= amt * gr[c]; if (!o_cov) esum[c] += amt * gr[c]; }
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < CS; ++c) go[c] += amt * gr[c];
+                        }
+                        // d alpha / d pos: once per pair, by its first pixel -- by the second if the first is empty (never visited)
+                        if (!gp || !(first || !o_cov)) return;
+                        const bool PisX = Px == x && Py == y;
+                        float G = 0.f;
+#pragma unroll
+                        for (int c = 0; c < CS; ++c) {
+                            const float cO = o_cov ? co[c] : ecol[c];
+                            G += gr[c] * (PisX ? cme[c] - cO : cO - cme[c]);
+                        }
+                        if (G == 0.0f) return;
+                        const float Ld = d == 0 ? ev.Lx : ev.Ly;
+                        const float gLz = -G / (s * Ld);
+                        const float gLd = -G * t / Ld;
+                        const float gLx = d == 0 ? gLd : 0.0f, gLy = d == 0 ? 0.0f : gLd;
+                        float g_qax = 0.f, g_qay = 0.f, g_wa = 0.f, g_qbx = 0.f, g_qby = 0.f, g_wb = 0.f;
+                        g_qay += gLx * ev.wb; g_wb += gLx * ev.qay; g_wa -= gLx * ev.qby; g_qby -= gLx * ev.wa;
+                        g_wa += gLy * ev.qbx; g_qbx += gLy * ev.wa; g_qax -= gLy * ev.wb; g_wb -= gLy * ev.qax;
+                        g_qax += gLz * ev.qby; g_qby += gLz * ev.qax; g_qay -= gLz * ev.qbx; g_qbx -= gLz * ev.qay;
+                        const float fxp = (float)Px + 0.5f - g.hw, fyp = (float)Py + 0.5f - g.hh;
+                        atomicAdd(gp + 4 * (size_t)va + 0, g_qax * g.hw);
+                        atomicAdd(gp + 4 * (size_t)va + 1, g_qay * g.hh);
+                        atomicAdd(gp + 4 * (size_t)va + 3, g_wa - fxp * g_qax - fyp * g_qay);
+                        atomicAdd(gp + 4 * (size_t)vb + 0, g_qbx * g.hw);
+                        atomicAdd(gp + 4 * (size_t)vb + 1, g_qby * g.hh);
+                        atomicAdd(gp + 4 * (size_t)vb + 3, g_wb - fxp * g_qbx - fyp * g_qby);
+                    });
+            };
+            if (x + 1 < W) {
+                const unsigned int e = id_at(x + 1, y);
+                if (pair_maybe(me, e)) visit(x, y, 0, me, zX, e, (e & 0xffffffu) ? a.rec[off + 1].z : 0.0f, x + 1, y, e, true);
+            }
+            if (y + 1 < H) {
+                const unsigned int e = id_at(x, y + 1);
+                if (pair_maybe(me, e)) visit(x, y, 1, me, zX, e, (e & 0xffffffu) ? a.rec[off + W].z : 0.0f, x, y + 1, e, true);
+            }
+            if (x > 0) {
+                const unsigned int e = id_at(x - 1, y);
+                if (pair_maybe(me, e)) visit(x - 1, y, 0, e, (e & 0xffffffu) ? a.rec[off - 1].z : 0.0f, me, zX, x - 1, y, e, false);
+            }
+            if (y > 0) {
+                const unsigned int e = id_at(x, y - 1);
+                if (pair_maybe(me, e)) visit(x, y - 1, 1, e, (e & 0xffffffu) ? a.rec[off - W].z : 0.0f, me, zX, x, y - 1, e, false);
+            }
+            const float rf = (float)a.ref[off];
+            if (PASS == 0) {
+                if (hit) {      // the antialiased colour replaces the plain one in this pixel's loss term and gradient
+                    const float d0 = rf - bgs;
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) {
+                        const float dn = rf - acc[c] * cs, dd = rf - cme[c] * cs;
+                        lsum += dn * dn - d0 * d0;
+                        lsum -= dd * dd - d0 * d0;
+                        a.g_aa[off * CS + c] = loss_grad(dn, cs, gs);
+                    }
+                }
+            } else {
+                // what k_shade scattered for this pixel was the un-antialiased gradient: chain the difference
+                float dl[CS];
+                bool nz = false;
+#pragma unroll
+                for (int c = 0; c < CS; ++c) { dl[c] = go[c] - loss_grad(rf - cme[c] * cs, cs, gs); nz |= dl[c] != 0.0f; }
+                if (nz) {
+                    const int boundary = a.boundary, Ht = a.Ht, Wt = a.Wt;
+                    const int t = (int)(me & 0xffffffu) - 1;
+                    float2 q0, q1, q2;
+                    if (a.tri_uv) { q0 = a.tri_uv[3 * t]; q1 = a.tri_uv[3 * t + 1]; q2 = a.tri_uv[3 * t + 2]; }
+                    else uv_indirect(a.uv, a.uv_tri, t, q0, q1, q2);
+                    const float w = 1.0f - rme.x - rme.y;
+                    const float tu = rme.x * q0.x + rme.y * q1.x + w * q2.x;
+                    const float tv = rme.x * q0.y + rme.y * q1.y + w * q2.y;
+                    const Taps tp = make_taps(tu, tv, Ht, Wt, CS, boundary);
+                    const float w00 = (1.0f - tp.fx) * (1.0f - tp.fy), w10 = tp.fx * (1.0f - tp.fy);
+                    const float w01 = (1.0f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
+                    float gfx = 0.f, gfy = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) {
+                        const float gc = dl[c];
+                        float t00, t10, t01, t11;
+                        load_taps(a.tex, tp, c, CS, t00, t10, t01, t11);
+                        mask_taps(tp, t00, t10, t01, t11);
+                        gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
+                        gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
+                        if (a.grad_tex && gc != 0.0f) {      // (boundary mode 'zero': the padding receives no gradient)
+                            if (tp.valid & 1u) atomicAdd(a.grad_tex + tp.i00 + c, gc * w00);
+                            if (tp.valid & 2u) atomicAdd(a.grad_tex + tp.i10 + c, gc * w10);
+                            if (tp.valid & 4u) atomicAdd(a.grad_tex + tp.i01 + c, gc * w01);
+                            if (tp.valid & 8u) atomicAdd(a.grad_tex + tp.i11 + c, gc * w11);
+                        }
+                    }
+                    if (gp) {
+                        const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
+                        const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv >= 0.0f && tv <= 1.0f)) ? 0.0f : 1.0f;
+                        const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
+                        const float gu = gtu * (q0.x - q2.x) + gtv * (q0.y - q2.y);
+                        const float gvv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
+                        if (gu != 0.0f || gvv != 0.0f) {
+                            vk[0] = a.tri[3 * t]; vk[1] = a.tri[3 * t + 1]; vk[2] = a.tri[3 * t + 2];
+                            const float fx = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
+                            const float fy = (2.0f * (float)y + 1.0f) / (float)H - 1.0f;
+                            float g0[3], g1[3], g2[3];
+                            shade_pixel_bwd<false>(g.pos[vk[0]], g.pos[vk[1]], g.pos[vk[2]], fx, fy, 2.0f / (float)W, 2.0f / (float)H,
+                                                   make_float4(gu, gvv, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), g0, g1, g2);
+                            gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
+                            gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
+                            gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
+                            tkey = t;
+                        }
+                    }
+                }
+            }
+        }
+        if (PASS == 1 && gp)      // (uniform) pixels of one triangle are often neighbours in the list: sum their runs, then nine atomics per run
+            wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) {
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    float *d = gp + 4 * (size_t)vk[kk];
+                    if (sm[3 * kk] != 0.0f) atomicAdd(d, sm[3 * kk]);
+                    if (sm[3 * kk + 1] != 0.0f) atomicAdd(d + 1, sm[3 * kk + 1]);
+                    if (sm[3 * kk + 2] != 0.0f) atomicAdd(d + 3, sm[3 * kk + 2]);
+                }
+            });
+    }
+    if (PASS == 0) {
+        lsum = wave_sum_dpp(lsum);
+        if (tid == 0 && lsum != 0.0f) {
+            const unsigned int slot = ((unsigned int)bxi + 31u * (unsigned int)byi + 977u * (unsigned int)b + 128u) % FPCDR_LOSS_SLOTS;
+            atomicAdd(a.loss_sum + slot, (double)lsum);
+        }
+    } else if (a.grad_tex) {
+        // empty pixels blended into covered ones: they all sample uv = (0,0) -- summed per wave, scattered once
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+            const float e = wave_sum_dpp(esum[c]);
+            if (tid == 0 && e != 0.0f) {
+                const Taps tp0 = make_taps(0.0f, 0.0f, a.Ht, a.Wt, CS, a.boundary);
+                if (tp0.valid & 1u) atomicAdd(a.grad_tex + tp0.i00 + c, e * ((1.0f - tp0.fx) * (1.0f - tp0.fy)));
+                if (tp0.valid & 2u) atomicAdd(a.grad_tex + tp0.i10 + c, e * (tp0.fx * (1.0f - tp0.fy)));
+                if (tp0.valid & 4u) atomicAdd(a.grad_tex + tp0.i01 + c, e * ((1.0f - tp0.fx) * tp0.fy));
+                if (tp0.valid & 8u) atomicAdd(a.grad_tex + tp0.i11 + c, e * (tp0.fx * tp0.fy));
+            }
+        }
+    }
+}
+
+template <int CS, int PASS>
+__global__ void __launch_bounds__(FNT) k_fix_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int cap, int OX, int OY,
+                                                  fpcdr_bin_decode dc, ObjArgs a) {
+    const int item = fpcdr_list_item(*count, cap);
+    if (item < 0) return;
+    const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+    int b, byi, bxi;
+    fpcdr_decode_bin(lin, dc, b, byi, bxi);
+    fix_body<CS, PASS>(b, bxi, byi, OX, OY, a);
+}
+template <int CS, int PASS>
+__global__ void __launch_bounds__(FNT) k_fix_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int first, int OX, int OY,
+                                                   fpcdr_bin_decode dc, ObjArgs a) {
+    const int n = *count;
+    for (int item = first + blockIdx.x; item < n; item += gridDim.x) {
+        const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+        int b, byi, bxi;
+        fpcdr_decode_bin(lin, dc, b, byi, bxi);
+        fix_body<CS, PASS>(b, bxi, byi, OX, OY, a);
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream) {
+    FPCDR_REQUIRE(p != nullptr, "null params");
+    FPCDR_REQUIRE(p->pos && p->tri && p->adj && p->scratch && p->uv && p->uv_tri && p->tex && p->ref, "null pointer");
+    FPCDR_REQUIRE(p->sil && p->idp && p->occ && p->cmask && p->rec && p->color && p->grad_aa && p->empty_color && p->loss_sum, "null pointer");
+    FPCDR_REQUIRE(p->B > 0 && p->V > 0 && p->T > 0 && p->H > 0 && p->W > 0 && p->Vt > 0 && p->Ht > 0 && p->Wt > 0 && p->C > 0,
+                  "sizes must be positive");
+    FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
+    FPCDR_REQUIRE(p->H <= 32767 && p->W <= 32767 && p->B <= 65535, "resolution / batch too large");
+    FPCDR_REQUIRE(p->T < (1 << 24), "more than 2^24 triangles");
+    FPCDR_REQUIRE(p->boundary_mode == FPCDR_BOUNDARY_WRAP || p->boundary_mode == FPCDR_BOUNDARY_CLAMP || p->boundary_mode == FPCDR_BOUNDARY_ZERO,
+                  "bad boundary mode");
+    FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30), "texture too large (the fused paths take < 2^30 texel values)");
+    FPCDR_REQUIRE(((size_t)p->occ & 3) == 0 && ((size_t)p->cmask & 7) == 0 && ((size_t)p->idp & 15) == 0 && ((size_t)p->rec & 15) == 0,
+                  "occ must be 4-byte, cmask 8-byte, idp and rec 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = fpcdr_launch_sil(p->pos, p->tri, p->adj, p->B, p->V, p->T, p->H, p->W, p->sil, nullptr, 0, st);
+    if (rc) return rc;
+    const int32_t *occ_list = nullptr, *n_occ = nullptr;
+    rc = fpcdr_launch_raster_ids(p, st, &occ_list, &n_occ);
+    if (rc) return rc;
+    const int OX = FPCDR_OCC_DIM(p->W), OY = FPCDR_OCC_DIM(p->H);
+    const long long nbins = (long long)p->B * OY * OX;
+    const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W);
+    ObjArgs a = {(const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, (const float2 *)p->tri_uv, p->tex, p->ref, p->sil,
+                 p->idp, p->occ, (uint8_t *)p->occ + q.occ_binflag, p->cmask, (float4 *)p->rec, p->color, p->grad_aa, p->empty_color,
+                 p->loss_sum, p->grad_pos, p->grad_tex, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt, p->boundary_mode,
+                 p->bg, p->color_scale, p->grad_scale};
+    const fpcdr_bin_decode dc = fpcdr_make_bin_decode(OX, OY);
+    const int cap = (p->cap_occ > 0 && p->cap_occ < nbins) ? p->cap_occ : (int)nbins;
+    const dim3 grid(fpcdr_list_grid(cap));
+    const bool sweep = cap < nbins;
+#define SHADE(CS, BM)                                                                                                             \
+    do {                                                                                                                          \
+        hipLaunchKernelGGL((k_shade_list<CS, BM>), grid, dim3(ONT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a);                   \
+        if (sweep) hipLaunchKernelGGL(k_shade_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(ONT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a); \
+    } while (0)
+#define FIX(CS, PASS)                                                                                                             \
+    do {                                                                                                                          \
+        hipLaunchKernelGGL((k_fix_list<CS, PASS>), grid, dim3(FNT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a);                   \
+        if (sweep) hipLaunchKernelGGL((k_fix_queue<CS, PASS>), dim3(FPCDR_SWEEP_WGS), dim3(FNT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a); \
+    } while (0)
+    const bool grads = p->grad_pos || p->grad_tex;
+    if (p->C == 1) {
+        if (p->boundary_mode == FPCDR_BOUNDARY_WRAP) SHADE(1, FPCDR_BOUNDARY_WRAP);      // the reference's case, as compile-time constants
+        else SHADE(1, -1);
+        FIX(1, 0);
+        if (grads) FIX(1, 1);
+    } else if (p->C == 3) {
+        SHADE(3, -1);
+        FIX(3, 0);
+        if (grads) FIX(3, 1);
+    } else {
+        SHADE(4, -1);
+        FIX(4, 0);
+        if (grads) FIX(4, 1);
+    }
+#undef SHADE
+#undef FIX
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}

@@ -121,3 +121,59 @@ __device__ __forceinline__ void shade_pixel_bwd(float4 v0, float4 v1, float4 v2,
     g2[0] = gp2x; g2[1] = gp2y; g2[2] = gw2 - fx * gp2x - fy * gp2y;
 }
 
+// ---------------------------------------------------------------------------------------------
+// One-pass objective (objective.hip): the pixel that is shaded also chains its gradient back, so the forward's intermediates are
+// KEPT instead of recomputed.  shade_uvz is shade_pixel without the derivative outputs, shade_uv_bwd is shade_pixel_bwd<false> on the
+// kept values: same operations in the same order, bit-identical results.
+struct ShadeKeep { float p0x, p0y, p1x, p1y, p2x, p2y, a0, a1, iw, b0, b1, uc, vc; };
+
+__device__ __forceinline__ void shade_uvz(float4 v0, float4 v1, float4 v2, float fx, float fy, ShadeKeep &k, float &u, float &v, float &zw) {
+    k.p0x = v0.x - fx * v0.w; k.p0y = v0.y - fy * v0.w;
+    k.p1x = v1.x - fx * v1.w; k.p1y = v1.y - fy * v1.w;
+    k.p2x = v2.x - fx * v2.w; k.p2y = v2.y - fy * v2.w;
+    k.a0 = k.p1x * k.p2y - k.p1y * k.p2x;
+    k.a1 = k.p2x * k.p0y - k.p2y * k.p0x;
+    const float a2 = k.p0x * k.p1y - k.p0y * k.p1x;
+    const float at = k.a0 + k.a1 + a2;
+    k.iw = 1.0f / at;
+    k.b0 = k.a0 * k.iw; k.b1 = k.a1 * k.iw;
+    const float z = (k.a0 * v0.z + k.a1 * v1.z + a2 * v2.z) / (k.a0 * v0.w + k.a1 * v1.w + a2 * v2.w);
+    zw = fminf(fmaxf(z, -1.0f), 1.0f);
+    k.uc = fminf(fmaxf(k.b0, 0.0f), 1.0f); k.vc = fminf(fmaxf(k.b1, 0.0f), 1.0f);
+    float sc = 1.0f;
+    if (__builtin_amdgcn_ballot_w64(k.uc + k.vc > 1.0f) != 0) {      // (wave vote first: see shade_pixel)
+        float sum = k.uc + k.vc;
+        asm volatile("; renormalise" : "+v"(sum));
+        if (sum > 1.0f) sc = 1.0f / sum;
+    }
+    u = k.uc * sc;
+    v = k.vc * sc;
+}
+
+__device__ __forceinline__ void shade_uv_bwd(const ShadeKeep &k, float fx, float fy, float gu, float gv, float (&g0)[3], float (&g1)[3],
+                                             float (&g2)[3]) {
+    float guc = gu, gvc = gv;
+    const float sum = k.uc + k.vc;
+    if (__builtin_amdgcn_ballot_w64(sum > 1.0f) != 0 && sum > 1.0f) {
+        float sum_ = sum;
+        asm volatile("; renormalise" : "+v"(sum_));
+        const float s = 1.0f / sum_;
+        const float dot = (k.uc * gu + k.vc * gv) * s * s;
+        guc = gu * s - dot;
+        gvc = gv * s - dot;
+    }
+    const float gb0 = (k.b0 >= 0.0f && k.b0 <= 1.0f) ? guc : 0.0f;
+    const float gb1 = (k.b1 >= 0.0f && k.b1 <= 1.0f) ? gvc : 0.0f;
+    float ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, giw = 0.f;
+    float gp0x = 0.f, gp0y = 0.f, gp1x = 0.f, gp1y = 0.f, gp2x = 0.f, gp2y = 0.f;
+    ga0 += gb0 * k.iw; ga1 += gb1 * k.iw;
+    giw += gb0 * k.a0 + gb1 * k.a1;
+    const float gat = -giw * k.iw * k.iw;
+    ga0 += gat; ga1 += gat; ga2 += gat;
+    gp1x += ga0 * k.p2y; gp2y += ga0 * k.p1x; gp1y -= ga0 * k.p2x; gp2x -= ga0 * k.p1y;
+    gp2x += ga1 * k.p0y; gp0y += ga1 * k.p2x; gp2y -= ga1 * k.p0x; gp0x -= ga1 * k.p2y;
+    gp0x += ga2 * k.p1y; gp1y += ga2 * k.p0x; gp0y -= ga2 * k.p1x; gp1x -= ga2 * k.p0y;
+    g0[0] = gp0x; g0[1] = gp0y; g0[2] = 0.f - fx * gp0x - fy * gp0y;
+    g1[0] = gp1x; g1[1] = gp1y; g1[2] = 0.f - fx * gp1x - fy * gp1y;
+    g2[0] = gp2x; g2[1] = gp2y; g2[2] = 0.f - fx * gp2x - fy * gp2y;
+}

@@ -322,18 +322,21 @@ __device__ __forceinline__ unsigned int window_mask(const uint8_t *__restrict__ 
 }
 __device__ __forceinline__ bool wbit(unsigned int m, int dx, int dy) { return (m >> ((dy + 1) * 4 + dx + 1)) & 1u; }
 
-template <bool ROUND_B>
+// ROUND_B: 0 = round A (live map); 1 = round B of the two-pass objective; 2 = round B of the one-pass objective (objective.hip):
+// list 0 = the occupied bins themselves, no second list
+template <int ROUND_B>
 __device__ __forceinline__ void bin_flags(const uint8_t *__restrict__ map, long long i, long long nbins, int OY, int OX, bool (&f)[NLISTS],
                                           unsigned int &m) {
     f[0] = false; f[1] = false; m = 0;
     if (i >= nbins) return;
     if (!ROUND_B) { f[0] = map[i] != 0; return; }
     m = window_mask(map, i, OY, OX);
+    if (ROUND_B == 2) { f[0] = wbit(m, 0, 0); return; }
     f[0] = wbit(m, 0, 0) || wbit(m, 1, 0) || wbit(m, 0, 1);                                        // k_aa_fix
     f[1] = f[0] || wbit(m, -1, 0) || wbit(m, 0, -1);                                              // k_render_aa_bwd
 }
 
-template <bool ROUND_B>
+template <int ROUND_B>
 __global__ void __launch_bounds__(256) k_list_count(const uint8_t *__restrict__ map, long long nbins, int OY, int OX,
                                                     int32_t *__restrict__ blk_counts, uint16_t *__restrict__ win,
                                                     const float *__restrict__ tex, int Ht, int Wt, int C, int boundary,
@@ -393,7 +396,7 @@ __global__ void __launch_bounds__(1024) k_list_scan(int32_t *__restrict__ blk_co
     }
 }
 
-template <bool ROUND_B>
+template <int ROUND_B>
 __global__ void __launch_bounds__(256) k_list_write(const uint8_t *__restrict__ map, long long nbins, int OY, int OX,
                                                     const int32_t *__restrict__ blk_offsets, int32_t *__restrict__ list0,
                                                     int32_t *__restrict__ list1) {
@@ -504,6 +507,8 @@ struct ShadeArgs {
     // MIP instantiations (the reference's enable_mip branch, fit.py:153-155): tex = level 0, mip[l - 1] = level l of the chain
     const float *mip[FPCDR_MAX_MIP];
     int n_levels;
+    // IDS instantiation (one-pass objective, objective.hip): out, per-bin planes of (triangle + 1) | silhouette bits << 24, [bin][32][32]
+    uint32_t *idp;
 };
 
 // texture coordinates of triangle t through the index buffer (callers that did not pre-gather uv[uv_tri])
@@ -516,7 +521,8 @@ __device__ __noinline__ void uv_indirect(const float2 *__restrict__ uv, const in
 // CS / BMODE: channel count and texture boundary mode as compile-time constants (0 / -1 = read them from ShadeArgs); the list
 // kernels of the objective are instantiated for the reference's case (one channel, 'wrap'), which strips the channel loops, the
 // index scaling and the mode branches from the ~200 instructions a shaded pixel costs
-template <bool WRITE_DB, bool SHADE, bool LOSS, bool QUEUE, int CS = 0, int BMODE = -1, bool MIP = false>
+// IDS: raster only -- the bin's winners leave as a 4 KB plane of (triangle + 1) | silhouette bits << 24 (sh.idp) and nothing else is written
+template <bool WRITE_DB, bool SHADE, bool LOSS, bool QUEUE, int CS = 0, int BMODE = -1, bool MIP = false, bool IDS = false>
 __device__ __forceinline__ void bins_body(const int b, const int bxi, const int byi, const int OX, const int OY,
                                           const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                           int V, int T, int H, int W, const TriRec *__restrict__ recs,
@@ -549,8 +555,8 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
     int total_hits = 0;   // block-uniform: triangles whose bounding box touches this bin
     const ImgBox ib = ibox[b];
     const bool bin_live = !(ib.x1 < bin_x0 || ib.x0 > bin_x1 || ib.y1 < bin_y0 || ib.y0 > bin_y1);
-    const bool sparse = SHADE && sh.occ != nullptr;
-    if (sparse && !QUEUE && b == 0 && bxi == 0 && byi == 0 && tid == 0) {   // (queue form: k_worklist writes it)
+    const bool sparse = (SHADE || IDS) && sh.occ != nullptr;
+    if (SHADE && sparse && !QUEUE && b == 0 && bxi == 0 && byi == 0 && tid == 0) {   // (queue form: k_worklist writes it)
         const Taps tp0 = make_taps(0.0f, 0.0f, sh.Ht, sh.Wt, sh.C, sh.boundary);
         for (int c = 0; c < 4; ++c) sh.empty_out[c] = c < sh.C ? bilerp(sh.tex, tp0, c, sh.C) : 0.0f;
     }
@@ -831,6 +837,21 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         }
         __syncthreads();
     }
+    if (IDS) {
+        // one-pass objective: the plane of this bin's winners, 16 bytes per thread (four adjacent pixels of row tid >> 3); the
+        // silhouette bits of a pixel's triangle ride above its id, so that the shading kernel classifies pixel pairs from ids alone
+        const uint8_t *const sil_img = sh.sil + (size_t)b * T;
+        const int r = tid >> 3, c4 = (tid & 7) * 4;
+        unsigned int e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long z = s_z[r * BIN + c4 + j];
+            const int t = z == Z_EMPTY ? -1 : (int)(unsigned int)z;
+            e[j] = t >= 0 ? (((unsigned int)ld32(sil_img, t) << 24) | (unsigned int)(t + 1)) : 0u;
+        }
+        reinterpret_cast<uint4 *>(sh.idp + bin_lin * (BIN * BIN))[tid] = make_uint4(e[0], e[1], e[2], e[3]);
+        return;
+    }
     const int zx = tid & 31, zy0 = tid >> 5;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1072,7 +1093,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
 #ifndef FPCDR_BINSQ_WPE
 #define FPCDR_BINSQ_WPE
 #endif
-template <bool WRITE_DB, bool SHADE, bool LOSS, int CS = 0, int BMODE = -1, bool MIP = false>
+template <bool WRITE_DB, bool SHADE, bool LOSS, int CS = 0, int BMODE = -1, bool MIP = false, bool IDS = false>
 __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
                                               int cap, int OX, int OY, fpcdr_bin_decode dc,
                                               const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
@@ -1085,7 +1106,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t 
     const int lin = __builtin_amdgcn_readfirstlane(list[item]);
     int b, byi, bxi;
     fpcdr_decode_bin(lin, dc, b, byi, bxi);
-    bins_body<WRITE_DB, SHADE, LOSS, true, CS, BMODE, MIP>(b, bxi, byi, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox, rast, rast_db, sh);
+    bins_body<WRITE_DB, SHADE, LOSS, true, CS, BMODE, MIP, IDS>(b, bxi, byi, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox, rast, rast_db, sh);
 }
 
 // strided form: entries first, first + gridDim.x, ... of the list.  The loop variable is scalar by construction, so the loop
@@ -1093,7 +1114,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t 
 // between two barriers -- made LLVM's structurizer wrap the barrier pair in a second loop level, and waves repeated
 // barriers out of step; and the body inlined into a loop runs ~25 % slower than stand-alone -- 150 spilled SGPRs --, which
 // is why this form only sweeps up what the hinted launch above did not reach.)
-template <bool WRITE_DB, bool SHADE, bool LOSS, bool MIP = false>
+template <bool WRITE_DB, bool SHADE, bool LOSS, bool MIP = false, bool IDS = false>
 __global__ void __launch_bounds__(256) FPCDR_BINSQ_WPE k_bins_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
                                               int first, int OX, int OY, fpcdr_bin_decode dc,
                                               const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
@@ -1106,7 +1127,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINSQ_WPE k_bins_queue(const int32_
         const int lin = __builtin_amdgcn_readfirstlane(list[item]);
         int b, byi, bxi;
         fpcdr_decode_bin(lin, dc, b, byi, bxi);
-        bins_body<WRITE_DB, SHADE, LOSS, true, 0, -1, MIP>(b, bxi, byi, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox, rast, rast_db, sh);
+        bins_body<WRITE_DB, SHADE, LOSS, true, 0, -1, MIP, IDS>(b, bxi, byi, OX, OY, pos, tri, V, T, H, W, recs, boxes, cboxes, ibox, rast, rast_db, sh);
         __syncthreads();     // the next bin's first LDS writes must not overtake this bin's last LDS reads
     }
 }
@@ -1471,10 +1492,10 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     int32_t *n_bins = hdr_bwd + 2, *n_fix = hdr_bwd + 3;     // all three counts live in the occ header, where the caller finds them
     const int nblk = fpcdr_cdiv((long long)nbins, 256);
     int32_t *blk = (int32_t *)(cm + q.cm_blk);          // [2][nblk] per-block counts, then offsets
-    hipLaunchKernelGGL(k_list_count<false>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, (uint16_t *)nullptr,
+    hipLaunchKernelGGL(k_list_count<0>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, (uint16_t *)nullptr,
                        p->tex, p->Ht, p->Wt, p->C, p->boundary_mode, p->empty_color);
     hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, n_bins, (int32_t *)nullptr);
-    hipLaunchKernelGGL(k_list_write<false>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, bin_list, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_list_write<0>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, bin_list, (int32_t *)nullptr);
     ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
                     occ_raw, p->empty_color, (const float2 *)p->tri_uv,
                     l->sil, l->ref, l->grad_aa, cmask, (unsigned long long *)(cm + q.cm_edges), l->loss_sum, l->bg, l->color_scale,
@@ -1512,12 +1533,64 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
                                (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (float4 *)p->rast,
                                (float4 *)nullptr, sh);
     }
-    hipLaunchKernelGGL(k_list_count<true>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, p->occ,
+    hipLaunchKernelGGL(k_list_count<1>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, p->occ,
                        (const float *)nullptr, 0, 0, 0, 0, (float *)nullptr);
     hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, n_fix, hdr_bwd);
-    hipLaunchKernelGGL(k_list_write<true>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, fix_list, bwd_list);
+    hipLaunchKernelGGL(k_list_write<1>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, fix_list, bwd_list);
     FPCDR_CHECK_LAUNCH();
     return fpcdr_launch_aa_fix(l, cmask, (const unsigned long long *)(cm + q.cm_edges), fix_list, n_fix, (int)nbins, st);
+}
+
+// First half of fpcdr_objective_fwd (objective.hip; not part of the C ABI): set-up, the list of live bins, the rasteriser in its IDS form
+// (id planes only) and the ordered list of OCCUPIED bins + window masks for the shading kernels.  The caller has run k_sil2.
+int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, const int32_t **occ_list, const int32_t **n_occ_dev) {
+    const RasterScratch rs = raster_scratch(p->scratch, p->B, p->T);
+    const int OX = fpcdr_cdiv(p->W, BIN), OY = fpcdr_cdiv(p->H, BIN);
+    const size_t nbins = (size_t)p->B * OY * OX;
+    FPCDR_REQUIRE(nbins < 0x7ffffff0ULL, "too many bins for one call");
+    const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W);
+    char *cm = (char *)p->cmask, *oc = (char *)p->occ;
+    int32_t *hdr = (int32_t *)(cm + q.cm_hdr), *bin_list = (int32_t *)(cm + q.cm_bin_list), *olist = (int32_t *)(cm + q.cm_fix_list);
+    uint8_t *live = (uint8_t *)(cm + q.cm_live);
+    int32_t *hdr_occ = (int32_t *)(oc + q.occ_hdr);
+    uint8_t *occ_raw = (uint8_t *)(oc + q.occ_raw);
+    hipLaunchKernelGGL(k_init_queue, dim3(256), dim3(256), 0, st, rs.ibox, p->B, (uint32_t *)live, (long long)(align_up(nbins, 4) / 4),
+                       (uint32_t *)oc, (long long)(q.occ_hdr / 4), hdr, hdr_occ);
+    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                       p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr);
+    int32_t *n_bins = hdr_occ + 2, *n_occ = hdr_occ + 3;      // (include/fpcdr.h FPCDR_OCC_COUNTS_OFFSET)
+    const int nblk = fpcdr_cdiv((long long)nbins, 256);
+    int32_t *blk = (int32_t *)(cm + q.cm_blk);
+    hipLaunchKernelGGL(k_list_count<0>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, (uint16_t *)nullptr,
+                       p->tex, p->Ht, p->Wt, p->C, p->boundary_mode, p->empty_color);
+    hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, n_bins, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_list_write<0>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, bin_list, (int32_t *)nullptr);
+    ShadeArgs sh = {};
+    sh.occ = occ_raw;
+    sh.sil = p->sil;
+    sh.idp = p->idp;
+    const fpcdr_bin_decode dc = fpcdr_make_bin_decode(OX, OY);
+    const int cap_bins = (p->cap_bins > 0 && (size_t)p->cap_bins < nbins) ? p->cap_bins : (int)nbins;
+    hipLaunchKernelGGL((k_bins_list<false, false, false, 0, -1, false, true>), dim3(fpcdr_list_grid(cap_bins)), dim3(256), 0, st, bin_list, n_bins,
+                       cap_bins, OX, OY, dc, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox,
+                       (float4 *)nullptr, (float4 *)nullptr, sh);
+    if ((size_t)cap_bins < nbins)
+        hipLaunchKernelGGL((k_bins_queue<false, false, false, false, true>), dim3(FPCDR_SWEEP_WGS), dim3(256), 0, st, bin_list, n_bins, cap_bins,
+                           OX, OY, dc, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox,
+                           (float4 *)nullptr, (float4 *)nullptr, sh);
+    hipLaunchKernelGGL(k_list_count<2>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, p->occ,
+                       (const float *)nullptr, 0, 0, 0, 0, (float *)nullptr);
+    hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, n_occ, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_list_write<2>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, olist, (int32_t *)nullptr);
+    FPCDR_CHECK_LAUNCH();
+    *occ_list = olist;
+    *n_occ_dev = n_occ;
+    return FPCDR_OK;
+}
+
+extern "C" size_t fpcdr_idplane_bytes(int32_t B, int32_t H, int32_t W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W) * (BIN * BIN) * sizeof(uint32_t);
 }
 
 extern "C" size_t fpcdr_occ_bytes(int32_t B, int32_t H, int32_t W) {

@@ -452,6 +452,8 @@ class FitConfig:
     grouped_adam: bool = True       # all ten Adam groups + the quaternion division as one launch (False: torch.optim.Adam(fused=True))
     sparse_objective: bool = True   # the three kernels skip image regions far from any geometry (same result)
     overlap_regularisers: bool = True   # fused path: mesh regularisers on a second stream beside the pixel objective
+    one_pass: bool = True           # fused path without mip: value AND gradient of the pixel term from one call (fpcdr_objective_fwd: the
+                                    # kernel that shades a pixel chains its gradient back; False: forward call + backward call)
     queued_backward: bool = True    # fused path: the backward kernel runs over the list of occupied bins the forward left (with launch
                                     # hints) instead of one workgroup per bin of the batch (cfg3: 2.35 M waves dispatched, five in six
                                     # to leave at once -- 1.85 -> 1.74 ms); eager steps only, a HIP graph has no hints
@@ -773,7 +775,8 @@ class Fitter:
             pix = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
                                      n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum,
                                      enable_mip=cfg.enable_mip, max_mip_level=cfg.max_mip_level,
-                                     queued_backward=cfg.queued_backward and not self.use_graph)
+                                     queued_backward=cfg.queued_backward and not self.use_graph,
+                                     one_pass=cfg.one_pass, unit_upstream=True)      # (the seeds below are 1)
             if side is not None:
                 main_stream.wait_stream(side)
                 reg.record_stream(main_stream)

@@ -405,6 +405,70 @@ class _pixel_objective_func(torch.autograd.Function):
         return (g_pos, g_tex) + (None,) * 15
 
 
+class _pixel_objective_onepass(torch.autograd.Function):
+    """The pixel objective with VALUE AND GRADIENT from one call (include/fpcdr.h, fpcdr_objective_fwd): the objective is a scalar, so
+    its gradient is d(objective)/d(input) times the one upstream number -- it is accumulated by the kernel that shades a pixel, while
+    barycentrics, taps, texels and vertices are in registers, and backward() only multiplies by what autograd hands over."""
+
+    @staticmethod
+    def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, ref_bg_sumsq, use_hints, want_grad, unit_upstream):
+        lib = _lib.load()
+        B, V, _ = pos.shape
+        T = tri.shape[0]
+        Ht, Wt, C = tex.shape
+        dev = pos.device
+        want_pos = bool(want_grad and ctx.needs_input_grad[0])
+        want_tex = bool(want_grad and ctx.needs_input_grad[1])
+        u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+        scratch = u8(lib.fpcdr_rasterize_scratch_bytes(B, T))
+        sil, idp = u8(B * T), u8(lib.fpcdr_idplane_bytes(B, H, W))
+        occ, cmask = u8(lib.fpcdr_occ_bytes(B, H, W)), u8(lib.fpcdr_cmask_bytes(B, H, W))
+        # records of the DEFERRED pixels (a pixel pair at a silhouette): dense addressing, written and read for a few per cent of the
+        # covered pixels only -- nothing else of the image ever exists in HBM
+        rec = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
+        color = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
+        g_aa = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
+        ecol = torch.empty(4, dtype=torch.float32, device=dev)
+        acc = torch.zeros(_lib.LOSS_SLOTS, dtype=torch.float64, device=dev)
+        g_pos = torch.zeros_like(pos) if want_pos else None
+        g_tex = torch.zeros_like(tex) if want_tex else None
+        tri_uv = _cached_tri_uv(uv, uv_tri)
+        p = _lib.Objective(pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
+                           uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tri_uv=_ptr(tri_uv), tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C,
+                           boundary_mode=boundary, ref=_ptr(ref), bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
+                           idp=_ptr(idp), occ=_ptr(occ), cmask=_ptr(cmask), rec=_ptr(rec), color=_ptr(color), grad_aa=_ptr(g_aa),
+                           empty_color=_ptr(ecol), loss_sum=_ptr(acc), grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex))
+        hints = _list_hints.setdefault(('onepass', dev.index, B, V, T, H, W), _ListHints()) if use_hints else None
+        if hints is not None:
+            p.cap_bins, p.cap_occ, _ = hints.poll()
+        _lib.call("fpcdr_objective_fwd", ctypes.byref(p), _stream())
+        if hints is not None:
+            nb = B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN)
+            off = (4 * nb + 3) // 4 * 4                       # FPCDR_OCC_COUNTS_OFFSET
+            hints.update(occ[off:off + 16].view(torch.int32))
+        bg_sum = (reference_background_sumsq(ref, bg).sum() if ref_bg_sumsq is None
+                  else torch.as_tensor(ref_bg_sumsq, device=dev)).to(torch.float64).contiguous()
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.call("fpcdr_objective_value", _ptr(acc), _lib.LOSS_SLOTS, _ptr(bg_sum), float(C), float(n_total), _ptr(out), _stream())
+        ctx.save_for_backward(*(t for t in (g_pos, g_tex) if t is not None))
+        ctx.have = (want_pos, want_tex)
+        ctx.unit = bool(unit_upstream)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = list(ctx.saved_tensors)
+        g_pos = saved.pop(0) if ctx.have[0] else None
+        g_tex = saved.pop(0) if ctx.have[1] else None
+        if (ctx.needs_input_grad[0] and g_pos is None) or (ctx.needs_input_grad[1] and g_tex is None):
+            raise RuntimeError("pixel_objective: the forward pass ran with gradients disabled")
+        if not ctx.unit:      # (unit_upstream: the caller guarantees d loss / d objective = 1, as the fit loop's `pix + reg` does)
+            g = g.to(torch.float32)
+            g_pos = g_pos * g if g_pos is not None else None
+            g_tex = g_tex * g if g_tex is not None else None
+        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 14
+
+
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
     """Per image sum over pixels of (ref - 255 * background)^2 (f64 [B]): the pixel loss (fit.py:579) of an image that
     shows nothing but background.  It depends on the reference images only, so a fit loop computes it once and hands it
@@ -419,7 +483,7 @@ def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
 
 def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_total=None, background=45.0 / 255.0,
                     boundary_mode='wrap', sparse=True, ref_bg_sumsq=None, launch_hints=True, queued_backward=False,
-                    enable_mip=False, max_mip_level=None):
+                    enable_mip=False, max_mip_level=None, one_pass=True, unit_upstream=False):
     """The whole pixel term of the reference's loss (fit.py:151-161 + the first term of :579) for a minibatch,
     as three kernels:  mean((ref - 255 * where(rast.w > 0, antialias(texture(interpolate(rasterize(pos)))), bg))^2)
     over n_total elements (default: all of this call's).  pos [B,V,4], tex [Ht,Wt,C] (C in 1,3,4), ref_u8 [B,H,W] uint8.
@@ -432,7 +496,10 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     kernel also runs over the compact list of occupied bins instead of one workgroup per bin (same result).
     enable_mip (sparse mode): the reference's other branch (fit.py:153-155) -- interpolate with the rasteriser's
     screen-space derivatives and texture 'linear-mipmap-linear' with max_mip_level -- inside the same three kernels; equals the
-    chain rasterize(output_db) -> interpolate(diff_attrs='all') -> texture(texd) -> antialias + pixel loss."""
+    chain rasterize(output_db) -> interpolate(diff_attrs='all') -> texture(texd) -> antialias + pixel loss.
+    one_pass (sparse mode without mip, the default): value and gradient from ONE call -- the kernel that shades a pixel also chains
+    its gradient back (fpcdr_objective_fwd); backward() multiplies by the upstream scalar, or returns the buffers as they are with
+    unit_upstream=True (the caller guarantees d loss / d objective = 1).  one_pass=False: the two-call form."""
     assert isinstance(glctx, RasterizeHipContext)
     _check_tensor('pos', pos, torch.float32, 3)
     _check_tensor('tri', tri, torch.int32, 2)
@@ -455,6 +522,10 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
         if not sparse:
             raise NotImplementedError("pixel_objective(enable_mip=True) runs in sparse mode (use the separate operators otherwise)")
         mip_levels = _num_mip_levels(tex.shape[0], tex.shape[1], max_mip_level)
+    if one_pass and sparse and not enable_mip:
+        return _pixel_objective_onepass.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
+                                              ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], ref_bg_sumsq,
+                                              bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream))
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                        ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq,
                                        bool(launch_hints), bool(queued_backward), mip_levels)

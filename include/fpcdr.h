@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FPCDR_ABI_VERSION 7
+#define FPCDR_ABI_VERSION 8
 
 enum {
     FPCDR_OK = 0,
@@ -230,6 +230,58 @@ typedef struct {
     float *grad_tex_mip[FPCDR_MAX_MIP];         /* per level, accumulated (the caller folds them into grad_tex: fpcdr_mip_downsample_bwd) */
 } fpcdr_render_aa_bwd_params;
 int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* ONE-PASS pixel objective (ABI v8) -- reference fit.py:151-161 + the pixel term of :579, VALUE AND GRADIENT in one call.
+ *
+ * The pixel objective is a scalar, so its gradient with respect to pos and tex does not depend on anything the caller does
+ * afterwards: it is d(objective)/d(input) times one upstream scalar.  This entry point therefore computes value and gradient
+ * together, while every covered pixel's barycentrics, taps, texels and vertices are still in registers, instead of writing
+ * rast / colour / d loss/d colour (24 B/px) for a second call to read back and re-derive (fpcdr_render_loss_fwd +
+ * fpcdr_render_aa_bwd; profiles/r04_backward_ablation.txt: 45 % of that backward's instructions were re-derivation):
+ *   1. the rasteriser (same kernels and rules as fpcdr_rasterize_fwd) leaves only a 4-byte id per pixel of the occupied
+ *      32 x 32 bins: (triangle + 1) | silhouette bits << 24;
+ *   2. one shading kernel per occupied bin: barycentrics, texture lookup, background + squared error, and -- with the loss
+ *      gradient of the UN-antialiased colour -- texture / interpolate / rasterize backward into grad_tex / grad_pos (per-bin LDS
+ *      accumulators, one flush).  Pixels one of whose four pixel pairs has different ids and a triangle with a silhouette edge
+ *      (read from the id planes, neighbours' border lines included) are DEFERRED: their (u, v, z/w), colour and gradient are also
+ *      written, sparsely, to rec / color / grad_aa;
+ *   3. two small kernels over the deferred pixels only (a few per cent of the covered ones): the exact antialias blend, the
+ *      correction of their loss terms, and the scatter of the DIFFERENCE of their gradient (everything is linear in it).
+ * grad_pos / grad_tex hold d(objective)/d(pos), d(objective)/d(tex) with the objective = grad_scale * sum of squares; the caller
+ * multiplies by its upstream scalar.  Same value and gradients as the operator chain (tests/test_gpu_objective.py).
+ * 'linear' lookup only (the mip-mapped branch stays with fpcdr_render_loss_fwd); C in {1, 3, 4}; instanced mode. */
+size_t fpcdr_idplane_bytes(int32_t B, int32_t H, int32_t W);   /* 4 KB per 32 x 32 bin of the batch */
+
+typedef struct {
+    const float *pos;       /* [B,V,4] */
+    const int32_t *tri;     /* [T,3] */
+    const int32_t *adj;     /* [T,3] fpcdr_topology_build */
+    int32_t B, V, T, H, W;
+    void *scratch;          /* fpcdr_rasterize_scratch_bytes(B,T) */
+    const float *uv;        /* [Vt,2] */
+    const int32_t *uv_tri;  /* [T,3] */
+    int32_t Vt;
+    const float *tri_uv;    /* optional [T,3,2] = uv[uv_tri] */
+    const float *tex;       /* [Ht,Wt,C] */
+    int32_t Ht, Wt, C, boundary_mode;
+    const uint8_t *ref;     /* [B,H,W] reference images, 8 bit */
+    float bg, color_scale, grad_scale;
+    uint8_t *sil;           /* scratch [B,T] */
+    uint32_t *idp;          /* scratch, fpcdr_idplane_bytes(B,H,W), 16-byte aligned */
+    uint16_t *occ;          /* scratch+out, fpcdr_occ_bytes(B,H,W): window masks; counts at FPCDR_OCC_COUNTS_OFFSET: [2] live bins of the
+                               rasteriser, [3] occupied bins (cap_bins / cap_occ of the next call) */
+    uint32_t *cmask;        /* scratch, fpcdr_cmask_bytes(B,H,W), 8-byte aligned */
+    float *rec;             /* scratch [B,H,W,4]: (u, v, z/w, -) of DEFERRED pixels only (dense addressing, sparse writes) */
+    float *color;           /* scratch [B,H,W,C]: colour of deferred pixels only */
+    float *grad_aa;         /* scratch [B,H,W,C]: d(objective)/d(antialiased colour) of deferred pixels only */
+    float *empty_color;     /* out [4]: the colour of an empty pixel (the texture at uv = (0,0)) */
+    double *loss_sum;       /* [FPCDR_LOSS_SLOTS] f64 accumulated: difference to an all-background image, as fpcdr_aa_loss_fwd (sparse) */
+    float *grad_pos;        /* [B,V,4] accumulated, or NULL */
+    float *grad_tex;        /* [Ht,Wt,C] accumulated, or NULL (both NULL: value only) */
+    int32_t cap_bins, cap_occ; /* launch-size hints (0 = none), as in fpcdr_aa_loss_fwd_params */
+} fpcdr_objective_params;
+int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* interpolate -- dr.interpolate(attr, rast, tri[, rast_db, diff_attrs])  reference fit.py:154,157 */

@@ -1,0 +1,122 @@
+"""The one-pass pixel objective (fpcdr_objective_fwd: value and gradient from one call, the shading kernel chains every pixel's
+gradient back itself; reference fit.py:151-161, 579, 611) against the two-call form and the chain of the four operators."""
+import pytest
+import torch
+
+from helpers import rel_l2, clip_positions, random_soup
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(geom, C, res, seed=1):
+    from fpc_diffrend_amd import scene
+    dev = 'cuda'
+    sc = scene.cfg('cfg1', n_frames=2)
+    sc.resolution = res
+    if geom == 'mesh':
+        pos, _ = clip_positions(sc, [0, 3, 7], frames=[0, 1])
+        tri = torch.tensor(sc.pos_idx, device=dev)
+        uv = torch.tensor(sc.uv, device=dev) * 1.2 - 0.05
+        uv_idx = torch.tensor(sc.uv_idx, device=dev)
+    else:      # an open soup: every triangle edge is a silhouette edge, overlaps everywhere -> many deferred pixels, depth pairs
+        n = {'soup': 60, 'few': 5}[geom]
+        pos, tri = random_soup(3, n, seed=21 + seed, spread=0.8, size=0.5 if geom == 'soup' else 0.9)
+        tri = tri.to(dev)
+        g0 = torch.Generator().manual_seed(8)
+        uv = (torch.rand(3 * n, 2, generator=g0) * 1.2 - 0.1).to(dev)
+        uv_idx = tri.clone()
+    g = torch.Generator().manual_seed(seed)
+    tex = torch.rand(48, 64, C, generator=g) * 0.5
+    ref = torch.randint(0, 141, (pos.shape[0], res[0], res[1]), generator=g, dtype=torch.uint8).to(dev)
+    return pos.to(dev), tri, uv, uv_idx, tex.to(dev), ref
+
+
+def _chain(ctx, p, tri, uv, uv_idx, t, ref, res, boundary):
+    import fpc_diffrend_amd.ops as dr
+    from fpc_diffrend_amd import fit
+    rast, _ = dr.rasterize(ctx, p, tri, res)
+    texc, _ = dr.interpolate(uv[None], rast, uv_idx)
+    col = dr.antialias(dr.texture(t[None], texc, filter_mode='linear', boundary_mode=boundary), rast, p, tri)
+    img = torch.where(rast[..., 3:] > 0, col, torch.tensor(fit.BACKGROUND, device=p.device))
+    return torch.mean((ref[..., None].float() - img * 255) ** 2)
+
+
+@pytest.mark.parametrize("geom,C,res,boundary", [('mesh', 1, (150, 200), 'wrap'), ('soup', 1, (97, 131), 'wrap'), ('soup', 3, (128, 160), 'clamp'),
+                                                ('few', 4, (64, 320), 'zero'), ('soup', 1, (33, 65), 'zero'), ('mesh', 3, (256, 256), 'wrap'),
+                                                ('few', 1, (32, 32), 'wrap'), ('soup', 1, (31, 17), 'clamp')])
+def test_one_pass_equals_two_call_form_and_operator_chain(geom, C, res, boundary):
+    import fpc_diffrend_amd.ops as dr
+    pos, tri, uv, uv_idx, tex, ref = _inputs(geom, C, res)
+    ctx = dr.RasterizeGLContext(device='cuda')
+    out = {}
+    for name in ("one", "two", "chain"):
+        p, t = pos.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+        if name == "chain":
+            loss = _chain(ctx, p, tri, uv, uv_idx, t, ref, res, boundary)
+        else:
+            loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, res, boundary_mode=boundary, one_pass=(name == "one"), launch_hints=False)
+        loss.backward()
+        out[name] = (float(loss), p.grad.double().cpu(), t.grad.double().cpu())
+    for other in ("two", "chain"):
+        assert abs(out["one"][0] - out[other][0]) <= 2e-6 * abs(out[other][0]), (other, out["one"][0], out[other][0])
+        assert rel_l2(out["one"][1], out[other][1]) < 1e-4, other
+        assert rel_l2(out["one"][2], out[other][2]) < 1e-4, other
+
+
+def test_one_pass_value_only_and_single_gradients_and_upstream():
+    """Without gradients the call computes the value alone; with one input requiring a gradient only that one is produced; the
+    upstream scalar multiplies both (unit_upstream=True hands the buffers over as they are)."""
+    import fpc_diffrend_amd.ops as dr
+    pos, tri, uv, uv_idx, tex, ref = _inputs('soup', 1, (97, 131))
+    ctx = dr.RasterizeGLContext(device='cuda')
+    res = (97, 131)
+    p, t = pos.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+    full = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, res)
+    full.backward()
+    with torch.no_grad():
+        v = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, res)
+    assert float(v) == float(full) and not v.requires_grad
+    v2 = dr.pixel_objective(ctx, pos, tri, uv, uv_idx, tex, ref, res)
+    assert float(v2) == float(full)
+    p2 = pos.clone().requires_grad_(True)
+    dr.pixel_objective(ctx, p2, tri, uv, uv_idx, tex, ref, res).backward()
+    assert rel_l2(p2.grad, p.grad) < 1e-6
+    t2 = tex.clone().requires_grad_(True)
+    dr.pixel_objective(ctx, pos, tri, uv, uv_idx, t2, ref, res).backward()
+    assert rel_l2(t2.grad, t.grad) < 1e-6
+    p3, t3 = pos.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+    (dr.pixel_objective(ctx, p3, tri, uv, uv_idx, t3, ref, res) * 3.5).backward()
+    assert rel_l2(p3.grad, 3.5 * p.grad) < 1e-6 and rel_l2(t3.grad, 3.5 * t.grad) < 1e-6
+    p4, t4 = pos.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+    dr.pixel_objective(ctx, p4, tri, uv, uv_idx, t4, ref, res, unit_upstream=True).backward()
+    assert rel_l2(p4.grad, p.grad) < 1e-6 and rel_l2(t4.grad, t.grad) < 1e-6
+
+
+def test_one_pass_launch_hints_do_not_change_the_result():
+    import fpc_diffrend_amd.ops as dr
+    pos, tri, uv, uv_idx, tex, ref = _inputs('mesh', 1, (150, 200))
+    ctx = dr.RasterizeGLContext(device='cuda')
+
+    def run(**kw):
+        p, t = pos.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+        loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, (150, 200), **kw)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), p.grad.double().cpu(), t.grad.double().cpu()
+
+    base = run(launch_hints=False)
+    dr._list_hints.clear()
+    first = run()
+    key = next(k for k in dr._list_hints if k[0] == 'onepass')
+    hints = dr._list_hints[key]
+    caps = hints.poll()
+    assert caps[0] >= 256 and caps[1] >= 256
+    second = run()
+    hints.event = None
+    hints.caps = (3, 2, 0)              # absurdly small: almost every bin goes through the strided sweeps
+    hints.update = lambda counts: None
+    third = run()
+    for r in (first, second, third):
+        assert abs(r[0] - base[0]) <= 1e-6 * abs(base[0])
+        assert rel_l2(r[1], base[1]) < 1e-5 and rel_l2(r[2], base[2]) < 1e-5
+    dr._list_hints.clear()

@@ -137,7 +137,8 @@ def test_abi_library_exports_every_declared_symbol():
              "fpcdr_interpolate_fwd_params": _lib.InterpolateFwd, "fpcdr_interpolate_bwd_params": _lib.InterpolateBwd,
              "fpcdr_texture_fwd_params": _lib.TextureFwd, "fpcdr_texture_bwd_params": _lib.TextureBwd,
              "fpcdr_antialias_fwd_params": _lib.AntialiasFwd, "fpcdr_antialias_bwd_params": _lib.AntialiasBwd,
-             "fpcdr_pixel_loss_params": _lib.PixelLoss, "fpcdr_adam_params": _lib.AdamParams}
+             "fpcdr_pixel_loss_params": _lib.PixelLoss, "fpcdr_adam_params": _lib.AdamParams,
+             "fpcdr_objective_params": _lib.Objective}
     structs = set(re.findall(r"\}\s*(fpcdr_[a-z0-9_]+_params)\s*;", header))
     assert structs == set(pairs), structs ^ set(pairs)
     with tempfile.TemporaryDirectory() as td:
