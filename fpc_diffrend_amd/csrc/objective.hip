@@ -48,6 +48,7 @@ struct ObjArgs {
     double *loss_sum; float *grad_pos; float *grad_tex;
     int B, V, T, H, W, Ht, Wt, boundary;
     float bg, color_scale, grad_scale;
+    unsigned long long *flags;      // optional (tests / diagnostics): the antialias flag planes of fpcdr_antialias_fwd, zero-filled by the caller
 };
 
 // texture coordinates of triangle t through the index buffer (callers that did not pre-gather uv[uv_tri]); out of line, see fused.hip
@@ -400,7 +401,7 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
             // pair (x0, y0) - (x0 + e_d): entries / depths in pair order; (ox, oy, eo) = the partner of X; first = X is the pair's first pixel
             auto visit = [&](int x0, int y0, int d, unsigned int e0, float z0, unsigned int e1, float z1, int ox, int oy, unsigned int eo,
                              bool first) {
-                for_active_edges(g, x0, y0, d, (int)(e0 & 0xffffffu), z0, (int)(e1 & 0xffffffu), z1,
+                const bool blended = for_active_edges(g, x0, y0, d, (int)(e0 & 0xffffffu), z0, (int)(e1 & 0xffffffu), z1,
                     [&](float t, int Px, int Py, int Qx, int Qy, int va, int vb, const EdgeEval &ev, float s) {
                         const bool far = t >= 0.5f;
                         const int rx = far ? Qx : Px, ry = far ? Qy : Py;      // the pixel that is blended
@@ -452,6 +453,12 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                         atomicAdd(gp + 4 * (size_t)vb + 1, g_qby * g.hh);
                         atomicAdd(gp + 4 * (size_t)vb + 3, g_wb - fxp * g_qbx - fyp * g_qby);
                     });
+                // diagnostics: bit of the pair's first pixel in plane d = "this pair was blended" (set by the first pixel, or by the
+                // second when the first is empty and never visited)
+                if (PASS == 0 && a.flags && blended && (first || (eo & 0xffffffu) == 0u)) {
+                    const int Wq = FPCDR_AA_ROW_WORDS(W);
+                    atomicOr(a.flags + (size_t)d * a.B * H * Wq + ((size_t)b * H + y0) * Wq + (x0 >> 6), 1ull << (x0 & 63));
+                }
             };
             if (x + 1 < W) {
                 const unsigned int e = id_at(x + 1, y);
@@ -621,7 +628,7 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
     ObjArgs a = {(const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, (const float2 *)p->tri_uv, p->tex, p->ref, p->sil,
                  p->idp, p->occ, (uint8_t *)p->occ + q.occ_binflag, p->cmask, (float4 *)p->rec, p->color, p->grad_aa, p->empty_color,
                  p->loss_sum, p->grad_pos, p->grad_tex, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt, p->boundary_mode,
-                 p->bg, p->color_scale, p->grad_scale};
+                 p->bg, p->color_scale, p->grad_scale, (unsigned long long *)p->flags};
     const fpcdr_bin_decode dc = fpcdr_make_bin_decode(OX, OY);
     const int cap = (p->cap_occ > 0 && p->cap_occ < nbins) ? p->cap_occ : (int)nbins;
     const dim3 grid(fpcdr_list_grid(cap));

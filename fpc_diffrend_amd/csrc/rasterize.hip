@@ -846,7 +846,8 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned long long z = s_z[r * BIN + c4 + j];
-            const int t = z == Z_EMPTY ? -1 : (int)(unsigned int)z;
+            // (the tile path resolves whole 16 x 16 tiles: a winner beyond the image's right / top border is not a pixel)
+            const int t = (z == Z_EMPTY || bin_x0 + c4 + j >= W || bin_y0 + r >= H) ? -1 : (int)(unsigned int)z;
             e[j] = t >= 0 ? (((unsigned int)ld32(sil_img, t) << 24) | (unsigned int)(t + 1)) : 0u;
         }
         reinterpret_cast<uint4 *>(sh.idp + bin_lin * (BIN * BIN))[tid] = make_uint4(e[0], e[1], e[2], e[3]);

@@ -411,7 +411,8 @@ class _pixel_objective_onepass(torch.autograd.Function):
     barycentrics, taps, texels and vertices are in registers, and backward() only multiplies by what autograd hands over."""
 
     @staticmethod
-    def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, ref_bg_sumsq, use_hints, want_grad, unit_upstream):
+    def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, ref_bg_sumsq, use_hints, want_grad, unit_upstream,
+                flags_out=None):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -437,7 +438,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
                            uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tri_uv=_ptr(tri_uv), tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C,
                            boundary_mode=boundary, ref=_ptr(ref), bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
                            idp=_ptr(idp), occ=_ptr(occ), cmask=_ptr(cmask), rec=_ptr(rec), color=_ptr(color), grad_aa=_ptr(g_aa),
-                           empty_color=_ptr(ecol), loss_sum=_ptr(acc), grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex))
+                           empty_color=_ptr(ecol), loss_sum=_ptr(acc), grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex), flags=_ptr(flags_out))
         hints = _list_hints.setdefault(('onepass', dev.index, B, V, T, H, W), _ListHints()) if use_hints else None
         if hints is not None:
             p.cap_bins, p.cap_occ, _ = hints.poll()
@@ -466,7 +467,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
             g = g.to(torch.float32)
             g_pos = g_pos * g if g_pos is not None else None
             g_tex = g_tex * g if g_tex is not None else None
-        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 14
+        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 15
 
 
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
@@ -483,7 +484,7 @@ def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
 
 def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_total=None, background=45.0 / 255.0,
                     boundary_mode='wrap', sparse=True, ref_bg_sumsq=None, launch_hints=True, queued_backward=False,
-                    enable_mip=False, max_mip_level=None, one_pass=True, unit_upstream=False):
+                    enable_mip=False, max_mip_level=None, one_pass=True, unit_upstream=False, aa_flags_out=None):
     """The whole pixel term of the reference's loss (fit.py:151-161 + the first term of :579) for a minibatch,
     as three kernels:  mean((ref - 255 * where(rast.w > 0, antialias(texture(interpolate(rasterize(pos)))), bg))^2)
     over n_total elements (default: all of this call's).  pos [B,V,4], tex [Ht,Wt,C] (C in 1,3,4), ref_u8 [B,H,W] uint8.
@@ -499,7 +500,9 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     chain rasterize(output_db) -> interpolate(diff_attrs='all') -> texture(texd) -> antialias + pixel loss.
     one_pass (sparse mode without mip, the default): value and gradient from ONE call -- the kernel that shades a pixel also chains
     its gradient back (fpcdr_objective_fwd); backward() multiplies by the upstream scalar, or returns the buffers as they are with
-    unit_upstream=True (the caller guarantees d loss / d objective = 1).  one_pass=False: the two-call form."""
+    unit_upstream=True (the caller guarantees d loss / d objective = 1).  one_pass=False: the two-call form.
+    aa_flags_out (one_pass; tests / diagnostics): a zero-filled int64 tensor of fpcdr_antialias_flags_bytes(B,H,W) / 8 words that
+    receives the antialias flag planes (which pixel pairs were blended)."""
     assert isinstance(glctx, RasterizeHipContext)
     _check_tensor('pos', pos, torch.float32, 3)
     _check_tensor('tri', tri, torch.int32, 2)
@@ -525,7 +528,7 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     if one_pass and sparse and not enable_mip:
         return _pixel_objective_onepass.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                               ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], ref_bg_sumsq,
-                                              bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream))
+                                              bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out)
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                        ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq,
                                        bool(launch_hints), bool(queued_backward), mip_levels)

@@ -280,6 +280,8 @@ typedef struct {
     float *grad_pos;        /* [B,V,4] accumulated, or NULL */
     float *grad_tex;        /* [Ht,Wt,C] accumulated, or NULL (both NULL: value only) */
     int32_t cap_bins, cap_occ; /* launch-size hints (0 = none), as in fpcdr_aa_loss_fwd_params */
+    uint64_t *flags;        /* optional (tests / diagnostics; NULL in production): the antialias flag planes of fpcdr_antialias_fwd --
+                               which pixel pairs were blended --, fpcdr_antialias_flags_bytes(B,H,W), zero-filled by the caller */
 } fpcdr_objective_params;
 int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream);
 

@@ -21,7 +21,7 @@ ft = fit.Fitter(sc, fit.FitConfig(max_iter=80000, init_texture="random", frames_
 for _ in range(2):
     ft.step()
 torch.cuda.synchronize()
-t = _lib.KernelTimer(names=["fpcdr_render_loss_fwd", "fpcdr_render_aa_bwd"])
+t = _lib.KernelTimer(names=["fpcdr_render_loss_fwd", "fpcdr_render_aa_bwd", "fpcdr_objective_fwd"])
 _lib.TIMER = t
 for _ in range(a.steps):
     ft.step()

@@ -548,7 +548,7 @@ def test_fit_from_a_take_on_disk_equals_the_in_memory_run(tmp_path):
 def test_objective_launch_hints_do_not_change_the_result():
     """The sparse objective sizes its list kernels from the bin counts of the previous call (ops._ListHints).  Whatever the
     hint -- none, right, or far too small (the strided sweep kernels then do nearly all the work) -- loss and gradients are the
-    same."""
+    same.  (The two-call form; the one-pass form: tests/test_gpu_objective.py.)"""
     import fpc_diffrend_amd.ops as dr
     from fpc_diffrend_amd import scene
     from helpers import clip_positions
@@ -564,7 +564,7 @@ def test_objective_launch_hints_do_not_change_the_result():
     def run(**kw):
         p = pos.to(dev).clone().requires_grad_(True)
         t = torch.tensor(sc.texture, device=dev).clone().requires_grad_(True)
-        loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, sc.resolution, **kw)
+        loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, sc.resolution, one_pass=False, **kw)
         loss.backward()
         torch.cuda.synchronize()
         return float(loss), p.grad.double().cpu(), t.grad.double().cpu()

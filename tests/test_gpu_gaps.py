@@ -271,21 +271,22 @@ def test_1080p_sweep_kernels_equal_the_hinted_launch():
         torch.cuda.synchronize()
         return float(loss), p.grad.double().cpu(), t.grad.double().cpu()
 
-    dr._list_hints.clear()
-    try:
-        base = run(launch_hints=False)
-        run(queued_backward=True)                     # leaves its counts behind
-        hints = dr._list_hints[next(iter(dr._list_hints))]
-        caps = hints.poll()
-        assert min(caps) > 1000, caps                 # thousands of bins per list at this size
-        hints.event = None
-        hints.caps = (3, 2, 5)
-        hints.update = lambda counts: None
-        swept = run(queued_backward=True)
-        assert abs(swept[0] - base[0]) <= 1e-6 * abs(base[0])
-        assert rel_l2(swept[1], base[1]) < 1e-5 and rel_l2(swept[2], base[2]) < 1e-5
-    finally:
+    for one_pass in (True, False):      # the one-call form (two lists: live bins, occupied bins) and the two-call form (three)
         dr._list_hints.clear()
+        try:
+            base = run(launch_hints=False, one_pass=one_pass)
+            run(queued_backward=True, one_pass=one_pass)                     # leaves its counts behind
+            hints = dr._list_hints[next(iter(dr._list_hints))]
+            caps = hints.poll()
+            assert min(caps[:2] if one_pass else caps) > 1000, caps         # thousands of bins per list at this size
+            hints.event = None
+            hints.caps = (3, 2, 5)
+            hints.update = lambda counts: None
+            swept = run(queued_backward=True, one_pass=one_pass)
+            assert abs(swept[0] - base[0]) <= 1e-6 * abs(base[0])
+            assert rel_l2(swept[1], base[1]) < 1e-5 and rel_l2(swept[2], base[2]) < 1e-5
+        finally:
+            dr._list_hints.clear()
 
 
 def test_cfg3_batch_of_288_images_equals_its_chunks():

@@ -161,7 +161,7 @@ def _one_image_against_oracle(dr, sc, pos1, tri, cam, seed):
     trig, uv, uv_idx = tri.to(dev), torch.tensor(sc.uv, device=dev), torch.tensor(sc.uv_idx, device=dev)
     tg = targets.reshape(1, H, W).to(dev)
     out = {}
-    for name in ("operators", "objective"):
+    for name in ("operators", "objective", "objective-two-call"):
         p = pos1.to(dev).clone().requires_grad_(True)
         tex = torch.tensor(sc.texture, device=dev).clone().requires_grad_(True)
         if name == "operators":
@@ -176,8 +176,14 @@ def _one_image_against_oracle(dr, sc, pos1, tri, cam, seed):
             assert rel_l2(rast, ref['rast']) < 1e-4
             img = torch.where(rast[..., 3:] > 0, aa, torch.tensor(fit.BACKGROUND, device=dev))
             assert rel_l2(img, ref['image']) < 1e-4
+        elif name == "objective":      # one call: value and gradient (the flag planes are a diagnostic output there)
+            from fpc_diffrend_amd import _lib
+            flags = torch.zeros(_lib.load().fpcdr_antialias_flags_bytes(1, H, W) // 8, dtype=torch.int64, device=dev)
+            obj = dr.pixel_objective(ctx, p, trig, uv, uv_idx, tex, tg, sc.resolution, aa_flags_out=flags)
+            obj.backward()
+            loss = float(obj)
         else:
-            obj = dr.pixel_objective(ctx, p, trig, uv, uv_idx, tex, tg, sc.resolution)
+            obj = dr.pixel_objective(ctx, p, trig, uv, uv_idx, tex, tg, sc.resolution, one_pass=False)
             flags = obj.grad_fn.saved_tensors[9]
             obj.backward()
             loss = float(obj)

@@ -43,7 +43,8 @@ def _chain(ctx, p, tri, uv, uv_idx, t, ref, res, boundary):
 
 @pytest.mark.parametrize("geom,C,res,boundary", [('mesh', 1, (150, 200), 'wrap'), ('soup', 1, (97, 131), 'wrap'), ('soup', 3, (128, 160), 'clamp'),
                                                 ('few', 4, (64, 320), 'zero'), ('soup', 1, (33, 65), 'zero'), ('mesh', 3, (256, 256), 'wrap'),
-                                                ('few', 1, (32, 32), 'wrap'), ('soup', 1, (31, 17), 'clamp')])
+                                                ('few', 1, (32, 32), 'wrap'), ('soup', 1, (31, 17), 'clamp'),
+                                                ('few', 1, (97, 131), 'wrap')])      # (big triangles over a ragged border: the tile path)
 def test_one_pass_equals_two_call_form_and_operator_chain(geom, C, res, boundary):
     import fpc_diffrend_amd.ops as dr
     pos, tri, uv, uv_idx, tex, ref = _inputs(geom, C, res)
