@@ -51,10 +51,13 @@ def algorithmic_bytes_per_px(C, with_db):
         "fpcdr_aa_loss_fwd": 4 * C + 16 + 1 + 4 * C,    # colour + rast + 8-bit ref in, d loss / d aa out
         "fpcdr_render_aa_bwd": 4 * C + 16,              # d loss / d aa + rast in, scatter only
         "fpcdr_render_loss_fwd": 16 + 4 * C + 1 + 4 * C,  # rast + colour + d loss / d aa written, 8-bit ref read
+        # one-pass objective (value + gradient in one call): the id plane written by the rasteriser and read by the shading kernel,
+        # the 8-bit reference read; nothing else of the image exists in HBM (deferred-pixel records: a few per cent, not counted)
+        "fpcdr_objective_fwd": 4 + 4 + 1,
     }
 
 
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r03_counters_cfg3.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r04_counters_cfg3.json")
 
 
 def kernel_source_sha16():
@@ -75,9 +78,13 @@ ENTRY_KERNELS = {
     "fpcdr_render_loss_fwd": ["k_sil2", "k_init_queue", "k_setup", "k_list_count<", "k_list_scan", "k_list_write<",
                               "k_bins_list<false, true, true", "k_bins_queue<false, true, true", "k_aa_fix_list<", "k_aa_fix_queue<"],
     "fpcdr_render_aa_bwd": ["k_render_aa_bwd<", "k_render_aa_bwd_list<", "k_render_aa_bwd_queue<"],
+    "fpcdr_objective_fwd": ["k_sil2", "k_init_queue", "k_setup", "k_list_count<", "k_list_scan", "k_list_write<",
+                            "k_bins_list<false, false, false", "k_bins_queue<false, false, false", "k_shade_list<", "k_shade_queue<",
+                            "k_fix_list<", "k_fix_queue<"],
     "fpcdr_antialias_bwd": ["k_copy_f4_chunk", "k_aa_bwd_fix<"],
     "fpcdr_blend_fwd": ["k_blend_fwd_lds"],
 }
+OBJECTIVE_CALLS = ("fpcdr_objective_fwd", "fpcdr_render_loss_fwd", "fpcdr_render_aa_bwd")   # one-pass form / two-call form
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
 F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X dense f32 matrix peak (MI355X_MICROARCH.md)
 
@@ -181,7 +188,7 @@ def reference_shaped_step(device, steps=40, frames=8):
     """The reference's OWN run shape (main.py:28-30, fit.py:525-526): ONE random (camera, frame) image of 1600 x 1200 per
     iteration, a 1024^2 x 1 texture, 30k triangles -- what a user who only switches the import gets.  Two surfaces:
       drop_in    rasterize / interpolate / texture / antialias as four operators + the reference's torch.where / mean loss
-      objective  ops.pixel_objective (the fused two-call path), eager and replayed as HIP graphs
+      objective  ops.pixel_objective (the one-pass objective: value and gradient from one call), eager and replayed as HIP graphs
     Wall-clock ms per step between synchronisations, images/s, and GPU launches per step of the eager form."""
     from fpc_diffrend_amd import fit, scene
     sc = scene.cfg("ref", n_frames=frames)
@@ -434,7 +441,12 @@ def main():
         import fpc_diffrend_amd.ops as dr_ops
         sparse_px = {}
         for key, h in dr_ops._list_hints.items():
-            if key[1] == fpg * n_cam:
+            if key[0] == 'onepass' and key[2] == fpg * n_cam:      # one-pass objective: live bins of the rasteriser, occupied bins
+                _, _, n_bins, n_occ = (int(v) for v in h.host.tolist())
+                sparse_px = {"fpcdr_objective_fwd": n_occ * 1024}
+                out["config"]["occupied_bins"] = {"rasteriser": n_bins, "shaded": n_occ,
+                                                  "of": fpg * n_cam * ((H + 31) // 32) * ((W + 31) // 32)}
+            elif key[0] != 'onepass' and key[1] == fpg * n_cam:
                 n_bwd, _, n_bins, n_fix = (int(v) for v in h.host.tolist())
                 sparse_px = {"fpcdr_render_loss_fwd": n_bins * 1024, "fpcdr_render_aa_bwd": n_bwd * 1024}
                 out["config"]["occupied_bins"] = {"rasteriser": n_bins, "antialias_fix": n_fix, "backward": n_bwd,
@@ -465,14 +477,16 @@ def main():
             dom = max(px_ops, key=lambda k: px_ops[k]["avg_ms"] * px_ops[k]["calls"])
             t_s = px_ops[dom]["avg_ms"] * 1e-3
             out["roofline"], pmc = hbm_roofline(dom)
-            out["roofline"]["note"] = ("achieved = algorithmic bytes of the SPARSE call (B/px x 1024 px x the bins on its list, counted "
+            out["roofline"]["note"] = ("fpcdr_objective_fwd computes value AND gradient in one call and moves 9 B/px (id plane out and in, "
+                                       "8-bit reference): it is bound by vector issue, not by HBM -- see roofline_valu.  "
+                                       "achieved = algorithmic bytes of the SPARSE call (B/px x 1024 px x the bins on its list, counted "
                                        "live) / HIP-event time inside the timed region; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the "
                                        "call's kernels from the committed PMC passes named in traffic_source (null, with the reason in "
                                        "traffic_unavailable, when they were measured on other kernel sources or their durations differ "
                                        "from this run's by more than 10 %); dense_equivalent counts every pixel of the batch although "
                                        "80 % are never touched")
             # the two calls of the objective take nearly the same time and swap places from run to run: both are reported
-            out["roofline_objective_calls"] = {n_: hbm_roofline(n_)[0] for n_ in ("fpcdr_render_loss_fwd", "fpcdr_render_aa_bwd") if n_ in px_ops}
+            out["roofline_objective_calls"] = {n_: hbm_roofline(n_)[0] for n_ in OBJECTIVE_CALLS if n_ in px_ops}
             if pmc and pmc.get("valu_issue_frac") is not None:
                 out["roofline_valu"] = {"kernel": dom, "bound": "valu-issue", "achieved": pmc["valu_insts"] / t_s / 1e9,
                                         "unit": "G wave-instructions/s", "peak": N_SIMD * (pmc["gui_active"] / 8.0) / 4.0 / t_s / 1e9 if t_s else None,
@@ -486,7 +500,7 @@ def main():
                                                 "SQ_INSTS_VALU), the share of lanes doing work in an issued instruction"}
             # vector wave-instructions per 64 pixels of the two objective calls (the figure an HBM-bound kernel could afford ~120 of)
             vpp = {}
-            for name_ in ("fpcdr_render_loss_fwd", "fpcdr_render_aa_bwd"):
+            for name_ in OBJECTIVE_CALLS:
                 if name_ in table and sparse_px.get(name_):
                     pm, _ = measured_counters(name_, args.workload, fpg * n_cam, C, t_ms=table[name_]["avg_ms"])
                     if pm and pm["valu_insts"]:
@@ -563,7 +577,7 @@ def main():
     if rank == 0:
         # the two objective calls run over bin lists (sparse mode): 25 / 20 B per pixel of the WHOLE batch divided by their time is a
         # dense-equivalent rate (it exceeds the HBM peak), not a roofline figure -- roofline_objective_calls has that
-        for name_ in ("fpcdr_render_loss_fwd", "fpcdr_render_aa_bwd"):
+        for name_ in OBJECTIVE_CALLS:
             row = out.get("kernels", {}).get(name_) if isinstance(out.get("kernels"), dict) else None
             if row and "algorithmic_GBps" in row:
                 row["dense_equivalent_GBps"] = row.pop("algorithmic_GBps")

@@ -80,7 +80,12 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     __shared__ unsigned int s_id[(OB + 2) * OS];
     __shared__ int s_vkey[FPCDR_VT_SLOTS];
     __shared__ double s_vacc[FPCDR_VT_SLOTS][3];
-    __shared__ double s_tex[OTW * OTW * CS];
+    // texel window: FIXED-POINT int32 cells.  With ~1 texel per pixel some lanes of a wave instruction nearly always share a cell, and
+    // then ds_add_f64 costs 20 cycles where ds_add_u32 costs 6 (scripts/micro/texwin_bench.hip, profiles/r04_texwin_bench.txt).  The
+    // scale is a power of two chosen per bin behind the barrier from the sum of |gradient| over the bin's pixels, which bounds every
+    // cell (the four weights of a pixel sum to 1): no overflow, 2^-21 of the bin's total per add, and sums that do not depend on order.
+    __shared__ int s_tex[OTW * OTW * CS];
+    __shared__ float s_gsum[ONT / 64];
     __shared__ int s_org[2];
     __shared__ unsigned int s_cmask[OB];
     __shared__ float s_fy[OB];
@@ -116,7 +121,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     }
     if (want_pos) vtable_init(vt, tid, ONT);
     if (want_tex)
-        for (int k = tid; k < OTW * OTW * CS; k += ONT) s_tex[k] = 0.0;
+        for (int k = tid; k < OTW * OTW * CS; k += ONT) s_tex[k] = 0;
     if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
     if (tid < OB) {
         s_cmask[tid] = 0u;
@@ -137,6 +142,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     int k_x0[4], k_y0[4];
     bool k_on[4];
     int ux0 = 0x7fffffff, uy0 = 0x7fffffff;
+    float gabs = 0.0f;      // sum of |d loss / d colour| over this thread's pixels
     float lsum = 0.0f;
     bool any_def = false;
 
@@ -202,7 +208,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             if (want_grad) {
                 bool nz = false;
 #pragma unroll
-                for (int c = 0; c < CS; ++c) { k_gc[k][c] = gq[c]; nz |= gq[c] != 0.0f; }
+                for (int c = 0; c < CS; ++c) { k_gc[k][c] = gq[c]; nz |= gq[c] != 0.0f; gabs += fabsf(gq[c]); }
                 if (want_tex && nz) {
                     k_on[k] = true;
                     k_fx[k] = tp.fx; k_fy[k] = tp.fy;
@@ -228,18 +234,34 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 }
             }
         }
+#ifdef FPCDR_OABL_NOSCAN
+        { float sink = 0.f; for (int q = 0; q < 9; ++q) sink += gv9[q]; asm volatile("" :: "v"(sink), "v"(tkey)); }
+        if (false)
+#else
         if (want_pos)      // (uniform)
+#endif
             wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) { vtable_add(vt, gp, vk, sm); });
     }
     if (want_tex) {
         const int mx = wave_min_dpp(ux0), my = wave_min_dpp(uy0);
         if (lane == 0 && mx != 0x7fffffff) { atomicMin(&s_org[0], mx); atomicMin(&s_org[1], my); }
+        gabs = wave_sum_dpp(gabs);
+        if (lane == 0) s_gsum[wave] = gabs;
     }
     lsum = wave_sum_dpp(lsum);
     if (lane == 0) s_lpart[wave] = lsum;
     const bool bin_def = __builtin_amdgcn_readfirstlane(__syncthreads_or(any_def ? 1 : 0)) != 0;
 
     // ---- phase 2: the four texel adds of every pixel into the window (taps outside it -- uv seams -- go to memory) ----
+    // fixed-point scale of the window: total <= 2^(e+1) (1.001: the float sums' rounding), so scale = 2^(29 - e) keeps every cell below 2^30
+    float tex_scale = 1.0f, tex_unscale = 1.0f;
+    if (want_tex) {
+        const float total = ((s_gsum[0] + s_gsum[1]) + (s_gsum[2] + s_gsum[3])) * 1.001f;
+        const int e = (int)((__float_as_uint(total) >> 23) & 0xffu) - 127;      // total in [2^e, 2^(e+1)); 0 / denormal: e = -127
+        const int se = min(max(29 - e, -100), 100);
+        tex_scale = __uint_as_float((unsigned int)(se + 127) << 23);
+        tex_unscale = __uint_as_float((unsigned int)(127 - se) << 23);
+    }
     if (want_tex) {
         const int ox = s_org[0], oy = s_org[1];
 #pragma unroll
@@ -255,17 +277,26 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             const float w00 = (valid & 1u) ? (1.0f - fx) * (1.0f - fy) : 0.0f, w10 = (valid & 2u) ? fx * (1.0f - fy) : 0.0f;
             const float w01 = (valid & 4u) ? (1.0f - fx) * fy : 0.0f, w11 = (valid & 8u) ? fx * fy : 0.0f;
             const int lx = x0 - ox, ly = y0 - oy;
+#ifdef FPCDR_OABL_NOTEXADD
+            asm volatile("" :: "v"(w00), "v"(w10), "v"(w01), "v"(w11), "v"(lx), "v"(ly), "v"(k_gc[k][0]));
+            if (false) {
+#else
             if (lx >= 0 && ly >= 0 && lx + 1 < OTW && ly + 1 < OTW) {
+#endif
 #pragma unroll
                 for (int c = 0; c < CS; ++c) {
-                    double *wp = s_tex + (ly * OTW + lx) * CS + c;
-                    const float gc = k_gc[k][c];
-                    lds_add_f64(wp, gc * w00);
-                    lds_add_f64(wp + CS, gc * w10);
-                    lds_add_f64(wp + OTW * CS, gc * w01);
-                    lds_add_f64(wp + OTW * CS + CS, gc * w11);
+                    int *wp = s_tex + (ly * OTW + lx) * CS + c;
+                    const float gc = k_gc[k][c] * tex_scale;      // (a power of two: exact)
+                    atomicAdd(wp, __float2int_rn(gc * w00));
+                    atomicAdd(wp + CS, __float2int_rn(gc * w10));
+                    atomicAdd(wp + OTW * CS, __float2int_rn(gc * w01));
+                    atomicAdd(wp + OTW * CS + CS, __float2int_rn(gc * w11));
                 }
+#ifdef FPCDR_OABL_NOTEXADD
+            } else if (false) {
+#else
             } else {
+#endif
                 const int ix0 = wrap_near(x0, Wt, boundary), ix1 = wrap_near(x0 == 0x7fffffff ? x0 : x0 + 1, Wt, boundary);
                 const int iy0 = wrap_near(y0, Ht, boundary), iy1 = wrap_near(y0 == 0x7fffffff ? y0 : y0 + 1, Ht, boundary);
 #pragma unroll
@@ -290,15 +321,21 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     if (!want_grad) return;
     __syncthreads();
     // ---- flush: every vertex slot and window cell once ----
+#ifndef FPCDR_OABL_NOVFLUSH
     if (want_pos) vtable_flush(vt, gp, tid, ONT);
+#endif
+#ifdef FPCDR_OABL_NOTEXFLUSH
+    if (false) {
+#else
     if (want_tex && s_org[0] != 0x7fffffff) {
+#endif
         const int ox = s_org[0], oy = s_org[1];
         for (int k = tid; k < OTW * OTW * CS; k += ONT) {
-            const float v = (float)s_tex[k];
-            if (v != 0.0f) {
+            const int vi = s_tex[k];
+            if (vi != 0) {
                 const int c = k % CS, cell = k / CS;
                 const int gx = wrap_near(ox + cell % OTW, Wt, boundary), gy = wrap_near(oy + cell / OTW, Ht, boundary);
-                atomicAdd(&at32(a.grad_tex, (unsigned int)((gy * Wt + gx) * CS + c)), v);
+                atomicAdd(&at32(a.grad_tex, (unsigned int)((gy * Wt + gx) * CS + c)), (float)vi * tex_unscale);
             }
         }
     }

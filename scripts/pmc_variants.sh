@@ -9,6 +9,6 @@ for n in "$@"; do
   rm -rf gpurun_out/pmcv_$n
   timeout -k 10 200 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d gpurun_out/pmcv_$n -- python3 scripts/prof_objective.py --ops 0 > gpurun_out/pmcv_$n.json 2> gpurun_out/pmcv_$n.err || { echo "FAILED $n"; exit 1; }
   echo "== $n $(tail -1 gpurun_out/pmcv_$n.json)"
-  python scripts/summarize_rocprof.py gpurun_out/pmcv_$n | grep -E "k_bins_list|k_aa_fix_list|k_render_aa_bwd|k_setup|k_sil2"
+  python scripts/summarize_rocprof.py gpurun_out/pmcv_$n | grep -E "k_bins_list|k_aa_fix_list|k_render_aa_bwd|k_setup|k_sil2|k_shade|k_fix"
   rm -rf gpurun_out/pmcv_$n
 done
