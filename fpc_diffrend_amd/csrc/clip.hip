@@ -129,14 +129,15 @@ __global__ void __launch_bounds__(256) k_lap_gather(const float *__restrict__ x,
 // The Laplacian term of the reference's objective (fit.py:581: weight * mesh_laplacian_smoothing(mesh)^2, one mesh per step; a batch
 // takes the mean of the squares) as ONE launch each way instead of a gather and a dozen torch kernels:
 //   per_f = mean_v || (L x_f)_v ||,   value = weight / F * sum_f per_f^2.
-// Forward: every workgroup adds its vertices' norms to its mesh's double accumulator; the LAST workgroup to finish (a ticket
-// counter behind a fence) forms the value, stores per_f for the backward and zeroes accumulators and ticket for the next call.
+// Forward: every workgroup adds its vertices' norms to its mesh's double accumulator (one relaxed device-scope add per workgroup);
+// a one-workgroup kernel behind it -- a kernel boundary orders the adds before its loads, no fence or ticket -- forms the value,
+// stores per_f for the backward and zeroes the accumulators for the next call.  (r3 let the last workgroup to finish do that behind
+// a ticket counter with relaxed atomics: correct on gfx950, where agent-scope read-modify-writes execute at the memory side, but
+// not by the memory model; a release fence per workgroup writes the XCD's whole L2 back and slowed a concurrent store stream 4x.)
 __global__ void __launch_bounds__(256) k_lap_penalty_fwd(const float *__restrict__ x, const int32_t *__restrict__ nbr,
-                                                         const float *__restrict__ inv_deg, int F, int V, int D, float weight,
-                                                         float *__restrict__ lap, double *__restrict__ acc, unsigned int *__restrict__ ticket,
-                                                         float *__restrict__ per, float *__restrict__ out) {
+                                                         const float *__restrict__ inv_deg, int F, int V, int D,
+                                                         float *__restrict__ lap, double *__restrict__ acc) {
     __shared__ double s_part[4];
-    __shared__ unsigned int s_ticket;
     const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     float nrm = 0.0f;
@@ -154,37 +155,27 @@ __global__ void __launch_bounds__(256) k_lap_penalty_fwd(const float *__restrict
     const float ws = wave_sum_dpp(nrm);
     if (lane == 0) s_part[wave] = (double)ws;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // No __threadfence here: on gfx950 a device-scope release writes the XCD's whole L2 back, and with ~2 000 workgroups doing it
-        // a concurrent store stream (the flag planes' zero-fill of the next forward call, on the other queue) ran 4x slower.  Both
-        // operations are device-scope read-modify-writes performed at the memory side; the ticket is taken only after the sum's
-        // atomic has RETURNED (the asm consumes its result), and the last workgroup reads the sums with device-scope atomic loads.
-        const double before = __hip_atomic_fetch_add(&acc[f], s_part[0] + s_part[1] + s_part[2] + s_part[3], __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(before));
-        s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (s_ticket != gridDim.x * gridDim.y - 1) return;
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(&acc[f], s_part[0] + s_part[1] + s_part[2] + s_part[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256) k_lap_penalty_finish(double *__restrict__ acc, int F, int V, float weight, float *__restrict__ per,
+                                                            float *__restrict__ out) {
+    __shared__ double s_tot[256];
     double tot = 0.0;
     for (int i = threadIdx.x; i < F; i += blockDim.x) {
-        const double p = __hip_atomic_load(&acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (double)V;
+        const double p = acc[i] / (double)V;
         per[i] = (float)p;
         tot += p * p;
-        __hip_atomic_store(&acc[i], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc[i] = 0.0;
     }
-    // block sum of doubles: through LDS (F is small)
-    __shared__ double s_tot[256];
     s_tot[threadIdx.x] = tot;
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
         if ((int)threadIdx.x < o) s_tot[threadIdx.x] += s_tot[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        out[0] = (float)((double)weight * s_tot[0] / (double)F);
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) out[0] = (float)((double)weight * s_tot[0] / (double)F);
 }
 
 // Backward: d value / d x = L^T y,  y_v = c_f * lap_v / ||lap_v||,  c_f = upstream * weight * 2 per_f / (F V)  (0 where lap_v = 0,
@@ -359,9 +350,10 @@ extern "C" int fpcdr_laplacian_penalty_fwd(const float *x, const int32_t *nbr, c
     FPCDR_REQUIRE(x && nbr && inv_deg && lap && acc && per && out, "null pointer");
     FPCDR_REQUIRE(F > 0 && V > 0 && D > 0 && F <= 65535, "bad sizes");
     FPCDR_REQUIRE(((size_t)acc & 7) == 0, "acc must be 8-byte aligned");
-    // acc: F doubles + one 8-byte slot for the ticket, zero on entry and zero again when the call has run
-    hipLaunchKernelGGL(k_lap_penalty_fwd, dim3(fpcdr_cdiv(V, 256), F), dim3(256), 0, (hipStream_t)stream, x, nbr, inv_deg, F, V, D, weight,
-                       lap, (double *)acc, (unsigned int *)((double *)acc + F), per, out);
+    // acc: F doubles (+ one spare 8-byte slot: the size of earlier ABI versions), zero on entry and zero again when the call has run
+    hipLaunchKernelGGL(k_lap_penalty_fwd, dim3(fpcdr_cdiv(V, 256), F), dim3(256), 0, (hipStream_t)stream, x, nbr, inv_deg, F, V, D,
+                       lap, (double *)acc);
+    hipLaunchKernelGGL(k_lap_penalty_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, (double *)acc, F, V, weight, per, out);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }

@@ -38,12 +38,18 @@ constexpr int OB = 32;            // pixels per bin side
 constexpr int OS = 36;            // LDS row stride of the id plane with its one-pixel apron (34 entries used)
 constexpr int OTW = FPCDR_OTEXWIN;
 constexpr int ONT = 256;          // threads of k_shade
-constexpr int FNT = 64;           // threads of k_fix: one wave per bin (a chain of dependent loads for a few dozen pixels)
+#ifndef FPCDR_FNT
+#define FPCDR_FNT 64
+#endif
+constexpr int FNT = FPCDR_FNT;    // threads of k_fix per bin (a chain of dependent loads for a few dozen pixels)
 
 struct ObjArgs {
     const float4 *pos; const int32_t *tri; const float2 *uv; const int32_t *uv_tri; const float2 *tri_uv;
     const float *tex; const uint8_t *ref; const uint8_t *sil;
     const uint32_t *idp; const uint16_t *occ; uint8_t *binflag; uint32_t *cmask;
+    float *esum;            // [ESLOTS][4]: gradient arriving at the colour of EMPTY pixels (k_fix<1> -> k_esum_finish), zeroed by the call
+    int32_t *def_list, *def_count;      // bins that hold a deferred pixel, appended by k_shade (k_fix runs over these only)
+    uint32_t *hitmask;      // [bins][32] row masks of the pixels that took part in a blend (k_fix<0> -> k_fix<1>); zeroed per bin by k_shade
     float4 *rec; float *color; float *g_aa; const float *empty_color;
     double *loss_sum; float *grad_pos; float *grad_tex;
     int B, V, T, H, W, Ht, Wt, boundary;
@@ -52,9 +58,13 @@ struct ObjArgs {
 };
 
 // texture coordinates of triangle t through the index buffer (callers that did not pre-gather uv[uv_tri]); out of line, see fused.hip
-__device__ __noinline__ void uv_indirect(const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri, int t, float2 &q0, float2 &q1,
-                                         float2 &q2) {
-    q0 = uv[uv_tri[3 * t]]; q1 = uv[uv_tri[3 * t + 1]]; q2 = uv[uv_tri[3 * t + 2]];
+// (returns BY VALUE, in registers: reference arguments of an out-of-line function live in scratch memory, and a kernel with a private
+//  segment is dispatched several times slower -- k_fix<1> spent 220 us launching 90 k one-wave workgroups, 47 us without scratch)
+struct UV3 { float2 q0, q1, q2; };
+__device__ __noinline__ UV3 uv_indirect(const float2 *__restrict__ uv, const int32_t *__restrict__ uv_tri, int t) {
+    UV3 r;
+    r.q0 = uv[uv_tri[3 * t]]; r.q1 = uv[uv_tri[3 * t + 1]]; r.q2 = uv[uv_tri[3 * t + 2]];
+    return r;
 }
 
 // d(grad_scale * sum of squares) / d colour for one channel: ONE expression for the three kernels, so that a deferred pixel no blend
@@ -65,42 +75,72 @@ __device__ __forceinline__ float loss_grad(float dd, float color_scale, float gr
 __device__ __forceinline__ bool pair_maybe(unsigned int a, unsigned int b) { return ((a ^ b) & 0xffffffu) != 0u && ((a | b) >> 24) != 0u; }
 
 struct I3 { int a, b, c; };
-struct UV3 { float2 q0, q1, q2; };
+
+// -DFPCDR_OPROF (scripts/prof_phases.py): wave-cycles of k_shade by phase, summed over all waves into a device array
+#ifdef FPCDR_OPROF
+__device__ unsigned long long g_oprof[16];
+#define OPROF_DECL long long oprof_t0 = 0, oprof_t1 = 0, oprof_t2 = 0, oprof_t3 = 0, oprof_t4 = 0, oprof_t5 = 0, oprof_t6 = 0, oprof_t7 = 0
+#define OPROF_T(i) oprof_t##i = clock64()
+#define OPROF_ADD(slot, a_, b_) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_oprof[slot], (unsigned long long)(oprof_t##b_ - oprof_t##a_)); } while (0)
+#else
+#define OPROF_DECL
+#define OPROF_T(i)
+#define OPROF_ADD(slot, a_, b_)
+#endif
 
 // ------------------------------------------------------------------------------------------------
-// k_shade: one 32 x 32 bin, 256 threads, four pixels per thread.  Pixel k of a thread: row 8 wave + 2 k + (lane >> 5), the odd row
-// right to left, so that the pixels of a triangle are neighbours in lane order and ONE segmented scan per pass sums the nine vertex
-// gradient components of every run (common.h wave_segment_reduce9).
+// k_shade: one 32 x 32 bin, 256 threads, four pixels per thread.  A wave pass covers two adjacent rows of the bin, the second one right
+// to left, so that the pixels of a triangle are neighbours in lane order and ONE segmented scan per pass sums the nine vertex gradient
+// components of every run (common.h wave_segment_reduce9).
+//
+// The texel window needs its origin -- the bin's smallest tap -- before the first add.  Pass 0 of the four waves covers the row pairs
+// 0/1, 10/11, 20/21, 30/31: for a locally affine uv map the smallest tap lies in the bin's first or last row, which pass 0 holds, and
+// no row is more than four from a sampled one; the window starts OWIN_MARGIN texels below the minimum of pass 0 and whatever still
+// falls outside (uv seams, a second surface in the bin) goes to memory with atomics.  So a pixel's four texel adds happen right where
+// its weights are formed: nothing is kept across a barrier (the two-phase form held 20 registers per thread for it: 88 VGPRs and
+// 5 waves per SIMD, where this form runs 7 -- worth 0.2 ms at cfg3 on the same instructions).
 #ifndef FPCDR_SHADE_WPE
 #define FPCDR_SHADE_WPE
 #endif
+#ifndef FPCDR_OWIN_MARGIN
+#define FPCDR_OWIN_MARGIN 0          // cfg3, 40-texel window: margin 0 / 1 / 2 / 3 -> 2.89 / 2.90 / 2.93 / 2.97 ms per call
+#endif
+constexpr int OWIN_MARGIN = FPCDR_OWIN_MARGIN;
+// row pair (rows 2 p, 2 p + 1) of wave w in pass k
+__device__ __forceinline__ int shade_row_pair(int k, int w) {
+    // k = 0: 0, 5, 10, 15;  k = 1: 1, 6, 11, 14;  k = 2: 2, 7, 12, 13;  k = 3: 3, 4, 8, 9
+    const unsigned int packed = k == 0 ? 0xFA50u : (k == 1 ? 0xEB61u : (k == 2 ? 0xDC72u : 0x9843u));
+    return (int)((packed >> (4 * w)) & 15u);
+}
+
 template <int CS, int BMODE>
 __device__ __forceinline__ void shade_body(const int b, const int bxi, const int byi, const int OX, const int OY, const ObjArgs &a) {
     const int boundary = BMODE >= 0 ? BMODE : a.boundary;
     __shared__ unsigned int s_id[(OB + 2) * OS];
     __shared__ int s_vkey[FPCDR_VT_SLOTS];
     __shared__ double s_vacc[FPCDR_VT_SLOTS][3];
-    // texel window: FIXED-POINT int32 cells.  With ~1 texel per pixel some lanes of a wave instruction nearly always share a cell, and
-    // then ds_add_f64 costs 20 cycles where ds_add_u32 costs 6 (scripts/micro/texwin_bench.hip, profiles/r04_texwin_bench.txt).  The
-    // scale is a power of two chosen per bin behind the barrier from the sum of |gradient| over the bin's pixels, which bounds every
-    // cell (the four weights of a pixel sum to 1): no overflow, 2^-21 of the bin's total per add, and sums that do not depend on order.
-    __shared__ int s_tex[OTW * OTW * CS];
-    __shared__ float s_gsum[ONT / 64];
+    __shared__ double s_tex[OTW * OTW * CS];      // texel window, doubles: ds_add_f64 (common.h lds_add_f64)
     __shared__ int s_org[2];
     __shared__ unsigned int s_cmask[OB];
     __shared__ float s_fy[OB];
     __shared__ float s_lpart[ONT / 64];
     const VTable vt = {s_vkey, s_vacc};
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = (lane & 32) ? 63 - lane : lane;
-    const int row0 = 8 * wave + (lane >> 5);
     const int bx0 = bxi * OB, by0 = byi * OB;
     const int x = bx0 + col;
     const int H = a.H, W = a.W, Ht = a.Ht, Wt = a.Wt;
     const size_t bin_lin = ((size_t)b * OY + byi) * OX + bxi;
     const unsigned int wmask = (unsigned int)__builtin_amdgcn_readfirstlane((int)a.occ[bin_lin]);
+#ifdef FPCDR_OABL_NOTEXGRAD
+    const bool want_tex = false, want_pos = a.grad_pos != nullptr, want_grad = want_tex || want_pos;
+#else
     const bool want_tex = a.grad_tex != nullptr, want_pos = a.grad_pos != nullptr, want_grad = want_tex || want_pos;   // (uniform)
+#endif
 
+    OPROF_DECL;
+    OPROF_T(0);
     // ---- phase 0: the bin's ids with a one-pixel apron from the neighbours' planes; tables ----
     {
         const uint4 v = reinterpret_cast<const uint4 *>(a.idp + bin_lin * (OB * OB))[tid];
@@ -121,13 +161,15 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     }
     if (want_pos) vtable_init(vt, tid, ONT);
     if (want_tex)
-        for (int k = tid; k < OTW * OTW * CS; k += ONT) s_tex[k] = 0;
+        for (int k = tid; k < OTW * OTW * CS; k += ONT) s_tex[k] = 0.0;
     if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
     if (tid < OB) {
         s_cmask[tid] = 0u;
         s_fy[tid] = (2.0f * (float)(by0 + tid) + 1.0f) / (float)H - 1.0f;      // NDC y of the bin's rows: one IEEE division per row
     }
+    OPROF_T(1);
     __syncthreads();
+    OPROF_T(2);
 
     const size_t img = (size_t)b * H * W;
     const size_t bin_off = img + (size_t)by0 * W + bx0;
@@ -136,23 +178,62 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     const float fx_col = (2.0f * (float)x + 1.0f) / (float)W - 1.0f;
     const float cs = a.color_scale, gs = a.grad_scale;
     const float bgs = a.bg * cs;
-
-    // what a pixel keeps for the texel adds behind the barrier (the window's origin is the bin's smallest tap, known only then)
-    float k_gc[4][CS], k_fx[4], k_fy[4];
-    int k_x0[4], k_y0[4];
-    bool k_on[4];
-    int ux0 = 0x7fffffff, uy0 = 0x7fffffff;
-    float gabs = 0.0f;      // sum of |d loss / d colour| over this thread's pixels
     float lsum = 0.0f;
     bool any_def = false;
+    int ox = 0, oy = 0;      // origin of the texel window (set behind the barrier after pass 0)
 
-    // ---- phase 1: shade, loss, chain back ----
+    // the four texel adds of one pixel: into the window, or -- outside it -- to memory
+    auto add_taps = [&](const float (&gc)[CS], float fx, float fy, int x0, int y0) {
+        unsigned int valid = 0xFu;
+        if (boundary == FPCDR_BOUNDARY_ZERO) {
+            const bool vx0 = x0 >= 0 && x0 < Wt, vx1 = x0 >= -1 && x0 < Wt - 1, vy0 = y0 >= 0 && y0 < Ht, vy1 = y0 >= -1 && y0 < Ht - 1;
+            valid = (vx0 && vy0 ? 1u : 0u) | (vx1 && vy0 ? 2u : 0u) | (vx0 && vy1 ? 4u : 0u) | (vx1 && vy1 ? 8u : 0u);
+        }
+        const float w00 = (valid & 1u) ? (1.0f - fx) * (1.0f - fy) : 0.0f, w10 = (valid & 2u) ? fx * (1.0f - fy) : 0.0f;
+        const float w01 = (valid & 4u) ? (1.0f - fx) * fy : 0.0f, w11 = (valid & 8u) ? fx * fy : 0.0f;
+        const int lx = x0 - ox, ly = y0 - oy;
+#ifdef FPCDR_OABL_NOTEXADD
+        asm volatile("" :: "v"(w00), "v"(w10), "v"(w01), "v"(w11), "v"(lx), "v"(ly), "v"(gc[0]));
+        if (false) {
+#else
+        // (unsigned compares: a tap below the origin wraps to a huge value; 0x7fffffff origin = no sample in pass 0: everything outside)
+        if ((unsigned int)lx < (unsigned int)(OTW - 1) && (unsigned int)ly < (unsigned int)(OTW - 1)) {
+#endif
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int zy = row0 + 2 * k, y = by0 + zy;
+            for (int c = 0; c < CS; ++c) {
+                double *wp = s_tex + (ly * OTW + lx) * CS + c;
+                lds_add_f64(wp, gc[c] * w00);
+                lds_add_f64(wp + CS, gc[c] * w10);
+                lds_add_f64(wp + OTW * CS, gc[c] * w01);
+                lds_add_f64(wp + OTW * CS + CS, gc[c] * w11);
+            }
+#ifdef FPCDR_OABL_NOTEXADD
+        } else if (false) {
+#else
+        } else {
+#endif
+            const int ix0 = wrap_near(x0, Wt, boundary), ix1 = wrap_near(x0 == 0x7fffffff ? x0 : x0 + 1, Wt, boundary);
+            const int iy0 = wrap_near(y0, Ht, boundary), iy1 = wrap_near(y0 == 0x7fffffff ? y0 : y0 + 1, Ht, boundary);
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                atomicAdd(&at32(a.grad_tex, (unsigned int)((iy0 * Wt + ix0) * CS + c)), gc[c] * w00);
+                atomicAdd(&at32(a.grad_tex, (unsigned int)((iy0 * Wt + ix1) * CS + c)), gc[c] * w10);
+                atomicAdd(&at32(a.grad_tex, (unsigned int)((iy1 * Wt + ix0) * CS + c)), gc[c] * w01);
+                atomicAdd(&at32(a.grad_tex, (unsigned int)((iy1 * Wt + ix1) * CS + c)), gc[c] * w11);
+            }
+        }
+    };
+
+    // pass 0 keeps its pixel's taps until the origin is known
+    float k_gc[CS], k_fx = 0.f, k_fy = 0.f;
+    int k_x0 = 0x7fffffff, k_y0 = 0x7fffffff;
+    bool k_on = false;
+
+    // ---- one pixel: shade, loss, chain back.  FIRST: pass 0 (texel adds deferred to behind the origin's barrier) ----
+    auto pixel = [&](const int k, const bool FIRST) {
+        const int zy = 2 * shade_row_pair(k, wave) + (lane >> 5), y = by0 + zy;
         const unsigned int me = s_id[(zy + 1) * OS + col + 1];
         const int id = (int)(me & 0xffffffu);      // (pixels beyond the image hold 0)
-        k_on[k] = false;
         int tkey = -1;
         int vk[3] = {0, 0, 0};
         float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -166,12 +247,11 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             const float4 v0 = ld32(pos_img, ti.a), v1 = ld32(pos_img, ti.b), v2 = ld32(pos_img, ti.c);
             const float fy = s_fy[zy];
             ShadeKeep K;
-            float u, v, zw;
-            shade_uvz(v0, v1, v2, fx_col, fy, K, u, v, zw);
+            float u, v, zw = 0.0f;
+            shade_uvz<false>(v0, v1, v2, fx_col, fy, K, u, v, zw);      // (z/w: deferred pixels only, below)
             // interpolate (fit.py:157) + texture 'linear' (fit.py:158): the arithmetic of the stand-alone kernels
-            float2 q0, q1, q2;
-            if (a.tri_uv) { const UV3 tq = ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t); q0 = tq.q0; q1 = tq.q1; q2 = tq.q2; }
-            else uv_indirect(a.uv, a.uv_tri, t, q0, q1, q2);
+            const UV3 tq = a.tri_uv ? ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t) : uv_indirect(a.uv, a.uv_tri, t);
+            const float2 q0 = tq.q0, q1 = tq.q1, q2 = tq.q2;
             const float w = 1.0f - u - v;
             const float tu = u * q0.x + v * q1.x + w * q2.x;
             const float tv = u * q0.y + v * q1.y + w * q2.y;
@@ -182,6 +262,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             const float d0 = rf - bgs;
             float colv[CS], gq[CS];
             float gfx = 0.f, gfy = 0.f;
+            bool nz = false;
 #pragma unroll
             for (int c = 0; c < CS; ++c) {
                 float t00, t10, t01, t11;
@@ -195,42 +276,44 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 const float dd = rf - colv[c] * cs;
                 lsum += dd * dd - d0 * d0;
                 gq[c] = loss_grad(dd, cs, gs);
+                nz |= gq[c] != 0.0f;
                 gfx += gq[c] * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
                 gfy += gq[c] * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
             }
             if (deferred) {      // k_fix reads these back: a few per cent of the covered pixels
                 any_def = true;
                 atomicOr(&s_cmask[zy], 1u << col);
+                zw = shade_zw(v0, v1, v2, K.a0, K.a1, K.p0x * K.p1y - K.p0y * K.p1x);
                 a.rec[off] = make_float4(u, v, zw, (float)id);
 #pragma unroll
                 for (int c = 0; c < CS; ++c) { a.color[off * CS + c] = colv[c]; a.g_aa[off * CS + c] = gq[c]; }
             }
-            if (want_grad) {
-                bool nz = false;
+            if (want_tex && nz) {
+                const int x0 = (int)floorf(prep_coord(tu, boundary) * (float)Wt - 0.5f);
+                const int y0 = (int)floorf(prep_coord(tv, boundary) * (float)Ht - 0.5f);
+                if (FIRST) {
+                    k_on = true;
+                    k_fx = tp.fx; k_fy = tp.fy; k_x0 = x0; k_y0 = y0;
 #pragma unroll
-                for (int c = 0; c < CS; ++c) { k_gc[k][c] = gq[c]; nz |= gq[c] != 0.0f; gabs += fabsf(gq[c]); }
-                if (want_tex && nz) {
-                    k_on[k] = true;
-                    k_fx[k] = tp.fx; k_fy[k] = tp.fy;
-                    k_x0[k] = (int)floorf(prep_coord(tu, boundary) * (float)Wt - 0.5f);
-                    k_y0[k] = (int)floorf(prep_coord(tv, boundary) * (float)Ht - 0.5f);
-                    ux0 = min(ux0, k_x0[k]); uy0 = min(uy0, k_y0[k]);
+                    for (int c = 0; c < CS; ++c) k_gc[c] = gq[c];
+                } else {
+                    add_taps(gq, tp.fx, tp.fy, x0, y0);
                 }
-                if (want_pos) {
-                    const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
-                    const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv >= 0.0f && tv <= 1.0f)) ? 0.0f : 1.0f;
-                    const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
-                    const float gu = gtu * (q0.x - q2.x) + gtv * (q0.y - q2.y);
-                    const float gvv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
-                    if (gu != 0.0f || gvv != 0.0f) {
-                        tkey = t;
-                        vk[0] = ti.a; vk[1] = ti.b; vk[2] = ti.c;
-                        float g0[3], g1[3], g2[3];
-                        shade_uv_bwd(K, fx_col, fy, gu, gvv, g0, g1, g2);
-                        gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
-                        gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
-                        gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
-                    }
+            }
+            if (want_pos) {
+                const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
+                const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv >= 0.0f && tv <= 1.0f)) ? 0.0f : 1.0f;
+                const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
+                const float gu = gtu * (q0.x - q2.x) + gtv * (q0.y - q2.y);
+                const float gvv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
+                if (gu != 0.0f || gvv != 0.0f) {
+                    tkey = t;
+                    vk[0] = ti.a; vk[1] = ti.b; vk[2] = ti.c;
+                    float g0[3], g1[3], g2[3];
+                    shade_uv_bwd(K, fx_col, fy, gu, gvv, g0, g1, g2);
+                    gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
+                    gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
+                    gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
                 }
             }
         }
@@ -241,104 +324,70 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         if (want_pos)      // (uniform)
 #endif
             wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) { vtable_add(vt, gp, vk, sm); });
-    }
+    };
+
+    // ---- pass 0: row pairs 0, 5, 10, 15; the window's origin ----
+    pixel(0, true);
     if (want_tex) {
-        const int mx = wave_min_dpp(ux0), my = wave_min_dpp(uy0);
+        const int mx = wave_min_dpp(k_x0), my = wave_min_dpp(k_y0);
         if (lane == 0 && mx != 0x7fffffff) { atomicMin(&s_org[0], mx); atomicMin(&s_org[1], my); }
-        gabs = wave_sum_dpp(gabs);
-        if (lane == 0) s_gsum[wave] = gabs;
+        OPROF_T(3);
+        __syncthreads();
+        OPROF_T(4);
+        ox = s_org[0]; oy = s_org[1];
+        if (ox != 0x7fffffff) { ox -= OWIN_MARGIN; oy -= OWIN_MARGIN; }
+        if (k_on) add_taps(k_gc, k_fx, k_fy, k_x0, k_y0);
+    } else {
+        OPROF_T(3);
+        OPROF_T(4);
     }
+    // ---- passes 1 .. 3 ----
+#pragma unroll
+    for (int k = 1; k < 4; ++k) pixel(k, false);
+
     lsum = wave_sum_dpp(lsum);
     if (lane == 0) s_lpart[wave] = lsum;
+    OPROF_T(5);
     const bool bin_def = __builtin_amdgcn_readfirstlane(__syncthreads_or(any_def ? 1 : 0)) != 0;
-
-    // ---- phase 2: the four texel adds of every pixel into the window (taps outside it -- uv seams -- go to memory) ----
-    // fixed-point scale of the window: total <= 2^(e+1) (1.001: the float sums' rounding), so scale = 2^(29 - e) keeps every cell below 2^30
-    float tex_scale = 1.0f, tex_unscale = 1.0f;
-    if (want_tex) {
-        const float total = ((s_gsum[0] + s_gsum[1]) + (s_gsum[2] + s_gsum[3])) * 1.001f;
-        const int e = (int)((__float_as_uint(total) >> 23) & 0xffu) - 127;      // total in [2^e, 2^(e+1)); 0 / denormal: e = -127
-        const int se = min(max(29 - e, -100), 100);
-        tex_scale = __uint_as_float((unsigned int)(se + 127) << 23);
-        tex_unscale = __uint_as_float((unsigned int)(127 - se) << 23);
-    }
-    if (want_tex) {
-        const int ox = s_org[0], oy = s_org[1];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!k_on[k]) continue;
-            const int x0 = k_x0[k], y0 = k_y0[k];
-            unsigned int valid = 0xFu;
-            if (boundary == FPCDR_BOUNDARY_ZERO) {
-                const bool vx0 = x0 >= 0 && x0 < Wt, vx1 = x0 >= -1 && x0 < Wt - 1, vy0 = y0 >= 0 && y0 < Ht, vy1 = y0 >= -1 && y0 < Ht - 1;
-                valid = (vx0 && vy0 ? 1u : 0u) | (vx1 && vy0 ? 2u : 0u) | (vx0 && vy1 ? 4u : 0u) | (vx1 && vy1 ? 8u : 0u);
-            }
-            const float fx = k_fx[k], fy = k_fy[k];
-            const float w00 = (valid & 1u) ? (1.0f - fx) * (1.0f - fy) : 0.0f, w10 = (valid & 2u) ? fx * (1.0f - fy) : 0.0f;
-            const float w01 = (valid & 4u) ? (1.0f - fx) * fy : 0.0f, w11 = (valid & 8u) ? fx * fy : 0.0f;
-            const int lx = x0 - ox, ly = y0 - oy;
-#ifdef FPCDR_OABL_NOTEXADD
-            asm volatile("" :: "v"(w00), "v"(w10), "v"(w01), "v"(w11), "v"(lx), "v"(ly), "v"(k_gc[k][0]));
-            if (false) {
-#else
-            if (lx >= 0 && ly >= 0 && lx + 1 < OTW && ly + 1 < OTW) {
-#endif
-#pragma unroll
-                for (int c = 0; c < CS; ++c) {
-                    int *wp = s_tex + (ly * OTW + lx) * CS + c;
-                    const float gc = k_gc[k][c] * tex_scale;      // (a power of two: exact)
-                    atomicAdd(wp, __float2int_rn(gc * w00));
-                    atomicAdd(wp + CS, __float2int_rn(gc * w10));
-                    atomicAdd(wp + OTW * CS, __float2int_rn(gc * w01));
-                    atomicAdd(wp + OTW * CS + CS, __float2int_rn(gc * w11));
-                }
-#ifdef FPCDR_OABL_NOTEXADD
-            } else if (false) {
-#else
-            } else {
-#endif
-                const int ix0 = wrap_near(x0, Wt, boundary), ix1 = wrap_near(x0 == 0x7fffffff ? x0 : x0 + 1, Wt, boundary);
-                const int iy0 = wrap_near(y0, Ht, boundary), iy1 = wrap_near(y0 == 0x7fffffff ? y0 : y0 + 1, Ht, boundary);
-#pragma unroll
-                for (int c = 0; c < CS; ++c) {
-                    const float gc = k_gc[k][c];
-                    atomicAdd(&at32(a.grad_tex, (unsigned int)((iy0 * Wt + ix0) * CS + c)), gc * w00);
-                    atomicAdd(&at32(a.grad_tex, (unsigned int)((iy0 * Wt + ix1) * CS + c)), gc * w10);
-                    atomicAdd(&at32(a.grad_tex, (unsigned int)((iy1 * Wt + ix0) * CS + c)), gc * w01);
-                    atomicAdd(&at32(a.grad_tex, (unsigned int)((iy1 * Wt + ix1) * CS + c)), gc * w11);
-                }
-            }
-        }
-    }
+    OPROF_T(6);
     // ---- the bin's deferred pixels for k_fix; loss ----
-    if (tid < OB) a.cmask[bin_lin * OB + tid] = s_cmask[tid];
+    if (tid < OB) { a.cmask[bin_lin * OB + tid] = s_cmask[tid]; a.hitmask[bin_lin * OB + tid] = 0u; }
     if (tid == 0) {
-        if (bin_def) a.binflag[bin_lin] = 1;      // (zero-filled by the call's first kernel)
+        if (bin_def) {
+            a.binflag[bin_lin] = 1;      // (zero-filled by the call's first kernel)
+            // k_fix runs over the bins with a deferred pixel only -- one in six of the occupied ones on a face rig.  (One-wave workgroups
+            // that leave at once are not free: k_fix<1> over ALL occupied bins was bound by workgroup dispatch, 220 us for 90 k of them.)
+            a.def_list[atomicAdd(a.def_count, 1)] = (int32_t)bin_lin;
+        }
         const double tot = (double)s_lpart[0] + (double)s_lpart[1] + (double)s_lpart[2] + (double)s_lpart[3];
         const unsigned int slot = ((unsigned int)bxi + 31u * (unsigned int)byi + 977u * (unsigned int)b) % FPCDR_LOSS_SLOTS;
         if (tot != 0.0) atomicAdd(a.loss_sum + slot, tot);
     }
+    OPROF_ADD(0, 0, 1); OPROF_ADD(1, 1, 2); OPROF_ADD(2, 2, 3); OPROF_ADD(3, 3, 4); OPROF_ADD(4, 4, 5); OPROF_ADD(5, 5, 6);
     if (!want_grad) return;
-    __syncthreads();
-    // ---- flush: every vertex slot and window cell once ----
+    // ---- flush: every vertex slot and window cell once (the barrier above has made all adds visible) ----
 #ifndef FPCDR_OABL_NOVFLUSH
     if (want_pos) vtable_flush(vt, gp, tid, ONT);
 #endif
 #ifdef FPCDR_OABL_NOTEXFLUSH
     if (false) {
 #else
-    if (want_tex && s_org[0] != 0x7fffffff) {
+    if (want_tex && ox != 0x7fffffff) {
 #endif
-        const int ox = s_org[0], oy = s_org[1];
         for (int k = tid; k < OTW * OTW * CS; k += ONT) {
-            const int vi = s_tex[k];
-            if (vi != 0) {
+            const float v = (float)s_tex[k];
+            if (v != 0.0f) {
                 const int c = k % CS, cell = k / CS;
                 const int gx = wrap_near(ox + cell % OTW, Wt, boundary), gy = wrap_near(oy + cell / OTW, Ht, boundary);
-                atomicAdd(&at32(a.grad_tex, (unsigned int)((gy * Wt + gx) * CS + c)), (float)vi * tex_unscale);
+                atomicAdd(&at32(a.grad_tex, (unsigned int)((gy * Wt + gx) * CS + c)), v);
             }
         }
     }
+    OPROF_T(7);
+    OPROF_ADD(6, 6, 7);
+#ifdef FPCDR_OPROF
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_oprof[7], 1ull);
+#endif
 }
 
 template <int CS, int BMODE>
@@ -375,19 +424,78 @@ __global__ void __launch_bounds__(ONT) k_shade_queue(const int32_t *__restrict__
 //           difference; the antialias op's d alpha / d pos; the share of empty pixels' colour (all sample uv = (0,0)).
 // Neighbour ids come from the id planes (own bin or a neighbour's), z/w and colour of a partner from the deferred records: both pixels
 // of a pair that passes pair_maybe are deferred.
+// Small open-addressed LDS accumulators of k_fix<1>: key -> NV doubles.  The few dozen pixels of a bin that took part in a blend share
+// vertices and texels: scattered float atomics retire slowly (the pass spent its time on ~650 of them per bin), so they are summed in
+// LDS first and every slot is flushed once.  A full table falls back to memory.
+constexpr int ESLOTS = 32;               // slots of the empty pixels' colour gradient (see k_esum_finish)
+constexpr int FVS = 64, FTS = 128;       // vertex / texel slots (LDS per wave decides how many bins a CU has in flight: 5.5 KB -> 28)
+__device__ __forceinline__ int hacc_slot(int *keys, int mask, int key) {
+    unsigned int slot = (((unsigned int)key * 2654435761u) >> 16) & (unsigned int)mask;
+    for (int probe = 0; probe <= mask; ++probe) {
+        const int o = atomicCAS(&keys[slot], -1, key);
+        if (o == -1 || o == key) return (int)slot;
+        slot = (slot + 1) & (unsigned int)mask;
+    }
+    return -1;
+}
+
+// (x, y, w) gradient of vertex `key` into the LDS table, or to memory when the table is full
+__device__ __forceinline__ void hacc_vadd(float *gp, int *vkeys, double *vacc, int key, float gx, float gy, float gw) {
+    const int sl = hacc_slot(vkeys, FVS - 1, key);
+    if (sl >= 0) { lds_add_f64(&vacc[3 * sl], gx); lds_add_f64(&vacc[3 * sl + 1], gy); lds_add_f64(&vacc[3 * sl + 2], gw); }
+    else { atomicAdd(gp + 4 * (size_t)key, gx); atomicAdd(gp + 4 * (size_t)key + 1, gy); atomicAdd(gp + 4 * (size_t)key + 3, gw); }
+}
+
+// d (blend weight) / d pos of one active edge, G = d loss / d (blend weight) (see k_aa_bwd_fix in antialias.hip).  OUT OF LINE: the
+// pair analysis is inlined at twelve sites (four pairs x three edges) and this tail with its table adds made k_fix<1> 220 us of
+// instruction fetch and registers (99 VGPRs) for a few dozen pixels per bin.
+#ifndef FPCDR_EDGE_INLINE
+#define FPCDR_EDGE_INLINE __noinline__
+#endif
+struct EdgeVals { float Lx, Ly, qax, qay, wa, qbx, qby, wb; };      // (by value: see uv_indirect)
+__device__ FPCDR_EDGE_INLINE void aa_edge_pos_grad(float *gp, int *vkeys, double *vacc, EdgeVals ev, float t, float s, int d, float G,
+                                              int Px, int Py, int va, int vb, float hw, float hh) {
+    const float Ld = d == 0 ? ev.Lx : ev.Ly;
+    const float gLz = -G / (s * Ld);
+    const float gLd = -G * t / Ld;
+    const float gLx = d == 0 ? gLd : 0.0f, gLy = d == 0 ? 0.0f : gLd;
+    float g_qax = 0.f, g_qay = 0.f, g_wa = 0.f, g_qbx = 0.f, g_qby = 0.f, g_wb = 0.f;
+    g_qay += gLx * ev.wb; g_wb += gLx * ev.qay; g_wa -= gLx * ev.qby; g_qby -= gLx * ev.wa;
+    g_wa += gLy * ev.qbx; g_qbx += gLy * ev.wa; g_qax -= gLy * ev.wb; g_wb -= gLy * ev.qax;
+    g_qax += gLz * ev.qby; g_qby += gLz * ev.qax; g_qay -= gLz * ev.qbx; g_qbx -= gLz * ev.qay;
+    const float fxp = (float)Px + 0.5f - hw, fyp = (float)Py + 0.5f - hh;
+    hacc_vadd(gp, vkeys, vacc, va, g_qax * hw, g_qay * hh, g_wa - fxp * g_qax - fyp * g_qay);
+    hacc_vadd(gp, vkeys, vacc, vb, g_qbx * hw, g_qby * hh, g_wb - fxp * g_qbx - fyp * g_qby);
+}
+
 template <int CS, int PASS>
 __device__ __forceinline__ void fix_body(const int b, const int bxi, const int byi, const int OX, const int OY, const ObjArgs &a) {
     __shared__ unsigned int s_mask[OB];
-    __shared__ int s_list[OB * OB];
+    __shared__ unsigned short s_list[OB * OB];
     __shared__ int s_n;
+    __shared__ int s_vk[PASS == 1 ? FVS : 1], s_tk[PASS == 1 ? FTS : 1];
+    __shared__ double s_va[PASS == 1 ? FVS * 3 : 1], s_ta[PASS == 1 ? FTS * CS : 1];
     const size_t bin_lin = ((size_t)b * OY + byi) * OX + bxi;
+#ifdef FPCDR_OPROF
+    const long long ft0 = clock64();
+#endif
     if (!__builtin_amdgcn_readfirstlane((int)a.binflag[bin_lin])) return;      // no deferred pixel in this bin
     const int tid = threadIdx.x, lane = tid & 63;
     const int bx0 = bxi * OB, by0 = byi * OB;
     const int H = a.H, W = a.W;
     const unsigned int wmask = (unsigned int)__builtin_amdgcn_readfirstlane((int)a.occ[bin_lin]);
-    if (tid < OB) s_mask[tid] = a.cmask[bin_lin * OB + tid];
+    // PASS 1 visits only the pixels PASS 0 found in a blend (as the blended pixel or as its partner): for every other deferred pixel the
+    // gradient through the antialias op IS the un-antialiased one, a difference of exactly zero
+    if (tid < OB) s_mask[tid] = PASS == 0 ? a.cmask[bin_lin * OB + tid] : a.hitmask[bin_lin * OB + tid];
     if (tid == 0) s_n = 0;
+    if (PASS == 1) {
+        for (int k = tid; k < FVS; k += FNT) { s_vk[k] = -1; s_va[3 * k] = 0.0; s_va[3 * k + 1] = 0.0; s_va[3 * k + 2] = 0.0; }
+        for (int k = tid; k < FTS; k += FNT) {
+            s_tk[k] = -1;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) s_ta[k * CS + c] = 0.0;
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < OB * OB / FNT; ++k) {
@@ -397,11 +505,20 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
         int base = 0;
         if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (c) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = pix;
+        if (c) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)pix;
     }
     __syncthreads();
     const int n = __builtin_amdgcn_readfirstlane(s_n);
+#ifdef FPCDR_OPROF
+    if (tid == 0) { atomicAdd(&g_oprof[8 + 2 * PASS], (unsigned long long)n); atomicAdd(&g_oprof[9 + 2 * PASS], 1ull); }
+#endif
     if (n == 0) return;
+#ifdef FPCDR_OPROF
+    const long long ft1 = clock64();
+#endif
+#ifdef FPCDR_FABL_A
+    if (PASS == 1) return;
+#endif
     float ecol[CS];
 #pragma unroll
     for (int c = 0; c < CS; ++c) ecol[c] = a.empty_color[c];
@@ -409,6 +526,18 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
     const AAGeom g = {a.pos + (size_t)b * a.V, a.tri, a.sil + (size_t)b * a.T, a.T, W, H, 0.5f * (float)W, 0.5f * (float)H};
     const float cs = a.color_scale, gs = a.grad_scale, bgs = a.bg * cs;
     float *const gp = (PASS == 1 && a.grad_pos) ? a.grad_pos + (size_t)b * a.V * 4 : nullptr;
+    // (x, y, w) gradient of vertex `key` / gradient of the texel at element offset `off` (+ channel c): into the LDS tables
+    auto vadd = [&](int key, float gx, float gy, float gw) { hacc_vadd(gp, s_vk, s_va, key, gx, gy, gw); };
+    auto tadd = [&](int off, const float (&v)[CS], float wgt) {      // off = texel index * CS
+        const int sl = hacc_slot(s_tk, FTS - 1, off);
+        if (sl >= 0) {
+#pragma unroll
+            for (int c = 0; c < CS; ++c) lds_add_f64(&s_ta[sl * CS + c], v[c] * wgt);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CS; ++c) atomicAdd(a.grad_tex + off + c, v[c] * wgt);
+        }
+    };
     auto id_at = [&](int xx, int yy) -> unsigned int {      // entry of an in-image pixel of this bin or of one of its eight neighbours
         const int dbx = (xx >> 5) - bxi, dby = (yy >> 5) - byi;
         if (!((wmask >> ((dby + 1) * 4 + dbx + 1)) & 1u)) return 0u;      // a bin that was not rasterised holds empty pixels
@@ -418,26 +547,41 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
     float esum[CS];
 #pragma unroll
     for (int c = 0; c < CS; ++c) esum[c] = 0.0f;
-    for (int base = 0; base < n; base += FNT) {      // (uniform trip count: the segmented scan of PASS 1 needs the whole wave)
+    // A lane takes ONE of the four pairs of a pixel -- lanes 4 i .. 4 i + 3: pixel i towards right, up, left, down -- and the quad's
+    // sums are formed with two DPP steps: the pair analysis is a chain of six dependent loads, and one lane walking its pixel's four
+    // pairs one after the other made k_fix<1> 210 us for three pixels per wave.  The rest of a pixel is its first lane's.
+    auto quad_sum = [](float v) {
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+        return v;
+    };
+    for (int base = 0; base < 4 * n; base += FNT) {      // (uniform trip count: the DPP steps and the segmented scan need the whole wave)
         const int i = base + tid;
-        const bool act = i < n;
-        const int pix = act ? s_list[i] : 0;
+        const bool act = i < 4 * n;
+        const int pix = act ? s_list[i >> 2] : 0;
+        const int dir = i & 3;
+        const bool lead = act && dir == 0;
         const int x = bx0 + (pix & 31), y = by0 + (pix >> 5);
         int tkey = -1;
         int vk[3] = {0, 0, 0};
         float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (act) {
-            const size_t off = img + (size_t)y * W + x;
-            const unsigned int me = a.idp[bin_lin * (OB * OB) + pix];
-            const float4 rme = a.rec[off];
-            const float zX = rme.z;
-            float cme[CS], acc[CS], go[CS];
+        const size_t off = img + (size_t)y * W + x;
+        unsigned int me = 0u;
+        float4 rme = make_float4(0.f, 0.f, 0.f, 0.f);
+        float cme[CS], acc[CS], go[CS];      // acc / go: THIS lane's pair's share (summed over the quad below)
 #pragma unroll
-            for (int c = 0; c < CS; ++c) { cme[c] = a.color[off * CS + c]; acc[c] = cme[c]; go[c] = PASS == 1 ? a.g_aa[off * CS + c] : 0.0f; }
-            bool hit = false;
+        for (int c = 0; c < CS; ++c) { cme[c] = 0.0f; acc[c] = 0.0f; go[c] = 0.0f; }
+        bool hit = false;
+        if (act) {
+            me = a.idp[bin_lin * (OB * OB) + pix];
+            rme = a.rec[off];
+            const float zX = rme.z;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) cme[c] = a.color[off * CS + c];
             // pair (x0, y0) - (x0 + e_d): entries / depths in pair order; (ox, oy, eo) = the partner of X; first = X is the pair's first pixel
             auto visit = [&](int x0, int y0, int d, unsigned int e0, float z0, unsigned int e1, float z1, int ox, int oy, unsigned int eo,
                              bool first) {
+                bool hit_o = false;      // PASS 0: X was blended with this (covered) partner
                 const bool blended = for_active_edges(g, x0, y0, d, (int)(e0 & 0xffffffu), z0, (int)(e1 & 0xffffffu), z1,
                     [&](float t, int Px, int Py, int Qx, int Qy, int va, int vb, const EdgeEval &ev, float s) {
                         const bool far = t >= 0.5f;
@@ -449,6 +593,7 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                         if (PASS == 0) {
                             if (!rX) return;
                             hit = true;
+                            hit_o |= o_cov;
 #pragma unroll
                             for (int c = 0; c < CS; ++c) acc[c] += amt * ((o_cov ? co[c] : ecol[c]) - cme[c]);
                             return;
@@ -457,13 +602,11 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                         float gr[CS];
 #pragma unroll
                         for (int c = 0; c < CS; ++c) gr[c] = a.g_aa[(img + (size_t)ry * W + rx) * CS + c];
-                        if (rX) {
+                        // (branch-free: with `if (rX) go -= .. else go += ..` the compiler addressed go / esum through a selected pointer
+                        //  and kept both in scratch memory)
+                        const float sa = rX ? -amt : amt, ea = (rX && !o_cov) ? amt : 0.0f;
 #pragma unroll
-                            for (int c = 0; c < CS; ++c) { go[c] -= amt * gr[c]; if (!o_cov) esum[c] += amt * gr[c]; }
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < CS; ++c) go[c] += amt * gr[c];
-                        }
+                        for (int c = 0; c < CS; ++c) { go[c] += sa * gr[c]; esum[c] += ea * gr[c]; }
                         // d alpha / d pos: once per pair, by its first pixel -- by the second if the first is empty (never visited)
                         if (!gp || !(first || !o_cov)) return;
                         const bool PisX = Px == x && Py == y;
@@ -474,22 +617,13 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                             G += gr[c] * (PisX ? cme[c] - cO : cO - cme[c]);
                         }
                         if (G == 0.0f) return;
-                        const float Ld = d == 0 ? ev.Lx : ev.Ly;
-                        const float gLz = -G / (s * Ld);
-                        const float gLd = -G * t / Ld;
-                        const float gLx = d == 0 ? gLd : 0.0f, gLy = d == 0 ? 0.0f : gLd;
-                        float g_qax = 0.f, g_qay = 0.f, g_wa = 0.f, g_qbx = 0.f, g_qby = 0.f, g_wb = 0.f;
-                        g_qay += gLx * ev.wb; g_wb += gLx * ev.qay; g_wa -= gLx * ev.qby; g_qby -= gLx * ev.wa;
-                        g_wa += gLy * ev.qbx; g_qbx += gLy * ev.wa; g_qax -= gLy * ev.wb; g_wb -= gLy * ev.qax;
-                        g_qax += gLz * ev.qby; g_qby += gLz * ev.qax; g_qay -= gLz * ev.qbx; g_qbx -= gLz * ev.qay;
-                        const float fxp = (float)Px + 0.5f - g.hw, fyp = (float)Py + 0.5f - g.hh;
-                        atomicAdd(gp + 4 * (size_t)va + 0, g_qax * g.hw);
-                        atomicAdd(gp + 4 * (size_t)va + 1, g_qay * g.hh);
-                        atomicAdd(gp + 4 * (size_t)va + 3, g_wa - fxp * g_qax - fyp * g_qay);
-                        atomicAdd(gp + 4 * (size_t)vb + 0, g_qbx * g.hw);
-                        atomicAdd(gp + 4 * (size_t)vb + 1, g_qby * g.hh);
-                        atomicAdd(gp + 4 * (size_t)vb + 3, g_wb - fxp * g_qbx - fyp * g_qby);
+                        const EdgeVals evv = {ev.Lx, ev.Ly, ev.qax, ev.qay, ev.wa, ev.qbx, ev.qby, ev.wb};
+                        aa_edge_pos_grad(gp, s_vk, s_va, evv, t, s, d, G, Px, Py, va, vb, g.hw, g.hh);
                     });
+                if (PASS == 0 && hit_o) {      // the partner's colour reaches the loss through X: it needs PASS 1 as well
+                    const size_t obin = (size_t)((long long)bin_lin + ((oy >> 5) - byi) * OX + ((ox >> 5) - bxi));
+                    atomicOr(a.hitmask + obin * OB + (oy & 31), 1u << (ox & 31));
+                }
                 // diagnostics: bit of the pair's first pixel in plane d = "this pair was blended" (set by the first pixel, or by the
                 // second when the first is empty and never visited)
                 if (PASS == 0 && a.flags && blended && (first || (eo & 0xffffffu) == 0u)) {
@@ -497,25 +631,29 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                     atomicOr(a.flags + (size_t)d * a.B * H * Wq + ((size_t)b * H + y0) * Wq + (x0 >> 6), 1ull << (x0 & 63));
                 }
             };
-            if (x + 1 < W) {
-                const unsigned int e = id_at(x + 1, y);
-                if (pair_maybe(me, e)) visit(x, y, 0, me, zX, e, (e & 0xffffffu) ? a.rec[off + 1].z : 0.0f, x + 1, y, e, true);
+            {      // this lane's pair of X: right, up, left or down
+                const int nx = x + (dir == 0 ? 1 : (dir == 2 ? -1 : 0)), ny = y + (dir == 1 ? 1 : (dir == 3 ? -1 : 0));
+                if (nx >= 0 && nx < W && ny >= 0 && ny < H) {
+                    const unsigned int e = id_at(nx, ny);
+                    if (pair_maybe(me, e)) {
+                        const float ze = (e & 0xffffffu) ? a.rec[img + (size_t)ny * W + nx].z : 0.0f;
+                        const bool first = dir < 2;      // X is the first pixel of its pairs towards +x / +y
+                        visit(first ? x : nx, first ? y : ny, dir & 1, first ? me : e, first ? zX : ze, first ? e : me, first ? ze : zX, nx, ny, e, first);
+                    }
+                }
             }
-            if (y + 1 < H) {
-                const unsigned int e = id_at(x, y + 1);
-                if (pair_maybe(me, e)) visit(x, y, 1, me, zX, e, (e & 0xffffffu) ? a.rec[off + W].z : 0.0f, x, y + 1, e, true);
-            }
-            if (x > 0) {
-                const unsigned int e = id_at(x - 1, y);
-                if (pair_maybe(me, e)) visit(x - 1, y, 0, e, (e & 0xffffffu) ? a.rec[off - 1].z : 0.0f, me, zX, x - 1, y, e, false);
-            }
-            if (y > 0) {
-                const unsigned int e = id_at(x, y - 1);
-                if (pair_maybe(me, e)) visit(x, y - 1, 1, e, (e & 0xffffffu) ? a.rec[off - W].z : 0.0f, me, zX, x, y - 1, e, false);
-            }
+        }
+        // the pixel's sums over its four pairs, in every lane of the quad
+        const bool hit_any = (__ballot(hit) >> (lane & ~3)) & 0xFull;
+#pragma unroll
+        for (int c = 0; c < CS; ++c) { acc[c] = quad_sum(acc[c]); go[c] = quad_sum(go[c]); }
+        if (lead) {
+#pragma unroll
+            for (int c = 0; c < CS; ++c) { acc[c] += cme[c]; if (PASS == 1) go[c] += a.g_aa[off * CS + c]; }
             const float rf = (float)a.ref[off];
             if (PASS == 0) {
-                if (hit) {      // the antialiased colour replaces the plain one in this pixel's loss term and gradient
+                if (hit_any) {      // the antialiased colour replaces the plain one in this pixel's loss term and gradient
+                    atomicOr(a.hitmask + bin_lin * OB + (pix >> 5), 1u << (pix & 31));
                     const float d0 = rf - bgs;
 #pragma unroll
                     for (int c = 0; c < CS; ++c) {
@@ -531,16 +669,18 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                 bool nz = false;
 #pragma unroll
                 for (int c = 0; c < CS; ++c) { dl[c] = go[c] - loss_grad(rf - cme[c] * cs, cs, gs); nz |= dl[c] != 0.0f; }
+#ifdef FPCDR_FABL_B
+                { float sink = 0.f; for (int c = 0; c < CS; ++c) sink += dl[c]; asm volatile("" :: "v"(sink)); nz = false; }
+#endif
                 if (nz) {
                     const int boundary = a.boundary, Ht = a.Ht, Wt = a.Wt;
                     const int t = (int)(me & 0xffffffu) - 1;
-                    float2 q0, q1, q2;
-                    if (a.tri_uv) { q0 = a.tri_uv[3 * t]; q1 = a.tri_uv[3 * t + 1]; q2 = a.tri_uv[3 * t + 2]; }
-                    else uv_indirect(a.uv, a.uv_tri, t, q0, q1, q2);
+                    const UV3 tq = a.tri_uv ? reinterpret_cast<const UV3 *>(a.tri_uv)[t] : uv_indirect(a.uv, a.uv_tri, t);
+                    const float2 q0 = tq.q0, q1 = tq.q1, q2 = tq.q2;
                     const float w = 1.0f - rme.x - rme.y;
                     const float tu = rme.x * q0.x + rme.y * q1.x + w * q2.x;
                     const float tv = rme.x * q0.y + rme.y * q1.y + w * q2.y;
-                    const Taps tp = make_taps(tu, tv, Ht, Wt, CS, boundary);
+                    const Taps tp = boundary == FPCDR_BOUNDARY_ZERO ? make_taps(tu, tv, Ht, Wt, CS, boundary) : make_taps_fast(tu, tv, Ht, Wt, CS, boundary);
                     const float w00 = (1.0f - tp.fx) * (1.0f - tp.fy), w10 = tp.fx * (1.0f - tp.fy);
                     const float w01 = (1.0f - tp.fx) * tp.fy, w11 = tp.fx * tp.fy;
                     float gfx = 0.f, gfy = 0.f;
@@ -552,12 +692,12 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                         mask_taps(tp, t00, t10, t01, t11);
                         gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
                         gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
-                        if (a.grad_tex && gc != 0.0f) {      // (boundary mode 'zero': the padding receives no gradient)
-                            if (tp.valid & 1u) atomicAdd(a.grad_tex + tp.i00 + c, gc * w00);
-                            if (tp.valid & 2u) atomicAdd(a.grad_tex + tp.i10 + c, gc * w10);
-                            if (tp.valid & 4u) atomicAdd(a.grad_tex + tp.i01 + c, gc * w01);
-                            if (tp.valid & 8u) atomicAdd(a.grad_tex + tp.i11 + c, gc * w11);
-                        }
+                    }
+                    if (a.grad_tex) {      // (boundary mode 'zero': the padding receives no gradient)
+                        if (tp.valid & 1u) tadd(tp.i00, dl, w00);
+                        if (tp.valid & 2u) tadd(tp.i10, dl, w10);
+                        if (tp.valid & 4u) tadd(tp.i01, dl, w01);
+                        if (tp.valid & 8u) tadd(tp.i11, dl, w11);
                     }
                     if (gp) {
                         const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
@@ -584,34 +724,64 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
         if (PASS == 1 && gp)      // (uniform) pixels of one triangle are often neighbours in the list: sum their runs, then nine atomics per run
             wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) {
 #pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
-                    float *d = gp + 4 * (size_t)vk[kk];
-                    if (sm[3 * kk] != 0.0f) atomicAdd(d, sm[3 * kk]);
-                    if (sm[3 * kk + 1] != 0.0f) atomicAdd(d + 1, sm[3 * kk + 1]);
-                    if (sm[3 * kk + 2] != 0.0f) atomicAdd(d + 3, sm[3 * kk + 2]);
-                }
+                for (int kk = 0; kk < 3; ++kk) vadd(vk[kk], sm[3 * kk], sm[3 * kk + 1], sm[3 * kk + 2]);
             });
     }
+#ifdef FPCDR_OPROF
+    if (PASS == 1 && tid == 0) { const long long ft2 = clock64(); atomicAdd(&g_oprof[12], (unsigned long long)(ft1 - ft0)); atomicAdd(&g_oprof[13], (unsigned long long)(ft2 - ft1)); atomicAdd(&g_oprof[14], 1ull); }
+#endif
     if (PASS == 0) {
         lsum = wave_sum_dpp(lsum);
-        if (tid == 0 && lsum != 0.0f) {
+        if (lane == 0 && lsum != 0.0f) {
             const unsigned int slot = ((unsigned int)bxi + 31u * (unsigned int)byi + 977u * (unsigned int)b + 128u) % FPCDR_LOSS_SLOTS;
             atomicAdd(a.loss_sum + slot, (double)lsum);
         }
-    } else if (a.grad_tex) {
-        // empty pixels blended into covered ones: they all sample uv = (0,0) -- summed per wave, scattered once
+    } else {
+        __syncthreads();
+        // flush of the tables: every vertex slot and texel slot once
+        if (gp)
+            for (int k = tid; k < FVS * 4; k += FNT) {
+                const int sl = k >> 2, comp = k & 3, key = s_vk[sl];
+                if (key >= 0 && comp != 2) {      // (x, y, -, w)
+                    const float v = (float)s_va[3 * sl + (comp == 3 ? 2 : comp)];
+                    if (v != 0.0f) atomicAdd(gp + 4 * (size_t)key + comp, v);
+                }
+            }
+        if (a.grad_tex)
+            for (int k = tid; k < FTS * CS; k += FNT) {
+                const int key = s_tk[k / CS];
+                if (key >= 0) {
+                    const float v = (float)s_ta[k];
+                    if (v != 0.0f) atomicAdd(a.grad_tex + key + k % CS, v);
+                }
+            }
+    }
+    if (PASS == 1 && a.grad_tex) {
+        // empty pixels blended into covered ones: they ALL sample uv = (0,0), i.e. the same four texels with the same weights.  Every
+        // wave adding to those four addresses itself serialised ~55 k atomics on four cache lines: 210 us of this kernel whatever else
+        // it did.  The scalar is summed in a few slots instead and scattered once by k_esum_finish.
+        const unsigned int slot = ((unsigned int)bxi + 31u * (unsigned int)byi + 977u * (unsigned int)b) % ESLOTS;
 #pragma unroll
         for (int c = 0; c < CS; ++c) {
             const float e = wave_sum_dpp(esum[c]);
-            if (tid == 0 && e != 0.0f) {
-                const Taps tp0 = make_taps(0.0f, 0.0f, a.Ht, a.Wt, CS, a.boundary);
-                if (tp0.valid & 1u) atomicAdd(a.grad_tex + tp0.i00 + c, e * ((1.0f - tp0.fx) * (1.0f - tp0.fy)));
-                if (tp0.valid & 2u) atomicAdd(a.grad_tex + tp0.i10 + c, e * (tp0.fx * (1.0f - tp0.fy)));
-                if (tp0.valid & 4u) atomicAdd(a.grad_tex + tp0.i01 + c, e * ((1.0f - tp0.fx) * tp0.fy));
-                if (tp0.valid & 8u) atomicAdd(a.grad_tex + tp0.i11 + c, e * (tp0.fx * tp0.fy));
-            }
+            if (lane == 0 && e != 0.0f) atomicAdd(a.esum + 4 * slot + c, e);
         }
     }
+}
+
+// the empty pixels' share of the texture gradient: sum of the slots, times the four bilinear weights of uv = (0,0)
+template <int CS>
+__global__ void __launch_bounds__(64) k_esum_finish(ObjArgs a) {
+    const int c = threadIdx.x;
+    if (c >= CS) return;
+    float e = 0.0f;
+    for (int sl = 0; sl < ESLOTS; ++sl) e += a.esum[4 * sl + c];
+    if (e == 0.0f) return;
+    const Taps tp0 = make_taps(0.0f, 0.0f, a.Ht, a.Wt, CS, a.boundary);
+    if (tp0.valid & 1u) atomicAdd(a.grad_tex + tp0.i00 + c, e * ((1.0f - tp0.fx) * (1.0f - tp0.fy)));
+    if (tp0.valid & 2u) atomicAdd(a.grad_tex + tp0.i10 + c, e * (tp0.fx * (1.0f - tp0.fy)));
+    if (tp0.valid & 4u) atomicAdd(a.grad_tex + tp0.i01 + c, e * ((1.0f - tp0.fx) * tp0.fy));
+    if (tp0.valid & 8u) atomicAdd(a.grad_tex + tp0.i11 + c, e * (tp0.fx * tp0.fy));
 }
 
 template <int CS, int PASS>
@@ -639,6 +809,14 @@ __global__ void __launch_bounds__(FNT) k_fix_queue(const int32_t *__restrict__ l
 
 }  // namespace
 
+#ifdef FPCDR_OPROF
+extern "C" int fpcdr_debug_oprof(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_oprof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_oprof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
 extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream) {
     FPCDR_REQUIRE(p != nullptr, "null params");
     FPCDR_REQUIRE(p->pos && p->tri && p->adj && p->scratch && p->uv && p->uv_tri && p->tex && p->ref, "null pointer");
@@ -662,8 +840,13 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
     const int OX = FPCDR_OCC_DIM(p->W), OY = FPCDR_OCC_DIM(p->H);
     const long long nbins = (long long)p->B * OY * OX;
     const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W);
+    // (the border-line region of cmask, 1 KB per bin, is free in this form: 128 B per bin of hit masks, then the slots)
+    float *esum_slots = (float *)((char *)p->cmask + q.cm_edges + (size_t)nbins * 128);
+    static_assert(ESLOTS * 4 * sizeof(float) <= 1024 - 128, "the slots must fit behind one bin's hit masks");
+    if (p->grad_tex) FPCDR_REQUIRE(hipMemsetAsync(esum_slots, 0, ESLOTS * 4 * sizeof(float), st) == hipSuccess, "memset failed");
     ObjArgs a = {(const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, (const float2 *)p->tri_uv, p->tex, p->ref, p->sil,
-                 p->idp, p->occ, (uint8_t *)p->occ + q.occ_binflag, p->cmask, (float4 *)p->rec, p->color, p->grad_aa, p->empty_color,
+                 p->idp, p->occ, (uint8_t *)p->occ + q.occ_binflag, p->cmask, esum_slots, (int32_t *)((char *)p->occ + q.occ_bwd_list),
+                 (int32_t *)((char *)p->occ + q.occ_hdr), (uint32_t *)((char *)p->cmask + q.cm_edges), (float4 *)p->rec, p->color, p->grad_aa, p->empty_color,
                  p->loss_sum, p->grad_pos, p->grad_tex, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt, p->boundary_mode,
                  p->bg, p->color_scale, p->grad_scale, (unsigned long long *)p->flags};
     const fpcdr_bin_decode dc = fpcdr_make_bin_decode(OX, OY);
@@ -675,10 +858,14 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         hipLaunchKernelGGL((k_shade_list<CS, BM>), grid, dim3(ONT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a);                   \
         if (sweep) hipLaunchKernelGGL(k_shade_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(ONT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a); \
     } while (0)
+    // k_fix: over the bins k_shade found a deferred pixel in (count at occ header [0]; p->cap_def: launch hint)
+    const int cap_d = (p->cap_def > 0 && p->cap_def < nbins) ? p->cap_def : (int)nbins;
+    const dim3 grid_d(fpcdr_list_grid(cap_d));
+    const bool sweep_d = cap_d < nbins;
 #define FIX(CS, PASS)                                                                                                             \
     do {                                                                                                                          \
-        hipLaunchKernelGGL((k_fix_list<CS, PASS>), grid, dim3(FNT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a);                   \
-        if (sweep) hipLaunchKernelGGL((k_fix_queue<CS, PASS>), dim3(FPCDR_SWEEP_WGS), dim3(FNT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a); \
+        hipLaunchKernelGGL((k_fix_list<CS, PASS>), grid_d, dim3(FNT), 0, st, a.def_list, a.def_count, cap_d, OX, OY, dc, a);       \
+        if (sweep_d) hipLaunchKernelGGL((k_fix_queue<CS, PASS>), dim3(FPCDR_SWEEP_WGS), dim3(FNT), 0, st, a.def_list, a.def_count, cap_d, OX, OY, dc, a); \
     } while (0)
     const bool grads = p->grad_pos || p->grad_tex;
     if (p->C == 1) {
@@ -686,14 +873,17 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         else SHADE(1, -1);
         FIX(1, 0);
         if (grads) FIX(1, 1);
+        if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<1>, dim3(1), dim3(64), 0, st, a);
     } else if (p->C == 3) {
         SHADE(3, -1);
         FIX(3, 0);
         if (grads) FIX(3, 1);
+        if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<3>, dim3(1), dim3(64), 0, st, a);
     } else {
         SHADE(4, -1);
         FIX(4, 0);
         if (grads) FIX(4, 1);
+        if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<4>, dim3(1), dim3(64), 0, st, a);
     }
 #undef SHADE
 #undef FIX

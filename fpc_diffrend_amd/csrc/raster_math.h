@@ -127,6 +127,14 @@ __device__ __forceinline__ void shade_pixel_bwd(float4 v0, float4 v1, float4 v2,
 // kept values: same operations in the same order, bit-identical results.
 struct ShadeKeep { float p0x, p0y, p1x, p1y, p2x, p2y, a0, a1, iw, b0, b1, uc, vc; };
 
+// z/w of shade_pixel from the three unnormalised barycentric weights
+__device__ __forceinline__ float shade_zw(float4 v0, float4 v1, float4 v2, float a0, float a1, float a2) {
+    const float z = (a0 * v0.z + a1 * v1.z + a2 * v2.z) / (a0 * v0.w + a1 * v1.w + a2 * v2.w);
+    return fminf(fmaxf(z, -1.0f), 1.0f);
+}
+
+// WANT_Z false: z/w is not formed (two IEEE divisions' worth of instructions; only deferred pixels store it)
+template <bool WANT_Z = true>
 __device__ __forceinline__ void shade_uvz(float4 v0, float4 v1, float4 v2, float fx, float fy, ShadeKeep &k, float &u, float &v, float &zw) {
     k.p0x = v0.x - fx * v0.w; k.p0y = v0.y - fy * v0.w;
     k.p1x = v1.x - fx * v1.w; k.p1y = v1.y - fy * v1.w;
@@ -137,8 +145,7 @@ __device__ __forceinline__ void shade_uvz(float4 v0, float4 v1, float4 v2, float
     const float at = k.a0 + k.a1 + a2;
     k.iw = 1.0f / at;
     k.b0 = k.a0 * k.iw; k.b1 = k.a1 * k.iw;
-    const float z = (k.a0 * v0.z + k.a1 * v1.z + a2 * v2.z) / (k.a0 * v0.w + k.a1 * v1.w + a2 * v2.w);
-    zw = fminf(fmaxf(z, -1.0f), 1.0f);
+    if (WANT_Z) zw = shade_zw(v0, v1, v2, k.a0, k.a1, a2);
     k.uc = fminf(fmaxf(k.b0, 0.0f), 1.0f); k.vc = fminf(fmaxf(k.b1, 0.0f), 1.0f);
     float sc = 1.0f;
     if (__builtin_amdgcn_ballot_w64(k.uc + k.vc > 1.0f) != 0) {      // (wave vote first: see shade_pixel)

@@ -29,7 +29,11 @@ def init(backend=None, force_group=False):
     if world <= 1:
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("MASTER_PORT", "29517")
+        if "MASTER_PORT" not in os.environ:      # a free port: concurrent one-rank runs on a box must not collide on a fixed one
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         world = 1
     rank = int(os.environ["RANK"])
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
@@ -58,6 +62,9 @@ class EarlyReduce:
 
     def _fire(self, p):
         if dist.is_initialized() and (dist.get_world_size() > 1 or self.always):
+            if p.grad.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("EarlyReduce cannot run inside a HIP-graph capture (the collective is issued from an autograd hook on "
+                                   "its own stream): use FitConfig(hip_graph=False) with early reduction, or leave the parameter in the bucket")
             self.work = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True)
             self.fired += 1
 

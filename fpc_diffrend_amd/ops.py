@@ -299,7 +299,7 @@ class _pixel_objective_func(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, sparse, ref_bg_sumsq, use_hints,
-                queued_backward, mip_levels=None):
+                queued_backward, mip_levels=None, grad_enabled=True):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -360,10 +360,13 @@ class _pixel_objective_func(torch.autograd.Function):
         bg_sum = None
         if sparse:
             # the kernel summed only the difference to an all-background image; the rest depends on ref alone
-            bg_sum = (reference_background_sumsq(ref, bg).sum() if ref_bg_sumsq is None else ref_bg_sumsq).to(torch.float64).contiguous()
+            bg_sum = (reference_background_sumsq(ref, bg).sum() if ref_bg_sumsq is None
+                      else torch.as_tensor(ref_bg_sumsq, device=dev)).to(torch.float64).contiguous()
         out = torch.empty((), dtype=torch.float32, device=dev)
         _lib.call("fpcdr_objective_value", _ptr(acc), _lib.LOSS_SLOTS, _ptr(bg_sum), float(C), float(n_total), _ptr(out), _stream())
-        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and ctx.hint_update is not None:      # forward only: read the counts back now
+        # forward only (no input wants a gradient, or the caller runs under no_grad -- needs_input_grad stays True there): read the
+        # counts back now; otherwise after the backward call has been enqueued
+        if not (grad_enabled and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])) and ctx.hint_update is not None:
             ctx.hint_update[0].update(ctx.hint_update[1])
             ctx.hint_update = None
         return out
@@ -402,7 +405,7 @@ class _pixel_objective_func(torch.autograd.Function):
             ctx.hint_update = None
         if not ctx.needs_input_grad[0]:
             g_pos = None
-        return (g_pos, g_tex) + (None,) * 15
+        return (g_pos, g_tex) + (None,) * 16
 
 
 class _pixel_objective_onepass(torch.autograd.Function):
@@ -441,7 +444,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
                            empty_color=_ptr(ecol), loss_sum=_ptr(acc), grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex), flags=_ptr(flags_out))
         hints = _list_hints.setdefault(('onepass', dev.index, B, V, T, H, W), _ListHints()) if use_hints else None
         if hints is not None:
-            p.cap_bins, p.cap_occ, _ = hints.poll()
+            p.cap_bins, p.cap_occ, p.cap_def = hints.poll()      # (live bins, occupied bins, bins with a deferred pixel)
         _lib.call("fpcdr_objective_fwd", ctypes.byref(p), _stream())
         if hints is not None:
             nb = B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN)
@@ -531,7 +534,7 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
                                               bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out)
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                        ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq,
-                                       bool(launch_hints), bool(queued_backward), mip_levels)
+                                       bool(launch_hints), bool(queued_backward), mip_levels, torch.is_grad_enabled())
 
 
 # ----------------------------------------------------------------------------------------------
@@ -675,6 +678,10 @@ class MipStack(list):
     def built_from(self, tex):
         return self._base() is tex and tex._version == self._version
 
+    def stale_for(self, tex):
+        """Built from this very tensor, which has been modified in place since (an optimiser step): the levels no longer match it."""
+        return self._base() is tex and tex._version != self._version
+
 
 def texture_construct_mip(tex, max_mip_level=None, cube_mode=False):
     """Pre-build a mip stack for `texture(..., mip=...)`.  Returns a MipStack (a list of the level tensors 1..n)."""
@@ -782,6 +789,11 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='aut
         if mip is not None:
             # a stack texture_construct_mip() built from this very tensor behaves like the internal chain (its gradient
             # collapses into tex); any other list of tensors is a custom stack whose levels receive their own gradients
+            if isinstance(mip, MipStack) and mip.stale_for(tex):
+                # (silently demoting it to a custom stack would sample stale levels AND cut their gradient off from tex, where
+                # nvdiffrast's mip wrapper keeps propagating it)
+                raise RuntimeError("texture(): `mip` was built by texture_construct_mip() from this tensor, which has been modified in "
+                                   "place since (e.g. an optimiser step): rebuild the stack, or pass mip=None to build it per call")
             custom = not (isinstance(mip, MipStack) and mip.built_from(tex))
             mips = tuple(m.contiguous() for m in mip)
             n_levels = min(len(mips), _lib.MAX_MIP)

@@ -269,8 +269,8 @@ typedef struct {
     float bg, color_scale, grad_scale;
     uint8_t *sil;           /* scratch [B,T] */
     uint32_t *idp;          /* scratch, fpcdr_idplane_bytes(B,H,W), 16-byte aligned */
-    uint16_t *occ;          /* scratch+out, fpcdr_occ_bytes(B,H,W): window masks; counts at FPCDR_OCC_COUNTS_OFFSET: [2] live bins of the
-                               rasteriser, [3] occupied bins (cap_bins / cap_occ of the next call) */
+    uint16_t *occ;          /* scratch+out, fpcdr_occ_bytes(B,H,W): window masks; counts at FPCDR_OCC_COUNTS_OFFSET: [0] bins with a deferred
+                               pixel, [2] live bins of the rasteriser, [3] occupied bins (cap_def / cap_bins / cap_occ of the next call) */
     uint32_t *cmask;        /* scratch, fpcdr_cmask_bytes(B,H,W), 8-byte aligned */
     float *rec;             /* scratch [B,H,W,4]: (u, v, z/w, -) of DEFERRED pixels only (dense addressing, sparse writes) */
     float *color;           /* scratch [B,H,W,C]: colour of deferred pixels only */
@@ -280,6 +280,8 @@ typedef struct {
     float *grad_pos;        /* [B,V,4] accumulated, or NULL */
     float *grad_tex;        /* [Ht,Wt,C] accumulated, or NULL (both NULL: value only) */
     int32_t cap_bins, cap_occ; /* launch-size hints (0 = none), as in fpcdr_aa_loss_fwd_params */
+    int32_t cap_def;        /* launch-size hint for the kernels over the bins that hold a deferred pixel (count at [0] of the occ header) */
+    int32_t reserved0;
     uint64_t *flags;        /* optional (tests / diagnostics; NULL in production): the antialias flag planes of fpcdr_antialias_fwd --
                                which pixel pairs were blended --, fpcdr_antialias_flags_bytes(B,H,W), zero-filled by the caller */
 } fpcdr_objective_params;
@@ -440,7 +442,7 @@ int fpcdr_mvp_bwd(const float *proj, const float *t_mv, const float *q_cam, cons
 int fpcdr_laplacian_gather(const float *x, const int32_t *nbr, const float *inv_deg, float *out, int32_t F, int32_t V, int32_t D,
                            int32_t transpose, void *stream);
 
-/* The Laplacian term of the objective in one launch each way (reference fit.py:581 squares pytorch3d's mesh_laplacian_smoothing of
+/* The Laplacian term of the objective in two launches forward (gather + norms, then a one-workgroup finish at the kernel boundary) and one backward (reference fit.py:581 squares pytorch3d's mesh_laplacian_smoothing of
  * the ONE mesh of its step; a batch takes the mean of the squares):
  *   per[f] = mean_v || (L x_f)_v ||,   out[0] = weight / F * sum_f per[f]^2,   L = D^-1 A - I as in fpcdr_laplacian_gather.
  * lap [F,V,3] and per [F] are saved for the backward call.  acc: (F + 1) * 8 bytes, 8-byte aligned, ZERO on entry; the call leaves

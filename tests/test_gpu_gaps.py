@@ -460,3 +460,46 @@ def test_near_plane_clipping_matches_oracle(dr, oracle_ops, res, T, seed):
     ref_img = torch.randint(0, 141, (2,) + tuple(res), generator=g, dtype=torch.uint8).cuda()
     loss = dr.pixel_objective(ctx, pos.cuda().requires_grad_(True), tri.cuda(), uv, tri.cuda(), tex.requires_grad_(True), ref_img, res)
     assert torch.isfinite(loss)
+
+
+def test_stale_mip_stack_is_refused_and_hints_refresh_without_backward(dr):
+    """(i) a stack from texture_construct_mip() whose base texture was modified in place (an optimiser step) must not be
+    demoted to a custom stack silently -- its levels are stale and their gradient would no longer reach tex; (ii) the launch hints of
+    the two-call objective are refreshed also when no backward pass will run (torch.no_grad(), evaluation loops); (iii) ref_bg_sumsq
+    may be a Python float."""
+    from fpc_diffrend_amd import scene
+    sc = scene.cfg('cfg1', n_frames=1)
+    dev = 'cuda'
+    pos, _ = clip_positions(sc, [0, 4], frames=[0])
+    tri, uv, uv_idx = (torch.tensor(a, device=dev) for a in (sc.pos_idx, sc.uv, sc.uv_idx))
+    ctx = dr.RasterizeGLContext(device=dev)
+    tex = torch.rand(1, 64, 64, 1, device=dev).requires_grad_(True)
+    rast, rast_db = dr.rasterize(ctx, pos.to(dev), tri, sc.resolution)
+    texc, texd = dr.interpolate(uv[None], rast, uv_idx, rast_db=rast_db, diff_attrs='all')
+    stack = dr.texture_construct_mip(tex, max_mip_level=3)
+    opt = torch.optim.SGD([tex], lr=0.1)
+    for step in range(2):
+        if step == 1:
+            with pytest.raises(RuntimeError, match="modified in place"):
+                dr.texture(tex, texc, texd, mip=stack, filter_mode='linear-mipmap-linear', max_mip_level=3)
+            stack = dr.texture_construct_mip(tex, max_mip_level=3)
+        col = dr.texture(tex, texc, texd, mip=stack, filter_mode='linear-mipmap-linear', max_mip_level=3)
+        opt.zero_grad()
+        col.sum().backward()
+        assert float(tex.grad.abs().sum()) > 0
+        opt.step()
+    # (ii) + (iii)
+    ref = torch.full((pos.shape[0],) + tuple(sc.resolution), 90, dtype=torch.uint8, device=dev)
+    bg = float(dr.reference_background_sumsq(ref).sum())
+    p = pos.to(dev).clone().requires_grad_(True)
+    t = torch.tensor(sc.texture, device=dev).clone().requires_grad_(True)
+    for one_pass in (False, True):
+        dr._list_hints.clear()
+        with torch.no_grad():
+            a = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, sc.resolution, one_pass=one_pass, ref_bg_sumsq=bg)
+        torch.cuda.synchronize()
+        hints = dr._list_hints[next(iter(dr._list_hints))]
+        assert hints.poll()[0] > 0, "the counts of a forward-only call were never read back"
+        b = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, sc.resolution, one_pass=one_pass)
+        assert abs(float(a) - float(b)) <= 1e-6 * abs(float(b))
+    dr._list_hints.clear()

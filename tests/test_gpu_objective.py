@@ -114,7 +114,7 @@ def test_one_pass_launch_hints_do_not_change_the_result():
     assert caps[0] >= 256 and caps[1] >= 256
     second = run()
     hints.event = None
-    hints.caps = (3, 2, 0)              # absurdly small: almost every bin goes through the strided sweeps
+    hints.caps = (3, 2, 1)              # absurdly small: almost every bin goes through the strided sweeps
     hints.update = lambda counts: None
     third = run()
     for r in (first, second, third):
