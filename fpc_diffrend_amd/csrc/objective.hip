@@ -229,6 +229,25 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     int k_x0 = 0x7fffffff, k_y0 = 0x7fffffff;
     bool k_on = false;
 
+    // ---- prefetch.  A pixel's chain is ids (LDS) -> vertex indices -> three vertices -> barycentrics -> texels: three dependent
+    // global round trips, four pixels one after the other = 75 % of a wave's life (scripts/prof_phases.py).  The indices of all four
+    // pixels are fetched up front and a pixel's vertices while the pixel before it is worked on, which leaves the texel fetch as the
+    // one exposed round trip per pixel.  (The compiler cannot hoist these loads itself: the pixel code holds global stores / atomics.)
+#ifndef FPCDR_SHADE_PREFETCH
+#define FPCDR_SHADE_PREFETCH 0      // measured at cfg3: 2.70 ms per call either way (93 VGPRs and 5 waves per SIMD with it, 73 and 6 without)
+#endif
+    I3 ti4[4];
+    float4 pn0 = make_float4(0.f, 0.f, 0.f, 0.f), pn1 = pn0, pn2 = pn0;      // vertices of the NEXT pixel to be worked on
+    if (FPCDR_SHADE_PREFETCH) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int zy = 2 * shade_row_pair(k, wave) + (lane >> 5);
+            const int id = (int)(s_id[(zy + 1) * OS + col + 1] & 0xffffffu);
+            ti4[k] = id > 0 ? ld32(reinterpret_cast<const I3 *>(a.tri), id - 1) : I3{0, 0, 0};
+        }
+        pn0 = ld32(pos_img, ti4[0].a); pn1 = ld32(pos_img, ti4[0].b); pn2 = ld32(pos_img, ti4[0].c);      // (an empty pixel reads vertex 0)
+    }
+
     // ---- one pixel: shade, loss, chain back.  FIRST: pass 0 (texel adds deferred to behind the origin's barrier) ----
     auto pixel = [&](const int k, const bool FIRST) {
         const int zy = 2 * shade_row_pair(k, wave) + (lane >> 5), y = by0 + zy;
@@ -237,14 +256,21 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         int tkey = -1;
         int vk[3] = {0, 0, 0};
         float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // this pixel's vertices arrived while the previous one was worked on; the next pixel's are requested now
+        const float4 pv0 = pn0, pv1 = pn1, pv2 = pn2;
+        if (FPCDR_SHADE_PREFETCH && k < 3) {
+            const I3 tn = ti4[k < 3 ? k + 1 : 3];
+            pn0 = ld32(pos_img, tn.a); pn1 = ld32(pos_img, tn.b); pn2 = ld32(pos_img, tn.c);
+        }
         if (id > 0) {
             const unsigned int nR = s_id[(zy + 1) * OS + col + 2], nL = s_id[(zy + 1) * OS + col];
             const unsigned int nU = s_id[(zy + 2) * OS + col + 1], nD = s_id[zy * OS + col + 1];
             const bool deferred = (x + 1 < W && pair_maybe(me, nR)) || (y + 1 < H && pair_maybe(me, nU)) || (x > 0 && pair_maybe(me, nL)) ||
                                   (y > 0 && pair_maybe(me, nD));
             const int t = id - 1;
-            const I3 ti = ld32(reinterpret_cast<const I3 *>(a.tri), t);
-            const float4 v0 = ld32(pos_img, ti.a), v1 = ld32(pos_img, ti.b), v2 = ld32(pos_img, ti.c);
+            const I3 ti = FPCDR_SHADE_PREFETCH ? ti4[k] : ld32(reinterpret_cast<const I3 *>(a.tri), t);
+            const float4 v0 = FPCDR_SHADE_PREFETCH ? pv0 : ld32(pos_img, ti.a), v1 = FPCDR_SHADE_PREFETCH ? pv1 : ld32(pos_img, ti.b),
+                         v2 = FPCDR_SHADE_PREFETCH ? pv2 : ld32(pos_img, ti.c);
             const float fy = s_fy[zy];
             ShadeKeep K;
             float u, v, zw = 0.0f;
