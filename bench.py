@@ -382,6 +382,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _lib.TIMER = None
+    elapsed_local = elapsed
     elapsed = fdist.max_over_ranks(elapsed, device)
 
     # a "frame" = all views of one time-frame; the ref workload renders ONE image (one view of one frame) per step and rank
@@ -415,6 +416,20 @@ def main():
         "final_loss": float(loss) if loss is not None else None,
         "hbm_allocated_peak_GB": torch.cuda.max_memory_allocated(device) / 1e9,
     }
+    # what a reader of a multi-GPU line needs to trust it: the collective backend, the physical device of every rank (two ranks on one
+    # GPU, or a gloo fallback, must be visible), each rank's own time per step (load imbalance) and the bins its frames occupied
+    import torch.distributed as tdist_
+    import fpc_diffrend_amd.ops as dr_ops_
+    my_bins = None
+    for key_, h_ in dr_ops_._list_hints.items():
+        if key_[0] == 'onepass' and key_[2] == fpg * n_cam:
+            my_bins = {"rasteriser": int(h_.host[2]), "shaded": int(h_.host[3]), "deferred": int(h_.host[0])}
+    per_rank = fdist.gather_objects({"rank": rank, "device": fdist.device_identity(device), "ms_per_step": 1000.0 * elapsed_local / args.steps,
+                                     "occupied_bins": my_bins, "allreduce_ms": allreduce_ms})
+    out["backend"] = tdist_.get_backend() if (tdist_.is_available() and tdist_.is_initialized()) else None
+    out["ranks_seen"] = len({r["device"] for r in per_rank})
+    out["ms_per_step_rank_min_max"] = [min(r["ms_per_step"] for r in per_rank), max(r["ms_per_step"] for r in per_rank)]
+    out["per_rank"] = per_rank
     if rank == 0 and timer is not None:
         bpp = algorithmic_bytes_per_px(C, args.mip)
         npix = frames_step * n_views_step * H * W

@@ -155,6 +155,28 @@ def barrier():
         dist.barrier()
 
 
+def gather_objects(obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (a single process: [obj])."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, obj)
+        return out
+    return [obj]
+
+
+def device_identity(device):
+    """A string that names the physical GPU a rank computes on (uuid, else PCI address): two ranks reporting the same one share a
+    GPU -- a launch that did not pin one process per device -- which a per-rank throughput figure alone would not show."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return f"{device.type}:{os.getpid()}"
+    p = torch.cuda.get_device_properties(device)
+    uid = getattr(p, "uuid", None)
+    if uid is not None:
+        return str(uid)
+    return "pci-%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+
+
 def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:

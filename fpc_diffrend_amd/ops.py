@@ -64,22 +64,49 @@ _hints = {}
 
 
 def _tag(t, hint, kind, const=None):
+    """Register the hint of a tensor THIS library has just produced (a fresh allocation that owns its storage)."""
     if len(_hints) > 256:
         for k in [k for k, e in _hints.items() if e[0]() is None]:
             del _hints[k]
-    _hints[t.data_ptr()] = (weakref.ref(t), t._version, tuple(t.shape), hint, kind, const)
+    st = t.untyped_storage()
+    _hints[t.data_ptr()] = (weakref.ref(t), t._version, tuple(t.shape), hint, kind, const, st.data_ptr(), st.nbytes())
 
 
 def _hint_of(t, kind):
+    """The hint of `t`, or None.  A hint is honoured only for the very tensor object an operator of this library returned, owning the
+    storage the library allocated for it (not a view, not re-pointed with set_() / .data = ...), with an unchanged version counter --
+    every in-place torch operation bumps it.  What no host-side check can see is a write that bypasses autograd's bookkeeping: a
+    foreign kernel, or `t.data.copy_(...)`; such a caller must call ops.drop_hints(t) (or work under ops.no_region_hints())."""
     if not region_hints:
         return None
     e = _hints.get(t.data_ptr())
     if e is None:
         return None
-    ref, version, shape, hint, k, const = e
+    ref, version, shape, hint, k, const, st_ptr, st_bytes = e
     if ref() is not t or t._version != version or tuple(t.shape) != shape or k != kind:
         return None
+    st = t.untyped_storage()
+    if t._base is not None or st.data_ptr() != st_ptr or st.nbytes() != st_bytes or t.storage_offset() != 0 or not t.is_contiguous():
+        return None
     return hint, const
+
+
+def drop_hints(*tensors):
+    """Forget the region hints of these tensors (call it after writing to one of them behind torch's back)."""
+    for t in tensors:
+        _hints.pop(t.data_ptr(), None)
+
+
+class no_region_hints:
+    """Context manager: the operators inside take the dense path (module switch `region_hints` restored on exit)."""
+
+    def __enter__(self):
+        global region_hints
+        self._old, region_hints = region_hints, False
+
+    def __exit__(self, *exc):
+        global region_hints
+        region_hints = self._old
 
 
 def _hint_bytes(B, H, W):

@@ -503,3 +503,30 @@ def test_stale_mip_stack_is_refused_and_hints_refresh_without_backward(dr):
         b = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, sc.resolution, one_pass=one_pass)
         assert abs(float(a) - float(b)) <= 1e-6 * abs(float(b))
     dr._list_hints.clear()
+
+
+def test_region_hint_is_dropped_for_anything_but_the_producers_own_tensor(dr):
+    """ops._hint_of honours a hint only for the very tensor rasterize() returned, owning its storage, unmodified (version counter);
+    a view, a re-pointed tensor, an in-place edit, drop_hints() or no_region_hints() all fall back to the dense path."""
+    from fpc_diffrend_amd import scene
+    sc = scene.cfg('cfg1', n_frames=1)
+    pos, _ = clip_positions(sc, [0, 4], frames=[0])
+    tri = torch.tensor(sc.pos_idx, device='cuda')
+    ctx = dr.RasterizeGLContext(device='cuda')
+    rast, _ = dr.rasterize(ctx, pos.cuda(), tri, sc.resolution)
+    assert dr._hint_of(rast, 'rast') is not None
+    assert dr._hint_of(rast[0:1], 'rast') is None and dr._hint_of(rast.view(-1, 4), 'rast') is None      # views
+    assert dr._hint_of(rast.clone(), 'rast') is None
+    with dr.no_region_hints():
+        assert dr._hint_of(rast, 'rast') is None
+    assert dr._hint_of(rast, 'rast') is not None
+    other = torch.zeros_like(rast)
+    keep = rast.data
+    rast.data = other                       # re-pointed at foreign storage
+    assert dr._hint_of(rast, 'rast') is None
+    rast.data = keep
+    rast.mul_(1.0)                          # an in-place edit bumps the version counter
+    assert dr._hint_of(rast, 'rast') is None
+    rast2, _ = dr.rasterize(ctx, pos.cuda(), tri, sc.resolution)
+    dr.drop_hints(rast2)
+    assert dr._hint_of(rast2, 'rast') is None

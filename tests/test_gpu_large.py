@@ -270,3 +270,28 @@ def test_4k_combined_mode_step_gradients_match_upstream_oracle(oracle_ops):
         assert a.grad is not None and float(b.grad.abs().max()) > 0, name
         e = rel_l2(a.grad, b.grad)
         assert e < 1e-4, (name, e)
+
+
+def test_cfg2_vertex_shading_graph_steps_equal_eager_steps_at_9_view_1080p():
+    """BASELINE configs[1] exactly as `bench.py --workload cfg2` runs it: one frame x nine 1920 x 1080 views of the 30k-triangle rig,
+    rasterize + interpolate of a per-vertex grey only (no texture), Adam on weights + pose, the step replayed as two HIP graphs.
+    The replayed steps follow the eager ones: same losses, same parameters after ten steps."""
+    import numpy as np
+    from fpc_diffrend_amd import fit, scene
+    out = {}
+    for graph in (False, True):
+        sc = scene.cfg('cfg2', n_frames=1)
+        cfg = fit.FitConfig(max_iter=80000, frames_per_step=0, init_texture="random", shading='vertex', optimize_texture=False, hip_graph=graph)
+        ft = fit.Fitter(sc, cfg, device='cuda')
+        assert tuple(ft.resolution) == (1080, 1920) and len(ft.cam_idxs) == 9 and ft.pos_idx.shape[0] == 30000
+        losses = [float(ft.step()) for _ in range(10)]
+        if graph:
+            assert ft._graphs is not None
+        out[graph] = (np.asarray(losses), [p.detach().double().cpu().clone() for p in ft.params])
+    a, b = out[False][0], out[True][0]
+    assert np.isfinite(b).all() and np.allclose(a, b, rtol=1e-4), (a, b)
+    # parameters: Adam divides by the gradient's running magnitude, so the order of the float atomics (and torch.optim.Adam in the
+    # captured step against the one-launch GroupedAdam of the eager one) moves a component whose gradient is near zero by up to lr per
+    # step, not by a fraction of itself: ten steps of 1e-3 on weights of ~8e-3 (measured: 3e-3 relative L2, losses equal to 1e-4)
+    for pe, pg in zip(out[False][1], out[True][1]):
+        assert rel_l2(pg, pe) < 5e-2 or float((pg - pe).abs().max()) < 5e-5, (rel_l2(pg, pe), float((pg - pe).abs().max()))
