@@ -68,7 +68,8 @@ class Objective(ctypes.Structure):
                 ("boundary_mode", _i), ("ref", _p), ("bg", ctypes.c_float), ("color_scale", ctypes.c_float),
                 ("grad_scale", ctypes.c_float), ("sil", _p), ("idp", _p), ("occ", _p), ("cmask", _p), ("rec", _p), ("color", _p),
                 ("grad_aa", _p), ("empty_color", _p), ("loss_sum", _p), ("grad_pos", _p), ("grad_tex", _p), ("cap_bins", _i),
-                ("cap_occ", _i), ("cap_def", _i), ("reserved0", _i), ("flags", _p)]
+                ("cap_occ", _i), ("cap_def", _i), ("reserved0", _i), ("flags", _p), ("mip", _i), ("n_levels", _i),
+                ("tex_mip", _p * MAX_MIP), ("grad_tex_mip", _p * MAX_MIP)]
 
 
 class InterpolateFwd(ctypes.Structure):

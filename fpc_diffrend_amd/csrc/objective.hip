@@ -57,6 +57,16 @@ struct ObjArgs {
     unsigned long long *flags;      // optional (tests / diagnostics): the antialias flag planes of fpcdr_antialias_fwd, zero-filled by the caller
 };
 
+// MIP instantiations (the reference's enable_mip branch, fit.py:153-155): level l of the chain = tex[l - 1] / grad[l - 1]; level 0 is
+// ObjArgs.tex / grad_tex
+// (the whole chain, level 0 included, as ONE kernel argument: the level is a run-time index, and a TexLevels assembled in a local
+//  variable is a private array -- 288 bytes of scratch memory per lane; indexed in the kernel-argument segment it is a scalar load)
+struct MipO {
+    TexLevels lv;      // tex[0] = ObjArgs.tex, grad[0] = ObjArgs.grad_tex; grad[] all null when no texture gradient is wanted
+    int n_levels;
+};
+constexpr int OTW1 = 24;      // texel window of level 1 (a bin's footprint there is a quarter of its level-0 one)
+
 // texture coordinates of triangle t through the index buffer (callers that did not pre-gather uv[uv_tri]); out of line, see fused.hip
 // (returns BY VALUE, in registers: reference arguments of an out-of-line function live in scratch memory, and a kernel with a private
 //  segment is dispatched several times slower -- k_fix<1> spent 220 us launching 90 k one-wave workgroups, 47 us without scratch)
@@ -113,9 +123,12 @@ __device__ __forceinline__ int shade_row_pair(int k, int w) {
     return (int)((packed >> (4 * w)) & 15u);
 }
 
-template <int CS, int BMODE>
-__device__ __forceinline__ void shade_body(const int b, const int bxi, const int byi, const int OX, const int OY, const ObjArgs &a) {
+template <int CS, int BMODE, bool MIP = false>
+__device__ __forceinline__ void shade_body(const int b, const int bxi, const int byi, const int OX, const int OY, const ObjArgs &a,
+                                           const MipO *ma = nullptr) {
     const int boundary = BMODE >= 0 ? BMODE : a.boundary;
+    __shared__ double s_tex1[MIP ? OTW1 * OTW1 * CS : 1];      // MIP: window of level 1 (coarser levels go to memory)
+    __shared__ int s_org1[2];
     __shared__ unsigned int s_id[(OB + 2) * OS];
     __shared__ int s_vkey[FPCDR_VT_SLOTS];
     __shared__ double s_vacc[FPCDR_VT_SLOTS][3];
@@ -162,7 +175,9 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     if (want_pos) vtable_init(vt, tid, ONT);
     if (want_tex)
         for (int k = tid; k < OTW * OTW * CS; k += ONT) s_tex[k] = 0.0;
-    if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; }
+    if (MIP && want_tex)
+        for (int k = tid; k < OTW1 * OTW1 * CS; k += ONT) s_tex1[k] = 0.0;
+    if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; s_org1[0] = 0x7fffffff; s_org1[1] = 0x7fffffff; }
     if (tid < OB) {
         s_cmask[tid] = 0u;
         s_fy[tid] = (2.0f * (float)(by0 + tid) + 1.0f) / (float)H - 1.0f;      // NDC y of the bin's rows: one IEEE division per row
@@ -181,6 +196,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     float lsum = 0.0f;
     bool any_def = false;
     int ox = 0, oy = 0;      // origin of the texel window (set behind the barrier after pass 0)
+    int ox1 = 0x7fffffff, oy1 = 0x7fffffff;      // MIP: origin of the level-1 window
 
     // the four texel adds of one pixel: into the window, or -- outside it -- to memory
     auto add_taps = [&](const float (&gc)[CS], float fx, float fy, int x0, int y0) {
@@ -274,14 +290,22 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             const float fy = s_fy[zy];
             ShadeKeep K;
             float u, v, zw = 0.0f;
-            shade_uvz<false>(v0, v1, v2, fx_col, fy, K, u, v, zw);      // (z/w: deferred pixels only, below)
+            float4 db = make_float4(0.f, 0.f, 0.f, 0.f);      // MIP: screen-space derivatives of the barycentrics (rast_db never exists in HBM)
+            const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
+            if (MIP) {
+                const Shade sd = shade_pixel(v0, v1, v2, fx_col, fy, sx, sy);
+                u = sd.u; v = sd.v; zw = sd.zw;
+                db = make_float4(sd.dudx, sd.dudy, sd.dvdx, sd.dvdy);
+            } else {
+                shade_uvz<false>(v0, v1, v2, fx_col, fy, K, u, v, zw);      // (z/w: deferred pixels only, below)
+            }
             // interpolate (fit.py:157) + texture 'linear' (fit.py:158): the arithmetic of the stand-alone kernels
             const UV3 tq = a.tri_uv ? ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t) : uv_indirect(a.uv, a.uv_tri, t);
             const float2 q0 = tq.q0, q1 = tq.q1, q2 = tq.q2;
             const float w = 1.0f - u - v;
             const float tu = u * q0.x + v * q1.x + w * q2.x;
             const float tv = u * q0.y + v * q1.y + w * q2.y;
-            const Taps tp = boundary == FPCDR_BOUNDARY_ZERO ? make_taps(tu, tv, Ht, Wt, CS, boundary) : make_taps_fast(tu, tv, Ht, Wt, CS, boundary);
+            const Taps tp = MIP ? Taps{} : (boundary == FPCDR_BOUNDARY_ZERO ? make_taps(tu, tv, Ht, Wt, CS, boundary) : make_taps_fast(tu, tv, Ht, Wt, CS, boundary));
             const unsigned int poff = (unsigned int)(zy * W + col);
             const size_t off = bin_off + poff;
             const float rf = (float)ld32(a.ref + bin_off, poff);
@@ -289,14 +313,24 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             float colv[CS], gq[CS];
             float gfx = 0.f, gfy = 0.f;
             bool nz = false;
+            // MIP: interpolate(..., rast_db, diff_attrs='all') + texture('linear-mipmap-linear') (fit.py:153-155), the arithmetic of the
+            // stand-alone kernels: the footprint of the texture coordinate from the barycentrics' screen derivatives
+            const float e0x = q0.x - q2.x, e0y = q0.y - q2.y, e1x = q1.x - q2.x, e1y = q1.y - q2.y;
+            float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MIP) {
+                da = make_float4(db.x * e0x + db.z * e1x, db.y * e0x + db.w * e1x, db.x * e0y + db.z * e1y, db.y * e0y + db.w * e1y);
+                mip_sample_fwd(ma->lv, 0, ma->n_levels, make_float2(tu, tv), true, da, 0.0f, Ht, Wt, CS, true, boundary, [&](int c, float vv) { colv[c] = vv; });
+            }
 #pragma unroll
             for (int c = 0; c < CS; ++c) {
-                float t00, t10, t01, t11;
+                float t00 = 0.f, t10 = 0.f, t01 = 0.f, t11 = 0.f;
+                if (!MIP) {
                 load_taps<true>(a.tex, tp, c, CS, t00, t10, t01, t11);      // (the entry point requires < 2^30 texel values)
                 mask_taps(tp, t00, t10, t01, t11);
                 const float top = t00 + (t10 - t00) * tp.fx;
                 const float bot = t01 + (t11 - t01) * tp.fx;
                 colv[c] = top + (bot - top) * tp.fy;
+                }
                 // background elsewhere (fit.py:161); squared error against the 8-bit reference (fit.py:579), as the difference to a
                 // background pixel (the all-background share of the loss depends on the references alone: fpcdr_ref_bg_sumsq)
                 const float dd = rf - colv[c] * cs;
@@ -309,12 +343,32 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             if (deferred) {      // k_fix reads these back: a few per cent of the covered pixels
                 any_def = true;
                 atomicOr(&s_cmask[zy], 1u << col);
-                zw = shade_zw(v0, v1, v2, K.a0, K.a1, K.p0x * K.p1y - K.p0y * K.p1x);
+                if (!MIP) zw = shade_zw(v0, v1, v2, K.a0, K.a1, K.p0x * K.p1y - K.p0y * K.p1x);
                 a.rec[off] = make_float4(u, v, zw, (float)id);
 #pragma unroll
                 for (int c = 0; c < CS; ++c) { a.color[off * CS + c] = colv[c]; a.g_aa[off * CS + c] = gq[c]; }
             }
-            if (want_tex && nz) {
+            float gtu_m = 0.f, gtv_m = 0.f;
+            float4 gda = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MIP && want_grad && nz) {
+                // texel gradients of levels 0 and 1 through the two LDS windows (origins: the prepass below), anything else to memory;
+                // the footprint's gradient goes back through the derivative outputs of the rasteriser
+                float gbias = 0.f;
+                const int lx0 = (int)floorf(prep_coord(tu, boundary) * (float)Wt - 0.5f) - ox;
+                const int ly0 = (int)floorf(prep_coord(tv, boundary) * (float)Ht - 0.5f) - oy;
+                const bool in0 = (unsigned int)lx0 < (unsigned int)(OTW - 1) && (unsigned int)ly0 < (unsigned int)(OTW - 1);
+                const int lx1 = (int)floorf(prep_coord(tu, boundary) * (float)(Wt >> 1) - 0.5f) - ox1;
+                const int ly1 = (int)floorf(prep_coord(tv, boundary) * (float)(Ht >> 1) - 0.5f) - oy1;
+                const bool in1 = (unsigned int)lx1 < (unsigned int)(OTW1 - 1) && (unsigned int)ly1 < (unsigned int)(OTW1 - 1);
+                mip_sample_bwd_to(ma->lv, 0, ma->n_levels, make_float2(tu, tv), true, da, 0.0f, Ht, Wt, CS, true, boundary, gq, gtu_m, gtv_m, gda, gbias,
+                                  [&](int level, int tap, size_t offs, int c, float vv) {
+                                      const int dx = tap & 1, dy = tap >> 1;
+                                      if (level == 0 && in0) lds_add_f64(&s_tex[((ly0 + dy) * OTW + lx0 + dx) * CS + c], vv);
+                                      else if (level == 1 && in1) lds_add_f64(&s_tex1[((ly1 + dy) * OTW1 + lx1 + dx) * CS + c], vv);
+                                      else atomicAdd(ma->lv.grad[level] + offs + c, vv);
+                                  });
+            }
+            if (!MIP && want_tex && nz) {
                 const int x0 = (int)floorf(prep_coord(tu, boundary) * (float)Wt - 0.5f);
                 const int y0 = (int)floorf(prep_coord(tv, boundary) * (float)Ht - 0.5f);
                 if (FIRST) {
@@ -329,14 +383,17 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             if (want_pos) {
                 const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
                 const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv >= 0.0f && tv <= 1.0f)) ? 0.0f : 1.0f;
-                const float gtu = gfx * (float)Wt * mu, gtv = gfy * (float)Ht * mv;
+                const float gtu = MIP ? gtu_m * mu : gfx * (float)Wt * mu, gtv = MIP ? gtv_m * mv : gfy * (float)Ht * mv;
                 const float gu = gtu * (q0.x - q2.x) + gtv * (q0.y - q2.y);
                 const float gvv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
-                if (gu != 0.0f || gvv != 0.0f) {
+                // MIP: interpolate backward of the derivative outputs, d (uv_da) / d (rast_db)
+                const float4 gdb = make_float4(gda.x * e0x + gda.z * e0y, gda.y * e0x + gda.w * e0y, gda.x * e1x + gda.z * e1y, gda.y * e1x + gda.w * e1y);
+                if (gu != 0.0f || gvv != 0.0f || (MIP && (gdb.x != 0.0f || gdb.y != 0.0f || gdb.z != 0.0f || gdb.w != 0.0f))) {
                     tkey = t;
                     vk[0] = ti.a; vk[1] = ti.b; vk[2] = ti.c;
                     float g0[3], g1[3], g2[3];
-                    shade_uv_bwd(K, fx_col, fy, gu, gvv, g0, g1, g2);
+                    if (MIP) shade_pixel_bwd<true>(v0, v1, v2, fx_col, fy, sx, sy, make_float4(gu, gvv, 0.f, 0.f), gdb, g0, g1, g2);
+                    else shade_uv_bwd(K, fx_col, fy, gu, gvv, g0, g1, g2);
                     gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
                     gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
                     gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
@@ -352,9 +409,37 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) { vtable_add(vt, gp, vk, sm); });
     };
 
+    if (MIP) {
+        // MIP: the scatter of a pixel's texel gradients is buried in the level / footprint arithmetic, so the origins of both windows
+        // come from a PREPASS that only forms the texture coordinate of the pass-0 pixels (one pixel in four shaded twice)
+        if (want_tex) {
+            const int zy = 2 * shade_row_pair(0, wave) + (lane >> 5);
+            const int id = (int)(s_id[(zy + 1) * OS + col + 1] & 0xffffffu);
+            int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = 0x7fffffff, y1 = 0x7fffffff;
+            if (id > 0) {
+                const int t = id - 1;
+                const I3 ti = ld32(reinterpret_cast<const I3 *>(a.tri), t);
+                ShadeKeep K;
+                float u, v, zw;
+                shade_uvz<false>(ld32(pos_img, ti.a), ld32(pos_img, ti.b), ld32(pos_img, ti.c), fx_col, s_fy[zy], K, u, v, zw);
+                const UV3 tq = a.tri_uv ? ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t) : uv_indirect(a.uv, a.uv_tri, t);
+                const float w = 1.0f - u - v;
+                const float tu = u * tq.q0.x + v * tq.q1.x + w * tq.q2.x, tv = u * tq.q0.y + v * tq.q1.y + w * tq.q2.y;
+                x0 = (int)floorf(prep_coord(tu, boundary) * (float)Wt - 0.5f); y0 = (int)floorf(prep_coord(tv, boundary) * (float)Ht - 0.5f);
+                x1 = (int)floorf(prep_coord(tu, boundary) * (float)(Wt >> 1) - 0.5f); y1 = (int)floorf(prep_coord(tv, boundary) * (float)(Ht >> 1) - 0.5f);
+            }
+            const int m0 = wave_min_dpp(x0), m1 = wave_min_dpp(y0), m2 = wave_min_dpp(x1), m3 = wave_min_dpp(y1);
+            if (lane == 0 && m0 != 0x7fffffff) { atomicMin(&s_org[0], m0); atomicMin(&s_org[1], m1); atomicMin(&s_org1[0], m2); atomicMin(&s_org1[1], m3); }
+            __syncthreads();
+            ox = s_org[0]; oy = s_org[1]; ox1 = s_org1[0]; oy1 = s_org1[1];
+            if (ox != 0x7fffffff) { ox -= OWIN_MARGIN + 1; oy -= OWIN_MARGIN + 1; ox1 -= 1; oy1 -= 1; }
+        }
+        pixel(0, false);
+    } else {
     // ---- pass 0: row pairs 0, 5, 10, 15; the window's origin ----
     pixel(0, true);
-    if (want_tex) {
+    }
+    if (!MIP && want_tex) {
         const int mx = wave_min_dpp(k_x0), my = wave_min_dpp(k_y0);
         if (lane == 0 && mx != 0x7fffffff) { atomicMin(&s_org[0], mx); atomicMin(&s_org[1], my); }
         OPROF_T(3);
@@ -409,6 +494,17 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             }
         }
     }
+    if (MIP && want_tex && ox1 != 0x7fffffff && ma->n_levels >= 1) {
+        const int Wt1 = Wt >> 1, Ht1 = Ht >> 1;
+        for (int k = tid; k < OTW1 * OTW1 * CS; k += ONT) {
+            const float v = (float)s_tex1[k];
+            if (v != 0.0f) {
+                const int c = k % CS, cell = k / CS;
+                const int gx = wrap_near(ox1 + cell % OTW1, Wt1, boundary), gy = wrap_near(oy1 + cell / OTW1, Ht1, boundary);
+                atomicAdd(ma->lv.grad[1] + (size_t)(gy * Wt1 + gx) * CS + c, v);
+            }
+        }
+    }
     OPROF_T(7);
     OPROF_ADD(6, 6, 7);
 #ifdef FPCDR_OPROF
@@ -425,6 +521,30 @@ __global__ void __launch_bounds__(ONT) FPCDR_SHADE_WPE k_shade_list(const int32_
     int b, byi, bxi;
     fpcdr_decode_bin(lin, dc, b, byi, bxi);
     shade_body<CS, BMODE>(b, bxi, byi, OX, OY, a);
+}
+
+// the MIP instantiation (boundary mode at run time): list form and strided sweep
+template <int CS>
+__global__ void __launch_bounds__(ONT) k_shade_mip_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int cap, int OX, int OY,
+                                                        fpcdr_bin_decode dc, ObjArgs a, MipO ma) {
+    const int item = fpcdr_list_item(*count, cap);
+    if (item < 0) return;
+    const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+    int b, byi, bxi;
+    fpcdr_decode_bin(lin, dc, b, byi, bxi);
+    shade_body<CS, -1, true>(b, bxi, byi, OX, OY, a, &ma);
+}
+template <int CS>
+__global__ void __launch_bounds__(ONT) k_shade_mip_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int first, int OX,
+                                                         int OY, fpcdr_bin_decode dc, ObjArgs a, MipO ma) {
+    const int n = *count;
+    for (int item = first + blockIdx.x; item < n; item += gridDim.x) {
+        const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+        int b, byi, bxi;
+        fpcdr_decode_bin(lin, dc, b, byi, bxi);
+        shade_body<CS, -1, true>(b, bxi, byi, OX, OY, a, &ma);
+        __syncthreads();
+    }
 }
 
 // strided sweep of the entries beyond the hinted launch (normally none; scalar loop variable: see k_bins_queue in rasterize.hip)
@@ -494,8 +614,9 @@ __device__ FPCDR_EDGE_INLINE void aa_edge_pos_grad(float *gp, int *vkeys, double
     hacc_vadd(gp, vkeys, vacc, vb, g_qbx * hw, g_qby * hh, g_wb - fxp * g_qbx - fyp * g_qby);
 }
 
-template <int CS, int PASS>
-__device__ __forceinline__ void fix_body(const int b, const int bxi, const int byi, const int OX, const int OY, const ObjArgs &a) {
+template <int CS, int PASS, bool MIP = false>
+__device__ __forceinline__ void fix_body(const int b, const int bxi, const int byi, const int OX, const int OY, const ObjArgs &a,
+                                         const MipO *ma = nullptr) {
     __shared__ unsigned int s_mask[OB];
     __shared__ unsigned short s_list[OB * OB];
     __shared__ int s_n;
@@ -698,7 +819,43 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
 #ifdef FPCDR_FABL_B
                 { float sink = 0.f; for (int c = 0; c < CS; ++c) sink += dl[c]; asm volatile("" :: "v"(sink)); nz = false; }
 #endif
-                if (nz) {
+                if (nz && MIP) {
+                    // the mip-mapped lookup (fit.py:153-155): footprint from the rasteriser's derivatives (recomputed), texel gradients of
+                    // every level straight to memory (a few dozen pixels per bin), the footprint's gradient back through the derivatives
+                    const int boundary = a.boundary, Ht = a.Ht, Wt = a.Wt;
+                    const int t = (int)(me & 0xffffffu) - 1;
+                    const UV3 tq = a.tri_uv ? reinterpret_cast<const UV3 *>(a.tri_uv)[t] : uv_indirect(a.uv, a.uv_tri, t);
+                    const float2 q0 = tq.q0, q1 = tq.q1, q2 = tq.q2;
+                    vk[0] = a.tri[3 * t]; vk[1] = a.tri[3 * t + 1]; vk[2] = a.tri[3 * t + 2];
+                    const float4 p0 = g.pos[vk[0]], p1 = g.pos[vk[1]], p2 = g.pos[vk[2]];
+                    const float fx = (2.0f * (float)x + 1.0f) / (float)W - 1.0f, fy = (2.0f * (float)y + 1.0f) / (float)H - 1.0f;
+                    const float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
+                    const Shade sd = shade_pixel(p0, p1, p2, fx, fy, sx, sy);
+                    const float w = 1.0f - rme.x - rme.y;
+                    const float tu = rme.x * q0.x + rme.y * q1.x + w * q2.x;
+                    const float tv = rme.x * q0.y + rme.y * q1.y + w * q2.y;
+                    const float e0x = q0.x - q2.x, e0y = q0.y - q2.y, e1x = q1.x - q2.x, e1y = q1.y - q2.y;
+                    const float4 da = make_float4(sd.dudx * e0x + sd.dvdx * e1x, sd.dudy * e0x + sd.dvdy * e1x,
+                                                  sd.dudx * e0y + sd.dvdx * e1y, sd.dudy * e0y + sd.dvdy * e1y);
+                    float gtu = 0.f, gtv = 0.f, gbias = 0.f;
+                    float4 gda = make_float4(0.f, 0.f, 0.f, 0.f);
+                    mip_sample_bwd(ma->lv, 0, ma->n_levels, make_float2(tu, tv), true, da, 0.0f, Ht, Wt, CS, true, boundary, dl, gtu, gtv, gda, gbias);
+                    if (gp) {
+                        const float mu = (boundary == FPCDR_BOUNDARY_CLAMP && !(tu >= 0.0f && tu <= 1.0f)) ? 0.0f : 1.0f;
+                        const float mv = (boundary == FPCDR_BOUNDARY_CLAMP && !(tv >= 0.0f && tv <= 1.0f)) ? 0.0f : 1.0f;
+                        gtu *= mu; gtv *= mv;
+                        const float gu = gtu * e0x + gtv * e0y, gvv = gtu * e1x + gtv * e1y;
+                        const float4 gdb = make_float4(gda.x * e0x + gda.z * e0y, gda.y * e0x + gda.w * e0y, gda.x * e1x + gda.z * e1y, gda.y * e1x + gda.w * e1y);
+                        if (gu != 0.0f || gvv != 0.0f || gdb.x != 0.0f || gdb.y != 0.0f || gdb.z != 0.0f || gdb.w != 0.0f) {
+                            float g0[3], g1[3], g2[3];
+                            shade_pixel_bwd<true>(p0, p1, p2, fx, fy, sx, sy, make_float4(gu, gvv, 0.f, 0.f), gdb, g0, g1, g2);
+                            gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
+                            gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
+                            gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
+                            tkey = t;
+                        }
+                    }
+                } else if (nz) {
                     const int boundary = a.boundary, Ht = a.Ht, Wt = a.Wt;
                     const int t = (int)(me & 0xffffffu) - 1;
                     const UV3 tq = a.tri_uv ? reinterpret_cast<const UV3 *>(a.tri_uv)[t] : uv_indirect(a.uv, a.uv_tri, t);
@@ -810,6 +967,29 @@ __global__ void __launch_bounds__(64) k_esum_finish(ObjArgs a) {
     if (tp0.valid & 8u) atomicAdd(a.grad_tex + tp0.i11 + c, e * (tp0.fx * tp0.fy));
 }
 
+template <int CS>
+__global__ void __launch_bounds__(FNT) k_fix_mip_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int cap, int OX, int OY,
+                                                      fpcdr_bin_decode dc, ObjArgs a, MipO ma) {
+    const int item = fpcdr_list_item(*count, cap);
+    if (item < 0) return;
+    const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+    int b, byi, bxi;
+    fpcdr_decode_bin(lin, dc, b, byi, bxi);
+    fix_body<CS, 1, true>(b, bxi, byi, OX, OY, a, &ma);
+}
+template <int CS>
+__global__ void __launch_bounds__(FNT) k_fix_mip_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int first, int OX, int OY,
+                                                       fpcdr_bin_decode dc, ObjArgs a, MipO ma) {
+    const int n = *count;
+    for (int item = first + blockIdx.x; item < n; item += gridDim.x) {
+        const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+        int b, byi, bxi;
+        fpcdr_decode_bin(lin, dc, b, byi, bxi);
+        fix_body<CS, 1, true>(b, bxi, byi, OX, OY, a, &ma);
+        __syncthreads();
+    }
+}
+
 template <int CS, int PASS>
 __global__ void __launch_bounds__(FNT) k_fix_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int cap, int OX, int OY,
                                                   fpcdr_bin_decode dc, ObjArgs a) {
@@ -857,6 +1037,13 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
     FPCDR_REQUIRE((long long)p->Ht * p->Wt * p->C < (1ll << 30), "texture too large (the fused paths take < 2^30 texel values)");
     FPCDR_REQUIRE(((size_t)p->occ & 3) == 0 && ((size_t)p->cmask & 7) == 0 && ((size_t)p->idp & 15) == 0 && ((size_t)p->rec & 15) == 0,
                   "occ must be 4-byte, cmask 8-byte, idp and rec 16-byte aligned");
+    if (p->mip) {
+        FPCDR_REQUIRE(p->n_levels >= 0 && p->n_levels <= FPCDR_MAX_MIP, "bad n_levels");
+        for (int lvl = 1; lvl <= p->n_levels; ++lvl) {
+            FPCDR_REQUIRE(p->tex_mip[lvl - 1] != nullptr && (!p->grad_tex || p->grad_tex_mip[lvl - 1] != nullptr), "missing mip level");
+            FPCDR_REQUIRE(!((p->Ht >> (lvl - 1)) & 1) && !((p->Wt >> (lvl - 1)) & 1), "mip levels need even sizes");
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     int rc = fpcdr_launch_sil(p->pos, p->tri, p->adj, p->B, p->V, p->T, p->H, p->W, p->sil, nullptr, 0, st);
     if (rc) return rc;
@@ -894,6 +1081,31 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         if (sweep_d) hipLaunchKernelGGL((k_fix_queue<CS, PASS>), dim3(FPCDR_SWEEP_WGS), dim3(FNT), 0, st, a.def_list, a.def_count, cap_d, OX, OY, dc, a); \
     } while (0)
     const bool grads = p->grad_pos || p->grad_tex;
+    if (p->mip) {      // the reference's enable_mip branch (fit.py:153-155)
+        MipO ma;
+        ma.lv.tex[0] = p->tex;
+        ma.lv.grad[0] = p->grad_tex;
+        for (int lvl = 1; lvl <= FPCDR_MAX_MIP; ++lvl) {
+            ma.lv.tex[lvl] = lvl <= p->n_levels ? p->tex_mip[lvl - 1] : nullptr;
+            ma.lv.grad[lvl] = (lvl <= p->n_levels && p->grad_tex) ? p->grad_tex_mip[lvl - 1] : nullptr;
+        }
+        ma.n_levels = p->n_levels;
+#define SHADE_MIP(CS)                                                                                                             \
+    do {                                                                                                                          \
+        hipLaunchKernelGGL(k_shade_mip_list<CS>, grid, dim3(ONT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a, ma);                 \
+        if (sweep) hipLaunchKernelGGL(k_shade_mip_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(ONT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a, ma); \
+    } while (0)
+#define FIX_MIP(CS)                                                                                                               \
+    do {                                                                                                                          \
+        hipLaunchKernelGGL(k_fix_mip_list<CS>, grid_d, dim3(FNT), 0, st, a.def_list, a.def_count, cap_d, OX, OY, dc, a, ma);       \
+        if (sweep_d) hipLaunchKernelGGL(k_fix_mip_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(FNT), 0, st, a.def_list, a.def_count, cap_d, OX, OY, dc, a, ma); \
+    } while (0)
+        if (p->C == 1) { SHADE_MIP(1); FIX(1, 0); if (grads) FIX_MIP(1); if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<1>, dim3(1), dim3(64), 0, st, a); }
+        else if (p->C == 3) { SHADE_MIP(3); FIX(3, 0); if (grads) FIX_MIP(3); if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<3>, dim3(1), dim3(64), 0, st, a); }
+        else { SHADE_MIP(4); FIX(4, 0); if (grads) FIX_MIP(4); if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<4>, dim3(1), dim3(64), 0, st, a); }
+#undef SHADE_MIP
+#undef FIX_MIP
+    } else
     if (p->C == 1) {
         if (p->boundary_mode == FPCDR_BOUNDARY_WRAP) SHADE(1, FPCDR_BOUNDARY_WRAP);      // the reference's case, as compile-time constants
         else SHADE(1, -1);

@@ -442,7 +442,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, ref_bg_sumsq, use_hints, want_grad, unit_upstream,
-                flags_out=None):
+                flags_out=None, mip_levels=None):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -469,10 +469,24 @@ class _pixel_objective_onepass(torch.autograd.Function):
                            boundary_mode=boundary, ref=_ptr(ref), bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
                            idp=_ptr(idp), occ=_ptr(occ), cmask=_ptr(cmask), rec=_ptr(rec), color=_ptr(color), grad_aa=_ptr(g_aa),
                            empty_color=_ptr(ecol), loss_sum=_ptr(acc), grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex), flags=_ptr(flags_out))
+        # mip_levels = n: the reference's enable_mip branch inside the same kernels (the chain is built here, box filter as texture())
+        chain = _build_mips(tex[None], mip_levels)[1:] if mip_levels is not None else []
+        g_chain = [torch.zeros_like(t) for t in chain] if want_tex else []
+        if mip_levels is not None:
+            p.mip, p.n_levels = 1, len(chain)
+            for l, t in enumerate(chain):
+                p.tex_mip[l] = _ptr(t)
+                if g_chain:
+                    p.grad_tex_mip[l] = _ptr(g_chain[l])
         hints = _list_hints.setdefault(('onepass', dev.index, B, V, T, H, W), _ListHints()) if use_hints else None
         if hints is not None:
             p.cap_bins, p.cap_occ, p.cap_def = hints.poll()      # (live bins, occupied bins, bins with a deferred pixel)
         _lib.call("fpcdr_objective_fwd", ctypes.byref(p), _stream())
+        if g_chain:      # fold the levels' gradients into the texture's (the box filter's backward, coarse to fine)
+            g_all = [g_tex[None]] + g_chain
+            for l in range(len(chain), 0, -1):
+                _, h, w, _ = g_all[l - 1].shape
+                _lib.call("fpcdr_mip_downsample_bwd", _ptr(g_all[l]), _ptr(g_all[l - 1]), 1, h, w, C, _stream())
         if hints is not None:
             nb = B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN)
             off = (4 * nb + 3) // 4 * 4                       # FPCDR_OCC_COUNTS_OFFSET
@@ -497,7 +511,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
             g = g.to(torch.float32)
             g_pos = g_pos * g if g_pos is not None else None
             g_tex = g_tex * g if g_tex is not None else None
-        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 15
+        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 16
 
 
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
@@ -528,7 +542,7 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     enable_mip (sparse mode): the reference's other branch (fit.py:153-155) -- interpolate with the rasteriser's
     screen-space derivatives and texture 'linear-mipmap-linear' with max_mip_level -- inside the same three kernels; equals the
     chain rasterize(output_db) -> interpolate(diff_attrs='all') -> texture(texd) -> antialias + pixel loss.
-    one_pass (sparse mode without mip, the default): value and gradient from ONE call -- the kernel that shades a pixel also chains
+    one_pass (sparse mode, with or without mip; the default): value and gradient from ONE call -- the kernel that shades a pixel also chains
     its gradient back (fpcdr_objective_fwd); backward() multiplies by the upstream scalar, or returns the buffers as they are with
     unit_upstream=True (the caller guarantees d loss / d objective = 1).  one_pass=False: the two-call form.
     aa_flags_out (one_pass; tests / diagnostics): a zero-filled int64 tensor of fpcdr_antialias_flags_bytes(B,H,W) / 8 words that
@@ -555,10 +569,10 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
         if not sparse:
             raise NotImplementedError("pixel_objective(enable_mip=True) runs in sparse mode (use the separate operators otherwise)")
         mip_levels = _num_mip_levels(tex.shape[0], tex.shape[1], max_mip_level)
-    if one_pass and sparse and not enable_mip:
+    if one_pass and sparse:
         return _pixel_objective_onepass.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                               ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], ref_bg_sumsq,
-                                              bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out)
+                                              bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out, mip_levels)
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                        ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq,
                                        bool(launch_hints), bool(queued_backward), mip_levels, torch.is_grad_enabled())

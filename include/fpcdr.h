@@ -250,7 +250,7 @@ int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *stream);
  *      correction of their loss terms, and the scatter of the DIFFERENCE of their gradient (everything is linear in it).
  * grad_pos / grad_tex hold d(objective)/d(pos), d(objective)/d(tex) with the objective = grad_scale * sum of squares; the caller
  * multiplies by its upstream scalar.  Same value and gradients as the operator chain (tests/test_gpu_objective.py).
- * 'linear' lookup only (the mip-mapped branch stays with fpcdr_render_loss_fwd); C in {1, 3, 4}; instanced mode. */
+ * 'linear' lookup, or -- mip = 1 -- the reference's mip-mapped branch; C in {1, 3, 4}; instanced mode. */
 size_t fpcdr_idplane_bytes(int32_t B, int32_t H, int32_t W);   /* 4 KB per 32 x 32 bin of the batch */
 
 typedef struct {
@@ -284,6 +284,12 @@ typedef struct {
     int32_t reserved0;
     uint64_t *flags;        /* optional (tests / diagnostics; NULL in production): the antialias flag planes of fpcdr_antialias_fwd --
                                which pixel pairs were blended --, fpcdr_antialias_flags_bytes(B,H,W), zero-filled by the caller */
+    /* the reference's enable_mip branch (fit.py:153-155): interpolate with the rasteriser's screen-space derivatives and texture
+     * 'linear-mipmap-linear', inside the same kernels (the derivatives never exist in HBM) */
+    int32_t mip;            /* 1 = mip-mapped lookup */
+    int32_t n_levels;       /* levels below tex, 0 .. FPCDR_MAX_MIP */
+    const float *tex_mip[FPCDR_MAX_MIP];   /* tex_mip[l - 1] = level l, [Ht >> l, Wt >> l, C] (fpcdr_mip_downsample) */
+    float *grad_tex_mip[FPCDR_MAX_MIP];    /* per level, accumulated (the caller folds them into grad_tex: fpcdr_mip_downsample_bwd) */
 } fpcdr_objective_params;
 int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream);
 

@@ -207,15 +207,16 @@ def test_fused_objective_with_mip_equals_the_operator_chain_and_the_oracle(dr, o
     img = torch.where(rast[..., 3:] > 0, col, torch.tensor(fit.BACKGROUND, device=dev))
     l1 = torch.mean((ref8.to(dev).float()[..., None] - img * 255) ** 2)
     l1.backward()
-    # the fused objective
-    p2 = pos.to(dev).requires_grad_(True)
-    t2 = tex0.clone().requires_grad_(True)
-    l2 = dr.pixel_objective(ctx, p2, tri, uv, uv_idx, t2, ref8.to(dev), sc.resolution, boundary_mode=boundary, enable_mip=True,
-                            max_mip_level=max_mip)
-    l2.backward()
-    assert abs(float(l2) - float(l1)) <= 2e-6 * abs(float(l1)), (float(l2), float(l1))
-    assert rel_l2(p2.grad, p1.grad) < TOL, rel_l2(p2.grad, p1.grad)
-    assert rel_l2(t2.grad, t1.grad) < TOL, rel_l2(t2.grad, t1.grad)
+    # the fused objective: the two-call form, then the one-pass form (value and gradient from one call; the one the checks below keep)
+    for one_pass in (False, True):
+        p2 = pos.to(dev).requires_grad_(True)
+        t2 = tex0.clone().requires_grad_(True)
+        l2 = dr.pixel_objective(ctx, p2, tri, uv, uv_idx, t2, ref8.to(dev), sc.resolution, boundary_mode=boundary, enable_mip=True,
+                                max_mip_level=max_mip, one_pass=one_pass)
+        l2.backward()
+        assert abs(float(l2) - float(l1)) <= 2e-6 * abs(float(l1)), (one_pass, float(l2), float(l1))
+        assert rel_l2(p2.grad, p1.grad) < TOL, (one_pass, rel_l2(p2.grad, p1.grad))
+        assert rel_l2(t2.grad, t1.grad) < TOL, (one_pass, rel_l2(t2.grad, t1.grad))
     assert float(t1.grad.abs().max()) > 0 and float(p1.grad.abs().max()) > 0
     if res is None and boundary == 'wrap' and C == 1:
         from oracle import fit as ofit
