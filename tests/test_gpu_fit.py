@@ -89,6 +89,14 @@ def test_smoke_step_matches_oracle(oracle_ops):
               f"{rel_l2(res[k], ref64[k]):.2e}, f32 oracle vs f64 {rel_l2(ref[k], ref64[k]):.2e}")
         assert e_ops < TOL, (k, e_ops)
         assert e_fused < TOL, (k, e_fused)
+        # the float64 evaluation of the same rules on the same visibility is the yardstick that is NOT this build's float32 arithmetic:
+        # the HIP path is no further from it than the float32 oracle itself is (profiles/r04_float_rules.txt: 1.6e-3 for positions --
+        # the depth test and the texel cells are step functions of rounded inputs --, 7e-6 for the texture), asserted, not printed
+        floor = rel_l2(ref[k], ref64[k])
+        assert (1e-4 if k == 'grad_pos_clip' else 1e-7) < floor < (1e-2 if k == 'grad_pos_clip' else 1e-4), (k, floor)
+        for name in (k, k + '_fused'):
+            d64 = rel_l2(res[name], ref64[k])
+            assert abs(d64 - floor) <= 0.02 * floor + 1e-7, (name, d64, floor)
     # (2) upstream of the ops (transform_clip, MVP chain, MFMA blend): chain the GPU's d loss / d pos_clip through
     # the CPU restatement in float64 and compare the parameter gradients
     up = ofit.smoke_upstream(sc, res['grad_pos_clip'].cpu(), cams)
@@ -175,8 +183,15 @@ def test_fused_render_equals_separate_ops(C, boundary):
     (col2 * gy).sum().backward()
     assert torch.equal(rast2, rast)
     assert torch.equal(col2, col)
-    # (the corner texel collects the random gradients of every empty pixel: float32 atomic order noise ~1e-4)
-    assert rel_l2(t2.grad, t1.grad) < 1e-3
+    # every texel but the four taps of uv = (0,0): the 1e-4 bar.  Those four collect the random gradient of EVERY empty pixel -- a float32
+    # sum of ~3e5 terms in the arbitrary order of the atomics, on both sides -- and are held to the conditioning of such a sum instead:
+    # a difference below 1e-5 of the sum of the terms' magnitudes (r3 asserted 1e-3 on the whole tensor because of them)
+    corner = torch.zeros(t1.grad.shape[:2], dtype=torch.bool, device=dev)
+    corner[0, 0] = corner[0, -1] = corner[-1, 0] = corner[-1, -1] = True
+    assert rel_l2(t2.grad[~corner], t1.grad[~corner]) < 1e-4
+    empty = (rast[..., 3] == 0)
+    terms = float(gy[empty].abs().sum())
+    assert float((t2.grad[corner] - t1.grad[corner]).abs().max()) < 1e-5 * terms, (float((t2.grad[corner] - t1.grad[corner]).abs().max()), terms)
     assert rel_l2(p2.grad, p1.grad) < 1e-4
 
 
