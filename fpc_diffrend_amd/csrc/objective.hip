@@ -1023,6 +1023,13 @@ extern "C" int fpcdr_debug_oprof(unsigned long long *out16, int reset) {
 }
 #endif
 
+extern "C" int fpcdr_silhouette_bits(const float *pos, const int32_t *tri, const int32_t *adj, int32_t B, int32_t V, int32_t T, int32_t H,
+                                     int32_t W, uint8_t *sil, void *stream) {
+    FPCDR_REQUIRE(pos && tri && adj && sil, "null pointer");
+    FPCDR_REQUIRE(B > 0 && V > 0 && T > 0 && H > 0 && W > 0 && B <= 65535, "bad sizes");
+    return fpcdr_launch_sil(pos, tri, adj, B, V, T, H, W, sil, nullptr, 0, (hipStream_t)stream);
+}
+
 extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream) {
     FPCDR_REQUIRE(p != nullptr, "null params");
     FPCDR_REQUIRE(p->pos && p->tri && p->adj && p->scratch && p->uv && p->uv_tri && p->tex && p->ref, "null pointer");
@@ -1045,7 +1052,7 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    int rc = fpcdr_launch_sil(p->pos, p->tri, p->adj, p->B, p->V, p->T, p->H, p->W, p->sil, nullptr, 0, st);
+    int rc = p->sil_ready ? FPCDR_OK : fpcdr_launch_sil(p->pos, p->tri, p->adj, p->B, p->V, p->T, p->H, p->W, p->sil, nullptr, 0, st);
     if (rc) return rc;
     const int32_t *occ_list = nullptr, *n_occ = nullptr;
     rc = fpcdr_launch_raster_ids(p, st, &occ_list, &n_occ);

@@ -1572,6 +1572,9 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
     sh.idp = p->idp;
     const fpcdr_bin_decode dc = fpcdr_make_bin_decode(OX, OY);
     const int cap_bins = (p->cap_bins > 0 && (size_t)p->cap_bins < nbins) ? p->cap_bins : (int)nbins;
+    // the silhouette bits computed by the caller on another stream (sil_ready): the rasteriser kernel is their first reader
+    if (p->sil_ready && p->sil_event)
+        FPCDR_REQUIRE(hipStreamWaitEvent(st, (hipEvent_t)p->sil_event, 0) == hipSuccess, "hipStreamWaitEvent(sil_event) failed");
     hipLaunchKernelGGL((k_bins_list<false, false, false, 0, -1, false, true>), dim3(fpcdr_list_grid(cap_bins)), dim3(256), 0, st, bin_list, n_bins,
                        cap_bins, OX, OY, dc, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox,
                        (float4 *)nullptr, (float4 *)nullptr, sh);

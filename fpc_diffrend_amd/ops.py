@@ -435,6 +435,17 @@ class _pixel_objective_func(torch.autograd.Function):
         return (g_pos, g_tex) + (None,) * 16
 
 
+_side_streams = {}
+
+
+def _side_stream(dev):
+    """One helper stream per device (the silhouette bits of the one-pass objective run on it beside the rasteriser's set-up)."""
+    st = _side_streams.get(dev.index)
+    if st is None:
+        st = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class _pixel_objective_onepass(torch.autograd.Function):
     """The pixel objective with VALUE AND GRADIENT from one call (include/fpcdr.h, fpcdr_objective_fwd): the objective is a scalar, so
     its gradient is d(objective)/d(input) times the one upstream number -- it is accumulated by the kernel that shades a pixel, while
@@ -442,7 +453,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, ref_bg_sumsq, use_hints, want_grad, unit_upstream,
-                flags_out=None, mip_levels=None):
+                flags_out=None, mip_levels=None, overlap_sil=True):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -478,9 +489,24 @@ class _pixel_objective_onepass(torch.autograd.Function):
                 p.tex_mip[l] = _ptr(t)
                 if g_chain:
                     p.grad_tex_mip[l] = _ptr(g_chain[l])
+        # the silhouette bits need the positions only: on a second stream they run beside the rasteriser's set-up kernel (not inside a
+        # graph capture, where the fork would become part of the caller's graph topology).  Forked HERE, behind the zero-fills of the
+        # gradient buffers above: started earlier the kernel shares the memory system with them (the 69 MB fill took 68 us instead of 12)
+        side = _side_stream(dev) if (overlap_sil and not torch.cuda.is_current_stream_capturing()) else None
+        if side is not None:
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _lib.call("fpcdr_silhouette_bits", _ptr(pos), _ptr(tri), _ptr(adj), B, V, T, H, W, _ptr(sil), ctypes.c_void_p(side.cuda_stream))
+                sil_event = torch.cuda.Event()
+                sil_event.record(side)
+            for t_ in (pos, tri, adj, sil):
+                t_.record_stream(side)
         hints = _list_hints.setdefault(('onepass', dev.index, B, V, T, H, W), _ListHints()) if use_hints else None
         if hints is not None:
             p.cap_bins, p.cap_occ, p.cap_def = hints.poll()      # (live bins, occupied bins, bins with a deferred pixel)
+        if side is not None:      # (the call waits for the event right before its first kernel that reads the bits)
+            p.sil_ready, p.sil_event = 1, ctypes.c_void_p(sil_event.cuda_event)
         _lib.call("fpcdr_objective_fwd", ctypes.byref(p), _stream())
         if g_chain:      # fold the levels' gradients into the texture's (the box filter's backward, coarse to fine)
             g_all = [g_tex[None]] + g_chain
@@ -511,7 +537,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
             g = g.to(torch.float32)
             g_pos = g_pos * g if g_pos is not None else None
             g_tex = g_tex * g if g_tex is not None else None
-        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 16
+        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 17
 
 
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):

@@ -281,7 +281,8 @@ typedef struct {
     float *grad_tex;        /* [Ht,Wt,C] accumulated, or NULL (both NULL: value only) */
     int32_t cap_bins, cap_occ; /* launch-size hints (0 = none), as in fpcdr_aa_loss_fwd_params */
     int32_t cap_def;        /* launch-size hint for the kernels over the bins that hold a deferred pixel (count at [0] of the occ header) */
-    int32_t reserved0;
+    int32_t sil_ready;      /* 1: `sil` already holds fpcdr_silhouette_bits() of this pos / tri / adj (a caller computes it on a second
+                               stream beside the rasteriser's set-up kernel: ~70 us of a 2.7 ms call at 288 x 1080p); 0: computed here */
     uint64_t *flags;        /* optional (tests / diagnostics; NULL in production): the antialias flag planes of fpcdr_antialias_fwd --
                                which pixel pairs were blended --, fpcdr_antialias_flags_bytes(B,H,W), zero-filled by the caller */
     /* the reference's enable_mip branch (fit.py:153-155): interpolate with the rasteriser's screen-space derivatives and texture
@@ -290,8 +291,17 @@ typedef struct {
     int32_t n_levels;       /* levels below tex, 0 .. FPCDR_MAX_MIP */
     const float *tex_mip[FPCDR_MAX_MIP];   /* tex_mip[l - 1] = level l, [Ht >> l, Wt >> l, C] (fpcdr_mip_downsample) */
     float *grad_tex_mip[FPCDR_MAX_MIP];    /* per level, accumulated (the caller folds them into grad_tex: fpcdr_mip_downsample_bwd) */
+    void *sil_event;        /* with sil_ready = 1: optional hipEvent_t recorded behind the caller's fpcdr_silhouette_bits on ITS stream; the
+                               call makes `stream` wait for it right before the first kernel that reads sil (behind the set-up kernels, which
+                               is the point: they overlap).  NULL: sil is complete in stream order */
 } fpcdr_objective_params;
 int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream);
+
+/* sil[b][t] = 3 bits, "edge e of triangle t is a silhouette edge in image b" (boundary edge, or the two triangles' opposite vertices
+ * project to the same side: DESIGN.md "Antialias rules"), as fpcdr_antialias_fwd and fpcdr_objective_fwd compute it themselves.
+ * pos [B,V,4], tri [T,3], adj [T,3] (fpcdr_topology_build), sil out [B,T] bytes. */
+int fpcdr_silhouette_bits(const float *pos, const int32_t *tri, const int32_t *adj, int32_t B, int32_t V, int32_t T, int32_t H, int32_t W,
+                          uint8_t *sil, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* interpolate -- dr.interpolate(attr, rast, tri[, rast_db, diff_attrs])  reference fit.py:154,157 */
