@@ -24,7 +24,7 @@ for case in range(n_cases):
     ref = torch.randint(0, 141, (B, H, W), generator=g, dtype=torch.uint8).to(dev)
     out = {}
     dr._list_hints.clear()
-    for name in ("chain", "fused", "fused again (launch hints, list backward)"):
+    for name in ("chain", "fused", "fused again (launch hints)", "two-call form"):      # fused = the one-pass objective (value + gradient in one call)
         p = pos.to(dev).clone().requires_grad_(True); t = tex0.to(dev).clone().requires_grad_(True)
         if name == "chain":
             rast, rdb = dr.rasterize(ctx, p, tri, (H, W))
@@ -39,7 +39,7 @@ for case in range(n_cases):
             loss = torch.mean((ref[..., None].float() - img * 255) ** 2)
         else:
             loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, (H, W), boundary_mode=boundary, enable_mip=mip, max_mip_level=3,
-                                      queued_backward=name.endswith(")"))
+                                      one_pass=(name != "two-call form"), queued_backward=True)
         loss.backward()
         torch.cuda.synchronize()
         out[name] = (float(loss), p.grad.double().cpu(), t.grad.double().cpu())
@@ -49,6 +49,6 @@ for case in range(n_cases):
         gp = rel_l2(out[name][1], out["chain"][1]) if float(out["chain"][1].abs().max()) > 0 else float(out[name][1].abs().max())
         gt = rel_l2(out[name][2], out["chain"][2]) if float(out["chain"][2].abs().max()) > 0 else float(out[name][2].abs().max())
         ok &= dl <= 3e-6 and gp < 1e-4 and gt < 1e-4
-        print(f"case {case:2d} B={B} {H}x{W} T={nt} C={C} {boundary:5s} mip={int(mip)} {name[:11]:11s} dloss {dl:.1e} dpos {gp:.1e} dtex {gt:.1e}", flush=True)
+        print(f"case {case:2d} B={B} {H}x{W} T={nt} C={C} {boundary:5s} mip={int(mip)} {name[:13]:13s} dloss {dl:.1e} dpos {gp:.1e} dtex {gt:.1e}", flush=True)
     assert ok, "mismatch"
 print("all cases agree")

@@ -121,3 +121,56 @@ def test_one_pass_launch_hints_do_not_change_the_result():
         assert abs(r[0] - base[0]) <= 1e-6 * abs(base[0])
         assert rel_l2(r[1], base[1]) < 1e-5 and rel_l2(r[2], base[2]) < 1e-5
     dr._list_hints.clear()
+
+
+def test_one_pass_edge_cases_clipping_empty_images_and_the_indirect_uv_path(monkeypatch):
+    """(i) triangles crossing the near plane (rule R1: clipped pieces under the triangle's id) and images that show nothing at all;
+    (ii) the C ABI's tri_uv = NULL path (uv looked up through uv_tri inside the kernels; the binding always pre-gathers);
+    (iii) the mip branch with absurdly small launch hints (its strided sweep kernels do the work): all against the operator chain."""
+    import fpc_diffrend_amd.ops as dr
+    from helpers import near_crossing_soup
+    dev = 'cuda'
+    ctx = dr.RasterizeGLContext(device=dev)
+    res = (96, 128)
+    pos, tri = near_crossing_soup(3, 40, seed=5)
+    pos[2, :, 3] = -1.0                                   # image 2: everything behind the camera -> an empty image
+    pos, tri = pos.to(dev), tri.to(dev)
+    g0 = torch.Generator().manual_seed(4)
+    uv = (torch.rand(tri.shape[0] * 3, 2, generator=g0) * 1.1).to(dev)
+    uv_idx = tri.clone()
+    tex = (torch.rand(32, 32, 1, generator=g0) * 0.5).to(dev)
+    ref = torch.randint(0, 141, (3,) + res, generator=g0, dtype=torch.uint8).to(dev)
+
+    def both(**kw):
+        out = []
+        for name in ("one", "chain"):
+            p, t = pos.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+            if name == "chain":
+                if kw.get("enable_mip"):
+                    from fpc_diffrend_amd import fit
+                    rast, rdb = dr.rasterize(ctx, p, tri, res)
+                    texc, texd = dr.interpolate(uv[None], rast, uv_idx, rast_db=rdb, diff_attrs='all')
+                    col = dr.antialias(dr.texture(t[None], texc, texd, filter_mode='linear-mipmap-linear', max_mip_level=2), rast, p, tri)
+                    img = torch.where(rast[..., 3:] > 0, col, torch.tensor(fit.BACKGROUND, device=dev))
+                    loss = torch.mean((ref[..., None].float() - img * 255) ** 2)
+                else:
+                    loss = _chain(ctx, p, tri, uv, uv_idx, t, ref, res, 'wrap')
+            else:
+                loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, res, **kw)
+            loss.backward()
+            out.append((float(loss), p.grad.double().cpu(), t.grad.double().cpu()))
+        (l1, gp1, gt1), (l2, gp2, gt2) = out
+        assert abs(l1 - l2) <= 2e-6 * abs(l2), (l1, l2)
+        assert rel_l2(gp1, gp2) < 1e-4 and rel_l2(gt1, gt2) < 1e-4, (rel_l2(gp1, gp2), rel_l2(gt1, gt2))
+        assert float(gp1[2].abs().max()) == 0.0            # the empty image contributes no gradient
+
+    both()
+    monkeypatch.setattr(dr, "_cached_tri_uv", lambda uv_, idx_: None)      # (ii)
+    both()
+    monkeypatch.undo()
+    dr._list_hints.clear()                                 # (iii)
+    both(enable_mip=True, max_mip_level=2)
+    h = dr._list_hints[next(k for k in dr._list_hints if k[0] == 'onepass')]
+    h.event, h.caps, h.update = None, (1, 1, 1), (lambda counts: None)
+    both(enable_mip=True, max_mip_level=2)
+    dr._list_hints.clear()
