@@ -492,6 +492,15 @@ def main():
             dom = max(px_ops, key=lambda k: px_ops[k]["avg_ms"] * px_ops[k]["calls"])
             t_s = px_ops[dom]["avg_ms"] * 1e-3
             out["roofline"], pmc = hbm_roofline(dom)
+            if dom == "fpcdr_objective_fwd" and sparse_px.get(dom):
+                # continuity with rounds 1-3, whose two calls wrote and re-read rast / colour / d loss/d colour: the SAME work priced at
+                # their 25 + 20 algorithmic bytes per pixel of the listed bins.  The one-pass call does not move those bytes -- that is
+                # the point of it -- so this is a rate of work done, comparable with the earlier rounds' frac, not traffic
+                eq_bytes = (16 + 4 * C + 1 + 4 * C + 4 * C + 16) * sparse_px[dom]
+                out["roofline"]["two_call_equivalent"] = {"bytes_per_px": 16 + 4 * C + 1 + 4 * C + 4 * C + 16, "bytes": eq_bytes,
+                                                          "GBps": eq_bytes / t_s / 1e9, "frac": eq_bytes / t_s / 1e9 / HBM_PEAK_GBS,
+                                                          "note": "the work of fpcdr_render_loss_fwd + fpcdr_render_aa_bwd (round 3: 45 B/px "
+                                                                  "on the listed bins, frac 0.14-0.15 per call) done in this call's time"}
             out["roofline"]["note"] = ("fpcdr_objective_fwd computes value AND gradient in one call and moves 9 B/px (id plane out and in, "
                                        "8-bit reference): it is bound by vector issue, not by HBM -- see roofline_valu.  "
                                        "achieved = algorithmic bytes of the SPARSE call (B/px x 1024 px x the bins on its list, counted "

@@ -69,7 +69,7 @@ class Objective(ctypes.Structure):
                 ("grad_scale", ctypes.c_float), ("sil", _p), ("idp", _p), ("occ", _p), ("cmask", _p), ("rec", _p), ("color", _p),
                 ("grad_aa", _p), ("empty_color", _p), ("loss_sum", _p), ("grad_pos", _p), ("grad_tex", _p), ("cap_bins", _i),
                 ("cap_occ", _i), ("cap_def", _i), ("sil_ready", _i), ("flags", _p), ("mip", _i), ("n_levels", _i),
-                ("tex_mip", _p * MAX_MIP), ("grad_tex_mip", _p * MAX_MIP), ("sil_event", _p)]
+                ("tex_mip", _p * MAX_MIP), ("grad_tex_mip", _p * MAX_MIP), ("binlist", _p), ("sil_event", _p)]
 
 
 class InterpolateFwd(ctypes.Structure):
@@ -146,6 +146,7 @@ SYMBOLS = {
     "fpcdr_objective_value": (_int, [_p, _i, _p, ctypes.c_double, ctypes.c_double, _p, _p]),
     "fpcdr_render_aa_bwd": (_int, [ctypes.POINTER(RenderAaBwd), _p]),
     "fpcdr_idplane_bytes": (_sz, [_i, _i, _i]),
+    "fpcdr_binlist_bytes": (_sz, [_i, _i, _i]),
     "fpcdr_objective_fwd": (_int, [ctypes.POINTER(Objective), _p]),
     "fpcdr_silhouette_bits": (_int, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "fpcdr_interpolate_fwd": (_int, [ctypes.POINTER(InterpolateFwd), _p]),

@@ -185,11 +185,34 @@ __device__ __noinline__ int clip_pieces(const float4 (&v)[3], double (&pc)[2][3]
     return n - 2;
 }
 
+// Per-bin triangle lists (BINLIST instantiation, the one-pass objective): the raster kernel's search for "which triangles touch my bin"
+// -- chunk boxes, then the 8-byte boxes of ~2 000 triangles of the live chunks, three barriers -- was 290 us of its 700 at cfg3 for a
+// quarter of its instructions: a chain of dependent loads, not work (profiles/r04_raster_ablation.txt).  Here the set-up kernel, which
+// holds every triangle's box anyway, bins its 256 triangles over the <= BL_LOCAL bins of its chunk box in LDS (count, one global
+// fetch-add per touched bin for the segment's place in the bin's list, fill) and the raster kernel reads its list: one count, one
+// gather.  A bin's list holds BL_CAP record slots; a bin that overflows (thousands of tiny triangles in one bin) keeps its count and
+// falls back to the chunk scan.  Order inside a list depends on scheduling; the winner of a pixel -- min over (depth, index) -- does not.
+constexpr int BL_CAP = 256;        // entries per bin list (a bin of the 30k rig holds ~120)
+constexpr int BL_LOCAL = 64;       // local bins of a chunk box binned in LDS (8 x 8); larger chunk boxes: per-triangle global appends
+
+__device__ __forceinline__ void binlist_append_global(int32_t *__restrict__ bin_cnt, int32_t *__restrict__ bin_list, uint8_t *__restrict__ live,
+                                                      size_t img_bins, int OX, TriBox bx, int slot) {
+    for (int gy = bx.y0 / BIN; gy <= bx.y1 / BIN; ++gy)
+        for (int gx = bx.x0 / BIN; gx <= bx.x1 / BIN; ++gx) {
+            const size_t gb = img_bins + (size_t)gy * OX + gx;
+            const int pos = atomicAdd(&bin_cnt[gb], 1);
+            if (pos < BL_CAP) bin_list[gb * BL_CAP + pos] = slot;
+            live[gb] = 1;
+        }
+}
+
+template <bool BINLIST = false>
 __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                 int B, int V, int T, int H, int W, TriRec *__restrict__ recs,
                                                 TriBox *__restrict__ boxes, TriBox *__restrict__ cboxes,
                                                 ImgBox *__restrict__ ibox, uint8_t *__restrict__ live,
-                                                const int32_t *__restrict__ ranges) {
+                                                const int32_t *__restrict__ ranges, int32_t *__restrict__ bin_cnt = nullptr,
+                                                int32_t *__restrict__ bin_list = nullptr) {
     // grid: x over 256-triangle chunks, y = image.  A block never straddles two images, so the union of
     // its triangles' bounding boxes can be reduced in the block: it is stored as the CHUNK box (meshes
     // keep neighbouring triangles at neighbouring indices, so a bin later skips most chunks with one
@@ -243,7 +266,8 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
                     boxes[img_slot + Tp + k] = box2;
                     atomicMin(&ibox[b].x0, (int)box2.x0); atomicMin(&ibox[b].y0, (int)box2.y0);
                     atomicMax(&ibox[b].x1, (int)box2.x1); atomicMax(&ibox[b].y1, (int)box2.y1);
-                    if (live)
+                    if (BINLIST) binlist_append_global(bin_cnt, bin_list, live, (size_t)b * OY * OX, OX, box2, Tp + k);
+                    else if (live)
                         for (int gy = box2.y0 / BIN; gy <= box2.y1 / BIN; ++gy)
                             for (int gx = box2.x0 / BIN; gx <= box2.x1 / BIN; ++gx) live[((size_t)b * OY + gy) * OX + gx] = 1;
                 }
@@ -251,6 +275,7 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
         }
         boxes[gid] = box;
     }
+    const TriBox mybox = {(int16_t)(bx1 >= 0 ? bx0 : 1), (int16_t)(bx1 >= 0 ? by0 : 1), (int16_t)(bx1 >= 0 ? bx1 : 0), (int16_t)(bx1 >= 0 ? by1 : 0)};
     // image bounding box: wave reduce -> block reduce -> at most four atomics per block
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -274,6 +299,44 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
         cboxes[(size_t)b * gridDim.x + blockIdx.x] = cb;
         if (live) { s_box[0][0] = bx0; s_box[0][1] = by0; s_box[0][2] = bx1; s_box[0][3] = by1; }
     }
+    if (BINLIST) {
+        // ---- per-bin lists: the chunk's triangles over the bins of the chunk box ----
+        __shared__ int s_cnt[BL_LOCAL], s_base[BL_LOCAL];
+        __syncthreads();
+        const int cx0 = s_box[0][0], cy0 = s_box[0][1], cx1 = s_box[0][2], cy1 = s_box[0][3];
+        if (cx1 < 0) return;                                  // (uniform) no triangle of this chunk reaches the image
+        const int gx0 = cx0 / BIN, gy0 = cy0 / BIN, nx = cx1 / BIN - gx0 + 1, ny = cy1 / BIN - gy0 + 1;
+        const size_t img_bins = (size_t)b * OY * OX;
+        const bool has = mybox.x0 <= mybox.x1;
+        if (nx * ny > BL_LOCAL) {                             // (uniform) a huge chunk box: every triangle appends for itself
+            if (has) binlist_append_global(bin_cnt, bin_list, live, img_bins, OX, mybox, t);
+            return;
+        }
+        if ((int)threadIdx.x < BL_LOCAL) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const int tx0 = has ? mybox.x0 / BIN - gx0 : 0, tx1 = has ? mybox.x1 / BIN - gx0 : -1;
+        const int ty0 = has ? mybox.y0 / BIN - gy0 : 0, ty1 = has ? mybox.y1 / BIN - gy0 : -1;
+        for (int ly = ty0; ly <= ty1; ++ly)
+            for (int lxb = tx0; lxb <= tx1; ++lxb) atomicAdd(&s_cnt[ly * nx + lxb], 1);
+        __syncthreads();
+        if ((int)threadIdx.x < nx * ny) {
+            const int lb = threadIdx.x, c = s_cnt[lb];
+            if (c > 0) {
+                const size_t gb = img_bins + (size_t)(gy0 + lb / nx) * OX + gx0 + lb % nx;
+                s_base[lb] = atomicAdd(&bin_cnt[gb], c);      // this chunk's segment of the bin's list
+                live[gb] = 1;
+            }
+            s_cnt[lb] = 0;                                    // (reused as the fill cursor)
+        }
+        __syncthreads();
+        for (int ly = ty0; ly <= ty1; ++ly)
+            for (int lxb = tx0; lxb <= tx1; ++lxb) {
+                const int lb = ly * nx + lxb;
+                const int pos = s_base[lb] + atomicAdd(&s_cnt[lb], 1);
+                if (pos < BL_CAP) bin_list[(img_bins + (size_t)(gy0 + ly) * OX + gx0 + lxb) * BL_CAP + pos] = t;
+            }
+        return;
+    }
     if (live) {
         // work-queue mode: every bin the chunk box touches becomes a work item of k_bins_queue (a superset of the bins
         // some triangle's box touches; all writers store 1)
@@ -295,12 +358,14 @@ __global__ void k_init_ibox(ImgBox *ibox, int B) {
 // work-queue mode: image boxes + zeroed live map, raw occupancy map and queue header (grid-stride)
 __global__ void __launch_bounds__(256) k_init_queue(ImgBox *ibox, int B, uint32_t *__restrict__ live_words, long long n_live_words,
                                                     uint32_t *__restrict__ occ_words, long long n_occ_words, int32_t *__restrict__ hdr,
-                                                    int32_t *__restrict__ hdr_bwd) {
+                                                    int32_t *__restrict__ hdr_bwd, int32_t *__restrict__ bin_cnt = nullptr, long long n_bins = 0) {
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
     if (i0 < B) ibox[i0] = {0x7fffffff, 0x7fffffff, -1, -1, 0, 0, 0, 0};
     if (i0 < 16) { hdr[i0] = 0; hdr_bwd[i0] = 0; }
     for (long long i = i0; i < n_live_words; i += stride) live_words[i] = 0u;
     for (long long i = i0; i < n_occ_words; i += stride) occ_words[i] = 0u;
+    if (bin_cnt)
+        for (long long i = i0; i < n_bins; i += stride) bin_cnt[i] = 0;      // per-bin triangle counts (k_setup<true>)
 }
 
 // ---- ordered compaction of per-bin flags into lists (ascending bin index: neighbouring bins, which share vertices and
@@ -509,6 +574,8 @@ struct ShadeArgs {
     int n_levels;
     // IDS instantiation (one-pass objective, objective.hip): out, per-bin planes of (triangle + 1) | silhouette bits << 24, [bin][32][32]
     uint32_t *idp;
+    // per-bin triangle lists of k_setup<true> (or null: every bin scans the chunk boxes)
+    const int32_t *bin_cnt, *bin_list;
 };
 
 // texture coordinates of triangle t through the index buffer (callers that did not pre-gather uv[uv_tri])
@@ -585,15 +652,23 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         int round_no = 0; // block-uniform: tile-path rounds done (parity selects the mask buffer)
         // The winner of a pixel is the minimum of (depth, triangle index), which does not depend on the order in which
         // triangles arrive: lists are filled with one LDS atomic per wave and consumed from the top, no ordered compaction.
+        const int32_t *gl = nullptr;      // the bin's own list (k_setup<true>): entries [gl_base, gl_base + n) instead of s_list
+        int gl_base = 0;
         auto process_batch = [&](const int n) {
             // consumes entries [pending - n, pending) of s_list; a barrier has been passed since they were appended
+#ifdef FPCDR_ABL_NOPROC
+            if (tid == 0) s_pending = pending - n;
+            pending -= n;
+            __syncthreads();
+            return;
+#endif
             // ---- lane path: a thread rasterises one triangle of the batch over its bounding box; a batch of at most 128 (64)
             // triangles -- the usual bin of a face mesh holds ~120 -- is walked by 2 (4) threads per triangle, rows interleaved,
             // so that all four waves share the work ----
             const int split = n <= 64 ? 4 : (n <= 128 ? 2 : 1);
             if (tid < n * split) {
                 const int part = (tid >= n) + (tid >= 2 * n) + (tid >= 3 * n);
-                const int t = s_list[pending - n + (tid - part * n)];
+                const int t = gl ? ld32(gl, (unsigned int)(gl_base + tid - part * n)) : s_list[pending - n + (tid - part * n)];
                 const TriRec r = ld32(rc, t);
                 const TriBox q = ld32(bx, t);
                 const int ext_x = max(r.X0, max(r.X1, r.X2)) - min(r.X0, min(r.X1, r.X2));
@@ -715,10 +790,17 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                 // this parity's masks are next written two rounds from now, with a barrier in between
                 for (int k = tid; k < 2 * NTILES * (BIGB / 64); k += 256) (&mask[0][0][0])[k] = 0ull;
             }
-            if (tid == 0) { s_pending = pending - n; s_nbig = 0; }
-            pending -= n;
+            if (tid == 0) { if (!gl) s_pending = pending - n; s_nbig = 0; }
+            if (!gl) pending -= n;
             __syncthreads();
         };
+        // ---- the bin's own triangle list (one count, one gather), unless it overflowed ----
+        const int n_listed = (IDS && sh.bin_cnt) ? __builtin_amdgcn_readfirstlane(sh.bin_cnt[bin_lin]) : -1;
+        if (n_listed >= 0 && n_listed <= BL_CAP) {
+            gl = sh.bin_list + bin_lin * BL_CAP;
+            total_hits = n_listed;
+            for (gl_base = 0; gl_base < n_listed; gl_base += BATCH) process_batch(min(BATCH, n_listed - gl_base));
+        } else
         for (int seg = 0; seg < n_chunks; seg += 256) {
             // ---- which of the next 256 chunks touch this bin?  (one box test per chunk) ----
             {
@@ -1356,8 +1438,8 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
     // empty bins overlap the compute-bound occupied ones.  r3: a stride permutation of each image's bins in dispatch order, so that
     // occupied and empty bins are in flight together at every moment, changes nothing -- 2.25 ms for strides 0 / n/55 / n/7 / n/1.6:
     // the long-lived occupied workgroups pile up on the CUs by themselves and the fill shares their 7 slots per CU.)
-    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, p->ranges);
+    hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, p->ranges, (int32_t *)nullptr, (int32_t *)nullptr);
     ShadeArgs sh = {};
     sh.op_hint = p->hint;
     if (p->rast_db)
@@ -1407,8 +1489,8 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
     TriBox *boxes = rs.boxes, *cboxes = rs.cboxes;
     ImgBox *ibox = rs.ibox;
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
-    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, (const int32_t *)nullptr);
+    hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
                     nullptr, p->empty_color, (const float2 *)p->tri_uv};
@@ -1488,8 +1570,8 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     // header in occ (survives the call; include/fpcdr.h FPCDR_OCC_COUNTS): [0] backward bins, [2] live bins, [3] antialias-fix bins
     hipLaunchKernelGGL(k_init_queue, dim3(256), dim3(256), 0, st, ibox, p->B, (uint32_t *)live, (long long)(align_up(nbins, 4) / 4),
                        (uint32_t *)oc, (long long)(q.occ_hdr / 4), hdr, hdr_bwd);
-    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, live, (const int32_t *)nullptr);
+    hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, live, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     int32_t *n_bins = hdr_bwd + 2, *n_fix = hdr_bwd + 3;     // all three counts live in the occ header, where the caller finds them
     const int nblk = fpcdr_cdiv((long long)nbins, 256);
     int32_t *blk = (int32_t *)(cm + q.cm_blk);          // [2][nblk] per-block counts, then offsets
@@ -1555,10 +1637,17 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
     uint8_t *live = (uint8_t *)(cm + q.cm_live);
     int32_t *hdr_occ = (int32_t *)(oc + q.occ_hdr);
     uint8_t *occ_raw = (uint8_t *)(oc + q.occ_raw);
+    // per-bin triangle lists (p->binlist: counts, then BL_CAP slots per bin), or the chunk scan for every bin when the caller gave none
+    int32_t *bin_cnt = (int32_t *)p->binlist, *tri_lists = bin_cnt ? bin_cnt + align_up(nbins, 64) : nullptr;
     hipLaunchKernelGGL(k_init_queue, dim3(256), dim3(256), 0, st, rs.ibox, p->B, (uint32_t *)live, (long long)(align_up(nbins, 4) / 4),
-                       (uint32_t *)oc, (long long)(q.occ_hdr / 4), hdr, hdr_occ);
-    hipLaunchKernelGGL(k_setup, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr);
+                       (uint32_t *)oc, (long long)(q.occ_hdr / 4), hdr, hdr_occ, bin_cnt, (long long)nbins);
+    if (bin_cnt)
+        hipLaunchKernelGGL(k_setup<true>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                           p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr, bin_cnt, tri_lists);
+    else
+        hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
+                           p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr, (int32_t *)nullptr,
+                           (int32_t *)nullptr);
     int32_t *n_bins = hdr_occ + 2, *n_occ = hdr_occ + 3;      // (include/fpcdr.h FPCDR_OCC_COUNTS_OFFSET)
     const int nblk = fpcdr_cdiv((long long)nbins, 256);
     int32_t *blk = (int32_t *)(cm + q.cm_blk);
@@ -1570,6 +1659,8 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
     sh.occ = occ_raw;
     sh.sil = p->sil;
     sh.idp = p->idp;
+    sh.bin_cnt = bin_cnt;
+    sh.bin_list = tri_lists;
     const fpcdr_bin_decode dc = fpcdr_make_bin_decode(OX, OY);
     const int cap_bins = (p->cap_bins > 0 && (size_t)p->cap_bins < nbins) ? p->cap_bins : (int)nbins;
     // the silhouette bits computed by the caller on another stream (sil_ready): the rasteriser kernel is their first reader
@@ -1590,6 +1681,12 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
     *occ_list = olist;
     *n_occ_dev = n_occ;
     return FPCDR_OK;
+}
+
+extern "C" size_t fpcdr_binlist_bytes(int32_t B, int32_t H, int32_t W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t nbins = (size_t)B * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W);
+    return (align_up(nbins, 64) + nbins * BL_CAP) * sizeof(int32_t);
 }
 
 extern "C" size_t fpcdr_idplane_bytes(int32_t B, int32_t H, int32_t W) {

@@ -453,7 +453,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, ref_bg_sumsq, use_hints, want_grad, unit_upstream,
-                flags_out=None, mip_levels=None, overlap_sil=True):
+                flags_out=None, mip_levels=None, overlap_sil=True, bin_lists=True):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -464,6 +464,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
         u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
         scratch = u8(lib.fpcdr_rasterize_scratch_bytes(B, T))
         sil, idp = u8(B * T), u8(lib.fpcdr_idplane_bytes(B, H, W))
+        binlist = u8(lib.fpcdr_binlist_bytes(B, H, W)) if bin_lists else None      # per-bin triangle lists (set-up kernel -> rasteriser)
         occ, cmask = u8(lib.fpcdr_occ_bytes(B, H, W)), u8(lib.fpcdr_cmask_bytes(B, H, W))
         # records of the DEFERRED pixels (a pixel pair at a silhouette): dense addressing, written and read for a few per cent of the
         # covered pixels only -- nothing else of the image ever exists in HBM
@@ -479,7 +480,8 @@ class _pixel_objective_onepass(torch.autograd.Function):
                            uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tri_uv=_ptr(tri_uv), tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C,
                            boundary_mode=boundary, ref=_ptr(ref), bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
                            idp=_ptr(idp), occ=_ptr(occ), cmask=_ptr(cmask), rec=_ptr(rec), color=_ptr(color), grad_aa=_ptr(g_aa),
-                           empty_color=_ptr(ecol), loss_sum=_ptr(acc), grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex), flags=_ptr(flags_out))
+                           empty_color=_ptr(ecol), loss_sum=_ptr(acc), grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex), flags=_ptr(flags_out),
+                           binlist=_ptr(binlist))
         # mip_levels = n: the reference's enable_mip branch inside the same kernels (the chain is built here, box filter as texture())
         chain = _build_mips(tex[None], mip_levels)[1:] if mip_levels is not None else []
         g_chain = [torch.zeros_like(t) for t in chain] if want_tex else []
@@ -537,7 +539,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
             g = g.to(torch.float32)
             g_pos = g_pos * g if g_pos is not None else None
             g_tex = g_tex * g if g_tex is not None else None
-        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 17
+        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 18
 
 
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
