@@ -340,7 +340,10 @@ __device__ __forceinline__ void wave_segment_reduce9(int key, const float (&val)
 // ---- per-workgroup vertex-gradient table in LDS (shared by the backward kernels) ------------------------------------
 // Scattered global f32 atomics retire slowly (one per run tail tripled the time of rasterize backward), so a workgroup sums
 // the (x, y, w) gradients of its vertices in a small open-addressed LDS table first and flushes every slot once.
-constexpr int FPCDR_VT_SLOTS = 256;
+#ifndef FPCDR_VT_SLOTS_N
+#define FPCDR_VT_SLOTS_N 256
+#endif
+constexpr int FPCDR_VT_SLOTS = FPCDR_VT_SLOTS_N;      // (a power of two)
 struct VTable {
     int *key;             // [FPCDR_VT_SLOTS], -1 = free
     double (*acc)[3];     // [FPCDR_VT_SLOTS][3] = (x, y, w) sums in double (lds_add_f64)

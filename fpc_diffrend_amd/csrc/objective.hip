@@ -98,6 +98,52 @@ __device__ unsigned long long g_oprof[16];
 #define OPROF_ADD(slot, a_, b_)
 #endif
 
+// Vertex table of k_shade with FLOAT accumulators (-DFPCDR_SHADE_VT32=1): 3 KB instead of 6, which together with 72 VGPRs lets a CU hold
+// seven workgroups instead of six.  Adds are compare-and-swap loops (common.h lds_add_f32); they happen at run tails only.
+#ifndef FPCDR_SHADE_VT32
+#define FPCDR_SHADE_VT32 0
+#endif
+struct VTableF {
+    int *key;
+    float (*acc)[3];
+};
+__device__ __forceinline__ void vtablef_init(const VTableF &t, int tid, int nthreads) {
+    for (int k = tid; k < FPCDR_VT_SLOTS; k += nthreads) { t.key[k] = -1; t.acc[k][0] = 0.f; t.acc[k][1] = 0.f; t.acc[k][2] = 0.f; }
+}
+__device__ __forceinline__ void vtablef_add(const VTableF &t, float *gp, const int (&vk)[3], const float (&sm)[9]) {
+    unsigned int slot[3];
+    int old[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) slot[kk] = (((unsigned int)vk[kk] * 2654435761u) >> 16) & (FPCDR_VT_SLOTS - 1);
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) old[kk] = atomicCAS(&t.key[slot[kk]], -1, vk[kk]);
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+        const int key = vk[kk];
+        bool done = (old[kk] == -1 || old[kk] == key);
+        for (int probe = 1; probe < FPCDR_VT_SLOTS && !done; ++probe) {
+            slot[kk] = (slot[kk] + 1) & (FPCDR_VT_SLOTS - 1);
+            const int o = atomicCAS(&t.key[slot[kk]], -1, key);
+            done = (o == -1 || o == key);
+        }
+        if (done) {
+            lds_add_f32(&t.acc[slot[kk]][0], sm[3 * kk]); lds_add_f32(&t.acc[slot[kk]][1], sm[3 * kk + 1]); lds_add_f32(&t.acc[slot[kk]][2], sm[3 * kk + 2]);
+        } else {
+            atomicAdd(gp + 4 * (size_t)key + 0, sm[3 * kk]); atomicAdd(gp + 4 * (size_t)key + 1, sm[3 * kk + 1]); atomicAdd(gp + 4 * (size_t)key + 3, sm[3 * kk + 2]);
+        }
+    }
+}
+__device__ __forceinline__ void vtablef_flush(const VTableF &t, float *gp, int tid, int nthreads) {
+    for (int k = tid; k < FPCDR_VT_SLOTS * 4; k += nthreads) {
+        const int slot = k >> 2, comp = k & 3;
+        const int key = t.key[slot];
+        if (key >= 0 && comp != 2) {
+            const float v = t.acc[slot][comp == 3 ? 2 : comp];
+            if (v != 0.0f) atomicAdd(gp + 4 * (size_t)key + comp, v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_shade: one 32 x 32 bin, 256 threads, four pixels per thread.  A wave pass covers two adjacent rows of the bin, the second one right
 // to left, so that the pixels of a triangle are neighbours in lane order and ONE segmented scan per pass sums the nine vertex gradient
@@ -131,7 +177,9 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     __shared__ int s_org1[2];
     __shared__ unsigned int s_id[(OB + 2) * OS];
     __shared__ int s_vkey[FPCDR_VT_SLOTS];
-    __shared__ double s_vacc[FPCDR_VT_SLOTS][3];
+    __shared__ double s_vacc[FPCDR_SHADE_VT32 ? 1 : FPCDR_VT_SLOTS][3];
+    __shared__ float s_vaccf[FPCDR_SHADE_VT32 ? FPCDR_VT_SLOTS : 1][3];
+    const VTableF vtf = {s_vkey, s_vaccf};
     __shared__ double s_tex[OTW * OTW * CS];      // texel window, doubles: ds_add_f64 (common.h lds_add_f64)
     __shared__ int s_org[2];
     __shared__ unsigned int s_cmask[OB];
@@ -172,7 +220,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         const int tx = side == 0 ? 0 : (side == 1 ? OB + 1 : i + 1), ty = side == 2 ? 0 : (side == 3 ? OB + 1 : i + 1);
         s_id[ty * OS + tx] = e;
     }
-    if (want_pos) vtable_init(vt, tid, ONT);
+    if (want_pos) { if (FPCDR_SHADE_VT32) vtablef_init(vtf, tid, ONT); else vtable_init(vt, tid, ONT); }
     if (want_tex)
         for (int k = tid; k < OTW * OTW * CS; k += ONT) s_tex[k] = 0.0;
     if (MIP && want_tex)
@@ -406,7 +454,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
 #else
         if (want_pos)      // (uniform)
 #endif
-            wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) { vtable_add(vt, gp, vk, sm); });
+            wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) { if (FPCDR_SHADE_VT32) vtablef_add(vtf, gp, vk, sm); else vtable_add(vt, gp, vk, sm); });
     };
 
     if (MIP) {
@@ -478,7 +526,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     if (!want_grad) return;
     // ---- flush: every vertex slot and window cell once (the barrier above has made all adds visible) ----
 #ifndef FPCDR_OABL_NOVFLUSH
-    if (want_pos) vtable_flush(vt, gp, tid, ONT);
+    if (want_pos) { if (FPCDR_SHADE_VT32) vtablef_flush(vtf, gp, tid, ONT); else vtable_flush(vt, gp, tid, ONT); }
 #endif
 #ifdef FPCDR_OABL_NOTEXFLUSH
     if (false) {

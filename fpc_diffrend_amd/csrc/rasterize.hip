@@ -248,6 +248,7 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
                     box = {1, 1, 0, 0};
                 }
             } else {      // a vertex at or behind w = 0: clip against the near plane, one or two pieces
+#ifndef FPCDR_ABL_NOCLIP
                 double pc[2][3][4];
                 const float4 vv[3] = {v0, v1, v2};
                 const int np = clip_pieces(vv, pc);
@@ -271,6 +272,7 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
                         for (int gy = box2.y0 / BIN; gy <= box2.y1 / BIN; ++gy)
                             for (int gx = box2.x0 / BIN; gx <= box2.x1 / BIN; ++gx) live[((size_t)b * OY + gy) * OX + gx] = 1;
                 }
+#endif
             }
         }
         boxes[gid] = box;
