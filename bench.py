@@ -281,8 +281,8 @@ def cpu_baseline(sc, seconds_budget=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)      # (a timed region of ~0.15 s at cfg3: long enough for a GPU-busy sampler to land in)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg5", "ref"],
                     help="ref: the reference's own run shape -- ONE random (camera, frame) image of 1600 x 1200 per step (main.py:28-30, "
                          "fit.py:525-526), replayed as HIP graphs")
