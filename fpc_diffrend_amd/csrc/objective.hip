@@ -365,9 +365,10 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             // stand-alone kernels: the footprint of the texture coordinate from the barycentrics' screen derivatives
             const float e0x = q0.x - q2.x, e0y = q0.y - q2.y, e1x = q1.x - q2.x, e1y = q1.y - q2.y;
             float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
+            MipKeep<MIP ? CS : 1> MK;      // level arithmetic, tap sets and texels of the lookup, kept for its backward
             if (MIP) {
                 da = make_float4(db.x * e0x + db.z * e1x, db.y * e0x + db.w * e1x, db.x * e0y + db.z * e1y, db.y * e0y + db.w * e1y);
-                mip_sample_fwd(ma->lv, 0, ma->n_levels, make_float2(tu, tv), true, da, 0.0f, Ht, Wt, CS, true, boundary, [&](int c, float vv) { colv[c] = vv; });
+                mip_lookup_fwd<MIP ? CS : 1>(ma->lv, ma->n_levels, make_float2(tu, tv), da, Ht, Wt, boundary, MK, reinterpret_cast<float (&)[MIP ? CS : 1]>(colv));
             }
 #pragma unroll
             for (int c = 0; c < CS; ++c) {
@@ -401,14 +402,13 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             if (MIP && want_grad && nz) {
                 // texel gradients of levels 0 and 1 through the two LDS windows (origins: the prepass below), anything else to memory;
                 // the footprint's gradient goes back through the derivative outputs of the rasteriser
-                float gbias = 0.f;
                 const int lx0 = (int)floorf(prep_coord(tu, boundary) * (float)Wt - 0.5f) - ox;
                 const int ly0 = (int)floorf(prep_coord(tv, boundary) * (float)Ht - 0.5f) - oy;
                 const bool in0 = (unsigned int)lx0 < (unsigned int)(OTW - 1) && (unsigned int)ly0 < (unsigned int)(OTW - 1);
                 const int lx1 = (int)floorf(prep_coord(tu, boundary) * (float)(Wt >> 1) - 0.5f) - ox1;
                 const int ly1 = (int)floorf(prep_coord(tv, boundary) * (float)(Ht >> 1) - 0.5f) - oy1;
                 const bool in1 = (unsigned int)lx1 < (unsigned int)(OTW1 - 1) && (unsigned int)ly1 < (unsigned int)(OTW1 - 1);
-                mip_sample_bwd_to(ma->lv, 0, ma->n_levels, make_float2(tu, tv), true, da, 0.0f, Ht, Wt, CS, true, boundary, gq, gtu_m, gtv_m, gda, gbias,
+                mip_lookup_bwd<MIP ? CS : 1>(ma->lv, ma->n_levels, MK, reinterpret_cast<const float (&)[MIP ? CS : 1]>(gq), Ht, Wt, gtu_m, gtv_m, gda,
                                   [&](int level, int tap, size_t offs, int c, float vv) {
                                       const int dx = tap & 1, dy = tap >> 1;
                                       if (level == 0 && in0) lds_add_f64(&s_tex[((ly0 + dy) * OTW + lx0 + dx) * CS + c], vv);

@@ -279,3 +279,90 @@ __device__ __forceinline__ void mip_sample_bwd(const TexLevels &lv, size_t b, in
     mip_sample_bwd_to(lv, b, n_levels, q, has_da, da, bias, Ht, Wt, C, trilinear, boundary, g, gu, gv, gda, gbias,
                       [&](int level, int, size_t off, int c, float v) { atomicAdd(lv.grad[level] + off + c, v); });
 }
+
+// ---- one trilinear lookup, forward AND backward (the one-pass objective's MIP instantiation, objective.hip) -------------------------
+// mip_sample_fwd + mip_sample_bwd_to build four tap sets and load every texel three times (forward, tap gradients, the level
+// fraction's gradient).  A pixel that is shaded and chained back by the same thread keeps the level arithmetic, the two tap sets and
+// the eight texels per channel instead: same formulas in the same order, so the values are those of the two generic routines.
+template <int CS>
+struct MipKeep {
+    Lod L;
+    float raw, fl;
+    int l0, l1;
+    Taps t0, t1;
+    float x0[CS][4], x1[CS][4];      // texels (00, 10, 01, 11) of level l0 / l1, masked for boundary mode 'zero'
+    float c0[CS], c1[CS];            // bilinear values of the two levels
+};
+
+template <int CS>
+__device__ __forceinline__ void mip_lookup_fwd(const TexLevels &lv, int n_levels, float2 q, float4 da, int Ht, int Wt, int boundary,
+                                               MipKeep<CS> &K, float (&col)[CS]) {
+    K.L = compute_lod(da, Ht, Wt, 0.0f);
+    K.raw = K.L.level;
+    const float level = fminf(fmaxf(K.raw, 0.0f), (float)n_levels);
+    K.l0 = min((int)floorf(level), n_levels);
+    K.fl = level - (float)K.l0;
+    K.l1 = min(K.l0 + 1, n_levels);
+    const int h0 = Ht >> K.l0, w0 = Wt >> K.l0, h1 = Ht >> K.l1, w1 = Wt >> K.l1;
+    K.t0 = boundary == FPCDR_BOUNDARY_ZERO ? make_taps(q.x, q.y, h0, w0, CS, boundary) : make_taps_fast(q.x, q.y, h0, w0, CS, boundary);
+    K.t1 = boundary == FPCDR_BOUNDARY_ZERO ? make_taps(q.x, q.y, h1, w1, CS, boundary) : make_taps_fast(q.x, q.y, h1, w1, CS, boundary);
+    const float *tx0 = lv.tex[K.l0], *tx1 = lv.tex[K.l1];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+        load_taps<true>(tx0, K.t0, c, CS, K.x0[c][0], K.x0[c][1], K.x0[c][2], K.x0[c][3]);
+        load_taps<true>(tx1, K.t1, c, CS, K.x1[c][0], K.x1[c][1], K.x1[c][2], K.x1[c][3]);
+    }
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+        mask_taps(K.t0, K.x0[c][0], K.x0[c][1], K.x0[c][2], K.x0[c][3]);
+        mask_taps(K.t1, K.x1[c][0], K.x1[c][1], K.x1[c][2], K.x1[c][3]);
+        const float top0 = K.x0[c][0] + (K.x0[c][1] - K.x0[c][0]) * K.t0.fx, bot0 = K.x0[c][2] + (K.x0[c][3] - K.x0[c][2]) * K.t0.fx;
+        const float top1 = K.x1[c][0] + (K.x1[c][1] - K.x1[c][0]) * K.t1.fx, bot1 = K.x1[c][2] + (K.x1[c][3] - K.x1[c][2]) * K.t1.fx;
+        K.c0[c] = top0 + (bot0 - top0) * K.t0.fy;
+        K.c1[c] = top1 + (bot1 - top1) * K.t1.fy;
+        col[c] = K.c0[c] + (K.c1[c] - K.c0[c]) * K.fl;
+    }
+}
+
+// scatter(level, tap 0..3, element offset inside the level's image, channel, value); gu, gv: gradient of the texture coordinate (the
+// caller applies the clamp-mode mask); gda: gradient of the footprint
+template <int CS, typename Scatter>
+__device__ __forceinline__ void mip_lookup_bwd(const TexLevels &lv, int n_levels, const MipKeep<CS> &K, const float (&g)[CS], int Ht, int Wt,
+                                               float &gu, float &gv, float4 &gda, Scatter &&scatter) {
+    const int w0 = Wt >> K.l0, h0 = Ht >> K.l0, w1 = Wt >> K.l1, h1 = Ht >> K.l1;
+    auto level_bwd = [&](int l, const Taps &t, const float (&x)[CS][4], float scale, float &gfx, float &gfy) {
+        const float w00 = (1.0f - t.fx) * (1.0f - t.fy), w10 = t.fx * (1.0f - t.fy), w01 = (1.0f - t.fx) * t.fy, w11 = t.fx * t.fy;
+        const bool want = lv.grad[l] != nullptr;
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+            const float gc = g[c] * scale;
+            gfx += gc * ((x[c][1] - x[c][0]) * (1.0f - t.fy) + (x[c][3] - x[c][2]) * t.fy);
+            gfy += gc * ((x[c][2] + (x[c][3] - x[c][2]) * t.fx) - (x[c][0] + (x[c][1] - x[c][0]) * t.fx));
+            if (want && gc != 0.0f) {
+                if (t.valid & 1u) scatter(l, 0, (size_t)t.i00, c, gc * w00);
+                if (t.valid & 2u) scatter(l, 1, (size_t)t.i10, c, gc * w10);
+                if (t.valid & 4u) scatter(l, 2, (size_t)t.i01, c, gc * w01);
+                if (t.valid & 8u) scatter(l, 3, (size_t)t.i11, c, gc * w11);
+            }
+        }
+    };
+    float gfx0 = 0.f, gfy0 = 0.f, gfx1 = 0.f, gfy1 = 0.f;
+    level_bwd(K.l0, K.t0, K.x0, 1.0f - K.fl, gfx0, gfy0);
+    level_bwd(K.l1, K.t1, K.x1, K.fl, gfx1, gfy1);
+    gu = gfx0 * (float)w0; gv = gfy0 * (float)h0;
+    gu += gfx1 * (float)w1;
+    gv += gfy1 * (float)h1;
+    float gfl = 0.f;
+#pragma unroll
+    for (int c = 0; c < CS; ++c) gfl += g[c] * (K.c1[c] - K.c0[c]);
+    const float glevel = (K.raw >= 0.0f && K.raw <= (float)n_levels) ? gfl : 0.0f;
+    const Lod &L = K.L;
+    const float gl2 = (L.l2 >= 1e-30f) ? glevel * 0.5f / (L.l2 * 0.6931471805599453f) : 0.0f;
+    const float gdf = gl2 * L.df / L.rt, gbq = gl2 * L.bq / L.rt;
+    const float gA = 0.5f * gl2 + 0.5f * gdf, gC = 0.5f * gl2 - 0.5f * gdf;
+    const float g_dudx = 2.0f * L.dudx * gA + L.dvdx * gbq;
+    const float g_dudy = 2.0f * L.dudy * gA + L.dvdy * gbq;
+    const float g_dvdx = 2.0f * L.dvdx * gC + L.dudx * gbq;
+    const float g_dvdy = 2.0f * L.dvdy * gC + L.dudy * gbq;
+    gda = make_float4(g_dudx * (float)Wt, g_dudy * (float)Wt, g_dvdx * (float)Ht, g_dvdy * (float)Ht);
+}
