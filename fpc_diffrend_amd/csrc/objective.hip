@@ -203,10 +203,12 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     OPROF_DECL;
     OPROF_T(0);
     // ---- phase 0: the bin's ids with a one-pixel apron from the neighbours' planes; tables ----
+    unsigned int sil_seen;      // silhouette bits of the entries this thread loads (own plane + apron), OR-ed
     {
         const uint4 v = reinterpret_cast<const uint4 *>(a.idp + bin_lin * (OB * OB))[tid];
         unsigned int *d = &s_id[((tid >> 3) + 1) * OS + (tid & 7) * 4 + 1];
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        sil_seen = (v.x | v.y | v.z | v.w) >> 24;
     }
     if (tid < 4 * OB) {
         const int side = tid >> 5, i = tid & 31;      // 0 left, 1 right, 2 below, 3 above
@@ -219,6 +221,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         }
         const int tx = side == 0 ? 0 : (side == 1 ? OB + 1 : i + 1), ty = side == 2 ? 0 : (side == 3 ? OB + 1 : i + 1);
         s_id[ty * OS + tx] = e;
+        sil_seen |= e >> 24;
     }
     if (want_pos) { if (FPCDR_SHADE_VT32) vtablef_init(vtf, tid, ONT); else vtable_init(vt, tid, ONT); }
     if (want_tex)
@@ -231,7 +234,9 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         s_fy[tid] = (2.0f * (float)(by0 + tid) + 1.0f) / (float)H - 1.0f;      // NDC y of the bin's rows: one IEEE division per row
     }
     OPROF_T(1);
-    __syncthreads();
+    // (barrier: plane, apron and tables are in place.)  A pixel pair can be deferred only if one of its triangles owns a silhouette edge:
+    // four bins in five of a face show none at all -- the interior of the mesh -- and skip the four neighbour tests of their pixels
+    const bool bin_sil = __builtin_amdgcn_readfirstlane(__syncthreads_or(sil_seen != 0u ? 1 : 0)) != 0;
     OPROF_T(2);
 
     const size_t img = (size_t)b * H * W;
@@ -327,10 +332,13 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             pn0 = ld32(pos_img, tn.a); pn1 = ld32(pos_img, tn.b); pn2 = ld32(pos_img, tn.c);
         }
         if (id > 0) {
-            const unsigned int nR = s_id[(zy + 1) * OS + col + 2], nL = s_id[(zy + 1) * OS + col];
-            const unsigned int nU = s_id[(zy + 2) * OS + col + 1], nD = s_id[zy * OS + col + 1];
-            const bool deferred = (x + 1 < W && pair_maybe(me, nR)) || (y + 1 < H && pair_maybe(me, nU)) || (x > 0 && pair_maybe(me, nL)) ||
-                                  (y > 0 && pair_maybe(me, nD));
+            bool deferred = false;
+            if (bin_sil) {      // (uniform)
+                const unsigned int nR = s_id[(zy + 1) * OS + col + 2], nL = s_id[(zy + 1) * OS + col];
+                const unsigned int nU = s_id[(zy + 2) * OS + col + 1], nD = s_id[zy * OS + col + 1];
+                deferred = (x + 1 < W && pair_maybe(me, nR)) || (y + 1 < H && pair_maybe(me, nU)) || (x > 0 && pair_maybe(me, nL)) ||
+                           (y > 0 && pair_maybe(me, nD));
+            }
             const int t = id - 1;
             const I3 ti = FPCDR_SHADE_PREFETCH ? ti4[k] : ld32(reinterpret_cast<const I3 *>(a.tri), t);
             const float4 v0 = FPCDR_SHADE_PREFETCH ? pv0 : ld32(pos_img, ti.a), v1 = FPCDR_SHADE_PREFETCH ? pv1 : ld32(pos_img, ti.b),
