@@ -457,7 +457,7 @@ def main():
         sparse_px = {}
         for key, h in dr_ops._list_hints.items():
             if key[0] == 'onepass' and key[2] == fpg * n_cam:      # one-pass objective: live bins of the rasteriser, occupied bins
-                _, _, n_bins, n_occ = (int(v) for v in h.host.tolist())
+                _, _, n_bins, n_occ = (int(v) for v in h.host[:4].tolist())
                 sparse_px = {"fpcdr_objective_fwd": n_occ * 1024}
                 out["config"]["occupied_bins"] = {"rasteriser": n_bins, "shaded": n_occ,
                                                   "of": fpg * n_cam * ((H + 31) // 32) * ((W + 31) // 32)}

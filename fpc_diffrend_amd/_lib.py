@@ -14,7 +14,7 @@ MAX_ATTR = 32
 MAX_MIP = 16
 LOSS_SLOTS = 256
 OCC_BIN = 32         # FPCDR_OCC_BIN
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
 BOUNDARY = {'wrap': 0, 'clamp': 1, 'zero': 2}
@@ -69,7 +69,9 @@ class Objective(ctypes.Structure):
                 ("grad_scale", ctypes.c_float), ("sil", _p), ("idp", _p), ("occ", _p), ("cmask", _p), ("rec", _p), ("color", _p),
                 ("grad_aa", _p), ("empty_color", _p), ("loss_sum", _p), ("grad_pos", _p), ("grad_tex", _p), ("cap_bins", _i),
                 ("cap_occ", _i), ("cap_def", _i), ("sil_ready", _i), ("flags", _p), ("mip", _i), ("n_levels", _i),
-                ("tex_mip", _p * MAX_MIP), ("grad_tex_mip", _p * MAX_MIP), ("binlist", _p), ("sil_event", _p)]
+                ("tex_mip", _p * MAX_MIP), ("grad_tex_mip", _p * MAX_MIP), ("binlist", _p), ("sil_event", _p),
+                ("zero_outputs", _i), ("counts_seq", _i), ("counts_out", _p), ("bg_sumsq", _p), ("bg_coeff", ctypes.c_double),
+                ("n_total", ctypes.c_double), ("value_out", _p), ("zero_extra", _p), ("zero_extra_bytes", ctypes.c_int64), ("setup_event", _p)]
 
 
 class InterpolateFwd(ctypes.Structure):

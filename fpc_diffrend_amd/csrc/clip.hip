@@ -79,6 +79,73 @@ __global__ void __launch_bounds__(256) k_clip_bwd_mvp(const float *__restrict__ 
     }
 }
 
+// Both gradients from ONE pass over grad_out (69 MB at 288 x 15 k vertices, read twice by the two kernels above: 2 x 16 us): a thread
+// takes CLIP_VPT vertices of one frame (a workgroup 256 * CLIP_VPT consecutive ones) through all views, as k_clip_bwd_verts does for
+// one; the 16 products of a view are summed over the thread's vertices first, then over the wave (DPP), then over the four waves through
+// an LDS row per view: one atomic per (view, entry) and workgroup.  (One vertex per thread spends the kernel on the 144 wave sums.)
+constexpr int CLIP_VIEWS = 16;      // views per LDS round
+constexpr int CLIP_VPT = 4;
+__global__ void __launch_bounds__(256) k_clip_bwd_both(const float *__restrict__ mvp, const float *__restrict__ verts,
+                                                       const float4 *__restrict__ g, int V, int Nc, float *__restrict__ g_verts,
+                                                       float *__restrict__ g_mvp) {
+    __shared__ float s_part[CLIP_VIEWS][4][16];
+    const int f = blockIdx.y;
+    const int v0 = blockIdx.x * (256 * CLIP_VPT) + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float pw[CLIP_VPT][4], gx[CLIP_VPT], gy[CLIP_VPT], gz[CLIP_VPT];
+    bool ok[CLIP_VPT];
+#pragma unroll
+    for (int u = 0; u < CLIP_VPT; ++u) {
+        const int v = v0 + u * 256;
+        ok[u] = v < V;
+        const float *pv = verts + ((size_t)f * V + (ok[u] ? v : 0)) * 3;
+        pw[u][0] = ok[u] ? pv[0] : 0.0f; pw[u][1] = ok[u] ? pv[1] : 0.0f; pw[u][2] = ok[u] ? pv[2] : 0.0f; pw[u][3] = ok[u] ? 1.0f : 0.0f;
+        gx[u] = 0.f; gy[u] = 0.f; gz[u] = 0.f;
+    }
+    for (int c0 = 0; c0 < Nc; c0 += CLIP_VIEWS) {
+        const int nc = min(CLIP_VIEWS, Nc - c0);
+        for (int c = 0; c < nc; ++c) {
+            const int b = f * Nc + c0 + c;
+            const float *m = mvp + (size_t)b * 16;
+            float4 q[CLIP_VPT];
+#pragma unroll
+            for (int u = 0; u < CLIP_VPT; ++u) q[u] = ok[u] ? g[(size_t)b * V + v0 + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int u = 0; u < CLIP_VPT; ++u) {
+                gx[u] += q[u].x * m[0] + q[u].y * m[4] + q[u].z * m[8] + q[u].w * m[12];
+                gy[u] += q[u].x * m[1] + q[u].y * m[5] + q[u].z * m[9] + q[u].w * m[13];
+                gz[u] += q[u].x * m[2] + q[u].y * m[6] + q[u].z * m[10] + q[u].w * m[14];
+                const float gi[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i * 4 + j] += gi[i] * pw[u][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float sm = wave_sum_dpp(acc[i]);
+                if (lane == 0) s_part[c][wave][i] = sm;
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nc * 16; e += 256) {
+            const int c = e >> 4, i = e & 15;
+            const float sm = s_part[c][0][i] + s_part[c][1][i] + s_part[c][2][i] + s_part[c][3][i];
+            if (sm != 0.0f) atomicAdd(g_mvp + (size_t)(f * Nc + c0 + c) * 16 + i, sm);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < CLIP_VPT; ++u)
+        if (ok[u]) {
+            float *o = g_verts + ((size_t)f * V + v0 + u * 256) * 3;
+            o[0] = gx[u]; o[1] = gy[u]; o[2] = gz[u];
+        }
+}
+
 // Uniform-Laplacian gather over a static, padded one-ring table (reference regulariser, fit.py:581 via pytorch3d):
 //   mode 0 (forward):   out[f][v] = inv_deg[v] * sum_n x[f][n] - x[f][v]            (L x,   L = D^-1 A - I)
 //   mode 1 (backward):  out[f][v] = sum_n inv_deg[n] * x[f][n] - x[f][v]            (L^T x, L^T = A D^-1 - I)
@@ -384,6 +451,12 @@ extern "C" int fpcdr_transform_clip_bwd(const float *mvp, const float *verts, co
     FPCDR_REQUIRE(mvp && verts && grad_out, "null pointer");
     FPCDR_REQUIRE(F > 0 && Nc > 0 && V > 0 && (long long)F * Nc <= 65535, "bad sizes");
     hipStream_t st = (hipStream_t)stream;
+    if (grad_verts && grad_mvp) {
+        hipLaunchKernelGGL(k_clip_bwd_both, dim3(fpcdr_cdiv(V, 256 * CLIP_VPT), F), dim3(256), 0, st, mvp, verts, (const float4 *)grad_out, V, Nc,
+                           grad_verts, grad_mvp);
+        FPCDR_CHECK_LAUNCH();
+        return FPCDR_OK;
+    }
     if (grad_verts)
         hipLaunchKernelGGL(k_clip_bwd_verts, dim3(fpcdr_cdiv(V, 256), F), dim3(256), 0, st, mvp, (const float4 *)grad_out, V, Nc,
                            grad_verts);

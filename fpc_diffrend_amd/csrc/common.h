@@ -36,7 +36,16 @@ int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, i
 int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask, const unsigned long long *edges,
                         const int32_t *fix_list, const int32_t *fix_count, int nbins, hipStream_t st);
 
-int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, const int32_t **occ_list, const int32_t **n_occ_dev);
+// buffers the first kernel of fpcdr_objective_fwd zero-fills beside its own maps (fpcdr_objective_params.zero_outputs): 4-byte words
+struct FpcdrZeroList {
+    static constexpr int MAXR = 24;
+    uint32_t *p[MAXR];
+    long long n[MAXR];
+    int count;
+    __host__ void add(void *ptr, long long words) { if (ptr && words > 0 && count < MAXR) { p[count] = (uint32_t *)ptr; n[count] = words; ++count; } }
+};
+int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, const int32_t **occ_list, const int32_t **n_occ_dev,
+                            const FpcdrZeroList &zl);
 
 // workgroups of the strided sweep behind a hinted single-shot launch (normally they find nothing to do)
 #define FPCDR_SWEEP_WGS 256

@@ -47,7 +47,7 @@ struct ObjArgs {
     const float4 *pos; const int32_t *tri; const float2 *uv; const int32_t *uv_tri; const float2 *tri_uv;
     const float *tex; const uint8_t *ref; const uint8_t *sil;
     const uint32_t *idp; const uint16_t *occ; uint8_t *binflag; uint32_t *cmask;
-    float *esum;            // [ESLOTS][4]: gradient arriving at the colour of EMPTY pixels (k_fix<1> -> k_esum_finish), zeroed by the call
+    float *esum;            // [ESLOTS][4]: gradient arriving at the colour of EMPTY pixels (k_fix<1> -> k_objective_finish), zeroed by the call
     int32_t *def_list, *def_count;      // bins that hold a deferred pixel, appended by k_shade (k_fix runs over these only)
     uint32_t *hitmask;      // [bins][32] row masks of the pixels that took part in a blend (k_fix<0> -> k_fix<1>); zeroed per bin by k_shade
     float4 *rec; float *color; float *g_aa; const float *empty_color;
@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(ONT) k_shade_queue(const int32_t *__restrict__
 // Small open-addressed LDS accumulators of k_fix<1>: key -> NV doubles.  The few dozen pixels of a bin that took part in a blend share
 // vertices and texels: scattered float atomics retire slowly (the pass spent its time on ~650 of them per bin), so they are summed in
 // LDS first and every slot is flushed once.  A full table falls back to memory.
-constexpr int ESLOTS = 32;               // slots of the empty pixels' colour gradient (see k_esum_finish)
+constexpr int ESLOTS = 32;               // slots of the empty pixels' colour gradient (see k_objective_finish)
 constexpr int FVS = 64, FTS = 128;       // vertex / texel slots (LDS per wave decides how many bins a CU has in flight: 5.5 KB -> 28)
 __device__ __forceinline__ int hacc_slot(int *keys, int mask, int key) {
     unsigned int slot = (((unsigned int)key * 2654435761u) >> 16) & (unsigned int)mask;
@@ -998,7 +998,7 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
     if (PASS == 1 && a.grad_tex) {
         // empty pixels blended into covered ones: they ALL sample uv = (0,0), i.e. the same four texels with the same weights.  Every
         // wave adding to those four addresses itself serialised ~55 k atomics on four cache lines: 210 us of this kernel whatever else
-        // it did.  The scalar is summed in a few slots instead and scattered once by k_esum_finish.
+        // it did.  The scalar is summed in a few slots instead and scattered once by k_objective_finish.
         const unsigned int slot = ((unsigned int)bxi + 31u * (unsigned int)byi + 977u * (unsigned int)b) % ESLOTS;
 #pragma unroll
         for (int c = 0; c < CS; ++c) {
@@ -1008,19 +1008,46 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
     }
 }
 
-// the empty pixels' share of the texture gradient: sum of the slots, times the four bilinear weights of uv = (0,0)
+// The last kernel of the call, one wave:
+//  * the empty pixels' share of the texture gradient: sum of the slots, times the four bilinear weights of uv = (0,0);
+//  * the objective's value from the loss slots (the arithmetic of k_objective_value, loss.hip);
+//  * the launch-hint counters of the occupancy header copied to where the caller wants them -- host-mapped memory as a rule -- with
+//    the caller's sequence number behind them.
+struct FinishArgs {
+    int32_t *counts_out; int32_t counts_seq;
+    const double *bg_sumsq; double bg_coeff, n_total; float *value_out;
+    int esum;
+};
 template <int CS>
-__global__ void __launch_bounds__(64) k_esum_finish(ObjArgs a) {
+__global__ void __launch_bounds__(64) k_objective_finish(ObjArgs a, FinishArgs f) {
     const int c = threadIdx.x;
-    if (c >= CS) return;
-    float e = 0.0f;
-    for (int sl = 0; sl < ESLOTS; ++sl) e += a.esum[4 * sl + c];
-    if (e == 0.0f) return;
-    const Taps tp0 = make_taps(0.0f, 0.0f, a.Ht, a.Wt, CS, a.boundary);
-    if (tp0.valid & 1u) atomicAdd(a.grad_tex + tp0.i00 + c, e * ((1.0f - tp0.fx) * (1.0f - tp0.fy)));
-    if (tp0.valid & 2u) atomicAdd(a.grad_tex + tp0.i10 + c, e * (tp0.fx * (1.0f - tp0.fy)));
-    if (tp0.valid & 4u) atomicAdd(a.grad_tex + tp0.i01 + c, e * ((1.0f - tp0.fx) * tp0.fy));
-    if (tp0.valid & 8u) atomicAdd(a.grad_tex + tp0.i11 + c, e * (tp0.fx * tp0.fy));
+    if (f.esum && c < CS) {
+        float e = 0.0f;
+        for (int sl = 0; sl < ESLOTS; ++sl) e += a.esum[4 * sl + c];
+        if (e != 0.0f) {
+            const Taps tp0 = make_taps(0.0f, 0.0f, a.Ht, a.Wt, CS, a.boundary);
+            if (tp0.valid & 1u) atomicAdd(a.grad_tex + tp0.i00 + c, e * ((1.0f - tp0.fx) * (1.0f - tp0.fy)));
+            if (tp0.valid & 2u) atomicAdd(a.grad_tex + tp0.i10 + c, e * (tp0.fx * (1.0f - tp0.fy)));
+            if (tp0.valid & 4u) atomicAdd(a.grad_tex + tp0.i01 + c, e * ((1.0f - tp0.fx) * tp0.fy));
+            if (tp0.valid & 8u) atomicAdd(a.grad_tex + tp0.i11 + c, e * (tp0.fx * tp0.fy));
+        }
+    }
+    if (f.value_out) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < FPCDR_LOSS_SLOTS; i += 64) acc += a.loss_sum[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (threadIdx.x == 0) {
+            if (f.bg_sumsq) acc = acc + f.bg_coeff * f.bg_sumsq[0];
+            f.value_out[0] = (float)(acc / f.n_total);
+        }
+    }
+    if (f.counts_out && threadIdx.x == 0) {
+        volatile int32_t *o = f.counts_out;
+        for (int i = 0; i < 4; ++i) o[i] = a.def_count[i];
+        __threadfence_system();
+        o[4] = f.counts_seq;
+    }
 }
 
 template <int CS>
@@ -1111,15 +1138,28 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
     int rc = p->sil_ready ? FPCDR_OK : fpcdr_launch_sil(p->pos, p->tri, p->adj, p->B, p->V, p->T, p->H, p->W, p->sil, nullptr, 0, st);
     if (rc) return rc;
     const int32_t *occ_list = nullptr, *n_occ = nullptr;
-    rc = fpcdr_launch_raster_ids(p, st, &occ_list, &n_occ);
-    if (rc) return rc;
     const int OX = FPCDR_OCC_DIM(p->W), OY = FPCDR_OCC_DIM(p->H);
     const long long nbins = (long long)p->B * OY * OX;
     const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W);
     // (the border-line region of cmask, 1 KB per bin, is free in this form: 128 B per bin of hit masks, then the slots)
     float *esum_slots = (float *)((char *)p->cmask + q.cm_edges + (size_t)nbins * 128);
     static_assert(ESLOTS * 4 * sizeof(float) <= 1024 - 128, "the slots must fit behind one bin's hit masks");
-    if (p->grad_tex) FPCDR_REQUIRE(hipMemsetAsync(esum_slots, 0, ESLOTS * 4 * sizeof(float), st) == hipSuccess, "memset failed");
+    // what the first kernel zero-fills beside its own maps: the slots, and with zero_outputs the caller's accumulators
+    FpcdrZeroList zl = {};
+    if (p->grad_tex) zl.add(esum_slots, ESLOTS * 4);
+    if (p->zero_outputs) {
+        zl.add(p->loss_sum, (long long)FPCDR_LOSS_SLOTS * 2);
+        zl.add(p->grad_pos, (long long)p->B * p->V * 4);
+        zl.add(p->grad_tex, (long long)p->Ht * p->Wt * p->C);
+        if (p->mip && p->grad_tex)
+            for (int lvl = 1; lvl <= p->n_levels; ++lvl) zl.add(p->grad_tex_mip[lvl - 1], (long long)(p->Ht >> lvl) * (p->Wt >> lvl) * p->C);
+    }
+    if (p->zero_extra) {
+        FPCDR_REQUIRE(p->zero_extra_bytes >= 0 && (p->zero_extra_bytes & 3) == 0 && ((size_t)p->zero_extra & 3) == 0, "zero_extra: 4-byte units");
+        zl.add(p->zero_extra, p->zero_extra_bytes / 4);
+    }
+    rc = fpcdr_launch_raster_ids(p, st, &occ_list, &n_occ, zl);
+    if (rc) return rc;
     ObjArgs a = {(const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, (const float2 *)p->tri_uv, p->tex, p->ref, p->sil,
                  p->idp, p->occ, (uint8_t *)p->occ + q.occ_binflag, p->cmask, esum_slots, (int32_t *)((char *)p->occ + q.occ_bwd_list),
                  (int32_t *)((char *)p->occ + q.occ_hdr), (uint32_t *)((char *)p->cmask + q.cm_edges), (float4 *)p->rec, p->color, p->grad_aa, p->empty_color,
@@ -1144,6 +1184,12 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         if (sweep_d) hipLaunchKernelGGL((k_fix_queue<CS, PASS>), dim3(FPCDR_SWEEP_WGS), dim3(FNT), 0, st, a.def_list, a.def_count, cap_d, OX, OY, dc, a); \
     } while (0)
     const bool grads = p->grad_pos || p->grad_tex;
+    const FinishArgs fin = {p->counts_out, p->counts_seq, p->bg_sumsq, p->bg_coeff, p->n_total, p->value_out, p->grad_tex ? 1 : 0};
+    FPCDR_REQUIRE(!p->value_out || p->n_total > 0.0, "value_out needs n_total > 0");
+#define FINISH(CS)                                                                                                                \
+    do {                                                                                                                          \
+        if (fin.esum || fin.value_out || fin.counts_out) hipLaunchKernelGGL(k_objective_finish<CS>, dim3(1), dim3(64), 0, st, a, fin); \
+    } while (0)
     if (p->mip) {      // the reference's enable_mip branch (fit.py:153-155)
         MipO ma;
         ma.lv.tex[0] = p->tex;
@@ -1163,9 +1209,9 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         hipLaunchKernelGGL(k_fix_mip_list<CS>, grid_d, dim3(FNT), 0, st, a.def_list, a.def_count, cap_d, OX, OY, dc, a, ma);       \
         if (sweep_d) hipLaunchKernelGGL(k_fix_mip_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(FNT), 0, st, a.def_list, a.def_count, cap_d, OX, OY, dc, a, ma); \
     } while (0)
-        if (p->C == 1) { SHADE_MIP(1); FIX(1, 0); if (grads) FIX_MIP(1); if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<1>, dim3(1), dim3(64), 0, st, a); }
-        else if (p->C == 3) { SHADE_MIP(3); FIX(3, 0); if (grads) FIX_MIP(3); if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<3>, dim3(1), dim3(64), 0, st, a); }
-        else { SHADE_MIP(4); FIX(4, 0); if (grads) FIX_MIP(4); if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<4>, dim3(1), dim3(64), 0, st, a); }
+        if (p->C == 1) { SHADE_MIP(1); FIX(1, 0); if (grads) FIX_MIP(1); FINISH(1); }
+        else if (p->C == 3) { SHADE_MIP(3); FIX(3, 0); if (grads) FIX_MIP(3); FINISH(3); }
+        else { SHADE_MIP(4); FIX(4, 0); if (grads) FIX_MIP(4); FINISH(4); }
 #undef SHADE_MIP
 #undef FIX_MIP
     } else
@@ -1174,20 +1220,21 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         else SHADE(1, -1);
         FIX(1, 0);
         if (grads) FIX(1, 1);
-        if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<1>, dim3(1), dim3(64), 0, st, a);
+        FINISH(1);
     } else if (p->C == 3) {
         SHADE(3, -1);
         FIX(3, 0);
         if (grads) FIX(3, 1);
-        if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<3>, dim3(1), dim3(64), 0, st, a);
+        FINISH(3);
     } else {
         SHADE(4, -1);
         FIX(4, 0);
         if (grads) FIX(4, 1);
-        if (p->grad_tex) hipLaunchKernelGGL(k_esum_finish<4>, dim3(1), dim3(64), 0, st, a);
+        FINISH(4);
     }
 #undef SHADE
 #undef FIX
+#undef FINISH
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }

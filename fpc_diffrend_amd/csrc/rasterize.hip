@@ -25,6 +25,7 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -370,6 +371,33 @@ __global__ void __launch_bounds__(256) k_init_queue(ImgBox *ibox, int B, uint32_
         for (long long i = i0; i < n_bins; i += stride) bin_cnt[i] = 0;      // per-bin triangle counts (k_setup<true>)
 }
 
+// the same for the one-pass objective, plus the caller's output buffers (zero_outputs): the gradient tables are 70 MB at 288 x 15 k
+// vertices, so 16-byte stores and a grid that fills the chip
+__global__ void __launch_bounds__(256) k_init_objective(ImgBox *ibox, int B, uint32_t *__restrict__ live_words, long long n_live_words,
+                                                        uint32_t *__restrict__ occ_words, long long n_occ_words, int32_t *__restrict__ hdr,
+                                                        int32_t *__restrict__ hdr_bwd, int32_t *__restrict__ bin_cnt, long long n_bins,
+                                                        FpcdrZeroList zl) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    if (i0 < B) ibox[i0] = {0x7fffffff, 0x7fffffff, -1, -1, 0, 0, 0, 0};
+    if (i0 < 16) { hdr[i0] = 0; hdr_bwd[i0] = 0; }
+    for (long long i = i0; i < n_live_words; i += stride) live_words[i] = 0u;
+    for (long long i = i0; i < n_occ_words; i += stride) occ_words[i] = 0u;
+    if (bin_cnt)
+        for (long long i = i0; i < n_bins; i += stride) bin_cnt[i] = 0;
+    for (int r = 0; r < zl.count; ++r) {
+        uint32_t *p = zl.p[r];
+        const long long n = zl.n[r];
+        long long done = 0;
+        if (((size_t)p & 15) == 0) {
+            uint4 *q = reinterpret_cast<uint4 *>(p);
+            const long long n4 = n >> 2;
+            for (long long i = i0; i < n4; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+            done = n4 << 2;
+        }
+        for (long long i = done + i0; i < n; i += stride) p[i] = 0u;
+    }
+}
+
 // ---- ordered compaction of per-bin flags into lists (ascending bin index: neighbouring bins, which share vertices and
 // texels, stay neighbours in launch order; appending with atomics scrambles them at wave granularity and cost the
 // backward pass 10 %) -- three tiny kernels: per-block counts, one-workgroup scan, ordered write ----
@@ -487,6 +515,54 @@ __global__ void __launch_bounds__(256) k_list_write(const uint8_t *__restrict__ 
         int off = blk_offsets[(size_t)k * gridDim.x + blockIdx.x];
         for (int w = 0; w < wave; ++w) off += s_c[k][w];
         list[off + __popcll(bal[k] & ((1ull << lane) - 1ull))] = (int32_t)i;
+    }
+}
+
+// ---- the same ordered compaction as TWO launches (one-pass objective: each round's three launches sit in the call's serial path):
+// k_list_count as above, then a write kernel in which every workgroup sums the counts of the workgroups before it itself (2 295 counts at
+// 288 x 1080p: nine loads per thread) instead of reading offsets a one-workgroup scan kernel has left.  Up to LW_MAX_BLOCKS workgroups;
+// the three-launch form beyond.  (A ONE-launch form -- workgroups publish their totals with a valid bit and wait for their predecessors'
+// -- was measured at 587 k bins: 21 / 33 us per round with 2 048 bins per workgroup, 40 / 41 us with 256, against 17 / 24 us for the three
+// launches: the waiting costs more than the launches.)
+constexpr int LW_MAX_BLOCKS = 16384;
+template <int ROUND_B>
+__global__ void __launch_bounds__(256) k_list_write_sum(const uint8_t *__restrict__ map, long long nbins, int OY, int OX,
+                                                        const int32_t *__restrict__ blk_counts, int32_t *__restrict__ list0,
+                                                        int32_t *__restrict__ list1, int32_t *__restrict__ count0, int32_t *__restrict__ count1) {
+    __shared__ int s_c[NLISTS][4];
+    __shared__ int s_pre[NLISTS][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nblk = gridDim.x, b = blockIdx.x;
+    int pre[NLISTS] = {0, 0};
+    for (int j = tid; j < b; j += 256) {
+        pre[0] += blk_counts[j];
+        if (list1) pre[1] += blk_counts[(size_t)nblk + j];
+    }
+    const long long i = (long long)b * 256 + tid;
+    bool f[NLISTS];
+    unsigned int m;
+    bin_flags<ROUND_B>(map, i, nbins, OY, OX, f, m);
+    unsigned long long bal[NLISTS];
+#pragma unroll
+    for (int k = 0; k < NLISTS; ++k) {
+        bal[k] = __ballot(f[k]);
+        int v = pre[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) { s_c[k][wave] = __popcll(bal[k]); s_pre[k][wave] = v; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NLISTS; ++k) {
+        int32_t *list = k == 0 ? list0 : list1;
+        if (!list) continue;
+        const int base = s_pre[k][0] + s_pre[k][1] + s_pre[k][2] + s_pre[k][3];
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += s_c[k][w];
+        if (f[k]) list[off + __popcll(bal[k] & ((1ull << lane) - 1ull))] = (int32_t)i;
+        if (b == nblk - 1 && tid == 0) {
+            int32_t *dst = k == 0 ? count0 : count1;
+            if (dst) *dst = base + s_c[k][0] + s_c[k][1] + s_c[k][2] + s_c[k][3];
+        }
     }
 }
 
@@ -1628,7 +1704,8 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
 
 // First half of fpcdr_objective_fwd (objective.hip; not part of the C ABI): set-up, the list of live bins, the rasteriser in its IDS form
 // (id planes only) and the ordered list of OCCUPIED bins + window masks for the shading kernels.  The caller has run k_sil2.
-int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, const int32_t **occ_list, const int32_t **n_occ_dev) {
+int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, const int32_t **occ_list, const int32_t **n_occ_dev,
+                            const FpcdrZeroList &zl_in) {
     const RasterScratch rs = raster_scratch(p->scratch, p->B, p->T);
     const int OX = fpcdr_cdiv(p->W, BIN), OY = fpcdr_cdiv(p->H, BIN);
     const size_t nbins = (size_t)p->B * OY * OX;
@@ -1641,8 +1718,16 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
     uint8_t *occ_raw = (uint8_t *)(oc + q.occ_raw);
     // per-bin triangle lists (p->binlist: counts, then BL_CAP slots per bin), or the chunk scan for every bin when the caller gave none
     int32_t *bin_cnt = (int32_t *)p->binlist, *tri_lists = bin_cnt ? bin_cnt + align_up(nbins, 64) : nullptr;
-    hipLaunchKernelGGL(k_init_queue, dim3(256), dim3(256), 0, st, rs.ibox, p->B, (uint32_t *)live, (long long)(align_up(nbins, 4) / 4),
-                       (uint32_t *)oc, (long long)(q.occ_hdr / 4), hdr, hdr_occ, bin_cnt, (long long)nbins);
+    // list building: two launches per round (k_list_count, k_list_write_sum) up to LW_MAX_BLOCKS workgroups, three beyond
+    const int nblk = fpcdr_cdiv((long long)nbins, 256);
+    const bool two_launch_lists = nblk <= LW_MAX_BLOCKS;
+    int32_t *blk = (int32_t *)(cm + q.cm_blk);
+    const FpcdrZeroList &zl = zl_in;
+    long long zero_words = 0;
+    for (int r = 0; r < zl.count; ++r) zero_words += zl.n[r];
+    const int init_grid = (int)std::min<long long>(2048, std::max<long long>(256, zero_words / 4096));
+    hipLaunchKernelGGL(k_init_objective, dim3(init_grid), dim3(256), 0, st, rs.ibox, p->B, (uint32_t *)live, (long long)(align_up(nbins, 4) / 4),
+                       (uint32_t *)oc, (long long)(q.occ_hdr / 4), hdr, hdr_occ, bin_cnt, (long long)nbins, zl);
     if (bin_cnt)
         hipLaunchKernelGGL(k_setup<true>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                            p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr, bin_cnt, tri_lists);
@@ -1650,13 +1735,18 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
         hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                            p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr, (int32_t *)nullptr,
                            (int32_t *)nullptr);
+    if (p->setup_event)
+        FPCDR_REQUIRE(hipEventRecord((hipEvent_t)p->setup_event, st) == hipSuccess, "hipEventRecord(setup_event) failed");
     int32_t *n_bins = hdr_occ + 2, *n_occ = hdr_occ + 3;      // (include/fpcdr.h FPCDR_OCC_COUNTS_OFFSET)
-    const int nblk = fpcdr_cdiv((long long)nbins, 256);
-    int32_t *blk = (int32_t *)(cm + q.cm_blk);
     hipLaunchKernelGGL(k_list_count<0>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, (uint16_t *)nullptr,
                        p->tex, p->Ht, p->Wt, p->C, p->boundary_mode, p->empty_color);
-    hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, n_bins, (int32_t *)nullptr);
-    hipLaunchKernelGGL(k_list_write<0>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, bin_list, (int32_t *)nullptr);
+    if (two_launch_lists)
+        hipLaunchKernelGGL(k_list_write_sum<0>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, bin_list, (int32_t *)nullptr,
+                           n_bins, (int32_t *)nullptr);
+    else {
+        hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, n_bins, (int32_t *)nullptr);
+        hipLaunchKernelGGL(k_list_write<0>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, bin_list, (int32_t *)nullptr);
+    }
     ShadeArgs sh = {};
     sh.occ = occ_raw;
     sh.sil = p->sil;
@@ -1677,8 +1767,13 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
                            (float4 *)nullptr, (float4 *)nullptr, sh);
     hipLaunchKernelGGL(k_list_count<2>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, p->occ,
                        (const float *)nullptr, 0, 0, 0, 0, (float *)nullptr);
-    hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, n_occ, (int32_t *)nullptr);
-    hipLaunchKernelGGL(k_list_write<2>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, olist, (int32_t *)nullptr);
+    if (two_launch_lists)
+        hipLaunchKernelGGL(k_list_write_sum<2>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, olist, (int32_t *)nullptr,
+                           n_occ, (int32_t *)nullptr);
+    else {
+        hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, n_occ, (int32_t *)nullptr);
+        hipLaunchKernelGGL(k_list_write<2>, dim3(nblk), dim3(256), 0, st, occ_raw, (long long)nbins, OY, OX, blk, olist, (int32_t *)nullptr);
+    }
     FPCDR_CHECK_LAUNCH();
     *occ_list = olist;
     *n_occ_dev = n_occ;

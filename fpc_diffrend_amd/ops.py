@@ -318,6 +318,32 @@ class _ListHints:
         self.event.record()
 
 
+class _MappedHints:
+    """The same for the one-pass objective, without a copy in the stream: the call's last kernel writes the counters straight into
+    pinned host memory (fpcdr_objective_params.counts_out) with the call's sequence number behind them; poll() uses whatever has
+    landed (a device-to-host copy per step was a blit kernel between two barriers: ~20 us of the step's serial tail)."""
+
+    def __init__(self):
+        self.host = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self.seq = 0
+        self.seen = 0
+        self.caps = (0, 0, 0)       # live bins, occupied bins, bins with a deferred pixel
+        self.frozen = False         # tests: keep `caps` as set
+
+    def poll(self):
+        if self.frozen:
+            return self.caps
+        n_def, _, n_bins, n_occ, seq = (int(v) for v in self.host[:5].tolist())
+        if seq != self.seen and seq == int(self.host[4]):      # (the counters of one call: [4] is written last)
+            self.seen = seq
+            self.caps = tuple(n + max(256, n // 8) if n > 0 else 0 for n in (n_bins, n_occ, n_def))
+        return self.caps
+
+    def next_seq(self):
+        self.seq = self.seq % 0x7ffffff0 + 1
+        return self.seq
+
+
 _list_hints = {}
 
 
@@ -453,7 +479,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, ref_bg_sumsq, use_hints, want_grad, unit_upstream,
-                flags_out=None, mip_levels=None, overlap_sil=True, bin_lists=True):
+                flags_out=None, mip_levels=None, zero_extra=None, setup_event=None, overlap_sil=True, bin_lists=True):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -472,19 +498,20 @@ class _pixel_objective_onepass(torch.autograd.Function):
         color = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
         g_aa = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
         ecol = torch.empty(4, dtype=torch.float32, device=dev)
-        acc = torch.zeros(_lib.LOSS_SLOTS, dtype=torch.float64, device=dev)
-        g_pos = torch.zeros_like(pos) if want_pos else None
-        g_tex = torch.zeros_like(tex) if want_tex else None
+        # (zero_outputs: the call's first kernel zero-fills its accumulators)
+        acc = torch.empty(_lib.LOSS_SLOTS, dtype=torch.float64, device=dev)
+        g_pos = torch.empty_like(pos) if want_pos else None
+        g_tex = torch.empty_like(tex) if want_tex else None
         tri_uv = _cached_tri_uv(uv, uv_tri)
         p = _lib.Objective(pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
                            uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tri_uv=_ptr(tri_uv), tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C,
                            boundary_mode=boundary, ref=_ptr(ref), bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
                            idp=_ptr(idp), occ=_ptr(occ), cmask=_ptr(cmask), rec=_ptr(rec), color=_ptr(color), grad_aa=_ptr(g_aa),
                            empty_color=_ptr(ecol), loss_sum=_ptr(acc), grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex), flags=_ptr(flags_out),
-                           binlist=_ptr(binlist))
+                           binlist=_ptr(binlist), zero_outputs=1)
         # mip_levels = n: the reference's enable_mip branch inside the same kernels (the chain is built here, box filter as texture())
         chain = _build_mips(tex[None], mip_levels)[1:] if mip_levels is not None else []
-        g_chain = [torch.zeros_like(t) for t in chain] if want_tex else []
+        g_chain = [torch.empty_like(t) for t in chain] if want_tex else []
         if mip_levels is not None:
             p.mip, p.n_levels = 1, len(chain)
             for l, t in enumerate(chain):
@@ -504,9 +531,22 @@ class _pixel_objective_onepass(torch.autograd.Function):
                 sil_event.record(side)
             for t_ in (pos, tri, adj, sil):
                 t_.record_stream(side)
-        hints = _list_hints.setdefault(('onepass', dev.index, B, V, T, H, W), _ListHints()) if use_hints else None
+        capturing = torch.cuda.is_current_stream_capturing()
+        hints = _list_hints.setdefault(('onepass', dev.index, B, V, T, H, W), _MappedHints()) if use_hints else None
         if hints is not None:
             p.cap_bins, p.cap_occ, p.cap_def = hints.poll()      # (live bins, occupied bins, bins with a deferred pixel)
+            if not capturing:      # (a graph replays fixed launch sizes: nothing to report)
+                p.counts_out, p.counts_seq = hints.host.data_ptr(), hints.next_seq()
+        # the value from the call's last kernel: (loss slots + C * background share) / n_total
+        bg_sum = (reference_background_sumsq(ref, bg).sum() if ref_bg_sumsq is None
+                  else torch.as_tensor(ref_bg_sumsq, device=dev)).to(torch.float64).contiguous()
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        p.bg_sumsq, p.bg_coeff, p.n_total, p.value_out = _ptr(bg_sum), float(C), float(n_total), _ptr(out)
+        if setup_event is not None and not capturing:      # (recorded by the call behind its set-up kernel; the handle exists once recorded)
+            setup_event.record()
+            p.setup_event = ctypes.c_void_p(setup_event.cuda_event)
+        if zero_extra is not None:      # (a caller's own small accumulators, zero-filled by the call's first kernel)
+            p.zero_extra, p.zero_extra_bytes = _ptr(zero_extra), zero_extra.numel() * zero_extra.element_size()
         if side is not None:      # (the call waits for the event right before its first kernel that reads the bits)
             p.sil_ready, p.sil_event = 1, ctypes.c_void_p(sil_event.cuda_event)
         _lib.call("fpcdr_objective_fwd", ctypes.byref(p), _stream())
@@ -515,14 +555,6 @@ class _pixel_objective_onepass(torch.autograd.Function):
             for l in range(len(chain), 0, -1):
                 _, h, w, _ = g_all[l - 1].shape
                 _lib.call("fpcdr_mip_downsample_bwd", _ptr(g_all[l]), _ptr(g_all[l - 1]), 1, h, w, C, _stream())
-        if hints is not None:
-            nb = B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN)
-            off = (4 * nb + 3) // 4 * 4                       # FPCDR_OCC_COUNTS_OFFSET
-            hints.update(occ[off:off + 16].view(torch.int32))
-        bg_sum = (reference_background_sumsq(ref, bg).sum() if ref_bg_sumsq is None
-                  else torch.as_tensor(ref_bg_sumsq, device=dev)).to(torch.float64).contiguous()
-        out = torch.empty((), dtype=torch.float32, device=dev)
-        _lib.call("fpcdr_objective_value", _ptr(acc), _lib.LOSS_SLOTS, _ptr(bg_sum), float(C), float(n_total), _ptr(out), _stream())
         ctx.save_for_backward(*(t for t in (g_pos, g_tex) if t is not None))
         ctx.have = (want_pos, want_tex)
         ctx.unit = bool(unit_upstream)
@@ -539,7 +571,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
             g = g.to(torch.float32)
             g_pos = g_pos * g if g_pos is not None else None
             g_tex = g_tex * g if g_tex is not None else None
-        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 18
+        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 20
 
 
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
@@ -556,7 +588,8 @@ def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
 
 def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_total=None, background=45.0 / 255.0,
                     boundary_mode='wrap', sparse=True, ref_bg_sumsq=None, launch_hints=True, queued_backward=False,
-                    enable_mip=False, max_mip_level=None, one_pass=True, unit_upstream=False, aa_flags_out=None):
+                    enable_mip=False, max_mip_level=None, one_pass=True, unit_upstream=False, aa_flags_out=None, zero_extra=None,
+                    setup_event=None):
     """The whole pixel term of the reference's loss (fit.py:151-161 + the first term of :579) for a minibatch,
     as three kernels:  mean((ref - 255 * where(rast.w > 0, antialias(texture(interpolate(rasterize(pos)))), bg))^2)
     over n_total elements (default: all of this call's).  pos [B,V,4], tex [Ht,Wt,C] (C in 1,3,4), ref_u8 [B,H,W] uint8.
@@ -574,7 +607,10 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     its gradient back (fpcdr_objective_fwd); backward() multiplies by the upstream scalar, or returns the buffers as they are with
     unit_upstream=True (the caller guarantees d loss / d objective = 1).  one_pass=False: the two-call form.
     aa_flags_out (one_pass; tests / diagnostics): a zero-filled int64 tensor of fpcdr_antialias_flags_bytes(B,H,W) / 8 words that
-    receives the antialias flag planes (which pixel pairs were blended)."""
+    receives the antialias flag planes (which pixel pairs were blended).  zero_extra (one_pass): a contiguous float32 / int32 tensor of the
+    caller's that the call's first kernel zero-fills along with its own buffers (a fit step's small gradient accumulators).  setup_event
+    (one_pass): a torch.cuda.Event the call records behind its set-up kernel (work on another stream that waits for it runs beside the
+    rasteriser instead of beside the set-up kernel); left as recorded on entry by the other forms."""
     assert isinstance(glctx, RasterizeHipContext)
     _check_tensor('pos', pos, torch.float32, 3)
     _check_tensor('tri', tri, torch.int32, 2)
@@ -597,10 +633,15 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
         if not sparse:
             raise NotImplementedError("pixel_objective(enable_mip=True) runs in sparse mode (use the separate operators otherwise)")
         mip_levels = _num_mip_levels(tex.shape[0], tex.shape[1], max_mip_level)
+    if zero_extra is not None and not (one_pass and sparse):
+        zero_extra.zero_()
+    if setup_event is not None and not (one_pass and sparse):
+        setup_event.record()
     if one_pass and sparse:
         return _pixel_objective_onepass.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                               ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], ref_bg_sumsq,
-                                              bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out, mip_levels)
+                                              bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out, mip_levels, zero_extra,
+                                              setup_event)
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                        ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq,
                                        bool(launch_hints), bool(queued_backward), mip_levels, torch.is_grad_enabled())

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FPCDR_ABI_VERSION 8
+#define FPCDR_ABI_VERSION 9
 
 enum {
     FPCDR_OK = 0,
@@ -232,7 +232,7 @@ typedef struct {
 int fpcdr_render_aa_bwd(const fpcdr_render_aa_bwd_params *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
-/* ONE-PASS pixel objective (ABI v8) -- reference fit.py:151-161 + the pixel term of :579, VALUE AND GRADIENT in one call.
+/* ONE-PASS pixel objective (ABI v8, v9) -- reference fit.py:151-161 + the pixel term of :579, VALUE AND GRADIENT in one call.
  *
  * The pixel objective is a scalar, so its gradient with respect to pos and tex does not depend on anything the caller does
  * afterwards: it is d(objective)/d(input) times one upstream scalar.  This entry point therefore computes value and gradient
@@ -298,6 +298,26 @@ typedef struct {
     void *sil_event;        /* with sil_ready = 1: optional hipEvent_t recorded behind the caller's fpcdr_silhouette_bits on ITS stream; the
                                call makes `stream` wait for it right before the first kernel that reads sil (behind the set-up kernels, which
                                is the point: they overlap).  NULL: sil is complete in stream order */
+    /* ABI v9: the launches around the call folded into its first and its last kernel (each was 5-20 us of a 2.6 ms call's serial tail) */
+    int32_t zero_outputs;   /* 1: the call's first kernel zero-fills loss_sum, grad_pos, grad_tex and grad_tex_mip (they need no initialisation);
+                               0: they are accumulated into, as above */
+    int32_t counts_seq;     /* any number that differs from call to call (see counts_out) */
+    int32_t *counts_out;    /* optional [8]: the last kernel copies the four counters at FPCDR_OCC_COUNTS_OFFSET of occ to [0..3] and then writes
+                               counts_seq to [4].  May be HOST memory the device can write (hipHostMalloc / pinned): the launch hints of the
+                               next call then need no device-to-host copy in the stream; a reader that sees its counts_seq at [4] reads
+                               counters at least as new as that call's */
+    const double *bg_sumsq; /* optional [1] (with value_out): the sum over the call's images of fpcdr_ref_bg_sumsq */
+    double bg_coeff;        /* its coefficient (the number of colour channels) */
+    double n_total;         /* the mean's denominator */
+    float *value_out;       /* optional [1]: (sum of loss_sum + bg_coeff * bg_sumsq[0]) / n_total, what fpcdr_objective_value computes, from the
+                               last kernel of the call */
+    void *zero_extra;       /* optional: zero_extra_bytes (a multiple of 4) of the caller's own that the first kernel zero-fills as well -- a fit
+                               step's small accumulators (the gradients of the camera matrices, poses and blend weights that its backward
+                               kernels add into) instead of one fill launch each */
+    int64_t zero_extra_bytes;
+    void *setup_event;      /* optional hipEvent_t the call records on `stream` right behind its set-up kernel: side work of the caller's that
+                               waits for it (on another stream) runs beside the rasteriser and the shading kernel, which are bound by vector
+                               issue, instead of beside the set-up kernel, which is bound by memory latency and slows down under company */
 } fpcdr_objective_params;
 int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream);
 

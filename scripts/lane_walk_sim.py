@@ -105,3 +105,20 @@ nb = len(bins)
 for sp in (1, 2, 4, 8):
     print('every triangle split over', sp, 'lanes:', round(sum(model(v, sp) for v in bins.values()) / nb), 'wave-instructions per bin (part-major),',
           round(sum(model(v, sp, order='lane') for v in bins.values()) / nb), '(lane-major)')
+
+# r4: the (triangle, row) form with its real costs.  Phase 1 is what the lane path does today per triangle (record + box fetch, edge set-up:
+# 110 per wave of triangles) plus 14 dwords of set-up stored to LDS and a block-wide prefix sum of the box heights (~40 per wave, 4 waves);
+# an item then finds its triangle by bisection of the prefix array (8 dependent LDS reads, ~32 instructions), reads the set-up back
+# (four ds_read_b128) and moves the edge functions to its row (~12): ~60 per wave of items, not the 40 the r3 model assumed.
+def rows_real(lst, item_setup=60):
+    tot = 0
+    for base in range(0, len(lst), 256):
+        b = lst[base:base + 256]
+        tot += -(-len(b) // 64) * (110 + 20) + 4 * 40
+        items = [bw for bw, bh in b for _ in range(bh)]
+        for w0 in range(0, len(items), 64):
+            tot += max(items[w0:w0 + 64]) * 8 + item_setup
+    return tot
+for s in (40, 60, 80):
+    print(f'(triangle, row) items with phase 1 and {s} instructions of item set-up:', round(sum(rows_real(v, s) for v in bins.values()) / nb),
+          'wave-instructions per bin; current', round(sum(cur(v) for v in bins.values()) / nb))

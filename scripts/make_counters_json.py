@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc passes (counter_collection.csv + kernel_trace.csv) -> one JSON: per kernel, the mean of every counter per
 dispatch and the mean duration in that pass.   python scripts/make_counters_json.py DIR... > counters.json
-Dispatches up to and including the first k_esum_finish (the last kernel of the one-pass objective; k_render_aa_bwd for the two-call form) are ignored (set-up, the targets rendered in small chunks, and the first
+Dispatches up to and including the first k_objective_finish (the last kernel of the one-pass objective; k_render_aa_bwd for the two-call form) are ignored (set-up, the targets rendered in small chunks, and the first
 fit step, whose list kernels run without launch hints at the full grid); of the rest, only dispatches whose grid lies within a factor two of the
 median grid of each kernel are averaged (the list kernels' grids follow the hints from step to step)."""
 import csv, glob, json, os, sys
@@ -32,7 +32,7 @@ for d in ARGS:
     first = None    # dispatch id of the first backward call
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_render_aa_bwd" in r["Kernel_Name"] or "k_esum_finish" in r["Kernel_Name"]:      # (two-call form / one-pass form)
+            if "k_render_aa_bwd" in r["Kernel_Name"] or "k_objective_finish" in r["Kernel_Name"]:      # (two-call form / one-pass form)
                 i = int(r["Dispatch_Id"])
                 first = i if first is None else min(first, i)
     first = first or 0

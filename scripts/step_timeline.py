@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:100], r.get("Queue_Id", "?")))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if r[2] == "k_setup"]
+starts = [i for i, r in enumerate(rows) if r[2] == "k_setup" or r[2].startswith("void k_setup<")]
 a, b = starts[-2], starts[-1]
 t0 = rows[a][0]
 busy_end = t0

@@ -281,7 +281,7 @@ def test_1080p_sweep_kernels_equal_the_hinted_launch():
             caps = hints.poll()
             assert min(caps[:2] if one_pass else caps) > 1000, caps         # thousands of bins per list at this size
             hints.event = None
-            hints.caps = (3, 2, 5)
+            hints.caps, hints.frozen = (3, 2, 5), True      # (frozen: the one-call form's hints; event / update: the two-call form's)
             hints.update = lambda counts: None
             swept = run(queued_backward=True, one_pass=one_pass)
             assert abs(swept[0] - base[0]) <= 1e-6 * abs(base[0])

@@ -113,9 +113,7 @@ def test_one_pass_launch_hints_do_not_change_the_result():
     caps = hints.poll()
     assert caps[0] >= 256 and caps[1] >= 256
     second = run()
-    hints.event = None
-    hints.caps = (3, 2, 1)              # absurdly small: almost every bin goes through the strided sweeps
-    hints.update = lambda counts: None
+    hints.caps, hints.frozen = (3, 2, 1), True      # absurdly small: almost every bin goes through the strided sweeps
     third = run()
     for r in (first, second, third):
         assert abs(r[0] - base[0]) <= 1e-6 * abs(base[0])
@@ -171,6 +169,6 @@ def test_one_pass_edge_cases_clipping_empty_images_and_the_indirect_uv_path(monk
     dr._list_hints.clear()                                 # (iii)
     both(enable_mip=True, max_mip_level=2)
     h = dr._list_hints[next(k for k in dr._list_hints if k[0] == 'onepass')]
-    h.event, h.caps, h.update = None, (1, 1, 1), (lambda counts: None)
+    h.caps, h.frozen = (1, 1, 1), True
     both(enable_mip=True, max_mip_level=2)
     dr._list_hints.clear()
