@@ -239,11 +239,20 @@ __global__ void __launch_bounds__(256) k_blend_bwd_w(const float *__restrict__ B
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
     }
-    if (kk < K) {
+    // the four waves' partial tiles summed through LDS first: one atomic per entry and WORKGROUP (the adders per address are what this
+    // kernel waits for: 375 per address with one atomic per wave, 94 so)
+    __shared__ float s_red[3][16][64];
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0 && kk < K) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = f0 + acc_row(r, lane);
-            if (f < F && acc[r] != 0.0f) atomicAdd(grad_w + (size_t)f * K + kk, acc[r]);
+            const float v = acc[r] + s_red[0][r][lane] + s_red[1][r][lane] + s_red[2][r][lane];
+            if (f < F && v != 0.0f) atomicAdd(grad_w + (size_t)f * K + kk, v);
         }
     }
 }

@@ -391,7 +391,10 @@ __global__ void __launch_bounds__(256) k_init_objective(ImgBox *ibox, int B, uin
         if (((size_t)p & 15) == 0) {
             uint4 *q = reinterpret_cast<uint4 *>(p);
             const long long n4 = n >> 2;
-            for (long long i = i0; i < n4; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            long long i = i0;
+            for (; i + 3 * stride < n4; i += 4 * stride) { q[i] = z; q[i + stride] = z; q[i + 2 * stride] = z; q[i + 3 * stride] = z; }
+            for (; i < n4; i += stride) q[i] = z;
             done = n4 << 2;
         }
         for (long long i = done + i0; i < n; i += stride) p[i] = 0u;
