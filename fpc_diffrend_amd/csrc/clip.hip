@@ -155,26 +155,48 @@ __global__ void __launch_bounds__(256) k_clip_bwd_both(const float *__restrict__
 // first pad ends it (a UV sphere has two poles of degree ~100 among vertices of degree 6).  Eight slots are
 // fetched together and their neighbours gathered together: the kernel is a chain of dependent loads otherwise
 // (one slot per trip is ~100 dependent round trips for the two pole threads, 40 us of a launch whose other threads are done after 3).
+// Rings longer than the first eight slots (a pole, the centre of a fan) are finished by the WHOLE WAVE, one such vertex at a time: lane l
+// takes slots 8 + l, 72 + l, ..., three DPP sums hand the result to the owner.  (Left to its own thread a ring of 150 is 19 dependent
+// rounds of index load + gather, ~40 us during which the launch's other 480 k threads have long finished.)  Every lane of the wave must
+// call this, `ok` = the lane has a vertex.
 template <typename Fetch>
-__device__ __forceinline__ void ring_sum(const int32_t *__restrict__ nbr, const float *__restrict__ inv_deg, int V, int D, int mode, int v,
+__device__ __forceinline__ void ring_sum(const int32_t *__restrict__ nbr, const float *__restrict__ inv_deg, int V, int D, int mode, int v, bool ok,
                                          Fetch fetch, float &sx, float &sy, float &sz) {
     constexpr int U = 8;
     sx = 0.f; sy = 0.f; sz = 0.f;
     int nb[U];
-    nb[U - 1] = 0;
-    for (int d0 = 0; d0 < D && (d0 == 0 || nb[U - 1] < V); d0 += U) {
 #pragma unroll
-        for (int d = 0; d < U; ++d) nb[d] = d0 + d < D ? nbr[(size_t)(d0 + d) * V + v] : V;
+    for (int d = 0; d < U; ++d) nb[d] = (ok && d < D) ? nbr[(size_t)d * V + v] : V;
+    {
         float wgt[U], gx[U], gy[U], gz[U];
 #pragma unroll
         for (int d = 0; d < U; ++d) {
-            const bool ok = nb[d] < V;
-            const int n = ok ? nb[d] : v;
-            wgt[d] = ok ? (mode ? inv_deg[n] : 1.0f) : 0.0f;
+            const bool in = nb[d] < V;
+            const int n = in ? nb[d] : (ok ? v : 0);
+            wgt[d] = in ? (mode ? inv_deg[n] : 1.0f) : 0.0f;
             fetch(n, gx[d], gy[d], gz[d]);
         }
 #pragma unroll
         for (int d = 0; d < U; ++d) { sx += wgt[d] * gx[d]; sy += wgt[d] * gy[d]; sz += wgt[d] * gz[d]; }
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned long long heavy = __ballot(D > U && nb[U - 1] < V);
+    while (heavy) {
+        const int leader = __builtin_ctzll(heavy);
+        heavy &= heavy - 1;
+        const int hv = __shfl(v, leader, 64);
+        float px = 0.f, py = 0.f, pz = 0.f;
+        for (int d = U + lane; d < D; d += 64) {
+            const int n = nbr[(size_t)d * V + hv];
+            if (n < V) {
+                const float w = mode ? inv_deg[n] : 1.0f;
+                float gx, gy, gz;
+                fetch(n, gx, gy, gz);
+                px += w * gx; py += w * gy; pz += w * gz;
+            }
+        }
+        px = wave_sum_dpp(px); py = wave_sum_dpp(py); pz = wave_sum_dpp(pz);
+        if (lane == leader) { sx += px; sy += py; sz += pz; }
     }
 }
 
@@ -183,11 +205,12 @@ __global__ void __launch_bounds__(256) k_lap_gather(const float *__restrict__ x,
                                                     float *__restrict__ out) {
     const int f = blockIdx.y;
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
+    const bool ok = v < V;
     const float *xf = x + (size_t)f * V * 3;
     float sx, sy, sz;
-    ring_sum(nbr, inv_deg, V, D, mode, v, [&](int n, float &a, float &b, float &c) { a = xf[3 * n]; b = xf[3 * n + 1]; c = xf[3 * n + 2]; },
+    ring_sum(nbr, inv_deg, V, D, mode, v, ok, [&](int n, float &a, float &b, float &c) { a = xf[3 * n]; b = xf[3 * n + 1]; c = xf[3 * n + 2]; },
              sx, sy, sz);
+    if (!ok) return;
     const float s = mode ? 1.0f : inv_deg[v];
     float *o = out + ((size_t)f * V + v) * 3;
     o[0] = s * sx - xf[3 * v]; o[1] = s * sy - xf[3 * v + 1]; o[2] = s * sz - xf[3 * v + 2];
@@ -208,11 +231,11 @@ __global__ void __launch_bounds__(256) k_lap_penalty_fwd(const float *__restrict
     const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     float nrm = 0.0f;
+    const float *xf = x + (size_t)f * V * 3;
+    float sx, sy, sz;
+    ring_sum(nbr, inv_deg, V, D, 0, v, v < V, [&](int n, float &a, float &b, float &c) { a = xf[3 * n]; b = xf[3 * n + 1]; c = xf[3 * n + 2]; },
+             sx, sy, sz);
     if (v < V) {
-        const float *xf = x + (size_t)f * V * 3;
-        float sx, sy, sz;
-        ring_sum(nbr, inv_deg, V, D, 0, v, [&](int n, float &a, float &b, float &c) { a = xf[3 * n]; b = xf[3 * n + 1]; c = xf[3 * n + 2]; },
-                 sx, sy, sz);
         const float s = inv_deg[v];
         const float lx = s * sx - xf[3 * v], ly = s * sy - xf[3 * v + 1], lz = s * sz - xf[3 * v + 2];
         float *o = lap + ((size_t)f * V + v) * 3;
@@ -253,7 +276,7 @@ __global__ void __launch_bounds__(256) k_lap_penalty_bwd(const float *__restrict
                                                          float *__restrict__ grad_x) {
     const int f = blockIdx.y;
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
+    const bool ok = v < V;
     const float *lf = lap + (size_t)f * V * 3;
     const float cf = upstream[0] * weight * 2.0f * per[f] / ((float)F * (float)V);
     auto y = [&](int n, float &a, float &b, float &c) {
@@ -263,7 +286,8 @@ __global__ void __launch_bounds__(256) k_lap_penalty_bwd(const float *__restrict
         a = s * lx; b = s * ly; c = s * lz;
     };
     float sx, sy, sz, yx, yy, yz;
-    ring_sum(nbr, inv_deg, V, D, 1, v, y, sx, sy, sz);
+    ring_sum(nbr, inv_deg, V, D, 1, v, ok, y, sx, sy, sz);
+    if (!ok) return;
     y(v, yx, yy, yz);
     float *o = grad_x + ((size_t)f * V + v) * 3;
     o[0] = sx - yx; o[1] = sy - yy; o[2] = sz - yz;

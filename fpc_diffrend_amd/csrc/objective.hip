@@ -155,6 +155,9 @@ __device__ __forceinline__ void vtablef_flush(const VTableF &t, float *gp, int t
 // falls outside (uv seams, a second surface in the bin) goes to memory with atomics.  So a pixel's four texel adds happen right where
 // its weights are formed: nothing is kept across a barrier (the two-phase form held 20 registers per thread for it: 88 VGPRs and
 // 5 waves per SIMD, where this form runs 7 -- worth 0.2 ms at cfg3 on the same instructions).
+#ifndef FPCDR_SHADE_MIP_WPE
+#define FPCDR_SHADE_MIP_WPE
+#endif
 #ifndef FPCDR_SHADE_WPE
 #define FPCDR_SHADE_WPE
 #endif
@@ -581,7 +584,7 @@ __global__ void __launch_bounds__(ONT) FPCDR_SHADE_WPE k_shade_list(const int32_
 
 // the MIP instantiation (boundary mode at run time): list form and strided sweep
 template <int CS>
-__global__ void __launch_bounds__(ONT) k_shade_mip_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int cap, int OX, int OY,
+__global__ void __launch_bounds__(ONT) FPCDR_SHADE_MIP_WPE k_shade_mip_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int cap, int OX, int OY,
                                                         fpcdr_bin_decode dc, ObjArgs a, MipO ma) {
     const int item = fpcdr_list_item(*count, cap);
     if (item < 0) return;
