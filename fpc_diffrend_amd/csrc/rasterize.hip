@@ -1738,8 +1738,6 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
         hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
                            p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr, (int32_t *)nullptr,
                            (int32_t *)nullptr);
-    if (p->setup_event)
-        FPCDR_REQUIRE(hipEventRecord((hipEvent_t)p->setup_event, st) == hipSuccess, "hipEventRecord(setup_event) failed");
     int32_t *n_bins = hdr_occ + 2, *n_occ = hdr_occ + 3;      // (include/fpcdr.h FPCDR_OCC_COUNTS_OFFSET)
     hipLaunchKernelGGL(k_list_count<0>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, (uint16_t *)nullptr,
                        p->tex, p->Ht, p->Wt, p->C, p->boundary_mode, p->empty_color);

@@ -325,22 +325,19 @@ class _laplacian_penalty(torch.autograd.Function):
     """weight * mean_f (mean_v ||(L x_f)_v||)^2 in one launch each way (fpcdr_laplacian_penalty_fwd / _bwd).
     eager: the gradient kernel runs in forward() already (the term depends on the vertices only), backward() hands the buffer over --
     times the upstream scalar, or as it is with unit (the caller guarantees d loss / d value = 1).  stream: both launches go to that
-    stream (forked from the current one here, joined in backward() or by the caller through `.event`): the autograd node itself stays on
+    stream (forked from the current one here, joined in backward()): the autograd node itself stays on
     the current stream, so the engine inserts no cross-stream synchronisation of its own."""
 
     @staticmethod
-    def forward(ctx, verts, nbr32, inv_deg, weight, eager=False, unit=False, stream=None, after=None):
+    def forward(ctx, verts, nbr32, inv_deg, weight, eager=False, unit=False, stream=None):
         if not verts.is_cuda:
             raise RuntimeError("the mesh regularisers run on the GPU only (fpcdr_laplacian_penalty_fwd); there is no CPU fallback")
         x = verts.contiguous()
         F, V, _ = x.shape
         eager = bool(eager and ctx.needs_input_grad[0])
         main = torch.cuda.current_stream(x.device)
-        if stream is not None:      # (after: an event on the current stream behind which the vertices are complete)
-            if after is not None:
-                stream.wait_event(after)
-            else:
-                stream.wait_stream(main)
+        if stream is not None:
+            stream.wait_stream(main)
         with torch.cuda.stream(stream if stream is not None else main):
             st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
             lap = torch.empty_like(x)
@@ -375,13 +372,13 @@ class _laplacian_penalty(torch.autograd.Function):
             torch.cuda.current_stream(g.device).wait_event(ctx.event)
         if ctx.eager:
             gx, = ctx.saved_tensors
-            return (gx if ctx.unit else gx * g.to(torch.float32)), None, None, None, None, None, None, None
+            return (gx if ctx.unit else gx * g.to(torch.float32)), None, None, None, None, None, None
         lap, nbr32, inv_deg, per = ctx.saved_tensors
         F, V, _ = lap.shape
         gx = torch.empty_like(lap)
         _lib.call("fpcdr_laplacian_penalty_bwd", _ptr(lap), _ptr(nbr32), _ptr(inv_deg), _ptr(per), _ptr(g.to(torch.float32).contiguous()),
                   _ptr(gx), ctx.weight, F, V, nbr32.shape[0], _stream())
-        return gx, None, None, None, None, None, None, None
+        return gx, None, None, None, None, None, None
 
 
 _unit_scalars = {}
@@ -395,13 +392,12 @@ def _unit_scalar(dev):
     return t
 
 
-def laplacian_penalty(verts, topo, weight, eager_grad=False, unit_upstream=False, stream=None, after=None):
+def laplacian_penalty(verts, topo, weight, eager_grad=False, unit_upstream=False, stream=None):
     """weight * mean over the meshes of verts [F,V,3] of mesh_laplacian_smoothing(mesh)^2 -- the reference's term (fit.py:581 squares
     the value of the ONE mesh of its step) -- as two launches per step instead of a gather and fifteen torch kernels.
     eager_grad: the gradient is computed with the value (backward() only multiplies by the upstream scalar, or not at all with
-    unit_upstream); stream: run both launches on that stream beside the caller's, behind everything the current stream holds or -- after --
-    behind that event of the current stream only (the backward() joins; a caller that never runs backward() waits for the stream itself)."""
-    return _laplacian_penalty.apply(verts, topo.nbr32, topo.inv_deg, weight, eager_grad, unit_upstream, stream, after)
+    unit_upstream); stream: run both launches on that stream beside the caller's (the backward() joins; a caller that never runs backward() waits for the stream itself)."""
+    return _laplacian_penalty.apply(verts, topo.nbr32, topo.inv_deg, weight, eager_grad, unit_upstream, stream)
 
 
 def mesh_normal_consistency(verts, topo):
@@ -521,7 +517,9 @@ class FitConfig:
     fused_objective: bool = True    # with fused_render and fused_loss: the whole pixel term as three kernels (ops.pixel_objective)
     grouped_adam: bool = True       # all ten Adam groups + the quaternion division as one launch (False: torch.optim.Adam(fused=True))
     sparse_objective: bool = True   # the three kernels skip image regions far from any geometry (same result)
-    overlap_regularisers: bool = True   # fused path: mesh regularisers on a second stream beside the pixel objective
+    overlap_regularisers: bool = False  # fused path: mesh regularisers on a second stream beside the pixel objective.  Off since the
+                                        # Laplacian term is two short launches (r4): the cross-stream waits cost what the overlap hides
+                                        # (profiles/r04_stream_overlap.txt); worth switching on with the torch-chain terms (edge, normals)
     one_pass: bool = True           # fused path without mip: value AND gradient of the pixel term from one call (fpcdr_objective_fwd: the
                                     # kernel that shades a pixel chains its gradient back; False: forward call + backward call)
     queued_backward: bool = True    # fused path: the backward kernel runs over the list of occupied bins the forward left (with launch
@@ -639,7 +637,6 @@ class Fitter:
         self._side_stream = torch.cuda.Stream(device=dev)
         self._one = torch.ones((), dtype=torch.float32, device=dev)
         self._zero = torch.zeros((), dtype=torch.float32, device=dev)
-        self._setup_event = torch.cuda.Event() if dev.type == 'cuda' else None
         self._background = torch.tensor(BACKGROUND, device=dev)     # (a device scalar made once: no host copy inside a HIP-graph capture)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
             self.optimizer, lr_lambda=lambda x: cfg.lr_ramp ** (float(x) / float(cfg.max_iter)))
@@ -837,18 +834,13 @@ class Fitter:
         if side is not None:
             torch.cuda.set_stream(main_stream)
             vtx_pos_split.record_stream(side)
-        # the Laplacian term as two launches, its gradient computed with the value (it depends on the vertices only) instead of in the
-        # serial tail of the step, where the vertex gradient of the pixel term would wait for it.  Its weight carries the 1 / world, so that
-        # d loss / d term = 1 exactly.  With the one-pass objective both launches go to the second stream BEHIND the objective's set-up
-        # kernel (setup_event): beside that kernel -- bound by memory latency -- they cost it 40 us, beside the rasteriser nothing.
-        def lap_term(stream=None, after=None):
-            return laplacian_penalty(vtx_pos_split, self.topo, cfg.weight_laplacian / self.world, eager_grad=True, unit_upstream=True,
-                                     stream=stream, after=after)
-        lap, lap_late = None, False
+        # the Laplacian term as two launches, its gradient computed with the value (it depends on the vertices only): backward() hands the
+        # buffer over.  Its weight carries the 1 / world, so that d loss / d term = 1 exactly.  (On the second stream with
+        # overlap_regularisers; on the main stream the two launches are ~25 us in front of the objective.)
+        lap = None
         if cfg.weight_laplacian and cfg.fused_loss:
-            lap_late = overlap and cfg.one_pass and cfg.sparse_objective
-            if not lap_late:
-                lap = lap_term(self._side_stream if overlap else None)
+            lap = laplacian_penalty(vtx_pos_split, self.topo, cfg.weight_laplacian / self.world, eager_grad=True, unit_upstream=True,
+                                    stream=self._side_stream if overlap else None)
         self.optimizer.zero_grad(set_to_none=True)
         if one_shot:
             bg_sum = None
@@ -870,10 +862,7 @@ class Fitter:
                                      n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum,
                                      enable_mip=cfg.enable_mip, max_mip_level=cfg.max_mip_level,
                                      queued_backward=cfg.queued_backward and not self.use_graph,
-                                     one_pass=cfg.one_pass, unit_upstream=True, zero_extra=zero_pool,      # (the seeds below are 1)
-                                     setup_event=self._setup_event if lap_late else None)
-            if lap_late:
-                lap = lap_term(self._side_stream, self._setup_event)
+                                     one_pass=cfg.one_pass, unit_upstream=True, zero_extra=zero_pool)      # (the seeds below are 1)
             # d loss / d pix = d loss / d reg = 1, handed over as a cached device scalar: `(pix + reg).backward()` would put an add and
             # a fill between the forward and the backward kernel; the sum is formed after the backward pass has been enqueued
             roots, seeds = [pix], [self._one]

@@ -464,6 +464,13 @@ class _pixel_objective_func(torch.autograd.Function):
 _side_streams = {}
 
 
+# The silhouette bits of the one-pass objective on a second stream, beside the rasteriser's set-up kernel (fpcdr_objective_params.sil_ready /
+# sil_event)?  Off: at cfg3 the ~60 us the overlap hides are what the set-up kernel -- bound by memory latency -- loses to the company plus the
+# ~10 us a cross-stream wait costs the main stream on this runtime, event long complete or not (2.78 ms per step without, 2.80 with;
+# profiles/r04_stream_overlap.txt).
+OVERLAP_SIL = False
+
+
 def _side_stream(dev):
     """One helper stream per device (the silhouette bits of the one-pass objective run on it beside the rasteriser's set-up)."""
     st = _side_streams.get(dev.index)
@@ -479,7 +486,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, ref_bg_sumsq, use_hints, want_grad, unit_upstream,
-                flags_out=None, mip_levels=None, zero_extra=None, setup_event=None, overlap_sil=True, bin_lists=True):
+                flags_out=None, mip_levels=None, zero_extra=None, overlap_sil=None, bin_lists=True):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -521,6 +528,8 @@ class _pixel_objective_onepass(torch.autograd.Function):
         # the silhouette bits need the positions only: on a second stream they run beside the rasteriser's set-up kernel (not inside a
         # graph capture, where the fork would become part of the caller's graph topology).  Forked HERE, behind the zero-fills of the
         # gradient buffers above: started earlier the kernel shares the memory system with them (the 69 MB fill took 68 us instead of 12)
+        if overlap_sil is None:
+            overlap_sil = OVERLAP_SIL
         side = _side_stream(dev) if (overlap_sil and not torch.cuda.is_current_stream_capturing()) else None
         if side is not None:
             main = torch.cuda.current_stream(dev)
@@ -542,9 +551,6 @@ class _pixel_objective_onepass(torch.autograd.Function):
                   else torch.as_tensor(ref_bg_sumsq, device=dev)).to(torch.float64).contiguous()
         out = torch.empty((), dtype=torch.float32, device=dev)
         p.bg_sumsq, p.bg_coeff, p.n_total, p.value_out = _ptr(bg_sum), float(C), float(n_total), _ptr(out)
-        if setup_event is not None and not capturing:      # (recorded by the call behind its set-up kernel; the handle exists once recorded)
-            setup_event.record()
-            p.setup_event = ctypes.c_void_p(setup_event.cuda_event)
         if zero_extra is not None:      # (a caller's own small accumulators, zero-filled by the call's first kernel)
             p.zero_extra, p.zero_extra_bytes = _ptr(zero_extra), zero_extra.numel() * zero_extra.element_size()
         if side is not None:      # (the call waits for the event right before its first kernel that reads the bits)
@@ -571,7 +577,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
             g = g.to(torch.float32)
             g_pos = g_pos * g if g_pos is not None else None
             g_tex = g_tex * g if g_tex is not None else None
-        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 20
+        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 19
 
 
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
@@ -588,8 +594,7 @@ def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
 
 def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_total=None, background=45.0 / 255.0,
                     boundary_mode='wrap', sparse=True, ref_bg_sumsq=None, launch_hints=True, queued_backward=False,
-                    enable_mip=False, max_mip_level=None, one_pass=True, unit_upstream=False, aa_flags_out=None, zero_extra=None,
-                    setup_event=None):
+                    enable_mip=False, max_mip_level=None, one_pass=True, unit_upstream=False, aa_flags_out=None, zero_extra=None):
     """The whole pixel term of the reference's loss (fit.py:151-161 + the first term of :579) for a minibatch,
     as three kernels:  mean((ref - 255 * where(rast.w > 0, antialias(texture(interpolate(rasterize(pos)))), bg))^2)
     over n_total elements (default: all of this call's).  pos [B,V,4], tex [Ht,Wt,C] (C in 1,3,4), ref_u8 [B,H,W] uint8.
@@ -608,9 +613,7 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     unit_upstream=True (the caller guarantees d loss / d objective = 1).  one_pass=False: the two-call form.
     aa_flags_out (one_pass; tests / diagnostics): a zero-filled int64 tensor of fpcdr_antialias_flags_bytes(B,H,W) / 8 words that
     receives the antialias flag planes (which pixel pairs were blended).  zero_extra (one_pass): a contiguous float32 / int32 tensor of the
-    caller's that the call's first kernel zero-fills along with its own buffers (a fit step's small gradient accumulators).  setup_event
-    (one_pass): a torch.cuda.Event the call records behind its set-up kernel (work on another stream that waits for it runs beside the
-    rasteriser instead of beside the set-up kernel); left as recorded on entry by the other forms."""
+    caller's that the call's first kernel zero-fills along with its own buffers (a fit step's small gradient accumulators)."""
     assert isinstance(glctx, RasterizeHipContext)
     _check_tensor('pos', pos, torch.float32, 3)
     _check_tensor('tri', tri, torch.int32, 2)
@@ -635,13 +638,10 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
         mip_levels = _num_mip_levels(tex.shape[0], tex.shape[1], max_mip_level)
     if zero_extra is not None and not (one_pass and sparse):
         zero_extra.zero_()
-    if setup_event is not None and not (one_pass and sparse):
-        setup_event.record()
     if one_pass and sparse:
         return _pixel_objective_onepass.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                               ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], ref_bg_sumsq,
-                                              bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out, mip_levels, zero_extra,
-                                              setup_event)
+                                              bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out, mip_levels, zero_extra)
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                        ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq,
                                        bool(launch_hints), bool(queued_backward), mip_levels, torch.is_grad_enabled())

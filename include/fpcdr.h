@@ -315,9 +315,6 @@ typedef struct {
                                step's small accumulators (the gradients of the camera matrices, poses and blend weights that its backward
                                kernels add into) instead of one fill launch each */
     int64_t zero_extra_bytes;
-    void *setup_event;      /* optional hipEvent_t the call records on `stream` right behind its set-up kernel: side work of the caller's that
-                               waits for it (on another stream) runs beside the rasteriser and the shading kernel, which are bound by vector
-                               issue, instead of beside the set-up kernel, which is bound by memory latency and slows down under company */
 } fpcdr_objective_params;
 int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream);
 

@@ -716,3 +716,70 @@ def test_reference_run_shape_one_random_view_per_step(fused):
     a, b = np.asarray(traj[False]), np.asarray(traj[True])
     assert np.isfinite(b).all() and len(set(np.round(a, 3))) > 6          # different images from step to step
     assert np.allclose(a, b, rtol=2e-3), (a, b)
+
+
+@pytest.mark.gpu
+def test_laplacian_penalty_eager_gradient_heavy_rings_and_second_stream():
+    """(i) eager_grad=True (the gradient kernel runs with the value; backward() hands the buffer over, times the upstream scalar unless
+    unit_upstream) == the lazy form, on the current stream and on a second one; (ii) a fan whose hub has 200 neighbours -- rings beyond
+    eight slots are finished by the whole wave, here in four rounds of 64 slots -- against the torch chain, value and gradient."""
+    from fpc_diffrend_amd import fit, scene
+    sc = scene.cfg('cfg1', n_frames=3)
+    topo = fit.MeshTopology(sc.pos_idx, sc.n_vertices, 'cuda')
+    g = torch.Generator().manual_seed(11)
+    verts = (torch.tensor(sc.v_base).reshape(1, -1, 3) + 0.1 * torch.randn(3, sc.n_vertices, 3, generator=g)).cuda()
+    v0 = verts.clone().requires_grad_(True)
+    l0 = fit.laplacian_penalty(v0, topo, 7.5)
+    (l0 * 0.3).backward()
+    side = torch.cuda.Stream()
+    for kw, up in ((dict(eager_grad=True), 0.3), (dict(eager_grad=True, unit_upstream=True), 1.0), (dict(eager_grad=True, stream=side), 0.3)):
+        v1 = verts.clone().requires_grad_(True)
+        l1 = fit.laplacian_penalty(v1, topo, 7.5, **kw)
+        (l1 * up).backward() if up != 1.0 else l1.backward()
+        torch.cuda.synchronize()
+        assert float(l1) == float(l0), kw
+        assert rel_l2(v1.grad * (0.3 / up), v0.grad) < 1e-6, kw
+    # the fan: vertex 0 in the middle of a 200-gon
+    n = 200
+    faces = np.asarray([[0, 1 + k, 1 + (k + 1) % n] for k in range(n)], dtype=np.int32)
+    topo2 = fit.MeshTopology(faces, n + 1, 'cuda')
+    assert int((topo2.nbr[0] < n + 1).sum()) == n
+    ang = torch.arange(n, dtype=torch.float32) * (2 * np.pi / n)
+    ring = torch.stack([torch.cos(ang), torch.sin(ang), 0.05 * torch.randn(n, generator=g)], dim=1)
+    xyz = torch.cat([torch.tensor([[0.1, -0.2, 0.3]]), ring])[None].repeat(2, 1, 1)
+    xyz = (xyz + 0.05 * torch.randn(xyz.shape, generator=g)).cuda()
+    v1 = xyz.clone().requires_grad_(True)
+    l1 = fit.laplacian_penalty(v1, topo2, 3.0, eager_grad=True)
+    l1.backward()
+    v2 = xyz.clone().requires_grad_(True)
+    l2 = 3.0 * (fit.mesh_laplacian_smoothing(v2, topo2, per_mesh=True) ** 2).mean()
+    l2.backward()
+    assert abs(float(l1) - float(l2)) < 2e-6 * abs(float(l2))
+    assert rel_l2(v1.grad, v2.grad) < 1e-5
+
+
+@pytest.mark.gpu
+def test_fitter_stream_overlap_options_do_not_change_the_step():
+    """FitConfig.overlap_regularisers (the Laplacian term on a second stream) and ops.OVERLAP_SIL (the silhouette bits beside the
+    set-up kernel) are scheduling options: loss and gradients of a step equal the single-stream default's."""
+    from fpc_diffrend_amd import fit, scene
+    import fpc_diffrend_amd.ops as dr
+    sc = scene.cfg('cfg1', n_frames=2)
+    results = []
+    try:
+        for overlap in (False, True):
+            dr.OVERLAP_SIL = overlap
+            cfg = fit.FitConfig(max_iter=10, cam_idxs=(0, 5), weight_laplacian=10.0, weight_meshedge=1.0 if overlap else 0.0,
+                                overlap_regularisers=overlap)
+            ft = fit.Fitter(sc, cfg, device='cuda')
+            ft.init_near_truth(0.7)
+            ft.cfg.weight_meshedge = 0.0 if not overlap else 1e-30      # (a torch-chain term keeps the side-stream branch alive, at no weight)
+            loss = ft.loss_and_backward(torch.arange(0, 2, device='cuda'))
+            torch.cuda.synchronize()
+            results.append((float(loss), ft.maps_intermediate['local'].grad.clone(), ft.tex_opt.grad.clone(), ft.per_frame_t.grad.clone()))
+    finally:
+        dr.OVERLAP_SIL = False
+    a, b = results
+    assert abs(a[0] - b[0]) < 1e-5 * abs(a[0])
+    for x, y in zip(a[1:], b[1:]):
+        assert rel_l2(x, y) < 1e-5
