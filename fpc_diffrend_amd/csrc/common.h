@@ -45,7 +45,7 @@ struct FpcdrZeroList {
     __host__ void add(void *ptr, long long words) { if (ptr && words > 0 && count < MAXR) { p[count] = (uint32_t *)ptr; n[count] = words; ++count; } }
 };
 int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, const int32_t **occ_list, const int32_t **n_occ_dev,
-                            const FpcdrZeroList &zl);
+                            const FpcdrZeroList &zl, bool sil_in_setup);
 
 // workgroups of the strided sweep behind a hinted single-shot launch (normally they find nothing to do)
 #define FPCDR_SWEEP_WGS 256

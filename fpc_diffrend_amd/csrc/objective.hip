@@ -1138,8 +1138,7 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    int rc = p->sil_ready ? FPCDR_OK : fpcdr_launch_sil(p->pos, p->tri, p->adj, p->B, p->V, p->T, p->H, p->W, p->sil, nullptr, 0, st);
-    if (rc) return rc;
+    int rc = FPCDR_OK;      // (the silhouette bits: the caller's (sil_ready), or the set-up kernel's)
     const int32_t *occ_list = nullptr, *n_occ = nullptr;
     const int OX = FPCDR_OCC_DIM(p->W), OY = FPCDR_OCC_DIM(p->H);
     const long long nbins = (long long)p->B * OY * OX;
@@ -1161,7 +1160,7 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         FPCDR_REQUIRE(p->zero_extra_bytes >= 0 && (p->zero_extra_bytes & 3) == 0 && ((size_t)p->zero_extra & 3) == 0, "zero_extra: 4-byte units");
         zl.add(p->zero_extra, p->zero_extra_bytes / 4);
     }
-    rc = fpcdr_launch_raster_ids(p, st, &occ_list, &n_occ, zl);
+    rc = fpcdr_launch_raster_ids(p, st, &occ_list, &n_occ, zl, !p->sil_ready);
     if (rc) return rc;
     ObjArgs a = {(const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, (const float2 *)p->tri_uv, p->tex, p->ref, p->sil,
                  p->idp, p->occ, (uint8_t *)p->occ + q.occ_binflag, p->cmask, esum_slots, (int32_t *)((char *)p->occ + q.occ_bwd_list),

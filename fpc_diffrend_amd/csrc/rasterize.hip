@@ -32,6 +32,7 @@ namespace {
 #include "texsample.h"
 #include "raster_math.h"
 #include "aa_pairs.h"
+#include "sil_bits.h"
 
 constexpr int SUBPIX = 256;
 constexpr int HALFPIX = 128;
@@ -207,13 +208,17 @@ __device__ __forceinline__ void binlist_append_global(int32_t *__restrict__ bin_
         }
 }
 
-template <bool BINLIST = false>
+// SIL: the thread also classifies its triangle's three edges for the antialias step (sil_bits.h) -- it holds the triangle's own three
+// vertices already, the three across the edges are gathered beside them (the stand-alone kernel, k_sil2, is 62 us at 288 x 30 k of
+// which this form leaves ~10: the same chain of index load -> position gather, walked once instead of twice).
+template <bool BINLIST = false, bool SIL = false>
 __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
                                                 int B, int V, int T, int H, int W, TriRec *__restrict__ recs,
                                                 TriBox *__restrict__ boxes, TriBox *__restrict__ cboxes,
                                                 ImgBox *__restrict__ ibox, uint8_t *__restrict__ live,
                                                 const int32_t *__restrict__ ranges, int32_t *__restrict__ bin_cnt = nullptr,
-                                                int32_t *__restrict__ bin_list = nullptr) {
+                                                int32_t *__restrict__ bin_list = nullptr, const int32_t *__restrict__ adj = nullptr,
+                                                uint8_t *__restrict__ sil = nullptr) {
     // grid: x over 256-triangle chunks, y = image.  A block never straddles two images, so the union of
     // its triangles' bounding boxes can be reduced in the block: it is stored as the CHUNK box (meshes
     // keep neighbouring triangles at neighbouring indices, so a bin later skips most chunks with one
@@ -233,6 +238,19 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
         if (ranges) {      // range mode: the image renders its own slice of the triangle list
             const long long first = ranges[2 * b], count = ranges[2 * b + 1];
             ok = ok && t >= first && t < first + count;
+        }
+        if (SIL) {      // (index validity only decides, as in sil_classify: `ok` below may also carry the range test)
+            const bool vok = !(i0 < 0 || i0 >= V || i1 < 0 || i1 >= V || i2 < 0 || i2 >= V);
+            unsigned int bits = 0;
+            if (vok) {
+                const int ad[3] = {adj[3 * t], adj[3 * t + 1], adj[3 * t + 2]};
+                const float4 *p = pos + (size_t)b * V;
+                const float4 o0 = ld32(p, (ad[0] >= 0 && ad[0] < V) ? (unsigned int)ad[0] : 0u);
+                const float4 o1 = ld32(p, (ad[1] >= 0 && ad[1] < V) ? (unsigned int)ad[1] : 0u);
+                const float4 o2 = ld32(p, (ad[2] >= 0 && ad[2] < V) ? (unsigned int)ad[2] : 0u);
+                bits = sil_bits_of(p[i0], p[i1], p[i2], o0, o1, o2, ad, V, 0.5f * (float)W, 0.5f * (float)H);
+            }
+            sil[(size_t)b * T + t] = (uint8_t)bits;
         }
         if (ok) {
             const float4 *p = pos + (size_t)b * V;
@@ -1708,7 +1726,7 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
 // First half of fpcdr_objective_fwd (objective.hip; not part of the C ABI): set-up, the list of live bins, the rasteriser in its IDS form
 // (id planes only) and the ordered list of OCCUPIED bins + window masks for the shading kernels.  The caller has run k_sil2.
 int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, const int32_t **occ_list, const int32_t **n_occ_dev,
-                            const FpcdrZeroList &zl_in) {
+                            const FpcdrZeroList &zl_in, bool sil_in_setup) {
     const RasterScratch rs = raster_scratch(p->scratch, p->B, p->T);
     const int OX = fpcdr_cdiv(p->W, BIN), OY = fpcdr_cdiv(p->H, BIN);
     const size_t nbins = (size_t)p->B * OY * OX;
@@ -1731,13 +1749,14 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
     const int init_grid = (int)std::min<long long>(2048, std::max<long long>(256, zero_words / 4096));
     hipLaunchKernelGGL(k_init_objective, dim3(init_grid), dim3(256), 0, st, rs.ibox, p->B, (uint32_t *)live, (long long)(align_up(nbins, 4) / 4),
                        (uint32_t *)oc, (long long)(q.occ_hdr / 4), hdr, hdr_occ, bin_cnt, (long long)nbins, zl);
-    if (bin_cnt)
-        hipLaunchKernelGGL(k_setup<true>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                           p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr, bin_cnt, tri_lists);
-    else
-        hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                           p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr, (int32_t *)nullptr,
-                           (int32_t *)nullptr);
+    // (sil_in_setup: the caller has not computed the silhouette bits -- the set-up kernel does, one walk of the index -> position chain)
+#define SETUP(BL, SL)                                                                                                              \
+    hipLaunchKernelGGL((k_setup<BL, SL>), dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,     \
+                       p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr, bin_cnt, tri_lists, \
+                       p->adj, p->sil)
+    if (bin_cnt) { if (sil_in_setup) SETUP(true, true); else SETUP(true, false); }
+    else { if (sil_in_setup) SETUP(false, true); else SETUP(false, false); }
+#undef SETUP
     int32_t *n_bins = hdr_occ + 2, *n_occ = hdr_occ + 3;      // (include/fpcdr.h FPCDR_OCC_COUNTS_OFFSET)
     hipLaunchKernelGGL(k_list_count<0>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, (uint16_t *)nullptr,
                        p->tex, p->Ht, p->Wt, p->C, p->boundary_mode, p->empty_color);
