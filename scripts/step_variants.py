@@ -1,6 +1,6 @@
 """ms per fit step at cfg3 for a few stream-overlap variants (HIP events around 40 steps)."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fpc_diffrend_amd import fit, scene
 import fpc_diffrend_amd.ops as dr
