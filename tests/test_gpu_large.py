@@ -289,9 +289,13 @@ def test_cfg2_vertex_shading_graph_steps_equal_eager_steps_at_9_view_1080p():
             assert ft._graphs is not None
         out[graph] = (np.asarray(losses), [p.detach().double().cpu().clone() for p in ft.params])
     a, b = out[False][0], out[True][0]
-    assert np.isfinite(b).all() and np.allclose(a, b, rtol=1e-4), (a, b)
+    # (spread over repetitions, scripts/dbg/cfg2_graph_spread.py: five runs in six agree to 1.1e-5 in the loss, one in six lands on the
+    #  other side of some early rounding and ends 2e-4 apart: the bounds below are what separates "follows the eager steps" from a broken
+    #  replay -- which is off by O(1) --, not a statement about the replay's arithmetic, which is the eager kernels')
+    assert np.isfinite(b).all() and np.allclose(a, b, rtol=1e-3), (a, b)
     # parameters: Adam divides by the gradient's running magnitude, so the order of the float atomics (and torch.optim.Adam in the
     # captured step against the one-launch GroupedAdam of the eager one) moves a component whose gradient is near zero by up to lr per
-    # step, not by a fraction of itself: ten steps of 1e-3 on weights of ~8e-3 (measured: 3e-3 relative L2, losses equal to 1e-4)
+    # step, not by a fraction of itself: ten steps of 1e-3 on weights of ~8e-3 (measured: 3e-3 relative L2 as a rule, 1.2e-1 on a tensor
+    # of 3e-5 absolute difference in the one-in-six case)
     for pe, pg in zip(out[False][1], out[True][1]):
-        assert rel_l2(pg, pe) < 5e-2 or float((pg - pe).abs().max()) < 5e-5, (rel_l2(pg, pe), float((pg - pe).abs().max()))
+        assert rel_l2(pg, pe) < 2e-1 or float((pg - pe).abs().max()) < 1e-4, (rel_l2(pg, pe), float((pg - pe).abs().max()))
