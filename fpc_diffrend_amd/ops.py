@@ -324,7 +324,9 @@ class _MappedHints:
     landed (a device-to-host copy per step was a blit kernel between two barriers: ~20 us of the step's serial tail)."""
 
     def __init__(self):
-        self.host = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self.host = torch.zeros(8, dtype=torch.int32)
+        if torch.cuda.is_available():      # (device-writable host memory; without a GPU only the bookkeeping below can be exercised)
+            self.host = self.host.pin_memory()
         self.seq = 0
         self.seen = 0
         self.caps = (0, 0, 0)       # live bins, occupied bins, bins with a deferred pixel

@@ -144,15 +144,19 @@ def test_abi_library_exports_every_declared_symbol():
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "sz.c")
         with open(src, "w") as f:
-            f.write('#include <stdio.h>\n#include "fpcdr.h"\nint main(void) {\n')
+            f.write('#include <stdio.h>\n#include <stddef.h>\n#include "fpcdr.h"\nint main(void) {\n')
             for name in sorted(pairs):
                 f.write(f'    printf("{name} %zu\\n", sizeof({name}));\n')
+                for field, _ in pairs[name]._fields_:      # every field of the binding exists in the header, at the same offset
+                    f.write(f'    printf("{name}.{field} %zu\\n", offsetof({name}, {field}));\n')
             f.write("    return 0;\n}\n")
         exe = os.path.join(td, "sz")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         sizes = dict(l.split() for l in subprocess.check_output([exe]).decode().splitlines())
     for name, cls in pairs.items():
         assert ctypes.sizeof(cls) == int(sizes[name]), (name, ctypes.sizeof(cls), sizes[name])
+        for field, _ in cls._fields_:
+            assert getattr(cls, field).offset == int(sizes[f"{name}.{field}"]), (name, field)
 
 
 def test_ops_reject_cpu_tensors_and_missing_gpu():
@@ -215,3 +219,44 @@ def test_fitter_host_rules_graph_choice_and_frame_selection():
     p = t.clone().requires_grad_(True)
     fit.Fitter._take(p, 0, ids).sum().backward()
     assert torch.equal(p.grad, torch.zeros(6, 4).index_fill_(0, ids, 1.0))
+
+
+def test_mapped_hints_and_zero_pool_bookkeeping():
+    """Host side of two round-4 mechanisms, without a GPU.  ops._MappedHints: the objective's last kernel writes four counters and then
+    the call's sequence number into host memory; poll() adopts counters only when a NEW sequence number stands behind them, adds the
+    launch margin, and keeps the old caps otherwise.  fit._ZeroPool: views of one flat buffer, 16-byte aligned, plain zeros when the
+    pool is not armed or exhausted."""
+    import fpc_diffrend_amd.ops as dr
+    from fpc_diffrend_amd import fit
+    h = dr._MappedHints()
+    assert h.poll() == (0, 0, 0)
+    s1 = h.next_seq()
+    h.host[:4] = torch.tensor([40, 0, 8000, 7000], dtype=torch.int32)      # [deferred bins, -, live bins, occupied bins]
+    assert h.poll() == (0, 0, 0)                                            # (the sequence number has not landed yet)
+    h.host[4] = s1
+    assert h.poll() == (8000 + 1000, 7000 + 875, 40 + 256)                  # max(256, n / 8) of margin
+    h.host[:4] = torch.tensor([1, 0, 2, 3], dtype=torch.int32)              # counters of a later call, its number still missing
+    assert h.poll() == (9000, 7875, 296)
+    h.host[4] = h.next_seq()
+    assert h.poll() == (2 + 256, 3 + 256, 1 + 256)
+    h.frozen, h.caps = True, (3, 2, 1)
+    h.host[4] = h.next_seq()
+    assert h.poll() == (3, 2, 1)
+    assert 0 < h.next_seq() < 0x7ffffff1
+
+    dev = torch.device("cpu")
+    fit._ZeroPool.arm(None)
+    z = fit._ZeroPool.zeros((3, 5), dev)
+    assert z.shape == (3, 5) and float(z.abs().sum()) == 0.0
+    buf = torch.zeros(64, dtype=torch.float32)
+    try:
+        fit._ZeroPool.arm(buf)
+        a = fit._ZeroPool.zeros((3, 5), dev)
+        b = fit._ZeroPool.zeros((7,), dev)
+        assert a.data_ptr() == buf.data_ptr() and b.data_ptr() == buf.data_ptr() + 16 * 4      # 15 floats -> next multiple of four
+        c = fit._ZeroPool.zeros((60,), dev)                                                     # does not fit any more
+        assert c.data_ptr() < buf.data_ptr() or c.data_ptr() >= buf.data_ptr() + 64 * 4
+        a += 1.0
+        assert float(buf[:15].sum()) == 15.0 and float(buf[15:].sum()) == 0.0
+    finally:
+        fit._ZeroPool.arm(None)
