@@ -856,22 +856,25 @@ class Fitter:
             # one flat buffer for the small accumulators of this step's backward kernels, zero-filled by the objective's first kernel
             zero_pool = None
             if cfg.one_pass and cfg.sparse_objective:
-                zero_pool = torch.empty(Fb * Nc * 16 + 7 * (Fb + Nc) + 64 + Fb * (self.datasets['local'].shape[1] + self.m3.shape[1]), dtype=torch.float32, device=self.device)
+                zero_pool = torch.empty(Fb * Nc * 16 + 7 * (Fb + Nc) + 64 + Fb * (self.datasets['local'].shape[1] + self.m3.shape[1]),
+                                        dtype=torch.float32, device=self.device)
+            try:      # (the pool is a module-level hand-over to this step's backward functions: never left armed)
                 _ZeroPool.arm(zero_pool)
-            pix = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
-                                     n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum,
-                                     enable_mip=cfg.enable_mip, max_mip_level=cfg.max_mip_level,
-                                     queued_backward=cfg.queued_backward and not self.use_graph,
-                                     one_pass=cfg.one_pass, unit_upstream=True, zero_extra=zero_pool)      # (the seeds below are 1)
-            # d loss / d pix = d loss / d reg = 1, handed over as a cached device scalar: `(pix + reg).backward()` would put an add and
-            # a fill between the forward and the backward kernel; the sum is formed after the backward pass has been enqueued
-            roots, seeds = [pix], [self._one]
-            for term in (reg, lap):
-                if term is not None and term.requires_grad:
-                    roots.append(term)
-                    seeds.append(self._one)
-            torch.autograd.backward(roots, seeds)
-            _ZeroPool.arm(None)
+                pix = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
+                                         n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum,
+                                         enable_mip=cfg.enable_mip, max_mip_level=cfg.max_mip_level,
+                                         queued_backward=cfg.queued_backward and not self.use_graph,
+                                         one_pass=cfg.one_pass, unit_upstream=True, zero_extra=zero_pool)      # (the seeds below are 1)
+                # d loss / d pix = d loss / d reg = 1, handed over as a cached device scalar: `(pix + reg).backward()` would put an add and
+                # a fill between the forward and the backward kernel; the sum is formed after the backward pass has been enqueued
+                roots, seeds = [pix], [self._one]
+                for term in (reg, lap):
+                    if term is not None and term.requires_grad:
+                        roots.append(term)
+                        seeds.append(self._one)
+                torch.autograd.backward(roots, seeds)
+            finally:
+                _ZeroPool.arm(None)
             if side is not None:
                 main_stream.wait_stream(side)    # the regularisers' forward and backward ran on the side stream
                 reg.record_stream(main_stream)
