@@ -172,6 +172,8 @@ SYMBOLS = {
     "fpcdr_blend_fwd": (_int, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_blend_bwd_w": (_int, [_p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_blend_bwd_basis": (_int, [_p, _p, _p, _i, _i, _i, _p]),
+    "fpcdr_rig_weights_fwd": (_int, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "fpcdr_rig_weights_bwd": (_int, [_p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p]),
     "fpcdr_pixel_loss": (_int, [ctypes.POINTER(PixelLoss), _p]),
     "fpcdr_adam_step": (_int, [ctypes.POINTER(AdamParams), _p]),
 }

@@ -284,6 +284,56 @@ __global__ void __launch_bounds__(256) k_blend_bwd_basis(const float *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The rig's weight algebra (reference fit.py:115-116: maps_intermediate . (maps . one-hot frame); a batch selects columns):
+//   w[fb][k] = sum_f mi[k][f] * maps[f][col(fb)],   col(fb) = cols ? cols[fb] : col0 + fb
+// written in the [Fb, K] layout the blend kernel reads.  150 x 32 x 32 multiply-adds: as torch ops it is a GEMM, a transposing copy and --
+// backward -- two GEMMs and two adds, 35 us of 5-9 us launches in the serial tail of a 2.8 ms step; here one launch each way.
+__global__ void __launch_bounds__(256) k_rig_weights_fwd(const float *__restrict__ mi, const float *__restrict__ maps,
+                                                         const int64_t *__restrict__ cols, int col0, int K, int Fr, int Fc, int Fb,
+                                                         float *__restrict__ w) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Fb * K) return;
+    const int fb = idx / K, k = idx - fb * K;
+    const int c = cols ? (int)cols[fb] : col0 + fb;
+    float s = 0.0f;
+#pragma unroll 8
+    for (int f = 0; f < Fr; ++f) s += mi[(size_t)k * Fr + f] * maps[(size_t)f * Fc + c];
+    w[idx] = s;
+}
+
+// g_mi[k][f] = sum_fb g_w[fb][k] * maps[f][col(fb)];   g_maps[f][c] = sum over the fb with col(fb) = c of sum_k mi[k][f] * g_w[fb][k]
+// (both overwritten; columns no frame of the batch selects get zero).  ONE WAVE per output entry, the lanes over the sum's terms: a
+// thread per entry walks up to Fb x K dependent load + multiply-add trips on its own (340 us at K = 150, Fb = 32; this form: a few).
+__global__ void __launch_bounds__(256) k_rig_weights_bwd(const float *__restrict__ mi, const float *__restrict__ maps,
+                                                         const int64_t *__restrict__ cols, int col0, const float *__restrict__ g_w,
+                                                         int K, int Fr, int Fc, int Fb, float *__restrict__ g_mi, float *__restrict__ g_maps) {
+    const int lane = threadIdx.x & 63;
+    int idx = blockIdx.x * 4 + (threadIdx.x >> 6);      // (wave-uniform)
+    if (idx < K * Fr) {
+        if (!g_mi) return;
+        const int k = idx / Fr, f = idx - k * Fr;
+        float s = 0.0f;
+        for (int fb = lane; fb < Fb; fb += 64) {
+            const int c = cols ? (int)cols[fb] : col0 + fb;
+            s += g_w[(size_t)fb * K + k] * maps[(size_t)f * Fc + c];
+        }
+        s = wave_sum_dpp(s);
+        if (lane == 0) g_mi[idx] = s;
+        return;
+    }
+    idx -= K * Fr;
+    if (idx >= Fr * Fc || !g_maps) return;
+    const int f = idx / Fc, c = idx - f * Fc;
+    float s = 0.0f;
+    for (int fb = 0; fb < Fb; ++fb) {
+        if ((cols ? (int)cols[fb] : col0 + fb) != c) continue;      // (uniform over the wave)
+        for (int k = lane; k < K; k += 64) s += mi[(size_t)k * Fr + f] * g_w[(size_t)fb * K + k];
+    }
+    s = wave_sum_dpp(s);
+    if (lane == 0) g_maps[idx] = s;
+}
+
 }  // namespace
 
 extern "C" int fpcdr_blend_fwd(const float *v_base, const float *Bmat, const float *w, float *out, int32_t M, int32_t K,
@@ -323,6 +373,28 @@ extern "C" int fpcdr_blend_bwd_basis(const float *w, const float *grad_out, floa
     FPCDR_REQUIRE(fpcdr_cdiv(K, 32) <= 65535, "K too large for one launch");
     dim3 grid(fpcdr_cdiv(fpcdr_cdiv(M, 32), 4), fpcdr_cdiv(K, 32));
     hipLaunchKernelGGL(k_blend_bwd_basis, grid, dim3(256), 0, (hipStream_t)stream, w, grad_out, grad_B, M, K, F);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_rig_weights_fwd(const float *mi, const float *maps, const int64_t *cols, int32_t col0, int32_t K, int32_t Fr, int32_t Fc,
+                                     int32_t Fb, float *w, void *stream) {
+    FPCDR_REQUIRE(mi && maps && w, "null pointer");
+    FPCDR_REQUIRE(K > 0 && Fr > 0 && Fc > 0 && Fb > 0 && (long long)Fb * K < (1ll << 30), "bad sizes");
+    FPCDR_REQUIRE(cols || (col0 >= 0 && col0 + Fb <= Fc), "column range outside maps");
+    hipLaunchKernelGGL(k_rig_weights_fwd, dim3(fpcdr_cdiv(Fb * K, 256)), dim3(256), 0, (hipStream_t)stream, mi, maps, cols, col0, K, Fr, Fc, Fb, w);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_rig_weights_bwd(const float *mi, const float *maps, const int64_t *cols, int32_t col0, const float *grad_w, int32_t K,
+                                     int32_t Fr, int32_t Fc, int32_t Fb, float *grad_mi, float *grad_maps, void *stream) {
+    FPCDR_REQUIRE(mi && maps && grad_w, "null pointer");
+    FPCDR_REQUIRE(K > 0 && Fr > 0 && Fc > 0 && Fb > 0 && (long long)Fb * K < (1ll << 30) && (long long)K * Fr + (long long)Fr * Fc < (1ll << 30),
+                  "bad sizes");
+    FPCDR_REQUIRE(cols || (col0 >= 0 && col0 + Fb <= Fc), "column range outside maps");
+    hipLaunchKernelGGL(k_rig_weights_bwd, dim3(fpcdr_cdiv(K * Fr + Fr * Fc, 4)), dim3(256), 0, (hipStream_t)stream, mi, maps, cols, col0,
+                       grad_w, K, Fr, Fc, Fb, grad_mi, grad_maps);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }

@@ -126,6 +126,46 @@ class _transform_clip_func(torch.autograd.Function):
         return g_mvp, g_verts
 
 
+class _rig_weights_func(torch.autograd.Function):
+    """(mi @ maps[:, ids]).t() as one launch each way (fpcdr_rig_weights_fwd / _bwd): reference fit.py:115-116 (and :58-62 with m2, m1)."""
+
+    @staticmethod
+    def forward(ctx, mi, maps, ids):
+        K, Fr = mi.shape
+        Fc = maps.shape[1]
+        if isinstance(ids, slice):
+            lo, hi, step = ids.indices(Fc)
+            assert step == 1
+            cols, col0, Fb = None, lo, hi - lo
+        else:
+            cols, col0, Fb = ids.to(torch.int64).contiguous(), 0, int(ids.shape[0])
+        w = torch.empty(Fb, K, dtype=torch.float32, device=mi.device)
+        _lib.call("fpcdr_rig_weights_fwd", _ptr(mi), _ptr(maps), _ptr(cols), col0, K, Fr, Fc, Fb, _ptr(w), _stream())
+        ctx.save_for_backward(mi, maps, *([cols] if cols is not None else []))
+        ctx.geom = (col0, K, Fr, Fc, Fb, cols is not None)
+        return w
+
+    @staticmethod
+    def backward(ctx, g):
+        col0, K, Fr, Fc, Fb, has_cols = ctx.geom
+        mi, maps = ctx.saved_tensors[:2]
+        cols = ctx.saved_tensors[2] if has_cols else None
+        g_mi = torch.empty_like(mi) if ctx.needs_input_grad[0] else None
+        g_maps = torch.empty_like(maps) if ctx.needs_input_grad[1] else None
+        _lib.call("fpcdr_rig_weights_bwd", _ptr(mi), _ptr(maps), _ptr(cols), col0, _ptr(g.contiguous()), K, Fr, Fc, Fb, _ptr(g_mi), _ptr(g_maps),
+                  _stream())
+        return g_mi, g_maps, None
+
+
+def rig_weights(mi, maps, ids):
+    """(mi @ maps[:, ids]).t(), [Fb,K]: the blend weights of a batch of frames (ids: a slice or an index tensor) from the rig's two maps --
+    on the GPU one launch each way instead of a GEMM, a transposing copy and, backward, two GEMMs and the slice's zero-fill + copy."""
+    if mi.is_cuda and mi.dtype == torch.float32 and mi.is_contiguous() and maps.is_contiguous() and \
+            not (isinstance(ids, slice) and ids.step not in (None, 1)):
+        return _rig_weights_func.apply(mi, maps, ids)
+    return torch.matmul(mi, maps[:, ids] if isinstance(ids, slice) else maps.index_select(1, ids)).t()
+
+
 def transform_clip_batched(mvp, verts):
     """mvp [F*Nc,4,4], verts [F,V,3] on the GPU -> pos_clip [F*Nc,V,4]; same values as camera.transform_clip."""
     assert mvp.shape[0] % verts.shape[0] == 0
@@ -702,14 +742,13 @@ class Fitter:
         one-hot frame vector (fit.py:536, 115-116); M e_f is column f of M, so the batch selects columns
         (a slice -- no copy -- when the frames are a contiguous range)."""
         if self.cfg.mode in ('prior', 'combined'):
-            mapped = torch.matmul(self.maps_intermediate['local'], self._take(self.maps['local'], 1, frame_ids))     # [K,Fb]
-            out = blend_batched(self.v_base, self.datasets['local'], mapped.t())
+            out = blend_batched(self.v_base, self.datasets['local'], rig_weights(self.maps_intermediate['local'], self.maps['local'], frame_ids))
             if self.cfg.mode == 'prior':
                 return out
-        basis = torch.matmul(self.m2, self._take(self.m1, 1, frame_ids))                                             # [F,Fb]
+        basis_t = rig_weights(self.m2, self.m1, frame_ids)                                                            # [Fb,F]
         if self.cfg.mode == 'free':
-            return blend_batched(self.v_base, self.m3, basis.t())
-        return out + 0.5 * blend_batched(None, self.m3, basis.t())    # learned_coefficient=0.5, fit.py:562
+            return blend_batched(self.v_base, self.m3, basis_t)
+        return out + 0.5 * blend_batched(None, self.m3, basis_t)    # learned_coefficient=0.5, fit.py:562
 
     @torch.no_grad()
     def render_targets(self, chunk=4):

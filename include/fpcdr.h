@@ -504,6 +504,15 @@ int fpcdr_blend_bwd_w(const float *Bmat, const float *grad_out, float *grad_w, i
 int fpcdr_blend_bwd_basis(const float *w, const float *grad_out, float *grad_B, int32_t M, int32_t K, int32_t F,
                           void *stream);
 
+/* The rig's weight algebra in front of the blend (ABI v9; reference fit.py:115-116 maps_intermediate . (maps . one-hot frame), :58-62
+ * m2 . (m1 . one-hot frame)): w[fb][k] = sum_f mi[k][f] * maps[f][col(fb)], col(fb) = cols ? cols[fb] : col0 + fb -- the batch's frames
+ * select columns of maps -- in the [Fb,K] layout fpcdr_blend_fwd reads.  mi [K,Fr], maps [Fr,Fc] row-major, cols [Fb] int64 or NULL.
+ * bwd: grad_mi [K,Fr] and grad_maps [Fr,Fc] are OVERWRITTEN (columns no frame selects get zero); either may be NULL. */
+int fpcdr_rig_weights_fwd(const float *mi, const float *maps, const int64_t *cols, int32_t col0, int32_t K, int32_t Fr, int32_t Fc,
+                          int32_t Fb, float *w, void *stream);
+int fpcdr_rig_weights_bwd(const float *mi, const float *maps, const int64_t *cols, int32_t col0, const float *grad_w, int32_t K,
+                          int32_t Fr, int32_t Fc, int32_t Fb, float *grad_mi, float *grad_maps, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* background composite + L2 pixel loss        reference fit.py:161 and the pixel term of :579   */
 /* ------------------------------------------------------------------------------------------ */

@@ -783,3 +783,25 @@ def test_fitter_stream_overlap_options_do_not_change_the_step():
     assert abs(a[0] - b[0]) < 1e-5 * abs(a[0])
     for x, y in zip(a[1:], b[1:]):
         assert rel_l2(x, y) < 1e-5
+
+
+@pytest.mark.gpu
+def test_rig_weights_kernel_matches_the_torch_products():
+    """fit.rig_weights (fpcdr_rig_weights_fwd / _bwd) == (mi @ maps[:, ids]).t() in value and in both gradients: every frame (a slice
+    over all columns), a contiguous sub-range (a rank's shard), an index tensor, an index tensor that draws a frame twice."""
+    from fpc_diffrend_amd import fit
+    g = torch.Generator().manual_seed(3)
+    K, F = 150, 32
+    for ids in (slice(0, F), slice(8, 24), torch.tensor([5, 0, 31, 17]), torch.tensor([2, 9, 2, 2, 30])):
+        dev_ids = ids if isinstance(ids, slice) else ids.cuda()
+        mi = torch.randn(K, F, generator=g).cuda().requires_grad_(True)
+        maps = torch.randn(F, F, generator=g).cuda().requires_grad_(True)
+        w = fit.rig_weights(mi, maps, dev_ids)
+        up = torch.randn(w.shape, generator=g).cuda()
+        (w * up).sum().backward()
+        mi2, maps2 = mi.detach().double().requires_grad_(True), maps.detach().double().requires_grad_(True)
+        w2 = torch.matmul(mi2, maps2[:, dev_ids]).t()
+        (w2 * up.double()).sum().backward()
+        assert w.shape == w2.shape and w.is_contiguous()
+        assert rel_l2(w, w2) < 1e-6, ids
+        assert rel_l2(mi.grad, mi2.grad) < 1e-6 and rel_l2(maps.grad, maps2.grad) < 1e-6, ids
