@@ -13,9 +13,18 @@ Outputs (data only -- inputs and expected outputs, no reference source text):
                          translation) and the reference's P and MV 4x4 float32 matrices; plus
                          translate(0,170,0)
     meshdata_golden.json a tiny hand-written OBJ (text) and the arrays MeshData parses from it
+    blend_golden.json    seeded inputs and the outputs + autograd gradients of the reference's blend / blend_free /
+                         blend_combined (src/torch/fit.py:47-129).  `import src.torch.fit` fails on the absent roma /
+                         nvdiffrast / pytorch3d (ordinary ModuleNotFoundErrors), but the three functions are
+                         self-contained torch code: their FunctionDef nodes are taken out of the parsed file (ast),
+                         compiled as they are and run on the CPU with `torch` as their only global.  No stand-in for
+                         any missing library is involved and no source text is stored.
+    numframes_golden.json  assertNumFrames (fit.py:29-43, os only; taken out the same way) on two throw-away
+                         directory trees: the (count, zero-pad digits) pairs and the assertion on unequal counts
 
     python tests/golden/make_golden.py
 """
+import ast
 import json
 import os
 import sys
@@ -84,7 +93,85 @@ def main():
                    "uv": md.uv.astype(np.float64).tolist(), "uv_dtype": str(md.uv.dtype),
                    "faces": md.faces.tolist(), "faces_dtype": str(md.faces.dtype),
                    "fuv": md.fuv.tolist(), "fuv_dtype": str(md.fuv.dtype)}, f, indent=1)
-    print("wrote camera_golden.json, meshdata_golden.json")
+    blend_golden()
+    numframes_golden()
+    print("wrote camera_golden.json, meshdata_golden.json, blend_golden.json, numframes_golden.json")
+
+
+def reference_functions(names, extra_globals):
+    """The named top-level functions of the reference's src/torch/fit.py, compiled from the file's own syntax tree (the module
+    itself cannot be imported: roma, nvdiffrast, pytorch3d, torchvision and imageio are absent)."""
+    path = os.path.join(REF, "src", "torch", "fit.py")
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    nodes = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in nodes) == sorted(names), [n.name for n in nodes]
+    ns = dict(extra_globals)
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), path, "exec"), ns)
+    return {n: ns[n] for n in names}, {n.name: (n.lineno, n.end_lineno) for n in nodes}
+
+
+def blend_golden():
+    import torch
+    fns, lines = reference_functions(("blend", "blend_free", "blend_combined"), {"torch": torch})
+    rng = np.random.default_rng(7)
+    M, K, F = 3 * 43, 7, 5                 # 3V (not a multiple of the MFMA tile), blendshapes, frames
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    inp = {"v_base": f32(rng.normal(size=M) * 5), "Bmat": f32(rng.normal(size=(M, K))), "M1": f32(rng.normal(size=(F, F)) * 0.5 + np.eye(F)),
+           "M2": f32(rng.normal(size=(K, F)) * 0.4), "m1": f32(rng.normal(size=(F, F)) * 0.3 + np.eye(F)),
+           "m2": f32(rng.normal(size=(F, F)) * 0.3 + np.eye(F)), "m3": f32(rng.normal(size=(M, F)) * 0.2),
+           "gy": f32(rng.normal(size=(F, M))), "learned_coefficient": 0.5}        # fit.py:562 passes the literal 0.5
+    out = {"inputs": {k: (v.astype(np.float64).tolist() if isinstance(v, np.ndarray) else v) for k, v in inp.items()},
+           "reference_lines": lines, "cases": {}}
+
+    def run(name, call, leaves):
+        """One frame at a time, as the reference does (frames = one-hot vector, fit.py:536): values [F,M] and, from
+        sum_f <out_f, gy_f>, the autograd gradients of the reference's own code."""
+        t = {k: torch.tensor(inp[k]).requires_grad_(k in leaves) for k in ("v_base", "Bmat", "M1", "M2", "m1", "m2", "m3")}
+        vals, total = [], 0.0
+        for f in range(F):
+            e = torch.zeros(F); e[f] = 1.0
+            o = call(t, e)
+            assert o.shape == (M,)
+            vals.append(o.detach().numpy().astype(np.float64).tolist())
+            total = total + (o * torch.tensor(inp["gy"][f])).sum()
+        total.backward()
+        out["cases"][name] = {"out": vals, "grads": {k: t[k].grad.numpy().astype(np.float64).tolist() for k in leaves}}
+
+    run("blend", lambda t, e: fns["blend"](t["v_base"], {"local": t["M1"]}, {"local": t["M2"]}, {"local": t["Bmat"]}, e),
+        ("v_base", "Bmat", "M1", "M2"))
+    # the 'global' in dataset branch (fit.py:122-128): no intermediate map, maps['local'] is [K,F]
+    run("blend_global_key", lambda t, e: fns["blend"](t["v_base"], {"local": t["M2"]}, {}, {"local": t["Bmat"], "global": None}, e),
+        ("v_base", "Bmat", "M2"))
+    run("blend_free", lambda t, e: fns["blend_free"](t["v_base"], t["m1"], t["m2"], t["m3"], e), ("v_base", "m1", "m2", "m3"))
+    run("blend_combined", lambda t, e: fns["blend_combined"](t["v_base"], t["m1"], t["m2"], t["m3"], {"local": t["M1"]}, {"local": t["M2"]},
+                                                          {"local": t["Bmat"]}, e, learned_coefficient=inp["learned_coefficient"]),
+        ("v_base", "Bmat", "M1", "M2", "m1", "m2", "m3"))
+    run("blend_combined_default_coefficient", lambda t, e: fns["blend_combined"](t["v_base"], t["m1"], t["m2"], t["m3"], {"local": t["M1"]},
+                                                                              {"local": t["M2"]}, {"local": t["Bmat"]}, e),
+        ("M1", "M2", "m1", "m2", "m3"))
+    with open(os.path.join(HERE, "blend_golden.json"), "w") as f:
+        json.dump(out, f)
+
+
+def numframes_golden():
+    fns, lines = reference_functions(("assertNumFrames",), {"os": os})
+    cases = []
+    for counts in ([3, 3, 3], [120, 120], [99], [100], [4, 5]):
+        with tempfile.TemporaryDirectory() as d:
+            cams = []
+            for i, n in enumerate(counts):
+                cams.append(f"cam{i}")
+                os.makedirs(os.path.join(d, cams[-1]))
+                for j in range(n):
+                    open(os.path.join(d, cams[-1], f"{j:04d}.tif"), "w").close()
+            try:
+                res = list(fns["assertNumFrames"](cams, d))
+            except AssertionError as e:
+                res = {"AssertionError": str(e)}
+        cases.append({"counts": counts, "result": res})
+    with open(os.path.join(HERE, "numframes_golden.json"), "w") as f:
+        json.dump({"reference_lines": lines, "cases": cases}, f, indent=1)
 
 
 if __name__ == "__main__":

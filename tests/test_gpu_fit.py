@@ -49,6 +49,67 @@ def test_blend_reference_forms_match_torch():
     assert rel_l2(fit.blend_combined(v, m1, m2, m3, maps, mi, ds, e, learned_coefficient=0.5), ref_c) < 1e-5
 
 
+@pytest.mark.parametrize("batched", [False, True])
+def test_blend_matches_reference_golden(batched):
+    """fit.blend / blend_free / blend_combined (MFMA kernel behind them) and the algebra Fitter.vertices runs (fpcdr_rig_weights +
+    fpcdr_blend) against tests/golden/blend_golden.json: outputs and autograd gradients of the reference's OWN three functions
+    (src/torch/fit.py:47-129) on seeded inputs, captured by tests/golden/make_golden.py.  batched=False calls them the reference's way,
+    one one-hot frame vector at a time (fit.py:536); batched=True hands all frames over as one-hot columns."""
+    import json
+    from fpc_diffrend_amd import fit
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "blend_golden.json")))
+    inp = {k: (torch.tensor(np.asarray(v, dtype=np.float32)) if isinstance(v, list) else v) for k, v in gold["inputs"].items()}
+    F, M = inp["gy"].shape
+    names = ("v_base", "Bmat", "M1", "M2", "m1", "m2", "m3")
+    calls = {
+        "blend": lambda t, e: fit.blend(t["v_base"], {"local": t["M1"]}, {"local": t["M2"]}, {"local": t["Bmat"]}, e),
+        "blend_global_key": lambda t, e: fit.blend(t["v_base"], {"local": t["M2"]}, {}, {"local": t["Bmat"], "global": None}, e),
+        "blend_free": lambda t, e: fit.blend_free(t["v_base"], t["m1"], t["m2"], t["m3"], e),
+        "blend_combined": lambda t, e: fit.blend_combined(t["v_base"], t["m1"], t["m2"], t["m3"], {"local": t["M1"]}, {"local": t["M2"]},
+                                                          {"local": t["Bmat"]}, e, learned_coefficient=inp["learned_coefficient"]),
+        "blend_combined_default_coefficient": lambda t, e: fit.blend_combined(t["v_base"], t["m1"], t["m2"], t["m3"], {"local": t["M1"]},
+                                                                              {"local": t["M2"]}, {"local": t["Bmat"]}, e),
+    }
+    assert set(calls) == set(gold["cases"])
+    for case, call in calls.items():
+        leaves = gold["cases"][case]["grads"]
+        t = {k: inp[k].cuda().requires_grad_(k in leaves) for k in names}
+        if batched:
+            out = call(t, torch.eye(F, device='cuda'))
+        else:
+            out = torch.stack([call(t, torch.eye(F, device='cuda')[f]) for f in range(F)])
+        want = torch.tensor(np.asarray(gold["cases"][case]["out"], dtype=np.float32))
+        assert out.shape == want.shape == (F, M)
+        assert float((out.detach().cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max()), case
+        (out * inp["gy"].cuda()).sum().backward()
+        for k, g in leaves.items():
+            assert rel_l2(t[k].grad, torch.tensor(np.asarray(g, dtype=np.float32))) < 1e-5, (case, k)
+    # what Fitter.vertices launches for the three modes: rig_weights (index tensor and slice forms) + blend_batched
+    for ids in (torch.arange(F, device='cuda'), slice(0, F), torch.tensor([3, 0, 4], device='cuda'), slice(1, 4)):
+        rows = torch.arange(F)[ids.cpu() if torch.is_tensor(ids) else ids]
+        t = {k: inp[k].cuda().requires_grad_(True) for k in names}
+        prior = fit.blend_batched(t["v_base"], t["Bmat"], fit.rig_weights(t["M2"], t["M1"], ids))
+        basis_t = fit.rig_weights(t["m2"], t["m1"], ids)
+        free = fit.blend_batched(t["v_base"], t["m3"], basis_t)
+        comb = prior + 0.5 * fit.blend_batched(None, t["m3"], basis_t)
+        for case, out in (("blend", prior), ("blend_free", free), ("blend_combined", comb)):
+            want = torch.tensor(np.asarray(gold["cases"][case]["out"], dtype=np.float32))[rows]
+            assert float((out.detach().cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max()), (case, ids)
+    # ... and its backward over all frames (ids = every frame, the last-but-one loop entry is a permutation: use arange again)
+    for case, mode in (("blend", "prior"), ("blend_free", "free"), ("blend_combined", "combined")):
+        leaves = gold["cases"][case]["grads"]
+        t = {k: inp[k].cuda().requires_grad_(k in leaves) for k in names}
+        ids = torch.arange(F, device='cuda')
+        if mode != "free":
+            out = fit.blend_batched(t["v_base"], t["Bmat"], fit.rig_weights(t["M2"], t["M1"], ids))
+        if mode != "prior":
+            basis_t = fit.rig_weights(t["m2"], t["m1"], ids)
+            out = fit.blend_batched(t["v_base"], t["m3"], basis_t) if mode == "free" else out + 0.5 * fit.blend_batched(None, t["m3"], basis_t)
+        (out * inp["gy"].cuda()).sum().backward()
+        for k, g in leaves.items():
+            assert rel_l2(t[k].grad, torch.tensor(np.asarray(g, dtype=np.float32))) < 1e-5, (case, k)
+
+
 def test_pixel_loss_fused_equals_reference_chain():
     from fpc_diffrend_amd import fit
     g = torch.Generator().manual_seed(2)

@@ -201,6 +201,28 @@ def test_meshdata_matches_reference_golden(tmp_path):
     assert look[1]['cam'] == "x_pod2primary" and look[1]['intr'].shape == (3, 3) and look[1]['trans_calib'].shape == (3, 1)
 
 
+def test_assert_num_frames_matches_reference_golden(tmp_path):
+    """data.assert_num_frames against the reference's own assertNumFrames (fit.py:29-43) as run by tests/golden/make_golden.py."""
+    from fpc_diffrend_amd import data
+    with open(os.path.join(GOLD, "numframes_golden.json")) as f:
+        g = json.load(f)
+    assert len(g["cases"]) >= 5
+    for k, case in enumerate(g["cases"]):
+        root = tmp_path / f"take{k}"
+        cams = []
+        for i, n in enumerate(case["counts"]):
+            cams.append(f"cam{i}")
+            (root / cams[-1]).mkdir(parents=True)
+            for j in range(n):
+                (root / cams[-1] / f"{j:04d}.tif").write_text("")
+        if isinstance(case["result"], dict):
+            with pytest.raises(AssertionError) as e:
+                data.assert_num_frames(cams, str(root))
+            assert str(e.value).startswith(case["result"]["AssertionError"])
+        else:
+            assert list(data.assert_num_frames(cams, str(root))) == case["result"]
+
+
 def test_fitter_host_rules_graph_choice_and_frame_selection():
     """Host-side rules of the fit loop that need no GPU: FitConfig.hip_graph='auto' (graphs for few images per step, eager launches
     with launch hints for large batches) and the frame selection helper (a slice over every frame is the tensor itself, a slice of

@@ -57,6 +57,33 @@ def test_oracle_camera_matches_reference_golden():
     np.testing.assert_array_equal(ofit.translate(0.0, 170.0, 0.0), np.asarray(gold["translate_0_170_0"], dtype=np.float32))
 
 
+def test_oracle_blend_matches_reference_golden():
+    """oracle.fit.vertices (the three blend modes, reference fit.py:47-129) against tests/golden/blend_golden.json: the outputs
+    and autograd gradients of the reference's OWN blend / blend_free / blend_combined, run on the CPU by tests/golden/make_golden.py
+    (the functions are taken out of the reference file's syntax tree; the module itself cannot be imported)."""
+    import json
+    import os
+    import types
+    import numpy as np
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "blend_golden.json")))
+    inp = {k: (torch.tensor(np.asarray(v, dtype=np.float32)) if isinstance(v, list) else v) for k, v in gold["inputs"].items()}
+    assert inp["learned_coefficient"] == 0.5        # the literal of fit.py:562, which oracle.fit.vertices hard-codes
+    F = inp["M1"].shape[0]
+    for mode, case in (("prior", "blend"), ("free", "blend_free"), ("combined", "blend_combined")):
+        leaves = gold["cases"][case]["grads"].keys()
+        t = {k: inp[k].clone().requires_grad_(k in leaves) for k in ("v_base", "Bmat", "M1", "M2", "m1", "m2", "m3")}
+        st = types.SimpleNamespace(mode=mode, **t)
+        out = ofit.vertices(st, torch.arange(F))                    # [F, 3V]: all frames as one batch
+        want = torch.tensor(np.asarray(gold["cases"][case]["out"], dtype=np.float32))
+        assert out.shape == want.shape
+        assert float((out.detach() - want).abs().max()) <= 2e-6 * float(want.abs().max()), case
+        (out * inp["gy"]).sum().backward()
+        for k, g in gold["cases"][case]["grads"].items():
+            g = torch.tensor(np.asarray(g, dtype=np.float32))
+            err = float((t[k].grad - g).norm() / g.norm())
+            assert err < 1e-5, (case, k, err)
+
+
 def test_oracle_trainer_follows_the_reference_update_rules(oracle_ops):
     """reference fit.py:493-505, 603-618: ten Adam groups in the reference's order and learning rates, lr * ramp^(i/max_iter),
     whole-tensor quaternion division (quirk Q3), and the combined mode's learned basis receiving its first gradient in the
