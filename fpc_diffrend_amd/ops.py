@@ -488,7 +488,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, ref_bg_sumsq, use_hints, want_grad, unit_upstream,
-                flags_out=None, mip_levels=None, zero_extra=None, overlap_sil=None, bin_lists=True):
+                flags_out=None, mip_levels=None, zero_extra=None, overlap_sil=None, bin_lists=True, idp_out=None):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -498,7 +498,11 @@ class _pixel_objective_onepass(torch.autograd.Function):
         want_tex = bool(want_grad and ctx.needs_input_grad[1])
         u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
         scratch = u8(lib.fpcdr_rasterize_scratch_bytes(B, T))
-        sil, idp = u8(B * T), u8(lib.fpcdr_idplane_bytes(B, H, W))
+        sil = u8(B * T)
+        if idp_out is not None:      # (tests / diagnostics: the caller keeps the id planes)
+            if idp_out.numel() * idp_out.element_size() != lib.fpcdr_idplane_bytes(B, H, W) or not idp_out.is_contiguous() or idp_out.device != dev:
+                raise ValueError("id_plane_out must be a contiguous device tensor of fpcdr_idplane_bytes(B, H, W) bytes")
+        idp = idp_out if idp_out is not None else u8(lib.fpcdr_idplane_bytes(B, H, W))
         binlist = u8(lib.fpcdr_binlist_bytes(B, H, W)) if bin_lists else None      # per-bin triangle lists (set-up kernel -> rasteriser)
         occ, cmask = u8(lib.fpcdr_occ_bytes(B, H, W)), u8(lib.fpcdr_cmask_bytes(B, H, W))
         # records of the DEFERRED pixels (a pixel pair at a silhouette): dense addressing, written and read for a few per cent of the
@@ -579,7 +583,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
             g = g.to(torch.float32)
             g_pos = g_pos * g if g_pos is not None else None
             g_tex = g_tex * g if g_tex is not None else None
-        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 19
+        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 20
 
 
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
@@ -596,7 +600,8 @@ def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
 
 def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_total=None, background=45.0 / 255.0,
                     boundary_mode='wrap', sparse=True, ref_bg_sumsq=None, launch_hints=True, queued_backward=False,
-                    enable_mip=False, max_mip_level=None, one_pass=True, unit_upstream=False, aa_flags_out=None, zero_extra=None):
+                    enable_mip=False, max_mip_level=None, one_pass=True, unit_upstream=False, aa_flags_out=None, zero_extra=None,
+                    id_plane_out=None):
     """The whole pixel term of the reference's loss (fit.py:151-161 + the first term of :579) for a minibatch,
     as three kernels:  mean((ref - 255 * where(rast.w > 0, antialias(texture(interpolate(rasterize(pos)))), bg))^2)
     over n_total elements (default: all of this call's).  pos [B,V,4], tex [Ht,Wt,C] (C in 1,3,4), ref_u8 [B,H,W] uint8.
@@ -615,7 +620,9 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     unit_upstream=True (the caller guarantees d loss / d objective = 1).  one_pass=False: the two-call form.
     aa_flags_out (one_pass; tests / diagnostics): a zero-filled int64 tensor of fpcdr_antialias_flags_bytes(B,H,W) / 8 words that
     receives the antialias flag planes (which pixel pairs were blended).  zero_extra (one_pass): a contiguous float32 / int32 tensor of the
-    caller's that the call's first kernel zero-fills along with its own buffers (a fit step's small gradient accumulators)."""
+    caller's that the call's first kernel zero-fills along with its own buffers (a fit step's small gradient accumulators).
+    id_plane_out (one_pass; tests / diagnostics): a zero-filled tensor of fpcdr_idplane_bytes(B,H,W) bytes that is used as the call's id
+    planes and so keeps them -- 1024 uint32 per 32 x 32 bin, bin-major, (triangle + 1) | silhouette bits << 24 (include/fpcdr.h)."""
     assert isinstance(glctx, RasterizeHipContext)
     _check_tensor('pos', pos, torch.float32, 3)
     _check_tensor('tri', tri, torch.int32, 2)
@@ -643,7 +650,10 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     if one_pass and sparse:
         return _pixel_objective_onepass.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                               ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], ref_bg_sumsq,
-                                              bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out, mip_levels, zero_extra)
+                                              bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out, mip_levels, zero_extra,
+                                              None, True, id_plane_out)
+    if id_plane_out is not None:
+        raise ValueError("id_plane_out is an output of the one-pass form")
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                        ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], bool(sparse), ref_bg_sumsq,
                                        bool(launch_hints), bool(queued_backward), mip_levels, torch.is_grad_enabled())

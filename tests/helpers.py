@@ -86,3 +86,11 @@ def near_crossing_soup(B, T, seed, frac=0.4):
     pos = torch.cat([v[..., :2] * 1.2, z, w], dim=-1).reshape(B, T * 3, 4).contiguous()
     tri = torch.arange(T * 3, dtype=torch.int32).reshape(T, 3)
     return pos, tri
+
+
+def decode_id_planes(idp, B, H, W):
+    """The id planes of fpcdr_objective_fwd (include/fpcdr.h: 1024 uint32 per 32 x 32 bin, bins in (image, bin row, bin column) order,
+    pixel (y & 31) * 32 + (x & 31) inside, value (triangle + 1) | silhouette bits << 24) -> triangle + 1 as [B,H,W] int32 (0 = empty)."""
+    OY, OX = (H + 31) // 32, (W + 31) // 32
+    v = idp.detach().cpu().contiguous().view(torch.int32).reshape(B, OY, OX, 32, 32) & 0xffffff
+    return v.permute(0, 1, 3, 2, 4).reshape(B, OY * 32, OX * 32)[:, :H, :W].contiguous()

@@ -290,12 +290,15 @@ def test_1080p_sweep_kernels_equal_the_hinted_launch():
             dr._list_hints.clear()
 
 
-def test_cfg3_batch_of_288_images_equals_its_chunks():
+def test_cfg3_batch_of_288_images_equals_its_chunks(oracle_ops):
     """The headline batch itself (32 frames x 9 views of 1920 x 1080: 587 520 bins on the lists, launch hints, 17 GB of buffers)
     against the same images in 8 calls of 36: an image's pixels and vertices are its own, so the loss is the sum of the chunks'
     (same n_total), the position gradients are those of the chunks (up to the order of the float atomics), and the texture
     gradient is their sum.  The first
-    288-image call runs without hints (full grids), the second with the counts the first left behind."""
+    288-image call runs without hints (full grids), the second with the counts the first left behind.
+    Slices of the 288-image call also go STRAIGHT TO THE ORACLE: the id planes the call's rasteriser left (diagnostic output
+    id_plane_out) bit-exact against the C rasteriser for eight images spread over the batch, and for two of them the antialias pair
+    flags (bit-exact) and d loss / d pos_clip (1e-4) against the float32 oracle's own evaluation of that image."""
     import fpc_diffrend_amd.ops as dr
     from fpc_diffrend_amd import scene
     nf = 32
@@ -313,18 +316,40 @@ def test_cfg3_batch_of_288_images_equals_its_chunks():
     n_total = B * H * W * tex0.shape[2]
     ctx = dr.RasterizeGLContext(device=dev)
 
-    def run(sl):
+    from fpc_diffrend_amd import _lib
+    from helpers import decode_aa_flags, decode_id_planes
+    from oracle import fit as ofit
+    lib = _lib.load()
+
+    def run(sl, **kw):
         p = pos[sl].clone().requires_grad_(True)
         t = tex0.clone().requires_grad_(True)
-        loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref[sl], sc.resolution, n_total=n_total)
+        loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref[sl], sc.resolution, n_total=n_total, **kw)
         loss.backward()
         return loss.detach().double(), p.grad, t.grad.double()
 
     dr._list_hints.clear()
     try:
         whole_first = run(slice(0, B))                 # no hints yet: every list kernel at its full grid
-        whole = run(slice(0, B))                       # sized from the first call's counts
+        idp = torch.zeros(lib.fpcdr_idplane_bytes(B, H, W), dtype=torch.uint8, device=dev)
+        flags = torch.zeros(lib.fpcdr_antialias_flags_bytes(B, H, W) // 8, dtype=torch.int64, device=dev)
+        whole = run(slice(0, B), id_plane_out=idp, aa_flags_out=flags)      # sized from the first call's counts
         torch.cuda.synchronize()
+        # slices of this call against the oracle
+        OY, OX, Wq = (H + 31) // 32, (W + 31) // 32, (W + 63) // 64
+        planes = idp.view(torch.int32).reshape(B, OY * OX * 1024)
+        fl = flags.reshape(2, B, H, Wq)
+        tri_c = tri.cpu()
+        for b in (0, 41, 100, 143, 144, 200, 259, 287):
+            ids = decode_id_planes(planes[b], 1, H, W)
+            ids_ref = oracle_ops.rasterize_ids(pos[b:b + 1].cpu(), tri_c, sc.resolution)
+            assert torch.equal(ids, ids_ref), f"image {b} of the 288-image call: {int((ids != ids_ref).sum())} ids differ from the oracle"
+        for b in (100, 259):
+            o = ofit.smoke_from_clip(sc, pos[b:b + 1].cpu(), ref[b].cpu().reshape(1, 1, H, W), cams=(b % 9,))
+            assert torch.equal(decode_aa_flags(fl[:, b:b + 1].contiguous(), 1, H, W), o['aa_flags']), f"image {b}: antialias pair set"
+            # the oracle's loss is the mean over ITS image, the call's over the whole batch: d/d pos differs by the factor B
+            assert rel_l2(whole[1][b:b + 1] * B, o['grad_pos_clip']) < 1e-4, (b, rel_l2(whole[1][b:b + 1] * B, o['grad_pos_clip']))
+        del idp, flags, planes, fl
         # (gradients are sums of float atomics: equal up to the order of the additions)
         assert abs(float(whole[0]) - float(whole_first[0])) <= 1e-9 * abs(float(whole[0]))
         assert rel_l2(whole[1].double().cpu(), whole_first[1].double().cpu()) < 1e-6
