@@ -406,7 +406,8 @@ def main():
                                   + (" + free-form vertex offsets" if args.workload == "cfg5" else "")),
                    "coverage": coverage, "frames_per_gpu": fpg, "views": n_cam, "resolution": [H, W], "triangles": int(sc.pos_idx.shape[0]),
                    "blendshapes": int(sc.blendshapes.shape[1]), "texture": list(sc.texture.shape),
-                   "parallelism": f"dp{world} (frames sharded, one RCCL all-reduce of {bucket.nbytes / 1e6:.1f} MB per step)"},
+                   "parallelism": (f"dp{world} (frames sharded, one RCCL all-reduce of {bucket.nbytes / 1e6:.1f} MB per step)" if world > 1
+                                   else "one GPU, no collective")},
         # the data-parallel exchange of one step: HIP-event time of the RCCL all-reduce of the flat gradient bucket on this rank
         # (mean over the timed steps; includes waiting for the slowest rank) and the bucket's size; null on one GPU
         "allreduce_ms": allreduce_ms,
@@ -478,7 +479,8 @@ def main():
                 return {"kernel": name_,
                         # what the counters say limits the call; achieved / peak / frac are the HBM figures the metric asks for
                         # (algorithmic bytes against the 8 TB/s peak), whatever the bound
-                        "bound": "valu-issue" if valu_bound else "hbm",
+                        # (no counters for this workload / these sources: no evidence either way -> null, not "hbm")
+                        "bound": None if not pmc_ else ("valu-issue" if valu_bound else "hbm"),
                         "achieved": a_, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_ / HBM_PEAK_GBS, "ms": px_ops[name_]["avg_ms"],
                         "algorithmic_bytes": alg_,
                         "traffic": pmc_["hbm_bytes"] if pmc_ else None,

@@ -289,13 +289,24 @@ __global__ void __launch_bounds__(256) k_blend_bwd_basis(const float *__restrict
 //   w[fb][k] = sum_f mi[k][f] * maps[f][col(fb)],   col(fb) = cols ? cols[fb] : col0 + fb
 // written in the [Fb, K] layout the blend kernel reads.  150 x 32 x 32 multiply-adds: as torch ops it is a GEMM, a transposing copy and --
 // backward -- two GEMMs and two adds, 35 us of 5-9 us launches in the serial tail of a 2.8 ms step; here one launch each way.
+// column of batch entry fb: negative indices count from the end (as maps[:, ids] does); -1 = outside maps (the torch form raises; a kernel
+// cannot: the forward writes NaN into that row -- loud downstream, no out-of-bounds read -- and the backward gives it no gradient;
+// fit.rig_weights(validate=True) checks on the host first)
+__device__ __forceinline__ int rig_col(const int64_t *__restrict__ cols, int col0, int fb, int Fc) {
+    if (!cols) return col0 + fb;
+    long long c = cols[fb];
+    if (c < 0) c += Fc;
+    return (c >= 0 && c < Fc) ? (int)c : -1;
+}
+
 __global__ void __launch_bounds__(256) k_rig_weights_fwd(const float *__restrict__ mi, const float *__restrict__ maps,
                                                          const int64_t *__restrict__ cols, int col0, int K, int Fr, int Fc, int Fb,
                                                          float *__restrict__ w) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= Fb * K) return;
     const int fb = idx / K, k = idx - fb * K;
-    const int c = cols ? (int)cols[fb] : col0 + fb;
+    const int c = rig_col(cols, col0, fb, Fc);
+    if (c < 0) { w[idx] = __int_as_float(0x7fc00000); return; }
     float s = 0.0f;
 #pragma unroll 8
     for (int f = 0; f < Fr; ++f) s += mi[(size_t)k * Fr + f] * maps[(size_t)f * Fc + c];
@@ -315,8 +326,8 @@ __global__ void __launch_bounds__(256) k_rig_weights_bwd(const float *__restrict
         const int k = idx / Fr, f = idx - k * Fr;
         float s = 0.0f;
         for (int fb = lane; fb < Fb; fb += 64) {
-            const int c = cols ? (int)cols[fb] : col0 + fb;
-            s += g_w[(size_t)fb * K + k] * maps[(size_t)f * Fc + c];
+            const int c = rig_col(cols, col0, fb, Fc);
+            if (c >= 0) s += g_w[(size_t)fb * K + k] * maps[(size_t)f * Fc + c];
         }
         s = wave_sum_dpp(s);
         if (lane == 0) g_mi[idx] = s;
@@ -327,7 +338,7 @@ __global__ void __launch_bounds__(256) k_rig_weights_bwd(const float *__restrict
     const int f = idx / Fc, c = idx - f * Fc;
     float s = 0.0f;
     for (int fb = 0; fb < Fb; ++fb) {
-        if ((cols ? (int)cols[fb] : col0 + fb) != c) continue;      // (uniform over the wave)
+        if (rig_col(cols, col0, fb, Fc) != c) continue;      // (uniform over the wave)
         for (int k = lane; k < K; k += 64) s += mi[(size_t)k * Fr + f] * g_w[(size_t)fb * K + k];
     }
     s = wave_sum_dpp(s);

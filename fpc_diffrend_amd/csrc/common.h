@@ -42,8 +42,15 @@ struct FpcdrZeroList {
     uint32_t *p[MAXR];
     long long n[MAXR];
     int count;
-    __host__ void add(void *ptr, long long words) { if (ptr && words > 0 && count < MAXR) { p[count] = (uint32_t *)ptr; n[count] = words; ++count; } }
+    bool overflow;
+    // (a dropped entry would be an un-zeroed accumulator, i.e. a wrong gradient: the entry points FPCDR_REQUIRE(!overflow))
+    __host__ void add(void *ptr, long long words) {
+        if (!ptr || words <= 0) return;
+        if (count >= MAXR) { overflow = true; return; }
+        p[count] = (uint32_t *)ptr; n[count] = words; ++count;
+    }
 };
+static_assert(FpcdrZeroList::MAXR >= 5 + FPCDR_MAX_MIP + 2, "esum, loss, grad_pos, grad_tex, zero_extra, every mip level's gradient (+ 2 spare)");
 int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, const int32_t **occ_list, const int32_t **n_occ_dev,
                             const FpcdrZeroList &zl, bool sil_in_setup);
 

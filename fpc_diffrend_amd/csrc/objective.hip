@@ -1160,6 +1160,7 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         FPCDR_REQUIRE(p->zero_extra_bytes >= 0 && (p->zero_extra_bytes & 3) == 0 && ((size_t)p->zero_extra & 3) == 0, "zero_extra: 4-byte units");
         zl.add(p->zero_extra, p->zero_extra_bytes / 4);
     }
+    FPCDR_REQUIRE(!zl.overflow, "too many buffers to zero-fill (FpcdrZeroList::MAXR)");
     rc = fpcdr_launch_raster_ids(p, st, &occ_list, &n_occ, zl, !p->sil_ready);
     if (rc) return rc;
     ObjArgs a = {(const float4 *)p->pos, p->tri, (const float2 *)p->uv, p->uv_tri, (const float2 *)p->tri_uv, p->tex, p->ref, p->sil,

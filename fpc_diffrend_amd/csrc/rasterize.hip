@@ -58,7 +58,7 @@ struct __attribute__((aligned(8))) TriRec {  // 40 bytes
 struct __attribute__((aligned(8))) TriBox {  // inclusive pixel bbox; x0 > x1 = dropped
     int16_t x0, y0, x1, y1;
 };
-struct ImgBox { int32_t x0, y0, x1, y1, n_over, pad0, pad1, pad2; };  // box folded with atomicMin/atomicMax; n_over: overflow records (below)
+struct ImgBox { int32_t x0, y0, x1, y1, n_over, n_clip, pad1, pad2; };  // box folded with atomicMin/atomicMax; n_over: overflow records (below); n_clip: entries of the image's clip list
 
 // Per-image record slots.  A triangle that crosses the near plane is clipped into one or two pieces (rule R1): the first takes the
 // triangle's own slot t, the second is appended to the image's OVERFLOW region -- slots [Tp, Tp + n_over), Tp = T rounded up to whole
@@ -154,6 +154,13 @@ __device__ __forceinline__ bool setup_piece(const double (&v)[3][4], int H, int 
     return true;
 }
 
+// NEAR-PLANE CLIPPING LIVES IN ITS OWN KERNEL (r5).  clip_pieces works on small double arrays indexed at run time -- 400 bytes of private
+// segment per lane -- and a kernel with a private segment pays for it on every dispatch, taken or not (the fit loop's rig stays 140 units in
+// front of the near plane: never).  k_setup therefore only APPENDS the index of a triangle with a vertex at w <= 0 to its image's clip list
+// and leaves the slot dropped; k_setup_clip -- one small workgroup per image, normally finding an empty list -- clips those triangles,
+// fills the slot with the first piece (folding its box into the chunk box the set-up kernel stored, the image box and the bin lists) and
+// appends the second to the overflow slots.  The rasteriser's result does not depend on the order of records or list entries.
+//
 // Rule R1 for a triangle with some w <= 0: Sutherland-Hodgman against the near plane z + w >= 0, in double, every crossing computed
 // from the vertex inside to the one outside (the same arithmetic, in the same order, as oracle/raster_ref.c clip_pieces).  Returns the
 // number of pieces (0 = dropped) and their vertices.
@@ -218,7 +225,7 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
                                                 ImgBox *__restrict__ ibox, uint8_t *__restrict__ live,
                                                 const int32_t *__restrict__ ranges, int32_t *__restrict__ bin_cnt = nullptr,
                                                 int32_t *__restrict__ bin_list = nullptr, const int32_t *__restrict__ adj = nullptr,
-                                                uint8_t *__restrict__ sil = nullptr) {
+                                                uint8_t *__restrict__ sil = nullptr, int32_t *__restrict__ clip = nullptr) {
     // grid: x over 256-triangle chunks, y = image.  A block never straddles two images, so the union of
     // its triangles' bounding boxes can be reduced in the block: it is stored as the CHUNK box (meshes
     // keep neighbouring triangles at neighbouring indices, so a bin later skips most chunks with one
@@ -266,32 +273,8 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
                 } else {
                     box = {1, 1, 0, 0};
                 }
-            } else {      // a vertex at or behind w = 0: clip against the near plane, one or two pieces
-#ifndef FPCDR_ABL_NOCLIP
-                double pc[2][3][4];
-                const float4 vv[3] = {v0, v1, v2};
-                const int np = clip_pieces(vv, pc);
-                if (np >= 1 && setup_piece(pc[0], H, W, t, r, box)) {
-                    recs[gid] = r;
-                    bx0 = box.x0; by0 = box.y0; bx1 = box.x1; by1 = box.y1;
-                } else {
-                    box = {1, 1, 0, 0};
-                }
-                TriBox box2;
-                if (np == 2 && setup_piece(pc[1], H, W, t, r, box2)) {
-                    // second piece: appended to the image's overflow slots (no chunk box there: bins scan every overflow chunk);
-                    // it folds itself into the image box and marks the bins it touches
-                    const int k = atomicAdd(&ibox[b].n_over, 1);
-                    recs[img_slot + Tp + k] = r;
-                    boxes[img_slot + Tp + k] = box2;
-                    atomicMin(&ibox[b].x0, (int)box2.x0); atomicMin(&ibox[b].y0, (int)box2.y0);
-                    atomicMax(&ibox[b].x1, (int)box2.x1); atomicMax(&ibox[b].y1, (int)box2.y1);
-                    if (BINLIST) binlist_append_global(bin_cnt, bin_list, live, (size_t)b * OY * OX, OX, box2, Tp + k);
-                    else if (live)
-                        for (int gy = box2.y0 / BIN; gy <= box2.y1 / BIN; ++gy)
-                            for (int gx = box2.x0 / BIN; gx <= box2.x1 / BIN; ++gx) live[((size_t)b * OY + gy) * OX + gx] = 1;
-                }
-#endif
+            } else {      // a vertex at or behind w = 0: k_setup_clip's (the slot stays dropped until then)
+                clip[(size_t)b * Tp + atomicAdd(&ibox[b].n_clip, 1)] = t;
             }
         }
         boxes[gid] = box;
@@ -367,6 +350,64 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
             const int gx0 = cx0 / BIN, gy0 = cy0 / BIN, nx = cx1 / BIN - gx0 + 1, ny = cy1 / BIN - gy0 + 1;
             for (int k = threadIdx.x; k < nx * ny; k += blockDim.x)
                 live[((size_t)b * OY + gy0 + k / nx) * OX + gx0 + k % nx] = 1;
+        }
+    }
+}
+
+// The triangles k_setup put on the clip lists (see clip_pieces): grid (1, B), the workgroup strides over its image's list.
+template <bool BINLIST>
+__global__ void __launch_bounds__(256) k_setup_clip(const float4 *__restrict__ pos, const int32_t *__restrict__ tri, int V, int T, int H, int W,
+                                                     TriRec *__restrict__ recs, TriBox *__restrict__ boxes, TriBox *__restrict__ cboxes,
+                                                     ImgBox *__restrict__ ibox, uint8_t *__restrict__ live, int32_t *__restrict__ bin_cnt,
+                                                     int32_t *__restrict__ bin_list, const int32_t *__restrict__ clip) {
+    const int b = blockIdx.x;
+    const int n = ibox[b].n_clip;
+    if (n == 0) return;
+    const int Tp = padded_slots(T);
+    const size_t img_slot = (size_t)b * 2 * Tp;
+    const int OX = (W + BIN - 1) / BIN, OY = (H + BIN - 1) / BIN;
+    const size_t img_bins = (size_t)b * OY * OX;
+    const float4 *p = pos + (size_t)b * V;
+    auto mark = [&](const TriBox &bx, int slot) {      // image box, bin lists / live map of one piece
+        atomicMin(&ibox[b].x0, (int)bx.x0); atomicMin(&ibox[b].y0, (int)bx.y0);
+        atomicMax(&ibox[b].x1, (int)bx.x1); atomicMax(&ibox[b].y1, (int)bx.y1);
+        if (BINLIST) binlist_append_global(bin_cnt, bin_list, live, img_bins, OX, bx, slot);
+        else if (live)
+            for (int gy = bx.y0 / BIN; gy <= bx.y1 / BIN; ++gy)
+                for (int gx = bx.x0 / BIN; gx <= bx.x1 / BIN; ++gx) live[img_bins + (size_t)gy * OX + gx] = 1;
+    };
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const int t = clip[(size_t)b * Tp + k];
+        const float4 vv[3] = {p[tri[3 * t]], p[tri[3 * t + 1]], p[tri[3 * t + 2]]};      // (k_setup checked the indices)
+        double pc[2][3][4];
+        const int np = clip_pieces(vv, pc);
+        TriRec r;
+        TriBox box;
+        if (np >= 1 && setup_piece(pc[0], H, W, t, r, box)) {
+            // first piece: the triangle's own slot; its box joins the chunk box k_setup stored (bins skip chunks by that box)
+            recs[img_slot + t] = r;
+            boxes[img_slot + t] = box;
+            unsigned long long *cb = reinterpret_cast<unsigned long long *>(cboxes + (size_t)b * (Tp / 256) + t / 256);
+            unsigned long long seen = *cb;
+            for (;;) {
+                TriBox o;
+                __builtin_memcpy(&o, &seen, 8);
+                TriBox u = box;
+                if (o.x0 <= o.x1) u = {(int16_t)min(o.x0, box.x0), (int16_t)min(o.y0, box.y0), (int16_t)max(o.x1, box.x1), (int16_t)max(o.y1, box.y1)};
+                unsigned long long want;
+                __builtin_memcpy(&want, &u, 8);
+                const unsigned long long got = atomicCAS(cb, seen, want);
+                if (got == seen) break;
+                seen = got;
+            }
+            mark(box, t);
+        }
+        if (np == 2 && setup_piece(pc[1], H, W, t, r, box)) {
+            // second piece: appended to the image's overflow slots (no chunk box there: bins scan every overflow chunk)
+            const int q = atomicAdd(&ibox[b].n_over, 1);
+            recs[img_slot + Tp + q] = r;
+            boxes[img_slot + Tp + q] = box;
+            mark(box, Tp + q);
         }
     }
 }
@@ -1496,8 +1537,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(const float4 *__restrict__ p
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// layout of the caller's scratch buffer: records and boxes (2 Tp slots per image: triangles + overflow), chunk boxes, image boxes
-struct RasterScratch { TriRec *recs; TriBox *boxes, *cboxes; ImgBox *ibox; size_t bytes; };
+// layout of the caller's scratch buffer: records and boxes (2 Tp slots per image: triangles + overflow), chunk boxes, image boxes, clip lists
+struct RasterScratch { TriRec *recs; TriBox *boxes, *cboxes; ImgBox *ibox; int32_t *clip; size_t bytes; };
 static RasterScratch raster_scratch(void *base, int B, int T) {
     const size_t n = (size_t)B * 2 * (size_t)padded_slots(T), nc = (size_t)B * (size_t)(padded_slots(T) / 256);
     char *s = (char *)base;
@@ -1506,7 +1547,8 @@ static RasterScratch raster_scratch(void *base, int B, int T) {
     r.boxes = (TriBox *)(s + align_up(n * sizeof(TriRec), 256));
     r.cboxes = (TriBox *)((char *)r.boxes + align_up(n * sizeof(TriBox), 256));
     r.ibox = (ImgBox *)((char *)r.cboxes + align_up(nc * sizeof(TriBox), 256));
-    r.bytes = (size_t)((char *)r.ibox - s) + align_up((size_t)B * sizeof(ImgBox), 256);
+    r.clip = (int32_t *)((char *)r.ibox + align_up((size_t)B * sizeof(ImgBox), 256));      // [B][Tp] clip lists (k_setup -> k_setup_clip)
+    r.bytes = (size_t)((char *)r.clip - s) + align_up((size_t)B * (size_t)padded_slots(T) * sizeof(int32_t), 256);
     return r;
 }
 
@@ -1538,7 +1580,10 @@ extern "C" int fpcdr_rasterize_fwd(const fpcdr_rasterize_fwd_params *p, void *st
     // occupied and empty bins are in flight together at every moment, changes nothing -- 2.25 ms for strides 0 / n/55 / n/7 / n/1.6:
     // the long-lived occupied workgroups pile up on the CUs by themselves and the fill shares their 7 slots per CU.)
     hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, p->ranges, (int32_t *)nullptr, (int32_t *)nullptr);
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, p->ranges, (int32_t *)nullptr, (int32_t *)nullptr,
+                       (const int32_t *)nullptr, (uint8_t *)nullptr, rs.clip);
+    hipLaunchKernelGGL(k_setup_clip<false>, dim3(p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes,
+                       ibox, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, rs.clip);
     ShadeArgs sh = {};
     sh.op_hint = p->hint;
     if (p->rast_db)
@@ -1589,7 +1634,10 @@ extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) 
     ImgBox *ibox = rs.ibox;
     hipLaunchKernelGGL(k_init_ibox, dim3(fpcdr_cdiv(p->B, 256)), dim3(256), 0, st, ibox, p->B);
     hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, (uint8_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
+                       (const int32_t *)nullptr, (uint8_t *)nullptr, rs.clip);
+    hipLaunchKernelGGL(k_setup_clip<false>, dim3(p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes,
+                       ibox, (uint8_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, rs.clip);
     dim3 grid(fpcdr_cdiv(p->W, BIN), fpcdr_cdiv(p->H, BIN), p->B);
     ShadeArgs sh = {(const float2 *)p->uv, p->uv_tri, p->tex, p->color, p->Ht, p->Wt, p->C, p->boundary_mode,
                     nullptr, p->empty_color, (const float2 *)p->tri_uv};
@@ -1670,7 +1718,10 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     hipLaunchKernelGGL(k_init_queue, dim3(256), dim3(256), 0, st, ibox, p->B, (uint32_t *)live, (long long)(align_up(nbins, 4) / 4),
                        (uint32_t *)oc, (long long)(q.occ_hdr / 4), hdr, hdr_bwd);
     hipLaunchKernelGGL(k_setup<false>, dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, live, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+                       p->B, p->V, p->T, p->H, p->W, recs, boxes, cboxes, ibox, live, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
+                       (const int32_t *)nullptr, (uint8_t *)nullptr, rs.clip);
+    hipLaunchKernelGGL(k_setup_clip<false>, dim3(p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, recs, boxes, cboxes,
+                       ibox, live, (int32_t *)nullptr, (int32_t *)nullptr, rs.clip);
     int32_t *n_bins = hdr_bwd + 2, *n_fix = hdr_bwd + 3;     // all three counts live in the occ header, where the caller finds them
     const int nblk = fpcdr_cdiv((long long)nbins, 256);
     int32_t *blk = (int32_t *)(cm + q.cm_blk);          // [2][nblk] per-block counts, then offsets
@@ -1753,10 +1804,17 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
 #define SETUP(BL, SL)                                                                                                              \
     hipLaunchKernelGGL((k_setup<BL, SL>), dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,     \
                        p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr, bin_cnt, tri_lists, \
-                       p->adj, p->sil)
+                       p->adj, p->sil, rs.clip)
     if (bin_cnt) { if (sil_in_setup) SETUP(true, true); else SETUP(true, false); }
     else { if (sil_in_setup) SETUP(false, true); else SETUP(false, false); }
 #undef SETUP
+    // (the triangles with a vertex at w <= 0, normally none: one workgroup per image looks at its list's count and leaves)
+    if (bin_cnt)
+        hipLaunchKernelGGL(k_setup_clip<true>, dim3(p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, rs.recs, rs.boxes,
+                           rs.cboxes, rs.ibox, live, bin_cnt, tri_lists, rs.clip);
+    else
+        hipLaunchKernelGGL(k_setup_clip<false>, dim3(p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri, p->V, p->T, p->H, p->W, rs.recs, rs.boxes,
+                           rs.cboxes, rs.ibox, live, (int32_t *)nullptr, (int32_t *)nullptr, rs.clip);
     int32_t *n_bins = hdr_occ + 2, *n_occ = hdr_occ + 3;      // (include/fpcdr.h FPCDR_OCC_COUNTS_OFFSET)
     hipLaunchKernelGGL(k_list_count<0>, dim3(nblk), dim3(256), 0, st, live, (long long)nbins, OY, OX, blk, (uint16_t *)nullptr,
                        p->tex, p->Ht, p->Wt, p->C, p->boundary_mode, p->empty_color);

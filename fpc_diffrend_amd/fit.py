@@ -50,39 +50,42 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-class _ZeroPool:
-    """Small zero-filled accumulators for the backward kernels of one fit step (gradients of the camera matrices, the poses, the blend
-    weights: three fill launches of 5-7 us in the step's serial tail otherwise).  The Fitter arms the pool with a fresh flat buffer per
-    step and hands that buffer to the pixel objective, whose first kernel zero-fills it (ops.pixel_objective(zero_extra=...)); the
-    backward functions below take views of it.  Not armed, or exhausted: plain torch.zeros."""
-    buf = None
-    off = 0
+class ZeroPool:
+    """Small zero-filled accumulators for the backward kernels of ONE fit step (gradients of the camera matrices, the poses, the blend
+    weights: three fill launches of 5-7 us in the step's serial tail otherwise).  The Fitter makes one per step around a fresh flat
+    buffer, hands that buffer to the pixel objective, whose first kernel zero-fills it (ops.pixel_objective(zero_extra=...)), and
+    passes the pool itself to the functions whose backward takes views of it (blend_batched / transform_clip_batched / _mvp_func,
+    argument `pool`).  No pool (None), a pool on another device, or an exhausted one: plain torch.zeros.  An object handed over
+    explicitly, not module state: two Fitters in one process, or a backward run outside a step, cannot meet each other's buffer."""
 
-    @classmethod
-    def arm(cls, buf):
-        cls.buf, cls.off = buf, 0
+    def __init__(self, buf=None):
+        self.buf, self.off = buf, 0
 
-    @classmethod
-    def zeros(cls, shape, device):
+    def zeros(self, shape, device):
         n = int(np.prod(shape))
-        if cls.buf is not None and cls.buf.device == device and cls.off + n <= cls.buf.numel():
-            v = cls.buf[cls.off:cls.off + n].view(shape)
-            cls.off += (n + 3) // 4 * 4      # (16-byte aligned views)
+        if self.buf is not None and self.buf.device == device and self.off + n <= self.buf.numel():
+            v = self.buf[self.off:self.off + n].view(shape)
+            self.off += (n + 3) // 4 * 4      # (16-byte aligned views)
             return v
         return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
+def _pool_zeros(pool, shape, device):
+    return pool.zeros(shape, device) if pool is not None else torch.zeros(shape, dtype=torch.float32, device=device)
 
 
 class _blend_func(torch.autograd.Function):
     """out[F,M] = v_base[M] + w[F,K] . Bmat[M,K]^T   (fpcdr_blend_fwd / _bwd_w / _bwd_basis)."""
 
     @staticmethod
-    def forward(ctx, v_base, Bmat, w):
+    def forward(ctx, v_base, Bmat, w, pool=None):
         lib = _lib.load()
         M, K = Bmat.shape
         F = w.shape[0]
         out = torch.empty(F, M, dtype=torch.float32, device=w.device)
         _lib.call("fpcdr_blend_fwd", _ptr(v_base), _ptr(Bmat), _ptr(w), _ptr(out), M, K, F, _stream())
         ctx.save_for_backward(Bmat, w)
+        ctx.pool = pool
         return out
 
     @staticmethod
@@ -99,20 +102,21 @@ class _blend_func(torch.autograd.Function):
             _lib.call("fpcdr_blend_bwd_basis", _ptr(w), _ptr(g), _ptr(g_B), M, K, F, _stream())
         g_w = None
         if ctx.needs_input_grad[2]:
-            g_w = _ZeroPool.zeros(tuple(w.shape), w.device)
+            g_w = _pool_zeros(ctx.pool, tuple(w.shape), w.device)
             _lib.call("fpcdr_blend_bwd_w", _ptr(Bmat), _ptr(g), _ptr(g_w), M, K, F, _stream())
-        return g_vb, g_B, g_w
+        return g_vb, g_B, g_w, None
 
 
 class _transform_clip_func(torch.autograd.Function):
     """camera.transform_clip for a minibatch on the GPU (fpcdr_transform_clip_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, mvp, verts):
+    def forward(ctx, mvp, verts, pool=None):
         B, F, V = mvp.shape[0], verts.shape[0], verts.shape[1]
         out = torch.empty(B, V, 4, dtype=torch.float32, device=verts.device)
         _lib.call("fpcdr_transform_clip_fwd", _ptr(mvp), _ptr(verts), _ptr(out), F, B // F, V, _stream())
         ctx.save_for_backward(mvp, verts)
+        ctx.pool = pool
         return out
 
     @staticmethod
@@ -120,17 +124,17 @@ class _transform_clip_func(torch.autograd.Function):
         mvp, verts = ctx.saved_tensors
         B, F, V = mvp.shape[0], verts.shape[0], verts.shape[1]
         g = g.contiguous()
-        g_mvp = _ZeroPool.zeros(tuple(mvp.shape), mvp.device) if ctx.needs_input_grad[0] else None
+        g_mvp = _pool_zeros(ctx.pool, tuple(mvp.shape), mvp.device) if ctx.needs_input_grad[0] else None
         g_verts = torch.empty_like(verts) if ctx.needs_input_grad[1] else None
         _lib.call("fpcdr_transform_clip_bwd", _ptr(mvp), _ptr(verts), _ptr(g), _ptr(g_verts), _ptr(g_mvp), F, B // F, V, _stream())
-        return g_mvp, g_verts
+        return g_mvp, g_verts, None
 
 
 class _rig_weights_func(torch.autograd.Function):
     """(mi @ maps[:, ids]).t() as one launch each way (fpcdr_rig_weights_fwd / _bwd): reference fit.py:115-116 (and :58-62 with m2, m1)."""
 
     @staticmethod
-    def forward(ctx, mi, maps, ids):
+    def forward(ctx, mi, maps, ids, validate=True):
         K, Fr = mi.shape
         Fc = maps.shape[1]
         if isinstance(ids, slice):
@@ -139,6 +143,11 @@ class _rig_weights_func(torch.autograd.Function):
             cols, col0, Fb = None, lo, hi - lo
         else:
             cols, col0, Fb = ids.to(torch.int64).contiguous(), 0, int(ids.shape[0])
+            # maps[:, ids] / index_select raise on an index outside [-Fc, Fc); the kernels wrap negatives and cannot raise (they write
+            # NaN rows forward and no gradient backward): checked here, at the price of one host read -- callers that made the indices
+            # themselves from a valid range (Fitter.pick_frames) pass validate=False
+            if validate and Fb and bool(((cols < -Fc) | (cols >= Fc)).any()):
+                raise IndexError(f"rig_weights: frame index out of range for {Fc} columns")
         w = torch.empty(Fb, K, dtype=torch.float32, device=mi.device)
         _lib.call("fpcdr_rig_weights_fwd", _ptr(mi), _ptr(maps), _ptr(cols), col0, K, Fr, Fc, Fb, _ptr(w), _stream())
         ctx.save_for_backward(mi, maps, *([cols] if cols is not None else []))
@@ -154,27 +163,30 @@ class _rig_weights_func(torch.autograd.Function):
         g_maps = torch.empty_like(maps) if ctx.needs_input_grad[1] else None
         _lib.call("fpcdr_rig_weights_bwd", _ptr(mi), _ptr(maps), _ptr(cols), col0, _ptr(g.contiguous()), K, Fr, Fc, Fb, _ptr(g_mi), _ptr(g_maps),
                   _stream())
-        return g_mi, g_maps, None
+        return g_mi, g_maps, None, None
 
 
-def rig_weights(mi, maps, ids):
+def rig_weights(mi, maps, ids, validate=True):
     """(mi @ maps[:, ids]).t(), [Fb,K]: the blend weights of a batch of frames (ids: a slice or an index tensor) from the rig's two maps --
-    on the GPU one launch each way instead of a GEMM, a transposing copy and, backward, two GEMMs and the slice's zero-fill + copy."""
+    on the GPU one launch each way instead of a GEMM, a transposing copy and, backward, two GEMMs and the slice's zero-fill + copy.
+    An index tensor follows maps[:, ids]: negative entries count from the end, anything outside [-Fc, Fc) raises IndexError
+    (validate=False skips that host-side check, and the read of the indices it costs, for indices known to be in range)."""
     if mi.is_cuda and mi.dtype == torch.float32 and mi.is_contiguous() and maps.is_contiguous() and \
             not (isinstance(ids, slice) and ids.step not in (None, 1)):
-        return _rig_weights_func.apply(mi, maps, ids)
-    return torch.matmul(mi, maps[:, ids] if isinstance(ids, slice) else maps.index_select(1, ids)).t()
+        return _rig_weights_func.apply(mi, maps, ids, validate)
+    return torch.matmul(mi, maps[:, ids]).t()
 
 
-def transform_clip_batched(mvp, verts):
-    """mvp [F*Nc,4,4], verts [F,V,3] on the GPU -> pos_clip [F*Nc,V,4]; same values as camera.transform_clip."""
+def transform_clip_batched(mvp, verts, pool=None):
+    """mvp [F*Nc,4,4], verts [F,V,3] on the GPU -> pos_clip [F*Nc,V,4]; same values as camera.transform_clip.  pool: a ZeroPool the
+    backward takes its small zero-filled accumulator from."""
     assert mvp.shape[0] % verts.shape[0] == 0
-    return _transform_clip_func.apply(mvp.contiguous(), verts.contiguous())
+    return _transform_clip_func.apply(mvp.contiguous(), verts.contiguous(), pool)
 
 
-def blend_batched(v_base, Bmat, w):
-    """v_base [M], Bmat [M,K], w [F,K] -> [F,M] on the GPU matrix cores."""
-    return _blend_func.apply(v_base.contiguous() if v_base is not None else None, Bmat.contiguous(), w.contiguous())
+def blend_batched(v_base, Bmat, w, pool=None):
+    """v_base [M], Bmat [M,K], w [F,K] -> [F,M] on the GPU matrix cores (pool: see transform_clip_batched)."""
+    return _blend_func.apply(v_base.contiguous() if v_base is not None else None, Bmat.contiguous(), w.contiguous(), pool)
 
 
 def _frame_matrix(frames):
@@ -266,7 +278,8 @@ class _mvp_func(torch.autograd.Function):
     """Model-view-projection matrices of a minibatch in one kernel each way (fpcdr_mvp_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, q_cam, t_cam, q_frame, t_frame, proj, t_mv):
+    def forward(ctx, q_cam, t_cam, q_frame, t_frame, proj, t_mv, pool=None):
+        ctx.pool = pool
         q_cam, t_cam, q_frame, t_frame = (a.contiguous() for a in (q_cam, t_cam, q_frame, t_frame))
         Fb, Nc = q_frame.shape[0], q_cam.shape[0]
         out = torch.empty(Fb * Nc, 4, 4, dtype=torch.float32, device=q_cam.device)
@@ -279,12 +292,12 @@ class _mvp_func(torch.autograd.Function):
     def backward(ctx, g):
         q_cam, t_cam, q_frame, t_frame, proj, t_mv = ctx.saved_tensors
         Fb, Nc = q_frame.shape[0], q_cam.shape[0]
-        grads = _ZeroPool.zeros((7 * (Fb + Nc),), g.device)
+        grads = _pool_zeros(ctx.pool, (7 * (Fb + Nc),), g.device)
         gq_cam, gt_cam = grads[:4 * Nc].view(Nc, 4), grads[4 * Nc:7 * Nc].view(Nc, 3)
         gq_frame, gt_frame = grads[7 * Nc:7 * Nc + 4 * Fb].view(Fb, 4), grads[7 * Nc + 4 * Fb:].view(Fb, 3)
         _lib.call("fpcdr_mvp_bwd", _ptr(proj), _ptr(t_mv), _ptr(q_cam), _ptr(t_cam), _ptr(q_frame), _ptr(t_frame),
                   _ptr(g.contiguous()), _ptr(gq_cam), _ptr(gt_cam), _ptr(gq_frame), _ptr(gt_frame), Fb, Nc, _stream())
-        return gq_cam, gt_cam, gq_frame, gt_frame, None, None
+        return gq_cam, gt_cam, gq_frame, gt_frame, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -396,9 +409,14 @@ class _laplacian_penalty(torch.autograd.Function):
             ctx.event = torch.cuda.Event()
             ctx.event.record(stream)
             x.record_stream(stream)
-            for t in (out, gx):          # allocated on `stream`, consumed on the current one
+            # allocated on `stream`, consumed on the current one (out, gx; lap and per by a non-eager backward(), which reads them on the
+            # stream of ITS caller after wait_event: without the record the caching allocator may hand their blocks to a new side-stream
+            # allocation while that kernel is still reading them)
+            for t in (out, gx) if eager else (out, lap, per):
                 if t is not None:
                     t.record_stream(main)
+            for t in (nbr32, inv_deg):   # the caller's tensors, read on `stream`
+                t.record_stream(stream)
         if eager:
             ctx.save_for_backward(gx)
         else:
@@ -716,16 +734,16 @@ class Fitter:
     def _n(frame_ids):
         return frame_ids.stop - frame_ids.start if isinstance(frame_ids, slice) else len(frame_ids)
 
-    def mvp(self, frame_ids, view_ids=None):
+    def mvp(self, frame_ids, view_ids=None, pool=None):
         """mvp[f,c] = P_c . Rt(q_f,t_f) . Rt(q_c,t_c) . MV_c . T(0,170,0)   (fit.py:541-553), [Fb*Nc,4,4].
-        view_ids: positions in cam_idxs of the cameras of this step (a device index tensor; None = all of them)."""
+        view_ids: positions in cam_idxs of the cameras of this step (a device index tensor; None = all of them).  pool: the step's ZeroPool."""
         if view_ids is not None:
             cams = self.cam_sel.index_select(0, view_ids)
             return _mvp_func.apply(self.q_opt.index_select(0, cams), self.t_opt.index_select(0, cams), self._take(self.per_frame_q, 0, frame_ids),
-                                   self._take(self.per_frame_t, 0, frame_ids), self.proj.index_select(0, view_ids), self.t_mv.index_select(0, view_ids))
+                                   self._take(self.per_frame_t, 0, frame_ids), self.proj.index_select(0, view_ids), self.t_mv.index_select(0, view_ids), pool)
         all_cams = self.cam_idxs == list(range(self.q_opt.shape[0]))    # no gather (and no sort in its backward) then
         q_c, t_c = (self.q_opt, self.t_opt) if all_cams else (self.q_opt[self.cam_sel], self.t_opt[self.cam_sel])
-        return _mvp_func.apply(q_c, t_c, self._take(self.per_frame_q, 0, frame_ids), self._take(self.per_frame_t, 0, frame_ids), self.proj, self.t_mv)
+        return _mvp_func.apply(q_c, t_c, self._take(self.per_frame_q, 0, frame_ids), self._take(self.per_frame_t, 0, frame_ids), self.proj, self.t_mv, pool)
 
     @staticmethod
     def _take(t, dim, ids):
@@ -737,18 +755,20 @@ class Fitter:
             return t[ids] if dim == 0 else t[:, ids]
         return t.index_select(dim, ids)
 
-    def vertices(self, frame_ids, iteration=None):
+    def vertices(self, frame_ids, iteration=None, pool=None):
         """Blended vertex buffers [Fb,3V] for a batch of frames (fit.py:555-562).  The reference multiplies by a
         one-hot frame vector (fit.py:536, 115-116); M e_f is column f of M, so the batch selects columns
         (a slice -- no copy -- when the frames are a contiguous range)."""
         if self.cfg.mode in ('prior', 'combined'):
-            out = blend_batched(self.v_base, self.datasets['local'], rig_weights(self.maps_intermediate['local'], self.maps['local'], frame_ids))
+            # (validate=False: the frame indices are pick_frames' own, drawn from this rank's range)
+            out = blend_batched(self.v_base, self.datasets['local'],
+                                rig_weights(self.maps_intermediate['local'], self.maps['local'], frame_ids, validate=False), pool)
             if self.cfg.mode == 'prior':
                 return out
-        basis_t = rig_weights(self.m2, self.m1, frame_ids)                                                            # [Fb,F]
+        basis_t = rig_weights(self.m2, self.m1, frame_ids, validate=False)                                            # [Fb,F]
         if self.cfg.mode == 'free':
-            return blend_batched(self.v_base, self.m3, basis_t)
-        return out + 0.5 * blend_batched(None, self.m3, basis_t)    # learned_coefficient=0.5, fit.py:562
+            return blend_batched(self.v_base, self.m3, basis_t, pool)
+        return out + 0.5 * blend_batched(None, self.m3, basis_t, pool)    # learned_coefficient=0.5, fit.py:562
 
     @torch.no_grad()
     def render_targets(self, chunk=4):
@@ -821,21 +841,28 @@ class Fitter:
             for m in (self.m1, self.m2, self.m3):
                 m.requires_grad = True
         Fb, Nc = self._n(frame_ids), (len(self.cam_idxs) if view_ids is None else int(view_ids.shape[0]))
-        vtx_pos = self.vertices(frame_ids)                            # [Fb,3V]
+        C = self.tex_opt.shape[2]
+        # (the mip branch of the reference's render(), fit.py:153-155, runs inside the same kernels)
+        one_shot = (cfg.fused_objective and cfg.fused_render and cfg.fused_loss and C in (1, 3, 4) and cfg.shading == 'texture'
+                    and (not cfg.enable_mip or cfg.sparse_objective))
+        # one flat buffer for the small accumulators of this step's backward kernels, zero-filled by the objective's first kernel; the
+        # pool around it goes to the functions whose backward takes views of it
+        zero_buf, pool = None, None
+        if one_shot and cfg.one_pass and cfg.sparse_objective:
+            zero_buf = torch.empty(Fb * Nc * 16 + 7 * (Fb + Nc) + 64 + Fb * (self.datasets['local'].shape[1] + self.m3.shape[1]),
+                                   dtype=torch.float32, device=self.device)
+            pool = ZeroPool(zero_buf)
+        vtx_pos = self.vertices(frame_ids, pool=pool)                 # [Fb,3V]
         vtx_pos_split = vtx_pos.reshape(Fb, -1, 3)
-        mvp = self.mvp(frame_ids, view_ids)
+        mvp = self.mvp(frame_ids, view_ids, pool)
         ref = None
         n_img_global = Fb * Nc * self.world
         local = slice(frame_ids.start - self.frame_lo, frame_ids.stop - self.frame_lo) if isinstance(frame_ids, slice) \
             else frame_ids - self.frame_lo
         ref = self.targets[local] if view_ids is None else self.targets[local].index_select(1, view_ids)
         ref = ref.reshape(Fb * Nc, *self.resolution)
-        C = self.tex_opt.shape[2]
         n_total = n_img_global * self.resolution[0] * self.resolution[1] * C
-        # (the mip branch of the reference's render(), fit.py:153-155, runs inside the same kernels)
-        one_shot = (cfg.fused_objective and cfg.fused_render and cfg.fused_loss and C in (1, 3, 4) and cfg.shading == 'texture'
-                    and (not cfg.enable_mip or cfg.sparse_objective))
-        pos_clip = transform_clip_batched(mvp, vtx_pos_split)        # camera.transform_clip (camera.py:11-23), batched
+        pos_clip = transform_clip_batched(mvp, vtx_pos_split, pool)  # camera.transform_clip (camera.py:11-23), batched
         if cfg.shading == 'vertex':
             colour, rast_out = self.render_vertex(self.glctx, pos_clip)
             n_total = n_img_global * self.resolution[0] * self.resolution[1]
@@ -892,28 +919,19 @@ class Fitter:
                 else:
                     bg = self.target_bg_sumsq[local]
                     bg_sum = (bg if view_ids is None else bg.index_select(1, view_ids)).sum()
-            # one flat buffer for the small accumulators of this step's backward kernels, zero-filled by the objective's first kernel
-            zero_pool = None
-            if cfg.one_pass and cfg.sparse_objective:
-                zero_pool = torch.empty(Fb * Nc * 16 + 7 * (Fb + Nc) + 64 + Fb * (self.datasets['local'].shape[1] + self.m3.shape[1]),
-                                        dtype=torch.float32, device=self.device)
-            try:      # (the pool is a module-level hand-over to this step's backward functions: never left armed)
-                _ZeroPool.arm(zero_pool)
-                pix = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
-                                         n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum,
-                                         enable_mip=cfg.enable_mip, max_mip_level=cfg.max_mip_level,
-                                         queued_backward=cfg.queued_backward and not self.use_graph,
-                                         one_pass=cfg.one_pass, unit_upstream=True, zero_extra=zero_pool)      # (the seeds below are 1)
-                # d loss / d pix = d loss / d reg = 1, handed over as a cached device scalar: `(pix + reg).backward()` would put an add and
-                # a fill between the forward and the backward kernel; the sum is formed after the backward pass has been enqueued
-                roots, seeds = [pix], [self._one]
-                for term in (reg, lap):
-                    if term is not None and term.requires_grad:
-                        roots.append(term)
-                        seeds.append(self._one)
-                torch.autograd.backward(roots, seeds)
-            finally:
-                _ZeroPool.arm(None)
+            pix = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
+                                     n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum,
+                                     enable_mip=cfg.enable_mip, max_mip_level=cfg.max_mip_level,
+                                     queued_backward=cfg.queued_backward and not self.use_graph,
+                                     one_pass=cfg.one_pass, unit_upstream=True, zero_extra=zero_buf)      # (the seeds below are 1)
+            # d loss / d pix = d loss / d reg = 1, handed over as a cached device scalar: `(pix + reg).backward()` would put an add and
+            # a fill between the forward and the backward kernel; the sum is formed after the backward pass has been enqueued
+            roots, seeds = [pix], [self._one]
+            for term in (reg, lap):
+                if term is not None and term.requires_grad:
+                    roots.append(term)
+                    seeds.append(self._one)
+            torch.autograd.backward(roots, seeds)
             if side is not None:
                 main_stream.wait_stream(side)    # the regularisers' forward and backward ran on the side stream
                 reg.record_stream(main_stream)

@@ -335,9 +335,13 @@ class _MappedHints:
     def poll(self):
         if self.frozen:
             return self.caps
-        n_def, _, n_bins, n_occ, seq = (int(v) for v in self.host[:5].tolist())
-        if seq != self.seen and seq == int(self.host[4]):      # (the counters of one call: [4] is written last)
-            self.seen = seq
+        # the device writes [0:4], fences, then writes [4]: the sequence number is read BEFORE and AFTER the counters and they are adopted
+        # only if both reads agree (and are new) -- a later call's counters landing in between cannot be mixed with this call's
+        before = int(self.host[4])
+        n_def, _, n_bins, n_occ = (int(v) for v in self.host[:4].tolist())
+        after = int(self.host[4])
+        if before == after and after != self.seen:
+            self.seen = after
             self.caps = tuple(n + max(256, n // 8) if n > 0 else 0 for n in (n_bins, n_occ, n_def))
         return self.caps
 
@@ -347,6 +351,26 @@ class _MappedHints:
 
 
 _list_hints = {}
+
+
+def _hints_for(key, cls):
+    """The hint record of a batch shape, made on first use -- never under HIP-graph capture (its pinned allocation would be a
+    hipHostMalloc inside the capture): a captured call simply runs unhinted then."""
+    h = _list_hints.get(key)
+    if h is None:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return None
+        h = _list_hints[key] = cls()
+    return h
+
+
+def clear_hints():
+    """Forget every launch hint.  The objective's last kernel writes its counters into the records' pinned host memory through a raw
+    pointer the allocator cannot see, so the device is drained first: dropping a record while a call is queued would return its block
+    to the pinned cache with a write still in flight."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    _list_hints.clear()
 
 
 class _pixel_objective_func(torch.autograd.Function):
@@ -390,7 +414,7 @@ class _pixel_objective_func(torch.autograd.Function):
         if sparse:
             # one call: the rasteriser settles every pixel antialiasing cannot touch, a second kernel the candidates it marks
             cmask = torch.empty(lib.fpcdr_cmask_bytes(B, H, W), dtype=torch.uint8, device=dev)
-            hints = _list_hints.setdefault((dev.index, B, V, T, H, W), _ListHints()) if use_hints else None
+            hints = _hints_for((dev.index, B, V, T, H, W), _ListHints) if use_hints else None
             if hints is not None:
                 q.cap_bins, q.cap_fix, ctx.cap_bwd = hints.poll()
             _lib.call("fpcdr_render_loss_fwd", ctypes.byref(p), ctypes.byref(q), _ptr(cmask), _stream())
@@ -547,7 +571,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
             for t_ in (pos, tri, adj, sil):
                 t_.record_stream(side)
         capturing = torch.cuda.is_current_stream_capturing()
-        hints = _list_hints.setdefault(('onepass', dev.index, B, V, T, H, W), _MappedHints()) if use_hints else None
+        hints = _hints_for(('onepass', dev.index, B, V, T, H, W), _MappedHints) if use_hints else None
         if hints is not None:
             p.cap_bins, p.cap_occ, p.cap_def = hints.poll()      # (live bins, occupied bins, bins with a deferred pixel)
             if not capturing:      # (a graph replays fixed launch sizes: nothing to report)
@@ -645,8 +669,12 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
         if not sparse:
             raise NotImplementedError("pixel_objective(enable_mip=True) runs in sparse mode (use the separate operators otherwise)")
         mip_levels = _num_mip_levels(tex.shape[0], tex.shape[1], max_mip_level)
-    if zero_extra is not None and not (one_pass and sparse):
-        zero_extra.zero_()
+    if zero_extra is not None:
+        # (the kernel zero-fills numel * itemsize bytes from data_ptr(): a view with gaps would have other storage overwritten)
+        if not (zero_extra.is_contiguous() and zero_extra.dtype in (torch.float32, torch.int32) and zero_extra.device == pos.device):
+            raise ValueError("zero_extra must be a contiguous float32 / int32 tensor on the device of pos")
+        if not (one_pass and sparse):
+            zero_extra.zero_()
     if one_pass and sparse:
         return _pixel_objective_onepass.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                               ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], ref_bg_sumsq,

@@ -23,7 +23,7 @@ for case in range(n_cases):
     tex0 = torch.rand(32, 64, C, generator=g) * 0.6
     ref = torch.randint(0, 141, (B, H, W), generator=g, dtype=torch.uint8).to(dev)
     out = {}
-    dr._list_hints.clear()
+    dr.clear_hints()
     for name in ("chain", "fused", "fused again (launch hints)", "two-call form"):      # fused = the one-pass objective (value + gradient in one call)
         p = pos.to(dev).clone().requires_grad_(True); t = tex0.to(dev).clone().requires_grad_(True)
         if name == "chain":

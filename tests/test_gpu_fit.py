@@ -646,7 +646,7 @@ def test_objective_launch_hints_do_not_change_the_result():
         return float(loss), p.grad.double().cpu(), t.grad.double().cpu()
 
     base = run(launch_hints=False)
-    dr._list_hints.clear()
+    dr.clear_hints()
     first = run(queued_backward=True)   # no hint yet; leaves its counts behind
     key = next(iter(dr._list_hints))
     hints = dr._list_hints[key]
@@ -660,7 +660,7 @@ def test_objective_launch_hints_do_not_change_the_result():
     for r in (first, second, third, fourth):
         assert abs(r[0] - base[0]) <= 1e-6 * abs(base[0])
         assert rel_l2(r[1], base[1]) < 1e-5 and rel_l2(r[2], base[2]) < 1e-5
-    dr._list_hints.clear()
+    dr.clear_hints()
 
 
 @pytest.mark.gpu
@@ -853,7 +853,8 @@ def test_rig_weights_kernel_matches_the_torch_products():
     from fpc_diffrend_amd import fit
     g = torch.Generator().manual_seed(3)
     K, F = 150, 32
-    for ids in (slice(0, F), slice(8, 24), torch.tensor([5, 0, 31, 17]), torch.tensor([2, 9, 2, 2, 30])):
+    # (negative entries count from the end, as maps[:, ids] takes them)
+    for ids in (slice(0, F), slice(8, 24), torch.tensor([5, 0, 31, 17]), torch.tensor([2, 9, 2, 2, 30]), torch.tensor([-1, 3, -32, -7])):
         dev_ids = ids if isinstance(ids, slice) else ids.cuda()
         mi = torch.randn(K, F, generator=g).cuda().requires_grad_(True)
         maps = torch.randn(F, F, generator=g).cuda().requires_grad_(True)
@@ -866,3 +867,15 @@ def test_rig_weights_kernel_matches_the_torch_products():
         assert w.shape == w2.shape and w.is_contiguous()
         assert rel_l2(w, w2) < 1e-6, ids
         assert rel_l2(mi.grad, mi2.grad) < 1e-6 and rel_l2(maps.grad, maps2.grad) < 1e-6, ids
+    # an index outside [-F, F): IndexError like the torch form; with the host check skipped the kernels neither read out of bounds
+    # nor stay silent -- NaN in that row forward, no gradient from it backward
+    for bad in (torch.tensor([0, F]), torch.tensor([-F - 1, 1])):
+        with pytest.raises(IndexError):
+            fit.rig_weights(mi.detach(), maps.detach(), bad.cuda())
+        mi3, maps3 = mi.detach().clone().requires_grad_(True), maps.detach().clone().requires_grad_(True)
+        w3 = fit.rig_weights(mi3, maps3, bad.cuda(), validate=False)
+        okrow = 0 if int(bad[0]) == 0 else 1
+        assert torch.isnan(w3[1 - okrow]).all() and torch.isfinite(w3[okrow]).all()
+        assert rel_l2(w3[okrow], (mi3.detach() @ maps3.detach()[:, int(bad[okrow])])) < 1e-6
+        w3[okrow].sum().backward()
+        assert torch.isfinite(mi3.grad).all() and torch.isfinite(maps3.grad).all()

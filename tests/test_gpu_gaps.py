@@ -273,7 +273,7 @@ def test_1080p_sweep_kernels_equal_the_hinted_launch():
         return float(loss), p.grad.double().cpu(), t.grad.double().cpu()
 
     for one_pass in (True, False):      # the one-call form (two lists: live bins, occupied bins) and the two-call form (three)
-        dr._list_hints.clear()
+        dr.clear_hints()
         try:
             base = run(launch_hints=False, one_pass=one_pass)
             run(queued_backward=True, one_pass=one_pass)                     # leaves its counts behind
@@ -287,7 +287,7 @@ def test_1080p_sweep_kernels_equal_the_hinted_launch():
             assert abs(swept[0] - base[0]) <= 1e-6 * abs(base[0])
             assert rel_l2(swept[1], base[1]) < 1e-5 and rel_l2(swept[2], base[2]) < 1e-5
         finally:
-            dr._list_hints.clear()
+            dr.clear_hints()
 
 
 def test_cfg3_batch_of_288_images_equals_its_chunks(oracle_ops):
@@ -328,7 +328,7 @@ def test_cfg3_batch_of_288_images_equals_its_chunks(oracle_ops):
         loss.backward()
         return loss.detach().double(), p.grad, t.grad.double()
 
-    dr._list_hints.clear()
+    dr.clear_hints()
     try:
         whole_first = run(slice(0, B))                 # no hints yet: every list kernel at its full grid
         idp = torch.zeros(lib.fpcdr_idplane_bytes(B, H, W), dtype=torch.uint8, device=dev)
@@ -366,7 +366,7 @@ def test_cfg3_batch_of_288_images_equals_its_chunks(oracle_ops):
         assert rel_l2(gtex.cpu(), whole[2].cpu()) < 1e-5
         assert torch.isfinite(whole[1]).all() and float(whole[1].abs().max()) > 0
     finally:
-        dr._list_hints.clear()
+        dr.clear_hints()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -520,7 +520,7 @@ def test_stale_mip_stack_is_refused_and_hints_refresh_without_backward(dr):
     p = pos.to(dev).clone().requires_grad_(True)
     t = torch.tensor(sc.texture, device=dev).clone().requires_grad_(True)
     for one_pass in (False, True):
-        dr._list_hints.clear()
+        dr.clear_hints()
         with torch.no_grad():
             a = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, sc.resolution, one_pass=one_pass, ref_bg_sumsq=bg)
         torch.cuda.synchronize()
@@ -528,7 +528,7 @@ def test_stale_mip_stack_is_refused_and_hints_refresh_without_backward(dr):
         assert hints.poll()[0] > 0, "the counts of a forward-only call were never read back"
         b = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, sc.resolution, one_pass=one_pass)
         assert abs(float(a) - float(b)) <= 1e-6 * abs(float(b))
-    dr._list_hints.clear()
+    dr.clear_hints()
 
 
 def test_region_hint_is_dropped_for_anything_but_the_producers_own_tensor(dr):

@@ -296,8 +296,8 @@ def test_4k_combined_mode_step_gradients_match_upstream_oracle(oracle_ops):
     grabbed = {}
     orig = fit.transform_clip_batched
 
-    def spy(mvp, verts):
-        out = orig(mvp, verts)
+    def spy(mvp, verts, pool=None):
+        out = orig(mvp, verts, pool)
         out.register_hook(lambda g: grabbed.__setitem__('g', g.detach().clone()))
         grabbed['pos'] = out.detach()
         return out

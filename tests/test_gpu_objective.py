@@ -106,7 +106,7 @@ def test_one_pass_launch_hints_do_not_change_the_result():
         return float(loss), p.grad.double().cpu(), t.grad.double().cpu()
 
     base = run(launch_hints=False)
-    dr._list_hints.clear()
+    dr.clear_hints()
     first = run()
     key = next(k for k in dr._list_hints if k[0] == 'onepass')
     hints = dr._list_hints[key]
@@ -118,7 +118,7 @@ def test_one_pass_launch_hints_do_not_change_the_result():
     for r in (first, second, third):
         assert abs(r[0] - base[0]) <= 1e-6 * abs(base[0])
         assert rel_l2(r[1], base[1]) < 1e-5 and rel_l2(r[2], base[2]) < 1e-5
-    dr._list_hints.clear()
+    dr.clear_hints()
 
 
 def test_one_pass_edge_cases_clipping_empty_images_and_the_indirect_uv_path(monkeypatch):
@@ -166,9 +166,9 @@ def test_one_pass_edge_cases_clipping_empty_images_and_the_indirect_uv_path(monk
     monkeypatch.setattr(dr, "_cached_tri_uv", lambda uv_, idx_: None)      # (ii)
     both()
     monkeypatch.undo()
-    dr._list_hints.clear()                                 # (iii)
+    dr.clear_hints()                                 # (iii)
     both(enable_mip=True, max_mip_level=2)
     h = dr._list_hints[next(k for k in dr._list_hints if k[0] == 'onepass')]
     h.caps, h.frozen = (1, 1, 1), True
     both(enable_mip=True, max_mip_level=2)
-    dr._list_hints.clear()
+    dr.clear_hints()

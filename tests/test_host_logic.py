@@ -246,8 +246,8 @@ def test_fitter_host_rules_graph_choice_and_frame_selection():
 def test_mapped_hints_and_zero_pool_bookkeeping():
     """Host side of two round-4 mechanisms, without a GPU.  ops._MappedHints: the objective's last kernel writes four counters and then
     the call's sequence number into host memory; poll() adopts counters only when a NEW sequence number stands behind them, adds the
-    launch margin, and keeps the old caps otherwise.  fit._ZeroPool: views of one flat buffer, 16-byte aligned, plain zeros when the
-    pool is not armed or exhausted."""
+    launch margin, and keeps the old caps otherwise.  fit.ZeroPool: views of one flat buffer, 16-byte aligned, plain zeros when the
+    pool has no buffer or is exhausted; two pools are independent objects."""
     import fpc_diffrend_amd.ops as dr
     from fpc_diffrend_amd import fit
     h = dr._MappedHints()
@@ -267,18 +267,16 @@ def test_mapped_hints_and_zero_pool_bookkeeping():
     assert 0 < h.next_seq() < 0x7ffffff1
 
     dev = torch.device("cpu")
-    fit._ZeroPool.arm(None)
-    z = fit._ZeroPool.zeros((3, 5), dev)
+    z = fit.ZeroPool().zeros((3, 5), dev)
     assert z.shape == (3, 5) and float(z.abs().sum()) == 0.0
+    assert fit._pool_zeros(None, (2, 2), dev).shape == (2, 2)
     buf = torch.zeros(64, dtype=torch.float32)
-    try:
-        fit._ZeroPool.arm(buf)
-        a = fit._ZeroPool.zeros((3, 5), dev)
-        b = fit._ZeroPool.zeros((7,), dev)
-        assert a.data_ptr() == buf.data_ptr() and b.data_ptr() == buf.data_ptr() + 16 * 4      # 15 floats -> next multiple of four
-        c = fit._ZeroPool.zeros((60,), dev)                                                     # does not fit any more
-        assert c.data_ptr() < buf.data_ptr() or c.data_ptr() >= buf.data_ptr() + 64 * 4
-        a += 1.0
-        assert float(buf[:15].sum()) == 15.0 and float(buf[15:].sum()) == 0.0
-    finally:
-        fit._ZeroPool.arm(None)
+    pool, other = fit.ZeroPool(buf), fit.ZeroPool(torch.zeros(8))
+    a = pool.zeros((3, 5), dev)
+    b = pool.zeros((7,), dev)
+    assert a.data_ptr() == buf.data_ptr() and b.data_ptr() == buf.data_ptr() + 16 * 4      # 15 floats -> next multiple of four
+    c = pool.zeros((60,), dev)                                                              # does not fit any more
+    assert c.data_ptr() < buf.data_ptr() or c.data_ptr() >= buf.data_ptr() + 64 * 4
+    a += 1.0
+    assert float(buf[:15].sum()) == 15.0 and float(buf[15:].sum()) == 0.0
+    assert other.off == 0 and other.zeros((4,), dev).data_ptr() == other.buf.data_ptr()     # (no shared state between pools)
