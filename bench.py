@@ -310,6 +310,10 @@ def main():
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     _lib.load()
+    # a multi-GPU line is only worth printing when it is what it claims: N ranks, RCCL (backend "nccl"), N distinct devices.  Checked
+    # HERE, before any work, and loudly (FPCDR_DIST_BACKEND=gloo rehearsals on one GPU set FPCDR_BENCH_ALLOW_ANY_BACKEND=1)
+    if os.environ.get("FPCDR_BENCH_ALLOW_ANY_BACKEND", "0") != "1":
+        fdist.check_world(args.gpus, device, require_backend="nccl" if world > 1 else None)
 
     fpg = args.frames_per_gpu or {"cfg1": 4, "cfg2": 1, "cfg3": 32, "cfg5": 4, "ref": 8}[args.workload]
     n_frames = fpg * world
@@ -411,6 +415,10 @@ def main():
         # the data-parallel exchange of one step: HIP-event time of the RCCL all-reduce of the flat gradient bucket on this rank
         # (mean over the timed steps; includes waiting for the slowest rank) and the bucket's size; null on one GPU
         "allreduce_ms": allreduce_ms,
+        # this rank's step time with the collective's own HIP-event time taken out: what a rank spends computing.  A multi-GPU line whose
+        # ms_per_step exceeds the one-GPU line by more than allreduce_ms lost the rest to waiting for the slowest rank (load imbalance:
+        # per_rank[*].occupied_bins) or to launch-side effects, not to xGMI
+        "step_ms_without_allreduce": (1000.0 * elapsed_local / args.steps - allreduce_ms) if allreduce_ms is not None else 1000.0 * elapsed_local / args.steps,
         "allreduce_ms_max_over_ranks": fdist.max_over_ranks(allreduce_ms, device) if allreduce_ms is not None else None,
         "bucket_bytes": bucket.nbytes,
         "early_tex_reduce_bytes": sum(p.numel() * 4 for p in early) if early else 0,

@@ -150,8 +150,13 @@ __device__ __forceinline__ int fpcdr_list_item(int n_entries, int cap) {
     if (!FPCDR_XCD_LISTS) return (int)blockIdx.x < m ? (int)blockIdx.x : -1;
     const int chunk = (m + 7) >> 3;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if (j >= chunk) return -1;
+    // (r5, measured and dropped: XCD x starting its eighth a fraction x * 0.25 / 0.382 / 0.5 / 0.618 / 0.75 of the way in, so that the eight
+    //  XCDs do not shade the same screen bin of the same camera in eight different frames at the same moment -- whose texel gradients go
+    //  to the same addresses: k_shade 1 577-1 613 us at cfg3 for every fraction, 1 611 without: the flush atomics are bound by the number
+    //  of 32-byte sector operations, not by collisions; profiles/r05_flush_experiments.txt)
     const int idx = x * chunk + j;
-    return (j < chunk && idx < m) ? idx : -1;
+    return idx < m ? idx : -1;
 }
 
 // ---- region hints (include/fpcdr.h) ----------------------------------------------------------
@@ -375,6 +380,9 @@ __device__ __forceinline__ void vtable_add(const VTable &t, float *gp, const int
     unsigned int slot[3];
     int old[3];
 #pragma unroll
+    // (r5, measured and dropped: slot = key & (SLOTS - 1), so that neighbouring vertex indices flush as neighbouring 16-byte pieces of
+    //  one 32-byte sector: k_shade 1 591 -> 1 651 us at cfg3, 1 698 with 512 slots -- the clustered keys cost the adds more probes than
+    //  the flush saves sectors)
     for (int kk = 0; kk < 3; ++kk) slot[kk] = (((unsigned int)vk[kk] * 2654435761u) >> 16) & (FPCDR_VT_SLOTS - 1);
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk) old[kk] = atomicCAS(&t.key[slot[kk]], -1, vk[kk]);     // three claims in flight

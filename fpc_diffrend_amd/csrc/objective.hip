@@ -571,6 +571,10 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
 #endif
 }
 
+// (r5, measured and dropped: SEVERAL list entries per workgroup, one after the other, so that a bin's flush atomics -- for which s_endpgm
+//  waits -- drain while the next bin is shaded: 1 597 us with one bin per workgroup, 1 630 with two in a loop (96 VGPRs: the loop's hoisted
+//  scalar loads; arguments re-read from the kernel-argument segment per trip), 1 615 with two unrolled (84 VGPRs, and 80 with five spills),
+//  1 639 with four.  What the flush costs is not the idle slot: profiles/r05_flush_experiments.txt.)
 template <int CS, int BMODE>
 __global__ void __launch_bounds__(ONT) FPCDR_SHADE_WPE k_shade_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int cap,
                                                                     int OX, int OY, fpcdr_bin_decode dc, ObjArgs a) {

@@ -93,6 +93,11 @@ constexpr int SMALL_EXTENT = 16384;
 #endif
 constexpr int LANE_MAX = FPCDR_LANE_MAX;
 constexpr int BIGB = 64;         // triangles per round of the tile path
+// (r5, measured and dropped: EARLY Z -- the lane path in two halves by the sign of the triangle's area, i.e. the layer of a closed mesh that
+//  faces the camera first, the bin's depth buffer summarised as one maximum per 8 x 8 block in between, and a triangle of the second half
+//  whose nearest depth lies behind every block its box touches skips its walk.  Exact (ids bit-identical at 1080p / 4K), and slower: 571 ->
+//  681 us with the facing layer first, 881 with the other first -- the lanes of a wave walk in lockstep, so two half-empty passes cost two
+//  walks unless a whole wave's triangles are culled; compacting the survivors first would need two more barriers and a prefix per batch.)
 // latency-bound: 7 waves per SIMD (r2 sweep of the LOSS list kernel: 5 -> 2.23 ms, 6 -> 2.23, 7 -> 2.11, 8 -> 2.20; its 22 KB of LDS allow 7 workgroups per CU)
 #ifndef FPCDR_BINS_WPE
 #define FPCDR_BINS_WPE __attribute__((amdgpu_waves_per_eu(7, 8)))
@@ -225,7 +230,15 @@ __global__ void __launch_bounds__(256) k_setup(const float4 *__restrict__ pos, c
                                                 ImgBox *__restrict__ ibox, uint8_t *__restrict__ live,
                                                 const int32_t *__restrict__ ranges, int32_t *__restrict__ bin_cnt = nullptr,
                                                 int32_t *__restrict__ bin_list = nullptr, const int32_t *__restrict__ adj = nullptr,
-                                                uint8_t *__restrict__ sil = nullptr, int32_t *__restrict__ clip = nullptr) {
+                                                uint8_t *__restrict__ sil = nullptr, int32_t *__restrict__ clip = nullptr,
+                                                uint4 *__restrict__ zero16 = nullptr, long long n_zero16 = 0) {
+    // (one-pass objective: the caller's position-gradient table -- 69 MB at 288 x 15 k vertices -- is zero-filled HERE, a 16-byte store or
+    //  two per thread beside the gathers this kernel waits for, instead of by the call's first kernel, where it was 12 us on its own)
+    if (zero16) {
+        const long long nthreads = (long long)gridDim.x * gridDim.y * blockDim.x;
+        for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_zero16; i += nthreads)
+            zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     // grid: x over 256-triangle chunks, y = image.  A block never straddles two images, so the union of
     // its triangles' bounding boxes can be reduced in the block: it is stored as the CHUNK box (meshes
     // keep neighbouring triangles at neighbouring indices, so a bin later skips most chunks with one
@@ -1794,7 +1807,20 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
     const int nblk = fpcdr_cdiv((long long)nbins, 256);
     const bool two_launch_lists = nblk <= LW_MAX_BLOCKS;
     int32_t *blk = (int32_t *)(cm + q.cm_blk);
-    const FpcdrZeroList &zl = zl_in;
+    // the largest buffer of the list, if it is 16-byte aligned, is left to the set-up kernel (see k_setup)
+    FpcdrZeroList zl = zl_in;
+    uint4 *big16 = nullptr;
+    long long big_n16 = 0;
+    {
+        int big = -1;
+        for (int r = 0; r < zl.count; ++r)
+            if (zl.n[r] >= (1ll << 20) && ((size_t)zl.p[r] & 15) == 0 && (zl.n[r] & 3) == 0 && (big < 0 || zl.n[r] > zl.n[big])) big = r;
+        if (big >= 0) {
+            big16 = reinterpret_cast<uint4 *>(zl.p[big]);
+            big_n16 = zl.n[big] >> 2;
+            zl.p[big] = zl.p[zl.count - 1]; zl.n[big] = zl.n[zl.count - 1]; --zl.count;
+        }
+    }
     long long zero_words = 0;
     for (int r = 0; r < zl.count; ++r) zero_words += zl.n[r];
     const int init_grid = (int)std::min<long long>(2048, std::max<long long>(256, zero_words / 4096));
@@ -1804,7 +1830,7 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
 #define SETUP(BL, SL)                                                                                                              \
     hipLaunchKernelGGL((k_setup<BL, SL>), dim3(fpcdr_cdiv(p->T, 256), p->B), dim3(256), 0, st, (const float4 *)p->pos, p->tri,     \
                        p->B, p->V, p->T, p->H, p->W, rs.recs, rs.boxes, rs.cboxes, rs.ibox, live, (const int32_t *)nullptr, bin_cnt, tri_lists, \
-                       p->adj, p->sil, rs.clip)
+                       p->adj, p->sil, rs.clip, big16, big_n16)
     if (bin_cnt) { if (sil_in_setup) SETUP(true, true); else SETUP(true, false); }
     else { if (sil_in_setup) SETUP(false, true); else SETUP(false, false); }
 #undef SETUP

@@ -41,12 +41,46 @@ def init(backend=None, force_group=False):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
         backend = os.environ.get("FPCDR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    device_id = None
     if torch.cuda.is_available():
         # one process per GPU; the modulo only matters when a test oversubscribes a box with fewer GPUs than ranks
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        if backend == "nccl":
+            # bind the communicator to this rank's device NOW: RCCL then initialises eagerly inside init_process_group instead of at
+            # the first collective (where a wrong device mapping or a missing xGMI peer would surface in the middle of the timed loop)
+            device_id = torch.device("cuda", torch.cuda.current_device())
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **({"device_id": device_id} if device_id is not None else {}))
     return rank, world, local_rank
+
+
+def check_world(expected_world, device, require_backend=None):
+    """Fail loudly, before any timed step, when a multi-rank run is not what it claims to be: the process group's size differs from
+    `expected_world`, the backend is not `require_backend` (a silent gloo fallback would still produce numbers), or two ranks compute on
+    the same physical device (device_identity).  Returns {"backend", "world", "ranks_seen"}.  A single process passes trivially."""
+    backend = dist.get_backend() if dist.is_initialized() else None
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    seen = len({d for d in gather_objects(device_identity(device))})
+    info = {"backend": backend, "world": world, "ranks_seen": seen}
+    if world != expected_world:
+        raise RuntimeError(f"expected {expected_world} ranks, the process group has {world}: {info}")
+    if expected_world > 1:
+        if require_backend is not None and backend != require_backend:
+            raise RuntimeError(f"multi-rank run over backend {backend!r}, not {require_backend!r}: {info}")
+        if seen < world:
+            raise RuntimeError(f"{world} ranks on {seen} distinct devices -- one process per GPU is required: {info}")
+    return info
+
+
+def shard_frames(n_frames, rank, world):
+    """The contiguous frame range of `rank`: [rank * F / world, (rank + 1) * F / world).  Frames must divide
+    evenly -- every rank steps the same number of images (weak scaling, identical launch shapes, one all-reduce per step in lockstep);
+    an uneven split is refused, not rounded."""
+    if n_frames <= 0 or world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad sharding request: {n_frames} frames, rank {rank} of {world}")
+    if n_frames % world != 0:
+        raise ValueError(f"{n_frames} frames do not divide evenly over {world} ranks: choose a frame count that is a multiple of the world size")
+    return rank * n_frames // world, (rank + 1) * n_frames // world
 
 
 class EarlyReduce:
@@ -56,12 +90,16 @@ class EarlyReduce:
     (transform_clip, MVP chain, blend) are still to run; GradBucket(early=[...]) leaves the parameter out of the bucket and waits
     for the handle before the optimiser step.  Not for HIP-graph capture (the collective is launched from an autograd hook)."""
 
-    def __init__(self, param, always=False):
-        self.param, self.work, self.always, self.fired = param, None, always, 0
+    def __init__(self, param, always=False, before=None):
+        # before: called right before the collective is issued (e.g. ops.join_texture_flush: with the texel windows' flush on a side
+        # stream the gradient handed to autograd is complete only once that stream has been joined)
+        self.param, self.work, self.always, self.fired, self.before = param, None, always, 0, before
         self._hook = param.register_post_accumulate_grad_hook(self._fire)
 
     def _fire(self, p):
         if dist.is_initialized() and (dist.get_world_size() > 1 or self.always):
+            if self.before is not None:
+                self.before()
             if p.grad.is_cuda and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("EarlyReduce cannot run inside a HIP-graph capture (the collective is issued from an autograd hook on "
                                    "its own stream): use FitConfig(hip_graph=False) with early reduction, or leave the parameter in the bucket")
@@ -81,9 +119,9 @@ class GradBucket:
     """Flat gradient bucket.  `bucket(params)` packs every existing .grad into one contiguous f32 buffer,
     all-reduces it (sum) and unpacks -- exactly one collective per optimisation step."""
 
-    def __init__(self, params, device, always_reduce=False, timed=False, early=()):
+    def __init__(self, params, device, always_reduce=False, timed=False, early=(), early_before=None):
         # early: parameters whose gradient is reduced on its own as soon as it exists (EarlyReduce); the bucket skips them
-        self.early = [EarlyReduce(p, always=always_reduce) for p in early]
+        self.early = [EarlyReduce(p, always=always_reduce, before=early_before) for p in early]
         early_ids = {id(p) for p in early}
         self.all_params = [p for p in params if id(p) not in early_ids]
         self.device = device

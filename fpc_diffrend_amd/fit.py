@@ -628,9 +628,9 @@ class Fitter:
         self.rank, self.world, self.reduce_fn = rank, world, reduce_fn
         dev = self.device
         F = sc.n_frames
-        assert F > 0 and F % world == 0, "frames must divide evenly over ranks"
+        from . import dist as _fdist
         self.n_frames = F
-        self.frame_lo, self.frame_hi = rank * F // world, (rank + 1) * F // world
+        self.frame_lo, self.frame_hi = _fdist.shard_frames(F, rank, world)      # (raises when F does not divide evenly over the ranks)
         self.resolution = tuple(cfg.resolution or sc.resolution)
         self.cam_idxs = list(cfg.cam_idxs)
         # ---- static scene tensors (fit.py:424-432) ----

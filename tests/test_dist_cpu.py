@@ -68,20 +68,64 @@ def _single(F=8, K=5):
     return torch.cat([p.detach().reshape(-1) for p in (M1, M2, tex)])
 
 
-@pytest.mark.parametrize("early", [False, True])
-def test_two_rank_data_parallel_equals_single_process(early, monkeypatch):
-    """early: the texture's gradient travels in its own all-reduce, launched from an autograd hook as soon as it exists
-    (dist.EarlyReduce), the rest in the bucket -- same replicas, same result."""
+@pytest.mark.parametrize("world,early", [(2, False), (2, True), (4, False), (4, True)])
+def test_data_parallel_replicas_equal_single_process(world, early, monkeypatch):
+    """World size 2 and 4 over gloo.  early: the texture's gradient travels in its own all-reduce, launched from an autograd hook as
+    soon as it exists (dist.EarlyReduce), the rest in the bucket -- same replicas, same result."""
     monkeypatch.setenv("FPCDR_TEST_EARLY", "1" if early else "0")
-    world = 2
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-    a, b = ret[0], ret[1]
-    assert torch.equal(a, b), "replicas diverged"
+    for r in range(1, world):
+        assert torch.equal(ret[0], ret[r]), f"replica {r} diverged"
     ref = _single()
-    assert torch.allclose(a, ref, atol=1e-6), float((a - ref).abs().max())
+    assert torch.allclose(ret[0], ref, atol=1e-6), float((ret[0] - ref).abs().max())
+
+
+def test_frame_sharding_rule_and_uneven_split_is_refused():
+    """dist.shard_frames: contiguous, disjoint, covering; a frame count that does not divide over the ranks raises (every rank must
+    step the same number of images), as does the Fitter's constructor through it."""
+    from fpc_diffrend_amd import dist as fdist
+    for F, world in ((256, 8), (32, 4), (6, 3), (5, 1)):
+        spans = [fdist.shard_frames(F, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == F
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and len({hi - lo for lo, hi in spans}) == 1
+    for F, world in ((10, 4), (33, 8), (1, 2)):
+        with pytest.raises(ValueError, match="divide evenly"):
+            fdist.shard_frames(F, 0, world)
+    with pytest.raises(ValueError):
+        fdist.shard_frames(8, 4, 4)
+
+
+def _check_world_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from fpc_diffrend_amd import dist as fdist
+    fdist.init(backend="gloo")
+    info = fdist.check_world(world, "cpu")                       # CPU ranks are distinct "devices" (one per process)
+    out = {"info": info}
+    for name, kw in (("size", dict(expected_world=world + 1, device="cpu")), ("backend", dict(expected_world=world, device="cpu", require_backend="nccl"))):
+        try:
+            fdist.check_world(**kw)
+            out[name] = None
+        except RuntimeError as e:
+            out[name] = str(e)
+    ret[rank] = out
+    tdist.destroy_process_group()
+
+
+def test_check_world_fails_loudly_on_a_wrong_group():
+    """dist.check_world (bench.py runs it before the timed region of a --gpus N > 1 run): passes on the real group, raises when the
+    group's size is not the one asked for or the backend is not the required one (a gloo fallback must not produce a scaling number)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_check_world_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r]["info"] == {"backend": "gloo", "world": 2, "ranks_seen": 2}
+        assert "expected 3 ranks" in ret[r]["size"] and "not 'nccl'" in ret[r]["backend"]
+    from fpc_diffrend_amd import dist as fdist
+    assert fdist.check_world(1, "cpu") == {"backend": None, "world": 1, "ranks_seen": 1}      # a single process passes trivially
 
 
 def test_grad_bucket_tracks_requires_grad_changes():
