@@ -215,7 +215,7 @@ def reference_shaped_step(device, steps=40, frames=8):
             if not graph:
                 row["launches_per_step"] = count_launches(ft.step)
             else:
-                row["launches_per_step"] = "two graph replays (forward + backward, Adam) + the per-step index copies"
+                row["launches_per_step"] = "one graph replay (forward + backward + Adam in one launch each) + one staged host-to-device copy"
             out[name] = row
             del ft
         except Exception as e:   # never take the measurement down

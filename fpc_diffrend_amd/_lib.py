@@ -14,7 +14,7 @@ MAX_ATTR = 32
 MAX_MIP = 16
 LOSS_SLOTS = 256
 OCC_BIN = 32         # FPCDR_OCC_BIN
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
 BOUNDARY = {'wrap': 0, 'clamp': 1, 'zero': 2}
@@ -121,12 +121,13 @@ ADAM_MAX_TENSORS = 16     # FPCDR_ADAM_MAX_TENSORS
 
 class AdamTensor(ctypes.Structure):
     _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("n", ctypes.c_int64),
-                ("step_size", ctypes.c_float), ("bc2_sqrt", ctypes.c_float), ("renorm", _i)]
+                ("step_size", ctypes.c_float), ("bc2_sqrt", ctypes.c_float), ("renorm", _i), ("table_row", _i)]
 
 
 class AdamParams(ctypes.Structure):
     _fields_ = [("n_tensors", _i), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
-                ("one_minus_beta1", ctypes.c_float), ("one_minus_beta2", ctypes.c_float), ("t", AdamTensor * ADAM_MAX_TENSORS)]
+                ("one_minus_beta1", ctypes.c_float), ("one_minus_beta2", ctypes.c_float), ("t", AdamTensor * ADAM_MAX_TENSORS),
+                ("step_table", _p)]
 
 
 # every symbol include/fpcdr.h declares: name -> (restype, argtypes)
@@ -166,6 +167,8 @@ SYMBOLS = {
     "fpcdr_transform_clip_bwd": (_int, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fpcdr_mvp_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "fpcdr_mvp_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "fpcdr_mvp_fwd_indexed": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "fpcdr_mvp_bwd_indexed": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "fpcdr_laplacian_gather": (_int, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fpcdr_laplacian_penalty_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, ctypes.c_float, _i, _i, _i, _p]),
     "fpcdr_laplacian_penalty_bwd": (_int, [_p, _p, _p, _p, _p, _p, ctypes.c_float, _i, _i, _i, _p]),

@@ -17,8 +17,9 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 }
 
 __global__ void __launch_bounds__(256) k_adam_step(fpcdr_adam_params P) {
-    const fpcdr_adam_tensor t = P.t[blockIdx.y];
+    fpcdr_adam_tensor t = P.t[blockIdx.y];
     const long long n = t.n;
+    if (P.step_table) { t.step_size = P.step_table[2 * t.table_row]; t.bc2_sqrt = P.step_table[2 * t.table_row + 1]; }
     const float step_size = t.step_size;
     if (!t.renorm) {
         if (!t.grad) return;
@@ -76,7 +77,8 @@ extern "C" int fpcdr_adam_step(const fpcdr_adam_params *p, void *stream) {
         FPCDR_REQUIRE(t.param != nullptr && t.n > 0, "null parameter tensor");
         FPCDR_REQUIRE(t.grad == nullptr || (t.exp_avg && t.exp_avg_sq), "a tensor with a gradient needs its two moment buffers");
         FPCDR_REQUIRE(t.grad != nullptr || t.renorm, "a tensor without a gradient has nothing to do");
-        FPCDR_REQUIRE(t.grad == nullptr || t.bc2_sqrt > 0.0f, "the bias correction must be positive");
+        FPCDR_REQUIRE(t.grad == nullptr || p->step_table || t.bc2_sqrt > 0.0f, "the bias correction must be positive");
+        FPCDR_REQUIRE(!p->step_table || (t.table_row >= 0 && t.table_row < FPCDR_ADAM_MAX_TENSORS), "table_row outside the table");
         if (!t.renorm && t.n > nmax) nmax = t.n;
     }
     const int bx = (int)fpcdr_cdiv(fpcdr_cdiv(nmax > 0 ? nmax : 1, 4), 256);

@@ -402,7 +402,80 @@ __global__ void k_mvp_bwd(const float *__restrict__ proj, const float *__restric
     rigid_bwd(q_cam + 4 * c, gC, gq_cam + 4 * c, gt_cam + 3 * c);
 }
 
+// The same with the frames / views of the step given as INDEX arrays into the full parameter tables (the reference's run shape draws one
+// random (camera, frame) per step: as torch ops that was seven index_select launches forward and four zero-fill + index_add pairs backward
+// around kernels that take 3 us).  frame_idx [Fb] or null (frames 0 .. Fb - 1); view_idx [Nc] or null: rows of proj / t_mv; cam_of_view
+// [views] or null: row of q_cam / t_cam for a view (the cameras a Fitter was given).  The backward adds into the FULL tables (zeroed by
+// the caller); two step entries that name the same row add into it, as index_select's backward does.
+__device__ __forceinline__ void mvp_rows(const long long *frame_idx, const long long *view_idx, const long long *cam_of_view, int f, int c,
+                                         int &fr, int &cv, int &cp) {
+    fr = frame_idx ? (int)frame_idx[f] : f;
+    cv = view_idx ? (int)view_idx[c] : c;
+    cp = cam_of_view ? (int)cam_of_view[cv] : cv;
+}
+__global__ void k_mvp_fwd_idx(const float *__restrict__ proj, const float *__restrict__ t_mv, const float *__restrict__ q_cam,
+                              const float *__restrict__ t_cam, const float *__restrict__ q_frame, const float *__restrict__ t_frame,
+                              const long long *__restrict__ frame_idx, const long long *__restrict__ view_idx,
+                              const long long *__restrict__ cam_of_view, int Fb, int Nc, float *__restrict__ mvp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Fb * Nc) return;
+    const int f = i / Nc, c = i - f * Nc;
+    int fr, cv, cp;
+    mvp_rows(frame_idx, view_idx, cam_of_view, f, c, fr, cv, cp);
+    const M4 B = m4_mul(rigid(q_cam + 4 * cp, t_cam + 3 * cp), m4_load(t_mv + 16 * cv));
+    const M4 X = m4_mul(rigid(q_frame + 4 * fr, t_frame + 3 * fr), B);
+    const M4 M = m4_mul(m4_load(proj + 16 * cv), X);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mvp[(size_t)i * 16 + 4 * r + k] = M.m[r][k];
+}
+__global__ void k_mvp_bwd_idx(const float *__restrict__ proj, const float *__restrict__ t_mv, const float *__restrict__ q_cam,
+                              const float *__restrict__ t_cam, const float *__restrict__ q_frame, const float *__restrict__ t_frame,
+                              const long long *__restrict__ frame_idx, const long long *__restrict__ view_idx,
+                              const long long *__restrict__ cam_of_view, const float *__restrict__ g_mvp, int Fb, int Nc,
+                              float *__restrict__ gq_cam, float *__restrict__ gt_cam, float *__restrict__ gq_frame, float *__restrict__ gt_frame) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Fb * Nc) return;
+    const int f = i / Nc, c = i - f * Nc;
+    int fr, cv, cp;
+    mvp_rows(frame_idx, view_idx, cam_of_view, f, c, fr, cv, cp);
+    const M4 MV = m4_load(t_mv + 16 * cv);
+    const M4 B = m4_mul(rigid(q_cam + 4 * cp, t_cam + 3 * cp), MV);
+    const M4 A = rigid(q_frame + 4 * fr, t_frame + 3 * fr);
+    const M4 gX = m4_mul_tn(m4_load(proj + 16 * cv), m4_load(g_mvp + (size_t)i * 16));
+    const M4 gA = m4_mul_nt(gX, B);
+    const M4 gC = m4_mul_nt(m4_mul_tn(A, gX), MV);
+    rigid_bwd(q_frame + 4 * fr, gA, gq_frame + 4 * fr, gt_frame + 3 * fr);
+    rigid_bwd(q_cam + 4 * cp, gC, gq_cam + 4 * cp, gt_cam + 3 * cp);
+}
+
 }  // namespace
+
+extern "C" int fpcdr_mvp_fwd_indexed(const float *proj, const float *t_mv, const float *q_cam, const float *t_cam, const float *q_frame,
+                                     const float *t_frame, const int64_t *frame_idx, const int64_t *view_idx, const int64_t *cam_of_view,
+                                     float *mvp, int32_t Fb, int32_t Nc, void *stream) {
+    FPCDR_REQUIRE(proj && t_mv && q_cam && t_cam && q_frame && t_frame && mvp, "null pointer");
+    FPCDR_REQUIRE(Fb > 0 && Nc > 0, "bad sizes");
+    hipLaunchKernelGGL(k_mvp_fwd_idx, dim3(fpcdr_cdiv((long long)Fb * Nc, 64)), dim3(64), 0, (hipStream_t)stream, proj, t_mv, q_cam, t_cam,
+                       q_frame, t_frame, (const long long *)frame_idx, (const long long *)view_idx, (const long long *)cam_of_view, Fb, Nc, mvp);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+
+extern "C" int fpcdr_mvp_bwd_indexed(const float *proj, const float *t_mv, const float *q_cam, const float *t_cam, const float *q_frame,
+                                     const float *t_frame, const int64_t *frame_idx, const int64_t *view_idx, const int64_t *cam_of_view,
+                                     const float *grad_mvp, float *gq_cam, float *gt_cam, float *gq_frame, float *gt_frame, int32_t Fb,
+                                     int32_t Nc, void *stream) {
+    FPCDR_REQUIRE(proj && t_mv && q_cam && t_cam && q_frame && t_frame && grad_mvp && gq_cam && gt_cam && gq_frame && gt_frame,
+                  "null pointer");
+    FPCDR_REQUIRE(Fb > 0 && Nc > 0, "bad sizes");
+    hipLaunchKernelGGL(k_mvp_bwd_idx, dim3(fpcdr_cdiv((long long)Fb * Nc, 64)), dim3(64), 0, (hipStream_t)stream, proj, t_mv, q_cam, t_cam,
+                       q_frame, t_frame, (const long long *)frame_idx, (const long long *)view_idx, (const long long *)cam_of_view, grad_mvp,
+                       Fb, Nc, gq_cam, gt_cam, gq_frame, gt_frame);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
 
 extern "C" int fpcdr_mvp_fwd(const float *proj, const float *t_mv, const float *q_cam, const float *t_cam, const float *q_frame,
                              const float *t_frame, float *mvp, int32_t Fb, int32_t Nc, void *stream) {

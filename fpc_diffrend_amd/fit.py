@@ -300,6 +300,39 @@ class _mvp_func(torch.autograd.Function):
         return gq_cam, gt_cam, gq_frame, gt_frame, None, None, None
 
 
+class _mvp_indexed_func(torch.autograd.Function):
+    """_mvp_func for a step that names its frames / views by index tensors into the FULL parameter tables (fpcdr_mvp_fwd_indexed /
+    _bwd_indexed): no index_select launches in front, no zero-fill + index_add pairs behind.  frame_idx [Fb] / view_idx [Nc]: int64 device
+    tensors or None; cam_of_view: the Fitter's cam_sel (view -> row of q_cam / t_cam) or None."""
+
+    @staticmethod
+    def forward(ctx, q_cam, t_cam, q_frame, t_frame, proj, t_mv, frame_idx, view_idx, cam_of_view, Fb, Nc, pool=None):
+        ctx.pool = pool
+        q_cam, t_cam, q_frame, t_frame = (a.contiguous() for a in (q_cam, t_cam, q_frame, t_frame))
+        out = torch.empty(Fb * Nc, 4, 4, dtype=torch.float32, device=q_cam.device)
+        _lib.call("fpcdr_mvp_fwd_indexed", _ptr(proj), _ptr(t_mv), _ptr(q_cam), _ptr(t_cam), _ptr(q_frame), _ptr(t_frame), _ptr(frame_idx),
+                  _ptr(view_idx), _ptr(cam_of_view), _ptr(out), Fb, Nc, _stream())
+        ctx.save_for_backward(q_cam, t_cam, q_frame, t_frame, proj, t_mv, *(t for t in (frame_idx, view_idx, cam_of_view) if t is not None))
+        ctx.have = (frame_idx is not None, view_idx is not None, cam_of_view is not None)
+        ctx.dims = (Fb, Nc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q_cam, t_cam, q_frame, t_frame, proj, t_mv = ctx.saved_tensors[:6]
+        rest = list(ctx.saved_tensors[6:])
+        frame_idx, view_idx, cam_of_view = (rest.pop(0) if h else None for h in ctx.have)
+        Fb, Nc = ctx.dims
+        nq, nf = q_cam.shape[0], q_frame.shape[0]
+        grads = _pool_zeros(ctx.pool, (7 * (nq + nf),), g.device)
+        gq_cam, gt_cam = grads[:4 * nq].view(nq, 4), grads[4 * nq:7 * nq].view(nq, 3)
+        gq_frame, gt_frame = grads[7 * nq:7 * nq + 4 * nf].view(nf, 4), grads[7 * nq + 4 * nf:].view(nf, 3)
+        _lib.call("fpcdr_mvp_bwd_indexed", _ptr(proj), _ptr(t_mv), _ptr(q_cam), _ptr(t_cam), _ptr(q_frame), _ptr(t_frame), _ptr(frame_idx),
+                  _ptr(view_idx), _ptr(cam_of_view), _ptr(g.contiguous()), _ptr(gq_cam), _ptr(gt_cam), _ptr(gq_frame), _ptr(gt_frame), Fb, Nc,
+                  _stream())
+        return (gq_cam, gt_cam, gq_frame, gt_frame) + (None,) * 8
+
+
 # ----------------------------------------------------------------------------------------------
 # mesh regularisers (pytorch3d in the reference: fit.py:16-19, 578-582) -- torch restatement
 # ----------------------------------------------------------------------------------------------
@@ -382,7 +415,7 @@ class _laplacian_penalty(torch.autograd.Function):
     the current stream, so the engine inserts no cross-stream synchronisation of its own."""
 
     @staticmethod
-    def forward(ctx, verts, nbr32, inv_deg, weight, eager=False, unit=False, stream=None):
+    def forward(ctx, verts, nbr32, inv_deg, weight, eager=False, unit=False, stream=None, acc=None):
         if not verts.is_cuda:
             raise RuntimeError("the mesh regularisers run on the GPU only (fpcdr_laplacian_penalty_fwd); there is no CPU fallback")
         x = verts.contiguous()
@@ -394,7 +427,11 @@ class _laplacian_penalty(torch.autograd.Function):
         with torch.cuda.stream(stream if stream is not None else main):
             st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
             lap = torch.empty_like(x)
-            acc = torch.zeros(F + 1, dtype=torch.float64, device=x.device)      # (the call leaves it zero; a fresh one keeps calls independent)
+            # acc: F + 1 doubles, zero on entry -- and the call leaves them zero again, so a caller that hands over its own buffer (the
+            # Fitter: one per instance) saves the fill launch of a fresh one per step
+            if acc is None:
+                acc = torch.zeros(F + 1, dtype=torch.float64, device=x.device)
+            assert acc.dtype == torch.float64 and acc.numel() >= F + 1 and acc.is_contiguous()
             per = torch.empty(F, dtype=torch.float32, device=x.device)
             out = torch.empty((), dtype=torch.float32, device=x.device)
             _lib.call("fpcdr_laplacian_penalty_fwd", _ptr(x), _ptr(nbr32), _ptr(inv_deg), _ptr(lap), _ptr(acc), _ptr(per), _ptr(out),
@@ -430,13 +467,13 @@ class _laplacian_penalty(torch.autograd.Function):
             torch.cuda.current_stream(g.device).wait_event(ctx.event)
         if ctx.eager:
             gx, = ctx.saved_tensors
-            return (gx if ctx.unit else gx * g.to(torch.float32)), None, None, None, None, None, None
+            return (gx if ctx.unit else gx * g.to(torch.float32)), None, None, None, None, None, None, None
         lap, nbr32, inv_deg, per = ctx.saved_tensors
         F, V, _ = lap.shape
         gx = torch.empty_like(lap)
         _lib.call("fpcdr_laplacian_penalty_bwd", _ptr(lap), _ptr(nbr32), _ptr(inv_deg), _ptr(per), _ptr(g.to(torch.float32).contiguous()),
                   _ptr(gx), ctx.weight, F, V, nbr32.shape[0], _stream())
-        return gx, None, None, None, None, None, None
+        return gx, None, None, None, None, None, None, None
 
 
 _unit_scalars = {}
@@ -450,12 +487,12 @@ def _unit_scalar(dev):
     return t
 
 
-def laplacian_penalty(verts, topo, weight, eager_grad=False, unit_upstream=False, stream=None):
+def laplacian_penalty(verts, topo, weight, eager_grad=False, unit_upstream=False, stream=None, acc=None):
     """weight * mean over the meshes of verts [F,V,3] of mesh_laplacian_smoothing(mesh)^2 -- the reference's term (fit.py:581 squares
     the value of the ONE mesh of its step) -- as two launches per step instead of a gather and fifteen torch kernels.
     eager_grad: the gradient is computed with the value (backward() only multiplies by the upstream scalar, or not at all with
     unit_upstream); stream: run both launches on that stream beside the caller's (the backward() joins; a caller that never runs backward() waits for the stream itself)."""
-    return _laplacian_penalty.apply(verts, topo.nbr32, topo.inv_deg, weight, eager_grad, unit_upstream, stream)
+    return _laplacian_penalty.apply(verts, topo.nbr32, topo.inv_deg, weight, eager_grad, unit_upstream, stream, acc)
 
 
 def mesh_normal_consistency(verts, topo):
@@ -497,11 +534,83 @@ class GroupedAdam(torch.optim.Optimizer):
     so a run with grouped_adam on and one with it off agree to a few ulps per step, not bit for bit).  `renorm` = the parameters
     divided by their whole-tensor norm after every step."""
 
-    def __init__(self, groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, renorm=()):
+    def __init__(self, groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, renorm=(), capturable=False):
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps))
         self._renorm = {id(p) for p in renorm}
         n = sum(len(g['params']) for g in self.param_groups)
         assert n <= _lib.ADAM_MAX_TENSORS, "more parameter tensors than one fpcdr_adam_step call takes"
+        # capturable: the launch may be captured in a HIP graph.  Its per-tensor (step_size, bc2_sqrt) then come from a device table
+        # that prepare() fills before every replay -- the step counters advance there, on the host, and step() leaves them alone
+        self.capturable = bool(capturable)
+        self._table_host = self._table_dev = None
+        self._ring, self._ring_i = [], 0
+
+    def _rows(self):
+        """(group, parameter, row of the device table) of EVERY parameter: a parameter's row is its position in the optimiser, whatever
+        gradients exist at the moment (prepare() runs in front of the backward pass, step() behind it)."""
+        out = []
+        for g in self.param_groups:
+            for p in g['params']:
+                out.append((g, p, len(out)))
+        return out
+
+    @torch.no_grad()
+    def prepare(self, host_out=None):
+        """capturable mode, once per step IN FRONT of the (captured or eager) launch: advance the step counters and write the
+        per-tensor (step_size, bc2_sqrt) -- with the learning rates the scheduler has set by now -- into the device table.  host_out: a
+        pinned float32 view of at least 2 * ADAM_MAX_TENSORS values that the CALLER copies to table_dev() itself (a fit step packs it
+        with its other per-step inputs into one copy); default: an own pinned buffer and an own asynchronous copy.
+        A parameter counts a step when it is trainable NOW (requires_grad): in this mode the call comes before the backward pass, so
+        "has a gradient" -- torch.optim.Adam's rule, and step()'s in the plain mode -- is not known yet; the fit loop's trainable
+        parameters all receive one every step."""
+        assert self.capturable
+        self.table_dev()
+        if host_out is None:
+            # (the copy below reads the pinned buffer when the GPU gets to it: a ring of buffers, each guarded by the event of its last copy,
+            #  so that a host running several steps ahead never rewrites a table that is still waiting to be copied)
+            if not self._ring:
+                self._ring = [[torch.zeros(2 * _lib.ADAM_MAX_TENSORS, dtype=torch.float32).pin_memory(), None] for _ in range(4)]
+            slot = self._ring[self._ring_i % len(self._ring)]
+            self._ring_i += 1
+            if slot[1] is not None:
+                slot[1].synchronize()
+            self._table_host = slot[0]
+        host = self._table_host if host_out is None else host_out
+        for g, p, k in self._rows():
+            host[2 * k], host[2 * k + 1] = 0.0, 1.0
+            if p.requires_grad:
+                b1, b2 = g['betas']
+                st = self._state_of(p)
+                st['step'] += 1
+                n_step = float(st['step'])
+                host[2 * k] = float(g['lr']) / (1.0 - b1 ** n_step)
+                host[2 * k + 1] = math.sqrt(1.0 - b2 ** n_step)
+        if host_out is None:
+            self._table_dev.copy_(self._table_host, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+
+    def set_table_dev(self, view):
+        """Use `view` (a float32 device tensor of 2 * ADAM_MAX_TENSORS values) as the table: a caller that copies it together with its own
+        per-step inputs (Fitter, graph mode) hands prepare() the matching host view and does the copy itself."""
+        assert view.dtype == torch.float32 and view.numel() >= 2 * _lib.ADAM_MAX_TENSORS and view.is_contiguous()
+        self._table_dev = view
+
+    def table_dev(self):
+        if self._table_dev is None:
+            dev = self.param_groups[0]['params'][0].device
+            self._table_dev = torch.zeros(2 * _lib.ADAM_MAX_TENSORS, dtype=torch.float32, device=dev)
+        return self._table_dev
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st['step'] = torch.zeros((), dtype=torch.float32)
+            st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if st['step'].is_cuda:      # (a checkpoint written by torch.optim.Adam(fused=True) keeps its counters on the GPU:
+            st['step'] = st['step'].cpu()      # one copy here instead of a host sync per tensor and step)
+        return st
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -509,33 +618,32 @@ class GroupedAdam(torch.optim.Optimizer):
         P = _lib.AdamParams()
         k = 0
         keep = []
+        row = -1
+        if self.capturable:
+            P.step_table = self.table_dev().data_ptr()
         for g in self.param_groups:
             b1, b2 = g['betas']
             assert (b1, b2, g['eps']) == (self.param_groups[0]['betas'] + (self.param_groups[0]['eps'],)), \
                 "one launch takes one (betas, eps) for all groups"
             P.beta1, P.beta2, P.eps, P.one_minus_beta1, P.one_minus_beta2 = b1, b2, g['eps'], 1.0 - b1, 1.0 - b2
             for p in g['params']:
+                row += 1
                 ren = id(p) in self._renorm
                 if p.grad is None and not ren:
                     continue
                 assert p.is_contiguous() and p.dtype == torch.float32
                 t = P.t[k]
-                t.param, t.n, t.renorm = p.data_ptr(), p.numel(), 1 if ren else 0
+                t.param, t.n, t.renorm, t.table_row = p.data_ptr(), p.numel(), 1 if ren else 0, row
                 t.step_size, t.bc2_sqrt = 0.0, 1.0
                 if p.grad is not None:
-                    st = self.state[p]
-                    if len(st) == 0:
-                        st['step'] = torch.zeros((), dtype=torch.float32)
-                        st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                        st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    if st['step'].is_cuda:      # (a checkpoint written by torch.optim.Adam(fused=True) keeps its counters on the GPU:
-                        st['step'] = st['step'].cpu()      # one copy here instead of a host sync per tensor and step)
-                    st['step'] += 1
-                    n_step = float(st['step'])
+                    st = self._state_of(p)
                     grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                     keep.append(grad)
                     t.grad, t.exp_avg, t.exp_avg_sq = grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
-                    t.step_size, t.bc2_sqrt = float(g['lr']) / (1.0 - b1 ** n_step), math.sqrt(1.0 - b2 ** n_step)
+                    if not self.capturable:      # (capturable: prepare() advanced the counter and filled the device table)
+                        st['step'] += 1
+                        n_step = float(st['step'])
+                        t.step_size, t.bc2_sqrt = float(g['lr']) / (1.0 - b1 ** n_step), math.sqrt(1.0 - b2 ** n_step)
                 k += 1
         P.n_tensors = k
         _lib.call("fpcdr_adam_step", ctypes.byref(P), _stream())
@@ -684,7 +792,12 @@ class Fitter:
                                              self.resolution)
         else:
             self.use_graph = bool(cfg.hip_graph)
-        if self.use_graph:      # replayed updates read the learning rates from device memory
+        if self.use_graph and cfg.grouped_adam:
+            # a replayed update reads its learning rates and bias corrections from a device table (GroupedAdam.prepare): ONE launch in the
+            # graph.  (torch.optim.Adam(capturable=True) is ~13 multi-tensor launches per parameter group: 140 of the 190 dispatches of a
+            # replayed one-image step, 0.6 ms of 4.5 us nodes)
+            self.optimizer = GroupedAdam(groups, lr=cfg.lr_base, renorm=(self.q_opt, self.per_frame_q), capturable=True)
+        elif self.use_graph:      # replayed updates read the learning rates from device memory
             for g in groups:
                 g['lr'] = torch.tensor(float(g['lr']), dtype=torch.float32, device=dev)
             self.optimizer = torch.optim.Adam(groups, lr=torch.tensor(cfg.lr_base, dtype=torch.float32, device=dev), capturable=True)
@@ -712,6 +825,7 @@ class Fitter:
         self.rng = np.random.default_rng(cfg.seed + 1000 * rank)
         # final shapes (fit.py:457); every rank fills the rows of its own frames, gather_result() joins the shards
         self._result_full = torch.zeros(F, self.v_base.shape[0], dtype=torch.float32, device=dev)
+        self._lap_acc = torch.zeros(self.frame_hi - self.frame_lo + 1, dtype=torch.float64, device=dev)   # (fpcdr_laplacian_penalty_fwd leaves it zero)
         self._result_pending = None
         self.iteration = 0
         self._log_file, self._log_t, self._log_it = None, None, 0
@@ -737,11 +851,16 @@ class Fitter:
     def mvp(self, frame_ids, view_ids=None, pool=None):
         """mvp[f,c] = P_c . Rt(q_f,t_f) . Rt(q_c,t_c) . MV_c . T(0,170,0)   (fit.py:541-553), [Fb*Nc,4,4].
         view_ids: positions in cam_idxs of the cameras of this step (a device index tensor; None = all of them).  pool: the step's ZeroPool."""
-        if view_ids is not None:
-            cams = self.cam_sel.index_select(0, view_ids)
-            return _mvp_func.apply(self.q_opt.index_select(0, cams), self.t_opt.index_select(0, cams), self._take(self.per_frame_q, 0, frame_ids),
-                                   self._take(self.per_frame_t, 0, frame_ids), self.proj.index_select(0, view_ids), self.t_mv.index_select(0, view_ids), pool)
         all_cams = self.cam_idxs == list(range(self.q_opt.shape[0]))    # no gather (and no sort in its backward) then
+        if view_ids is not None or torch.is_tensor(frame_ids):
+            # rows named by index: one launch each way on the full parameter tables (the gathers happen inside the kernels)
+            if isinstance(frame_ids, slice):
+                f_idx = torch.arange(frame_ids.start, frame_ids.stop, device=self.device)
+            else:
+                f_idx = frame_ids
+            Nc = len(self.cam_idxs) if view_ids is None else int(view_ids.shape[0])
+            return _mvp_indexed_func.apply(self.q_opt, self.t_opt, self.per_frame_q, self.per_frame_t, self.proj, self.t_mv, f_idx.contiguous(),
+                                           view_ids, None if all_cams else self.cam_sel, int(f_idx.shape[0]), Nc, pool)
         q_c, t_c = (self.q_opt, self.t_opt) if all_cams else (self.q_opt[self.cam_sel], self.t_opt[self.cam_sel])
         return _mvp_func.apply(q_c, t_c, self._take(self.per_frame_q, 0, frame_ids), self._take(self.per_frame_t, 0, frame_ids), self.proj, self.t_mv, pool)
 
@@ -818,6 +937,44 @@ class Fitter:
         self._frame_idx.copy_(sel)
         return self._frame_idx
 
+    def _stage_inputs(self):
+        """Graph mode: everything a replayed step reads that changes from step to step -- the frame numbers and camera positions drawn for
+        it, the optimiser's (step size, bias correction) table -- goes through ONE pinned buffer and ONE asynchronous copy into fixed
+        device memory (three copies from pageable memory before: 130 us of host-side gaps in a 0.33 ms one-image step).  A ring of
+        pinned buffers, each guarded by the event of its copy, lets the host run ahead.  Returns (frame_ids, view_ids, prepared)."""
+        n_local = self.frame_hi - self.frame_lo
+        kf = self.cfg.frames_per_step if 0 < self.cfg.frames_per_step < n_local else 0
+        kv = self.cfg.views_per_step if 0 < self.cfg.views_per_step < len(self.cam_idxs) else 0
+        cap = isinstance(self.optimizer, GroupedAdam) and self.optimizer.capturable
+        if getattr(self, "_stage_dev", None) is None:
+            n = kf + kv + _lib.ADAM_MAX_TENSORS          # int64 words; the table's 2 x ADAM_MAX_TENSORS floats are ADAM_MAX_TENSORS of them
+            self._stage_dev = torch.zeros(n, dtype=torch.int64, device=self.device)
+            self._stage_ring = []
+            for _ in range(4):
+                t = torch.zeros(n, dtype=torch.int64).pin_memory()
+                self._stage_ring.append([t, t.numpy(), t[kf + kv:].view(torch.float32).numpy(), None])
+            self._stage_i = 0
+            self._frame_idx = self._stage_dev[:kf] if kf else None
+            self._view_idx = self._stage_dev[kf:kf + kv] if kv else None
+            if cap:
+                self.optimizer.set_table_dev(self._stage_dev[kf + kv:].view(torch.float32))
+        slot = self._stage_ring[self._stage_i % len(self._stage_ring)]
+        self._stage_i += 1
+        if slot[3] is not None:
+            slot[3].synchronize()
+        if kf:
+            slot[1][:kf] = np.sort(self.rng.choice(n_local, size=kf, replace=False)) + self.frame_lo
+        if kv:
+            slot[1][kf:kf + kv] = np.sort(self.rng.choice(len(self.cam_idxs), size=kv, replace=False))
+        if cap:
+            self.optimizer.prepare(host_out=slot[2])
+        if kf or kv or cap:
+            self._stage_dev.copy_(slot[0], non_blocking=True)
+            slot[3] = torch.cuda.Event()
+            slot[3].record()
+        frame_ids = self._frame_idx if kf else slice(self.frame_lo, self.frame_hi)
+        return frame_ids, (self._view_idx if kv else None), cap
+
     def pick_views(self):
         """The cameras of this step: None = all of cam_idxs, else a device tensor of k random positions in cam_idxs."""
         k = self.cfg.views_per_step
@@ -831,15 +988,18 @@ class Fitter:
         self._view_idx.copy_(sel)
         return self._view_idx
 
+    def _mode_switch(self):
+        # fit.py:603-608 switches the learned basis on AFTER the forward pass of the first iteration i > max_iter / 2, so
+        # it receives its first gradient in the iteration after that one
+        if self.cfg.mode == 'combined' and (self.iteration - 1) > self.cfg.max_iter / 2:
+            for m in (self.m1, self.m2, self.m3):
+                m.requires_grad = True
+
     def loss_and_backward(self, frame_ids, view_ids=None):
         """Forward + backward of fit.py:556-611 for a batch of frames x cameras (view_ids: see mvp).  Returns the loss (tensor)."""
         cfg = self.cfg
         i = self.iteration
-        # fit.py:603-608 switches the learned basis on AFTER the forward pass of the first iteration i > max_iter / 2, so
-        # it receives its first gradient in the iteration after that one
-        if cfg.mode == 'combined' and (i - 1) > cfg.max_iter / 2:
-            for m in (self.m1, self.m2, self.m3):
-                m.requires_grad = True
+        self._mode_switch()
         Fb, Nc = self._n(frame_ids), (len(self.cam_idxs) if view_ids is None else int(view_ids.shape[0]))
         C = self.tex_opt.shape[2]
         # (the mip branch of the reference's render(), fit.py:153-155, runs inside the same kernels)
@@ -849,7 +1009,8 @@ class Fitter:
         # pool around it goes to the functions whose backward takes views of it
         zero_buf, pool = None, None
         if one_shot and cfg.one_pass and cfg.sparse_objective:
-            zero_buf = torch.empty(Fb * Nc * 16 + 7 * (Fb + Nc) + 64 + Fb * (self.datasets['local'].shape[1] + self.m3.shape[1]),
+            n_pose = (self.q_opt.shape[0] + self.per_frame_q.shape[0]) if (view_ids is not None or torch.is_tensor(frame_ids)) else (Fb + Nc)
+            zero_buf = torch.empty(Fb * Nc * 16 + 7 * n_pose + 64 + Fb * (self.datasets['local'].shape[1] + self.m3.shape[1]),
                                    dtype=torch.float32, device=self.device)
             pool = ZeroPool(zero_buf)
         vtx_pos = self.vertices(frame_ids, pool=pool)                 # [Fb,3V]
@@ -858,8 +1019,18 @@ class Fitter:
         ref = None
         n_img_global = Fb * Nc * self.world
         local = slice(frame_ids.start - self.frame_lo, frame_ids.stop - self.frame_lo) if isinstance(frame_ids, slice) \
-            else frame_ids - self.frame_lo
-        ref = self.targets[local] if view_ids is None else self.targets[local].index_select(1, view_ids)
+            else (frame_ids - self.frame_lo if self.frame_lo else frame_ids)
+        # the step's reference images.  A random (frame, view) subset is ONE gather of the images it names from the flat [F * Nc, H, W]
+        # table (the reference's run shape draws one image per step: selecting the frame's nine images first and the view second copied
+        # 17 MB for 1.9 MB -- 39 of the step's ~330 us of kernels)
+        flat_sel = None
+        if view_ids is None:
+            ref = self.targets[local]
+        else:
+            n_cam_all = self.targets.shape[1]
+            f_idx = torch.arange(local.start, local.stop, device=self.device) if isinstance(local, slice) else local
+            flat_sel = (f_idx[:, None] * n_cam_all + view_ids[None, :]).reshape(-1)
+            ref = self.targets.reshape(-1, *self.resolution).index_select(0, flat_sel)
         ref = ref.reshape(Fb * Nc, *self.resolution)
         n_total = n_img_global * self.resolution[0] * self.resolution[1] * C
         pos_clip = transform_clip_batched(mvp, vtx_pos_split, pool)  # camera.transform_clip (camera.py:11-23), batched
@@ -906,7 +1077,7 @@ class Fitter:
         lap = None
         if cfg.weight_laplacian and cfg.fused_loss:
             lap = laplacian_penalty(vtx_pos_split, self.topo, cfg.weight_laplacian / self.world, eager_grad=True, unit_upstream=True,
-                                    stream=self._side_stream if overlap else None)
+                                    stream=self._side_stream if overlap else None, acc=self._lap_acc)
         self.optimizer.zero_grad(set_to_none=True)
         if one_shot:
             bg_sum = None
@@ -916,9 +1087,11 @@ class Fitter:
                     if getattr(self, "_bg_sum_key", None) != key:
                         self._bg_sum_key, self._bg_sum_all = key, self.target_bg_sumsq[local].sum()
                     bg_sum = self._bg_sum_all
+                elif flat_sel is not None:
+                    bg = self.target_bg_sumsq.reshape(-1).index_select(0, flat_sel)
+                    bg_sum = bg.reshape(()) if bg.numel() == 1 else bg.sum()
                 else:
-                    bg = self.target_bg_sumsq[local]
-                    bg_sum = (bg if view_ids is None else bg.index_select(1, view_ids)).sum()
+                    bg_sum = self.target_bg_sumsq[local].sum()
             pix = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
                                      n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum,
                                      enable_mip=cfg.enable_mip, max_mip_level=cfg.max_mip_level,
@@ -986,7 +1159,9 @@ class Fitter:
             self._flush_result()
             self._result_full[frame_ids] = v
 
-    def _update(self):
+    def _update(self, prepared=False):
+        if isinstance(self.optimizer, GroupedAdam) and self.optimizer.capturable and not prepared:
+            self.optimizer.prepare()      # (an eager step of a graph-mode Fitter: warm-up, or a new set of trainable tensors)
         self.optimizer.step()
         if isinstance(self.optimizer, GroupedAdam):     # (the division of fit.py:616-618 happened inside the launch)
             return
@@ -996,15 +1171,20 @@ class Fitter:
 
     def step(self):
         """One Adam step (fit.py:524-618): forward, backward, gradient all-reduce, update, schedule, renormalise."""
-        frame_ids = self.pick_frames()
-        view_ids = self.pick_views()
+        prepared = False
+        self._mode_switch()      # (before the optimiser's table of this step is written: a parameter that turns trainable now counts this step)
+        if self.use_graph:
+            frame_ids, view_ids, prepared = self._stage_inputs()
+        else:
+            frame_ids = self.pick_frames()
+            view_ids = self.pick_views()
         if self.use_graph and self.iteration >= self.GRAPH_WARMUP:
-            loss = self._step_graphed(frame_ids, view_ids)
+            loss = self._step_graphed(frame_ids, view_ids, prepared)
         else:
             loss = self.loss_and_backward(frame_ids, view_ids)
             if self.reduce_fn is not None:
                 self.reduce_fn(self.params)
-            self._update()
+            self._update(prepared)
         self.scheduler.step()
         if self.cfg.log_interval:
             self._log_step(frame_ids, loss)
@@ -1054,7 +1234,7 @@ class Fitter:
         H, W = resolution
         return images_per_step * ((H + 31) // 32) * ((W + 31) // 32) <= cls.GRAPH_AUTO_BINS
 
-    def _step_graphed(self, frame_ids, view_ids=None):
+    def _step_graphed(self, frame_ids, view_ids=None, prepared=False):
         """Replay (capturing first if needed) graph A = forward + backward into fixed gradient buffers and graph B =
         Adam + quaternion renormalisation; the gradient all-reduce runs between them, outside any graph.  The set of
         trainable tensors is part of the key: 'combined' mode switches the free-form basis on half way (fit.py:603-608)."""
@@ -1066,24 +1246,34 @@ class Fitter:
             loss = self.loss_and_backward(frame_ids, view_ids)
             if self.reduce_fn is not None:
                 self.reduce_fn(self.params)
-            self._update()
+            self._update(prepared)
             return loss
+        cap_adam = isinstance(self.optimizer, GroupedAdam) and self.optimizer.capturable
         if self._graphs is None:
             if _lib.TIMER is not None:
                 raise RuntimeError("per-kernel timing (KernelTimer) cannot be recorded inside a HIP graph")
             torch.cuda.synchronize()
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # ONE graph when nothing has to run between the backward pass and the update (a single rank); with a gradient all-reduce the
+            # update is a second graph behind it
+            one_graph = self.reduce_fn is None
+            ga, gb = torch.cuda.CUDAGraph(), (None if one_graph else torch.cuda.CUDAGraph())
             self.optimizer.zero_grad(set_to_none=True)
             with torch.cuda.graph(ga):
                 loss = self.loss_and_backward(frame_ids, view_ids)
-            with torch.cuda.graph(gb, pool=ga.pool()):
-                self._update()
+                if one_graph:
+                    self._update(prepared=True)
+            if not one_graph:
+                with torch.cuda.graph(gb, pool=ga.pool()):
+                    self._update(prepared=True)
             self._graphs = (ga, gb, loss)      # capture does not execute: fall through to the first replay
         ga, gb, loss = self._graphs
+        if cap_adam and not prepared:
+            self.optimizer.prepare()           # step counters, learning rates of this step -> the device table the captured launch reads
         ga.replay()
-        if self.reduce_fn is not None:
-            self.reduce_fn(self.params)
-        gb.replay()
+        if gb is not None:
+            if self.reduce_fn is not None:
+                self.reduce_fn(self.params)
+            gb.replay()
         return loss
 
     @torch.no_grad()

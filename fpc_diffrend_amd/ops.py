@@ -351,6 +351,7 @@ class _MappedHints:
 
 
 _list_hints = {}
+SMALL_BATCH_BINS = 16384      # (eight full-HD images) batches up to this many 32 x 32 bins run their list kernels unhinted: see _pixel_objective_onepass
 
 
 def _hints_for(key, cls):
@@ -574,6 +575,12 @@ class _pixel_objective_onepass(torch.autograd.Function):
         hints = _hints_for(('onepass', dev.index, B, V, T, H, W), _MappedHints) if use_hints else None
         if hints is not None:
             p.cap_bins, p.cap_occ, p.cap_def = hints.poll()      # (live bins, occupied bins, bins with a deferred pixel)
+            # a batch of few bins -- one image of the reference's run shape has 1 900 -- is launched at its full size whatever the
+            # hint says: a sized launch has a strided sweep launched behind it (four per call, 4.6 us each), and the dead workgroups
+            # of a full launch cost less than that
+            nbins = B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN)
+            if nbins <= SMALL_BATCH_BINS and not hints.frozen:
+                p.cap_bins, p.cap_occ, p.cap_def = 0, 0, 0
             if not capturing:      # (a graph replays fixed launch sizes: nothing to report)
                 p.counts_out, p.counts_seq = hints.host.data_ptr(), hints.next_seq()
         # the value from the call's last kernel: (loss slots + C * background share) / n_total

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FPCDR_ABI_VERSION 9
+#define FPCDR_ABI_VERSION 10
 
 enum {
     FPCDR_OK = 0,
@@ -471,6 +471,18 @@ int fpcdr_mvp_fwd(const float *proj, const float *t_mv, const float *q_cam, cons
 int fpcdr_mvp_bwd(const float *proj, const float *t_mv, const float *q_cam, const float *t_cam, const float *q_frame,
                   const float *t_frame, const float *grad_mvp, float *gq_cam, float *gt_cam, float *gq_frame, float *gt_frame,
                   int32_t Fb, int32_t Nc, void *stream);
+/* The same for a step that names its frames and views by INDEX into the full parameter tables (reference fit.py:525-526 draws one random
+ * camera and frame per iteration and selects their rows with one-hot products, fit.py:547-550).  frame_idx [Fb] / view_idx [Nc]: int64 device
+ * arrays or NULL (= 0 .. n - 1); view_idx indexes proj / t_mv, cam_of_view [views] (or NULL = identity) maps a view to its row of q_cam /
+ * t_cam.  The backward ADDS into the full-size tables gq_cam / gt_cam / gq_frame / gt_frame (the caller zero-fills them). */
+int fpcdr_mvp_fwd_indexed(const float *proj, const float *t_mv, const float *q_cam, const float *t_cam, const float *q_frame,
+                          const float *t_frame, const int64_t *frame_idx, const int64_t *view_idx, const int64_t *cam_of_view, float *mvp,
+                          int32_t Fb, int32_t Nc, void *stream);
+int fpcdr_mvp_bwd_indexed(const float *proj, const float *t_mv, const float *q_cam, const float *t_cam, const float *q_frame,
+                          const float *t_frame, const int64_t *frame_idx, const int64_t *view_idx, const int64_t *cam_of_view,
+                          const float *grad_mvp, float *gq_cam, float *gt_cam, float *gq_frame, float *gt_frame, int32_t Fb, int32_t Nc,
+                          void *stream);
+
 
 /* uniform mesh Laplacian (reference fit.py:581, pytorch3d mesh_laplacian_smoothing 'uniform'), gather form:
  *   transpose = 0: out = L x,  L = D^-1 A - I;   transpose = 1: out = L^T x (the backward of the former)
@@ -552,12 +564,17 @@ typedef struct {
                               the first bias correction, divided in double precision as torch does */
     float bc2_sqrt;        /* sqrt(1 - beta2^step) */
     int32_t renorm;
+    int32_t table_row;     /* ABI v10, with fpcdr_adam_params.step_table: this tensor's row of the table (step_size / bc2_sqrt above unused) */
 } fpcdr_adam_tensor;
 typedef struct {
     int32_t n_tensors;
     float beta1, beta2, eps;
     float one_minus_beta1, one_minus_beta2;   /* rounded from the double-precision differences, as torch does */
     fpcdr_adam_tensor t[FPCDR_ADAM_MAX_TENSORS];
+    /* ABI v10: optional DEVICE table of (step_size, bc2_sqrt) pairs, row t[i].table_row for tensor i; when given it replaces the two fields
+     * of t[] -- a step captured in a HIP graph replays fixed kernel arguments, and its learning-rate schedule and bias corrections arrive
+     * through this table (one small host-to-device copy per step in front of the replay) */
+    const float *step_table;
 } fpcdr_adam_params;
 int fpcdr_adam_step(const fpcdr_adam_params *p, void *stream);
 

@@ -11,18 +11,19 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--fill", type=float, default=0.0, help="head height as a fraction of the image height (default: the scene's 0.6)")
 ap.add_argument("--frames-per-step", type=int, default=0, help="frames drawn per step (0: all)")
 ap.add_argument("--views-per-step", type=int, default=0, help="cameras drawn per step (0: all); 1 + --frames-per-step 1 = the reference's run shape")
+ap.add_argument("--graph", type=int, default=0, help="1: FitConfig.hip_graph=True (the step replayed as HIP graphs; no per-call timer then)")
 ap.add_argument("--ops", type=int, default=1, help="also run the eight operator calls of render() + backward once at the full batch (their kernels' counters)")
 a = ap.parse_args()
 sc = scene.cfg(a.workload, n_frames=a.frames)
 if a.fill:
     sc.cams = scene.make_cameras(sc.resolution, fill=a.fill)
-ft = fit.Fitter(sc, fit.FitConfig(max_iter=80000, init_texture="random", frames_per_step=a.frames_per_step, views_per_step=a.views_per_step),
-                device="cuda")
-for _ in range(2):
+ft = fit.Fitter(sc, fit.FitConfig(max_iter=80000, init_texture="random", frames_per_step=a.frames_per_step, views_per_step=a.views_per_step,
+                                  hip_graph=bool(a.graph)), device="cuda")
+for _ in range(2 + (fit.Fitter.GRAPH_WARMUP + 3 if a.graph else 0)):
     ft.step()
 torch.cuda.synchronize()
 t = _lib.KernelTimer(names=["fpcdr_render_loss_fwd", "fpcdr_render_aa_bwd", "fpcdr_objective_fwd"])
-_lib.TIMER = t
+_lib.TIMER = None if a.graph else t
 for _ in range(a.steps):
     ft.step()
 _lib.TIMER = None
