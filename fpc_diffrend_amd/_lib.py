@@ -8,6 +8,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FPCDR_LIB_PATH") or os.path.join(_HERE, "libfpcdr.so")  # override: A/B builds
+TWOCALL_LIB_PATH = os.environ.get("FPCDR_TWOCALL_LIB_PATH") or os.path.join(_HERE, "libfpcdr_twocall.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 MAX_ATTR = 32
@@ -139,15 +140,10 @@ SYMBOLS = {
     "fpcdr_rasterize_scratch_bytes": (_sz, [_i, _i]),
     "fpcdr_rasterize_fwd": (_int, [ctypes.POINTER(RasterizeFwd), _p]),
     "fpcdr_rasterize_bwd": (_int, [ctypes.POINTER(RasterizeBwd), _p]),
-    "fpcdr_render_fwd": (_int, [ctypes.POINTER(RenderFwd), _p]),
-    "fpcdr_render_bwd": (_int, [ctypes.POINTER(RenderBwd), _p]),
-    "fpcdr_aa_loss_fwd": (_int, [ctypes.POINTER(AaLossFwd), _p]),
-    "fpcdr_render_loss_fwd": (_int, [ctypes.POINTER(RenderFwd), ctypes.POINTER(AaLossFwd), _p, _p]),
     "fpcdr_occ_bytes": (_sz, [_i, _i, _i]),
     "fpcdr_cmask_bytes": (_sz, [_i, _i, _i]),
     "fpcdr_ref_bg_sumsq": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, _p, _p]),
     "fpcdr_objective_value": (_int, [_p, _i, _p, ctypes.c_double, ctypes.c_double, _p, _p]),
-    "fpcdr_render_aa_bwd": (_int, [ctypes.POINTER(RenderAaBwd), _p]),
     "fpcdr_idplane_bytes": (_sz, [_i, _i, _i]),
     "fpcdr_binlist_bytes": (_sz, [_i, _i, _i]),
     "fpcdr_objective_fwd": (_int, [ctypes.POINTER(Objective), _p]),
@@ -181,7 +177,17 @@ SYMBOLS = {
     "fpcdr_adam_step": (_int, [ctypes.POINTER(AdamParams), _p]),
 }
 
+# the two-call form of the pixel objective + the fused render pair (include/fpcdr_twocall.h): exported by libfpcdr_twocall.so only
+SYMBOLS_TWOCALL = {
+    "fpcdr_render_fwd": (_int, [ctypes.POINTER(RenderFwd), _p]),
+    "fpcdr_render_bwd": (_int, [ctypes.POINTER(RenderBwd), _p]),
+    "fpcdr_aa_loss_fwd": (_int, [ctypes.POINTER(AaLossFwd), _p]),
+    "fpcdr_render_loss_fwd": (_int, [ctypes.POINTER(RenderFwd), ctypes.POINTER(AaLossFwd), _p, _p]),
+    "fpcdr_render_aa_bwd": (_int, [ctypes.POINTER(RenderAaBwd), _p]),
+}
+
 _lib = None
+_lib_twocall = None
 
 
 def build(force=False):
@@ -220,6 +226,28 @@ def load():
     return lib
 
 
+def load_twocall():
+    """libfpcdr_twocall.so: the superseded two-call form of the pixel objective and the fused render pair (include/fpcdr_twocall.h).
+    A complete library of its own -- every symbol of fpcdr.h plus SYMBOLS_TWOCALL -- loaded only when one of those entry points is
+    asked for (ops.pixel_objective(one_pass=False), ops.render_textured); the fit loop never does."""
+    global _lib_twocall
+    if _lib_twocall is not None:
+        return _lib_twocall
+    load()      # (binds the HIP runtime torch uses)
+    if not os.path.exists(TWOCALL_LIB_PATH):
+        raise RuntimeError(f"{TWOCALL_LIB_PATH} not found: run `make -C {CSRC}` (or __graft_entry__.build()). The two-call form of the "
+                           "pixel objective and ops.render_textured live in this second library; there is no fallback.")
+    lib = ctypes.CDLL(TWOCALL_LIB_PATH)
+    for name, (res, args) in list(SYMBOLS.items()) + list(SYMBOLS_TWOCALL.items()):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fpcdr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libfpcdr_twocall.so ABI version {lib.fpcdr_abi_version()} != binding {ABI_VERSION}; rebuild the extension")
+    _lib_twocall = lib
+    return lib
+
+
 class KernelTimer:
     """Per-entry-point device time, measured with HIP events recorded on the launch stream (torch's current
     stream, the one every fpcdr_* launch goes to).  Used by bench.py for the roofline figures."""
@@ -241,9 +269,11 @@ class KernelTimer:
 TIMER = None  # set to a KernelTimer() to time every C-ABI call
 
 
-def call(name, *args):
-    """Invoke one C-ABI entry point, raise on a non-zero return code."""
-    fn = getattr(load(), name)
+def call(name, *args, twocall=False):
+    """Invoke one C-ABI entry point, raise on a non-zero return code.  twocall (or a name of SYMBOLS_TWOCALL): from libfpcdr_twocall.so --
+    a code path of the two-call form makes ALL its calls there, so that the scratch layouts its kernels share come from one library."""
+    twocall = twocall or name in SYMBOLS_TWOCALL
+    fn = getattr(load_twocall() if twocall else load(), name)
     t = TIMER
     if t is not None and (t.names is None or name in t.names):
         import torch
@@ -255,10 +285,10 @@ def call(name, *args):
         t.add(name, e0, e1)
     else:
         rc = fn(*args)
-    check(rc)
+    check(rc, twocall)
 
 
-def check(rc):
+def check(rc, twocall=False):
     if rc != 0:
-        msg = load().fpcdr_last_error()
+        msg = (load_twocall() if twocall else load()).fpcdr_last_error()
         raise RuntimeError(f"fpcdr error {rc}: {msg.decode() if msg else '?'}")

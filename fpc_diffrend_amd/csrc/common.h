@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "../../include/fpcdr.h"
+#include "../../include/fpcdr_twocall.h"
 
 #define FPCDR_WAVE 64
 

@@ -195,37 +195,6 @@ __global__ void __launch_bounds__(256) FPCDR_AAL_WPE k_aa_loss(const float *__re
     }
 }
 
-// sum over one image of (ref - bg_scaled)^2: grid (chunks, images), 16 pixels per thread and trip
-__global__ void __launch_bounds__(256) k_ref_bg_sumsq(const uint8_t *__restrict__ ref, long long px, float bgs,
-                                                      double *__restrict__ out) {
-    __shared__ double s_part[4];
-    const uint8_t *r = ref + (size_t)blockIdx.y * px;
-    double acc = 0.0;
-    const long long nvec = ((size_t)r % 16 == 0) ? px / 16 : 0;   // 16-byte loads when the image base is aligned
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
-        const uint4 v = ((const uint4 *)r)[i];
-        const unsigned int w[4] = {v.x, v.y, v.z, v.w};
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float d = (float)((w[k] >> (8 * j)) & 255u) - bgs;
-                s += d * d;
-            }
-        acc += (double)s;
-    }
-    for (long long i = nvec * 16 + (long long)blockIdx.x * 256 + threadIdx.x; i < px; i += (long long)gridDim.x * 256) {
-        const float d = (float)r[i] - bgs;
-        acc += (double)(d * d);
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out + blockIdx.y, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Backward of the whole pixel objective, one workgroup per 32x32-pixel bin, four pixels per thread:
 //   g_c = g_aa + antialias corrections (gather form, only where a flag bit says a pair was blended)
@@ -445,9 +414,6 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
             }
         }
     }
-#ifdef FPCDR_ABL_EARLY
-    { float sink = 0.f; for (int k = 0; k < BWD_NPX; ++k) for (int c = 0; c < CS; ++c) sink += go[k][c]; asm volatile("" :: "v"(sink)); return; }
-#endif
     // most bins of an image see no gradient at all: leave before touching the tables
     bool any_px = false;
 #pragma unroll
@@ -596,12 +562,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
                 mask_taps(tp, t00, t10, t01, t11);
                 gfx += gc * ((t10 - t00) * (1.0f - tp.fy) + (t11 - t01) * tp.fy);
                 gfy += gc * ((t01 + (t11 - t01) * tp.fx) - (t00 + (t10 - t00) * tp.fx));
-#ifdef FPCDR_ABL_NOTEX
-                asm volatile("" :: "v"(gc * w00), "v"(gc * w10), "v"(gc * w01), "v"(gc * w11), "v"(in_win));
-                if (false) {
-#else
                 if (grad_tex && gc != 0.0f) {
-#endif
                     if (in_win) {
                         double *w = s_tex + (ly * TEXW + lx) * CS + c;
                         lds_add_f64(w, gc * w00);
@@ -642,12 +603,7 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
             vk[0] = mip_vk[0]; vk[1] = mip_vk[1]; vk[2] = mip_vk[2];
         } else if (tkey >= 0) {
             { const I3 ti = ld32(reinterpret_cast<const I3 *>(tri), tkey); vk[0] = ti.a; vk[1] = ti.b; vk[2] = ti.c; }
-#ifdef FPCDR_ABL_NOSHADEBWD
-            gv9[0] = gu; gv9[4] = gvv;
-            if (false) {
-#else
             {
-#endif
             const float fx = fx_col;
             const float fy = s_fy[rowk0 + 2 * k];
             float g0[3], g1[3], g2[3];
@@ -658,10 +614,6 @@ __device__ __forceinline__ void render_aa_bwd_body(const int b, const int bxi, c
             gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
             }
         }
-#ifdef FPCDR_ABL_NOVERT
-        { float sink = 0.f; for (int q = 0; q < 9; ++q) sink += gv9[q]; asm volatile("" :: "v"(sink)); }
-        if (false)
-#endif
 #ifdef FPCDR_SEG_GENERIC
         wave_segment_reduce<9>(tkey, gv9, [&](int, const float (&sm)[9]) {
 #else
@@ -998,41 +950,9 @@ __global__ void __launch_bounds__(FIX_NT) k_aa_fix_queue(const int32_t *__restri
     }
 }
 
-// per-image silhouette classification (same arithmetic as k_sil in antialias.hip).  The kernel is a chain of gathers with two dozen
-// instructions behind them -- latency, not issue, is its cost -- so a thread classifies its triangle in SIL_NI images: the six
-// indices (own vertices, vertices across the three edges) are loaded once, and the 6 x SIL_NI position gathers are all in flight
-// before the first is used (the vertex across an edge used to be fetched only after the edge's line had been computed).
-__global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
-                                              const int32_t *__restrict__ adj, int B, int V, int T, float hw, float hh,
-                                              uint8_t *__restrict__ sil, uint4 *__restrict__ zero_dst, unsigned long long zero_n16) {
-    // grid (triangle chunks, groups of SIL_NI images): a flat thread index would cost every thread a 64-bit division
-    const int b0 = blockIdx.y * SIL_NI, t = blockIdx.x * blockDim.x + threadIdx.x;
-    // fpcdr_render_loss_fwd: the antialias flag planes of the call (149 MB at cfg3) are zeroed HERE, by stores that cost this
-    // latency-bound kernel next to nothing, instead of by a 32-50 us fill of the caller's in front of the call
-    if (zero_dst) {
-        const unsigned long long stride = (unsigned long long)gridDim.x * gridDim.y * blockDim.x;
-        for (unsigned long long i = ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < zero_n16; i += stride)
-            zero_dst[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    if (t >= T) return;
-    sil_classify(pos, tri, adj, B, V, T, hw, hh, sil, b0, t);      // (sil_bits.h: same arithmetic as k_sil in antialias.hip)
-}
-
 }  // namespace
 
-// ---- pieces of fpcdr_render_loss_fwd (rasterize.hip) that live in this file; not part of the C ABI ----
-int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, int B, int V, int T, int H, int W, uint8_t *sil,
-                     void *zero_dst, size_t zero_bytes, hipStream_t st) {
-    if (zero_dst && (((size_t)zero_dst | zero_bytes) & 15)) {      // (not 16-byte shaped: a plain memset)
-        FPCDR_REQUIRE(hipMemsetAsync(zero_dst, 0, zero_bytes, st) == hipSuccess, "memset of the flag planes failed");
-        zero_dst = nullptr;
-    }
-    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv(T, 256), fpcdr_cdiv(B, SIL_NI)), dim3(256), 0, st, (const float4 *)pos, tri, adj, B, V, T,
-                       0.5f * (float)W, 0.5f * (float)H, sil, (uint4 *)zero_dst, (unsigned long long)(zero_bytes / 16));
-    FPCDR_CHECK_LAUNCH();
-    return FPCDR_OK;
-}
-
+// ---- a piece of fpcdr_render_loss_fwd (rasterize.hip) that lives in this file; not part of the C ABI ----
 int fpcdr_launch_aa_fix(const fpcdr_aa_loss_fwd_params *p, const uint32_t *cmask, const unsigned long long *edges,
                         const int32_t *fix_list, const int32_t *fix_count, int nbins, hipStream_t st) {
     const int cap = (p->cap_fix > 0 && p->cap_fix < nbins) ? p->cap_fix : nbins;
@@ -1063,8 +983,10 @@ extern "C" int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream
     FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
     FPCDR_REQUIRE(p->B <= 65535 && fpcdr_cdiv(p->H, 32) <= 65535, "image batch / height too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv(p->T, 256), fpcdr_cdiv(p->B, SIL_NI)), dim3(256), 0, st, (const float4 *)p->pos, p->tri,
-                       p->adj, p->B, p->V, p->T, 0.5f * (float)p->W, 0.5f * (float)p->H, p->sil, (uint4 *)nullptr, 0ull);
+    {
+        const int rc_sil = fpcdr_launch_sil(p->pos, p->tri, p->adj, p->B, p->V, p->T, p->H, p->W, p->sil, nullptr, 0, st);      // (objective.hip)
+        if (rc_sil) return rc_sil;
+    }
     dim3 grid(fpcdr_cdiv(p->W, 64), fpcdr_cdiv(p->H, 32), p->B);
 #define LAUNCH(CS, SP)                                                                                                         \
     hipLaunchKernelGGL((k_aa_loss<CS, SP>), grid, dim3(256), 0, st, p->color, (const float4 *)p->rast, (const float4 *)p->pos, \
@@ -1081,17 +1003,6 @@ extern "C" int fpcdr_aa_loss_fwd(const fpcdr_aa_loss_fwd_params *p, void *stream
         else LAUNCH(4, false);
     }
 #undef LAUNCH
-    FPCDR_CHECK_LAUNCH();
-    return FPCDR_OK;
-}
-
-extern "C" int fpcdr_ref_bg_sumsq(const uint8_t *ref, int64_t n_images, int64_t px_per_image, float bg_scaled, double *out,
-                                  void *stream) {
-    FPCDR_REQUIRE(ref && out, "null pointer");
-    FPCDR_REQUIRE(n_images > 0 && n_images <= 65535 && px_per_image > 0, "bad sizes");
-    const int chunks = (int)std::min<long long>(64, (px_per_image + 4095) / 4096);
-    hipLaunchKernelGGL(k_ref_bg_sumsq, dim3(chunks, (unsigned)n_images), dim3(256), 0, (hipStream_t)stream, ref,
-                       (long long)px_per_image, bg_scaled, out);
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }

@@ -8,6 +8,8 @@
 // and writes d loss / d colour (4C B/px); the sum of squares is reduced wave -> block -> one f64 atomic.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 __global__ void __launch_bounds__(256) k_pixel_loss(const float *__restrict__ color, const float4 *__restrict__ rast,
@@ -47,6 +49,37 @@ __global__ void __launch_bounds__(64) k_objective_value(const double *__restrict
     }
 }
 
+// sum over one image of (ref - bg_scaled)^2: grid (chunks, images), 16 pixels per thread and trip
+__global__ void __launch_bounds__(256) k_ref_bg_sumsq(const uint8_t *__restrict__ ref, long long px, float bgs,
+                                                      double *__restrict__ out) {
+    __shared__ double s_part[4];
+    const uint8_t *r = ref + (size_t)blockIdx.y * px;
+    double acc = 0.0;
+    const long long nvec = ((size_t)r % 16 == 0) ? px / 16 : 0;   // 16-byte loads when the image base is aligned
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const uint4 v = ((const uint4 *)r)[i];
+        const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = (float)((w[k] >> (8 * j)) & 255u) - bgs;
+                s += d * d;
+            }
+        acc += (double)s;
+    }
+    for (long long i = nvec * 16 + (long long)blockIdx.x * 256 + threadIdx.x; i < px; i += (long long)gridDim.x * 256) {
+        const float d = (float)r[i] - bgs;
+        acc += (double)(d * d);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + blockIdx.y, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
 }  // namespace
 
 extern "C" int fpcdr_objective_value(const double *loss_slots, int32_t n_slots, const double *bg_sumsq, double bg_coeff,
@@ -70,3 +103,15 @@ extern "C" int fpcdr_pixel_loss(const fpcdr_pixel_loss_params *p, void *stream) 
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }
+
+extern "C" int fpcdr_ref_bg_sumsq(const uint8_t *ref, int64_t n_images, int64_t px_per_image, float bg_scaled, double *out,
+                                  void *stream) {
+    FPCDR_REQUIRE(ref && out, "null pointer");
+    FPCDR_REQUIRE(n_images > 0 && n_images <= 65535 && px_per_image > 0, "bad sizes");
+    const int chunks = (int)std::min<long long>(64, (px_per_image + 4095) / 4096);
+    hipLaunchKernelGGL(k_ref_bg_sumsq, dim3(chunks, (unsigned)n_images), dim3(256), 0, (hipStream_t)stream, ref,
+                       (long long)px_per_image, bg_scaled, out);
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
+

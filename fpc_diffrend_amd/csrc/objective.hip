@@ -22,14 +22,12 @@
 
 #include <stdlib.h>
 
-int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, int B, int V, int T, int H, int W, uint8_t *sil,
-                     void *zero_dst, size_t zero_bytes, hipStream_t st);
-
 namespace {
 
 #include "texsample.h"
 #include "raster_math.h"
 #include "aa_pairs.h"
+#include "sil_bits.h"
 
 #ifndef FPCDR_OTEXWIN
 #define FPCDR_OTEXWIN 40          // texel window of a bin (see fused.hip: capacity swept 8 .. 64 at ~1 texel per pixel)
@@ -98,52 +96,6 @@ __device__ unsigned long long g_oprof[16];
 #define OPROF_ADD(slot, a_, b_)
 #endif
 
-// Vertex table of k_shade with FLOAT accumulators (-DFPCDR_SHADE_VT32=1): 3 KB instead of 6, which together with 72 VGPRs lets a CU hold
-// seven workgroups instead of six.  Adds are compare-and-swap loops (common.h lds_add_f32); they happen at run tails only.
-#ifndef FPCDR_SHADE_VT32
-#define FPCDR_SHADE_VT32 0
-#endif
-struct VTableF {
-    int *key;
-    float (*acc)[3];
-};
-__device__ __forceinline__ void vtablef_init(const VTableF &t, int tid, int nthreads) {
-    for (int k = tid; k < FPCDR_VT_SLOTS; k += nthreads) { t.key[k] = -1; t.acc[k][0] = 0.f; t.acc[k][1] = 0.f; t.acc[k][2] = 0.f; }
-}
-__device__ __forceinline__ void vtablef_add(const VTableF &t, float *gp, const int (&vk)[3], const float (&sm)[9]) {
-    unsigned int slot[3];
-    int old[3];
-#pragma unroll
-    for (int kk = 0; kk < 3; ++kk) slot[kk] = (((unsigned int)vk[kk] * 2654435761u) >> 16) & (FPCDR_VT_SLOTS - 1);
-#pragma unroll
-    for (int kk = 0; kk < 3; ++kk) old[kk] = atomicCAS(&t.key[slot[kk]], -1, vk[kk]);
-#pragma unroll
-    for (int kk = 0; kk < 3; ++kk) {
-        const int key = vk[kk];
-        bool done = (old[kk] == -1 || old[kk] == key);
-        for (int probe = 1; probe < FPCDR_VT_SLOTS && !done; ++probe) {
-            slot[kk] = (slot[kk] + 1) & (FPCDR_VT_SLOTS - 1);
-            const int o = atomicCAS(&t.key[slot[kk]], -1, key);
-            done = (o == -1 || o == key);
-        }
-        if (done) {
-            lds_add_f32(&t.acc[slot[kk]][0], sm[3 * kk]); lds_add_f32(&t.acc[slot[kk]][1], sm[3 * kk + 1]); lds_add_f32(&t.acc[slot[kk]][2], sm[3 * kk + 2]);
-        } else {
-            atomicAdd(gp + 4 * (size_t)key + 0, sm[3 * kk]); atomicAdd(gp + 4 * (size_t)key + 1, sm[3 * kk + 1]); atomicAdd(gp + 4 * (size_t)key + 3, sm[3 * kk + 2]);
-        }
-    }
-}
-__device__ __forceinline__ void vtablef_flush(const VTableF &t, float *gp, int tid, int nthreads) {
-    for (int k = tid; k < FPCDR_VT_SLOTS * 4; k += nthreads) {
-        const int slot = k >> 2, comp = k & 3;
-        const int key = t.key[slot];
-        if (key >= 0 && comp != 2) {
-            const float v = t.acc[slot][comp == 3 ? 2 : comp];
-            if (v != 0.0f) atomicAdd(gp + 4 * (size_t)key + comp, v);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_shade: one 32 x 32 bin, 256 threads, four pixels per thread.  A wave pass covers two adjacent rows of the bin, the second one right
 // to left, so that the pixels of a triangle are neighbours in lane order and ONE segmented scan per pass sums the nine vertex gradient
@@ -180,9 +132,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     __shared__ int s_org1[2];
     __shared__ unsigned int s_id[(OB + 2) * OS];
     __shared__ int s_vkey[FPCDR_VT_SLOTS];
-    __shared__ double s_vacc[FPCDR_SHADE_VT32 ? 1 : FPCDR_VT_SLOTS][3];
-    __shared__ float s_vaccf[FPCDR_SHADE_VT32 ? FPCDR_VT_SLOTS : 1][3];
-    const VTableF vtf = {s_vkey, s_vaccf};
+    __shared__ double s_vacc[FPCDR_VT_SLOTS][3];
     __shared__ double s_tex[OTW * OTW * CS];      // texel window, doubles: ds_add_f64 (common.h lds_add_f64)
     __shared__ int s_org[2];
     __shared__ unsigned int s_cmask[OB];
@@ -197,11 +147,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     const int H = a.H, W = a.W, Ht = a.Ht, Wt = a.Wt;
     const size_t bin_lin = ((size_t)b * OY + byi) * OX + bxi;
     const unsigned int wmask = (unsigned int)__builtin_amdgcn_readfirstlane((int)a.occ[bin_lin]);
-#ifdef FPCDR_OABL_NOTEXGRAD
-    const bool want_tex = false, want_pos = a.grad_pos != nullptr, want_grad = want_tex || want_pos;
-#else
     const bool want_tex = a.grad_tex != nullptr, want_pos = a.grad_pos != nullptr, want_grad = want_tex || want_pos;   // (uniform)
-#endif
 
     OPROF_DECL;
     OPROF_T(0);
@@ -226,7 +172,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         s_id[ty * OS + tx] = e;
         sil_seen |= e >> 24;
     }
-    if (want_pos) { if (FPCDR_SHADE_VT32) vtablef_init(vtf, tid, ONT); else vtable_init(vt, tid, ONT); }
+    if (want_pos) vtable_init(vt, tid, ONT);
     if (want_tex)
         for (int k = tid; k < OTW * OTW * CS; k += ONT) s_tex[k] = 0.0;
     if (MIP && want_tex)
@@ -264,13 +210,8 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         const float w00 = (valid & 1u) ? (1.0f - fx) * (1.0f - fy) : 0.0f, w10 = (valid & 2u) ? fx * (1.0f - fy) : 0.0f;
         const float w01 = (valid & 4u) ? (1.0f - fx) * fy : 0.0f, w11 = (valid & 8u) ? fx * fy : 0.0f;
         const int lx = x0 - ox, ly = y0 - oy;
-#ifdef FPCDR_OABL_NOTEXADD
-        asm volatile("" :: "v"(w00), "v"(w10), "v"(w01), "v"(w11), "v"(lx), "v"(ly), "v"(gc[0]));
-        if (false) {
-#else
         // (unsigned compares: a tap below the origin wraps to a huge value; 0x7fffffff origin = no sample in pass 0: everything outside)
         if ((unsigned int)lx < (unsigned int)(OTW - 1) && (unsigned int)ly < (unsigned int)(OTW - 1)) {
-#endif
 #pragma unroll
             for (int c = 0; c < CS; ++c) {
                 double *wp = s_tex + (ly * OTW + lx) * CS + c;
@@ -279,11 +220,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 lds_add_f64(wp + OTW * CS, gc[c] * w01);
                 lds_add_f64(wp + OTW * CS + CS, gc[c] * w11);
             }
-#ifdef FPCDR_OABL_NOTEXADD
-        } else if (false) {
-#else
         } else {
-#endif
             const int ix0 = wrap_near(x0, Wt, boundary), ix1 = wrap_near(x0 == 0x7fffffff ? x0 : x0 + 1, Wt, boundary);
             const int iy0 = wrap_near(y0, Ht, boundary), iy1 = wrap_near(y0 == 0x7fffffff ? y0 : y0 + 1, Ht, boundary);
 #pragma unroll
@@ -301,25 +238,6 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     int k_x0 = 0x7fffffff, k_y0 = 0x7fffffff;
     bool k_on = false;
 
-    // ---- prefetch.  A pixel's chain is ids (LDS) -> vertex indices -> three vertices -> barycentrics -> texels: three dependent
-    // global round trips, four pixels one after the other = 75 % of a wave's life (scripts/prof_phases.py).  The indices of all four
-    // pixels are fetched up front and a pixel's vertices while the pixel before it is worked on, which leaves the texel fetch as the
-    // one exposed round trip per pixel.  (The compiler cannot hoist these loads itself: the pixel code holds global stores / atomics.)
-#ifndef FPCDR_SHADE_PREFETCH
-#define FPCDR_SHADE_PREFETCH 0      // measured at cfg3: 2.70 ms per call either way (93 VGPRs and 5 waves per SIMD with it, 73 and 6 without)
-#endif
-    I3 ti4[4];
-    float4 pn0 = make_float4(0.f, 0.f, 0.f, 0.f), pn1 = pn0, pn2 = pn0;      // vertices of the NEXT pixel to be worked on
-    if (FPCDR_SHADE_PREFETCH) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int zy = 2 * shade_row_pair(k, wave) + (lane >> 5);
-            const int id = (int)(s_id[(zy + 1) * OS + col + 1] & 0xffffffu);
-            ti4[k] = id > 0 ? ld32(reinterpret_cast<const I3 *>(a.tri), id - 1) : I3{0, 0, 0};
-        }
-        pn0 = ld32(pos_img, ti4[0].a); pn1 = ld32(pos_img, ti4[0].b); pn2 = ld32(pos_img, ti4[0].c);      // (an empty pixel reads vertex 0)
-    }
-
     // ---- one pixel: shade, loss, chain back.  FIRST: pass 0 (texel adds deferred to behind the origin's barrier) ----
     auto pixel = [&](const int k, const bool FIRST) {
         const int zy = 2 * shade_row_pair(k, wave) + (lane >> 5), y = by0 + zy;
@@ -328,12 +246,6 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         int tkey = -1;
         int vk[3] = {0, 0, 0};
         float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        // this pixel's vertices arrived while the previous one was worked on; the next pixel's are requested now
-        const float4 pv0 = pn0, pv1 = pn1, pv2 = pn2;
-        if (FPCDR_SHADE_PREFETCH && k < 3) {
-            const I3 tn = ti4[k < 3 ? k + 1 : 3];
-            pn0 = ld32(pos_img, tn.a); pn1 = ld32(pos_img, tn.b); pn2 = ld32(pos_img, tn.c);
-        }
         if (id > 0) {
             bool deferred = false;
             if (bin_sil) {      // (uniform)
@@ -343,9 +255,10 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                            (y > 0 && pair_maybe(me, nD));
             }
             const int t = id - 1;
-            const I3 ti = FPCDR_SHADE_PREFETCH ? ti4[k] : ld32(reinterpret_cast<const I3 *>(a.tri), t);
-            const float4 v0 = FPCDR_SHADE_PREFETCH ? pv0 : ld32(pos_img, ti.a), v1 = FPCDR_SHADE_PREFETCH ? pv1 : ld32(pos_img, ti.b),
-                         v2 = FPCDR_SHADE_PREFETCH ? pv2 : ld32(pos_img, ti.c);
+            // (measured and dropped in r4: the four pixels' vertex indices fetched up front and a pixel's vertices while the one before it is
+            //  worked on -- 93 VGPRs and 5 waves per SIMD against 73 and 6, the call 2.70 ms either way)
+            const I3 ti = ld32(reinterpret_cast<const I3 *>(a.tri), t);
+            const float4 v0 = ld32(pos_img, ti.a), v1 = ld32(pos_img, ti.b), v2 = ld32(pos_img, ti.c);
             const float fy = s_fy[zy];
             ShadeKeep K;
             float u, v, zw = 0.0f;
@@ -459,13 +372,8 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 }
             }
         }
-#ifdef FPCDR_OABL_NOSCAN
-        { float sink = 0.f; for (int q = 0; q < 9; ++q) sink += gv9[q]; asm volatile("" :: "v"(sink), "v"(tkey)); }
-        if (false)
-#else
         if (want_pos)      // (uniform)
-#endif
-            wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) { if (FPCDR_SHADE_VT32) vtablef_add(vtf, gp, vk, sm); else vtable_add(vt, gp, vk, sm); });
+            wave_segment_reduce9(tkey, gv9, [&](int, const float (&sm)[9]) { vtable_add(vt, gp, vk, sm); });
     };
 
     if (MIP) {
@@ -536,14 +444,8 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     OPROF_ADD(0, 0, 1); OPROF_ADD(1, 1, 2); OPROF_ADD(2, 2, 3); OPROF_ADD(3, 3, 4); OPROF_ADD(4, 4, 5); OPROF_ADD(5, 5, 6);
     if (!want_grad) return;
     // ---- flush: every vertex slot and window cell once (the barrier above has made all adds visible) ----
-#ifndef FPCDR_OABL_NOVFLUSH
-    if (want_pos) { if (FPCDR_SHADE_VT32) vtablef_flush(vtf, gp, tid, ONT); else vtable_flush(vt, gp, tid, ONT); }
-#endif
-#ifdef FPCDR_OABL_NOTEXFLUSH
-    if (false) {
-#else
+    if (want_pos) vtable_flush(vt, gp, tid, ONT);
     if (want_tex && ox != 0x7fffffff) {
-#endif
         for (int k = tid; k < OTW * OTW * CS; k += ONT) {
             const float v = (float)s_tex[k];
             if (v != 0.0f) {
@@ -726,9 +628,6 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
 #ifdef FPCDR_OPROF
     const long long ft1 = clock64();
 #endif
-#ifdef FPCDR_FABL_A
-    if (PASS == 1) return;
-#endif
     float ecol[CS];
 #pragma unroll
     for (int c = 0; c < CS; ++c) ecol[c] = a.empty_color[c];
@@ -879,9 +778,6 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                 bool nz = false;
 #pragma unroll
                 for (int c = 0; c < CS; ++c) { dl[c] = go[c] - loss_grad(rf - cme[c] * cs, cs, gs); nz |= dl[c] != 0.0f; }
-#ifdef FPCDR_FABL_B
-                { float sink = 0.f; for (int c = 0; c < CS; ++c) sink += dl[c]; asm volatile("" :: "v"(sink)); nz = false; }
-#endif
                 if (nz && MIP) {
                     // the mip-mapped lookup (fit.py:153-155): footprint from the rasteriser's derivatives (recomputed), texel gradients of
                     // every level straight to memory (a few dozen pixels per bin), the footprint's gradient back through the derivatives
@@ -1103,7 +999,40 @@ __global__ void __launch_bounds__(FNT) k_fix_queue(const int32_t *__restrict__ l
     }
 }
 
+// per-image silhouette classification (same arithmetic as k_sil in antialias.hip).  The kernel is a chain of gathers with two dozen
+// instructions behind them -- latency, not issue, is its cost -- so a thread classifies its triangle in SIL_NI images: the six
+// indices (own vertices, vertices across the three edges) are loaded once, and the 6 x SIL_NI position gathers are all in flight
+// before the first is used (the vertex across an edge used to be fetched only after the edge's line had been computed).
+__global__ void __launch_bounds__(256) k_sil2(const float4 *__restrict__ pos, const int32_t *__restrict__ tri,
+                                              const int32_t *__restrict__ adj, int B, int V, int T, float hw, float hh,
+                                              uint8_t *__restrict__ sil, uint4 *__restrict__ zero_dst, unsigned long long zero_n16) {
+    // grid (triangle chunks, groups of SIL_NI images): a flat thread index would cost every thread a 64-bit division
+    const int b0 = blockIdx.y * SIL_NI, t = blockIdx.x * blockDim.x + threadIdx.x;
+    // fpcdr_render_loss_fwd: the antialias flag planes of the call (149 MB at cfg3) are zeroed HERE, by stores that cost this
+    // latency-bound kernel next to nothing, instead of by a 32-50 us fill of the caller's in front of the call
+    if (zero_dst) {
+        const unsigned long long stride = (unsigned long long)gridDim.x * gridDim.y * blockDim.x;
+        for (unsigned long long i = ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < zero_n16; i += stride)
+            zero_dst[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (t >= T) return;
+    sil_classify(pos, tri, adj, B, V, T, hw, hh, sil, b0, t);      // (sil_bits.h: same arithmetic as k_sil in antialias.hip)
+}
+
 }  // namespace
+
+// (also a piece of the two-call form's fpcdr_render_loss_fwd; not part of the C ABI)
+int fpcdr_launch_sil(const float *pos, const int32_t *tri, const int32_t *adj, int B, int V, int T, int H, int W, uint8_t *sil,
+                     void *zero_dst, size_t zero_bytes, hipStream_t st) {
+    if (zero_dst && (((size_t)zero_dst | zero_bytes) & 15)) {      // (not 16-byte shaped: a plain memset)
+        FPCDR_REQUIRE(hipMemsetAsync(zero_dst, 0, zero_bytes, st) == hipSuccess, "memset of the flag planes failed");
+        zero_dst = nullptr;
+    }
+    hipLaunchKernelGGL(k_sil2, dim3(fpcdr_cdiv(T, 256), fpcdr_cdiv(B, SIL_NI)), dim3(256), 0, st, (const float4 *)pos, tri, adj, B, V, T,
+                       0.5f * (float)W, 0.5f * (float)H, sil, (uint4 *)zero_dst, (unsigned long long)(zero_bytes / 16));
+    FPCDR_CHECK_LAUNCH();
+    return FPCDR_OK;
+}
 
 #ifdef FPCDR_OPROF
 extern "C" int fpcdr_debug_oprof(unsigned long long *out16, int reset) {

@@ -34,6 +34,10 @@ namespace {
 #include "aa_pairs.h"
 #include "sil_bits.h"
 
+#ifndef FPCDR_TWOCALL
+#define FPCDR_TWOCALL 0
+#endif
+
 constexpr int SUBPIX = 256;
 constexpr int HALFPIX = 128;
 constexpr double GUARD = 16777216.0;  // 2^24
@@ -780,9 +784,6 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         const Taps tp0 = make_taps(0.0f, 0.0f, sh.Ht, sh.Wt, sh.C, sh.boundary);
         for (int c = 0; c < 4; ++c) sh.empty_out[c] = c < sh.C ? bilerp(sh.tex, tp0, c, sh.C) : 0.0f;
     }
-#ifdef FPCDR_ABL_EXIT0
-    if (sparse) { if (tid == 0) sh.occ[bin_lin] = 0; return; }
-#endif
     if (sparse && !bin_live) {   // nothing of this image near the bin: no pixel is written, the consumers skip it too
         if (tid == 0) sh.occ[bin_lin] = 0;
         return;
@@ -809,12 +810,6 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         int gl_base = 0;
         auto process_batch = [&](const int n) {
             // consumes entries [pending - n, pending) of s_list; a barrier has been passed since they were appended
-#ifdef FPCDR_ABL_NOPROC
-            if (tid == 0) s_pending = pending - n;
-            pending -= n;
-            __syncthreads();
-            return;
-#endif
             // ---- lane path: a thread rasterises one triangle of the batch over its bounding box; a batch of at most 128 (64)
             // triangles -- the usual bin of a face mesh holds ~120 -- is walked by 2 (4) threads per triangle, rows interleaved,
             // so that all four waves share the work ----
@@ -849,11 +844,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                     const int rx0 = Px - r.X0;
                     int ry = Py - r.Y0;
                     unsigned long long *zrow = &s_z[(y0 + part - bin_y0) * BIN + (x0 - bin_x0)];
-#ifdef FPCDR_ABL_NOLANE
-                    const int bh = 0;
-#else
                     const int bh = y1 - y0 + 1;
-#endif
                     // rows outside, columns inside: the inner trip is three additions and one test (the flattened loop that
                     // this replaces spent two thirds of its instructions on wrap-around selects)
                     const int B0s = B0 * SUBPIX * split, B1s = B1 * SUBPIX * split, B2s = B2 * SUBPIX * split;
@@ -1021,9 +1012,6 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         while (pending > 0) process_batch(min(pending, BATCH));
     }
 
-#ifdef FPCDR_ABL_SCANONLY
-    if (sparse) { if (tid == 0) sh.occ[bin_lin] = 0; return; }
-#endif
     if (sparse) {
         if (tid == 0) sh.occ[bin_lin] = total_hits > 0 ? 1 : 0;
         if (total_hits == 0) return;
@@ -1129,12 +1117,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         const int zy = zy0 + 8 * k, py = bin_y0 + zy;
         if (px >= W || py >= H) continue;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef FPCDR_ABL_NOSHADE
-        const int t = -1;
-        if (win[k] >= 0) o.w = (float)(win[k] + 1);
-#else
         const int t = win[k];
-#endif
         if (t >= 0) {
             const I3 ti = ld32(reinterpret_cast<const I3 *>(tri), t);
             const float fx = (2.0f * (float)px + 1.0f) / (float)W - 1.0f;
@@ -1206,13 +1189,6 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                 if (fx0 + j < W) at32(dst_bin, poff + j) = e[j];
         }
     };
-#ifdef FPCDR_ABL_NOLOSSPASS
-    if (LOSS) {
-        const size_t bin_id0 = bin_lin;
-        if (tid < BIN) sh.cmask[bin_id0 * BIN + tid] = 0u;
-        return;
-    }
-#endif
     if (SHADE && !LOSS) {
         if (stage) {     // (uniform)
             __syncthreads();
@@ -1459,6 +1435,7 @@ __global__ void __launch_bounds__(256) k_grad(const float4 *__restrict__ pos, co
     vtable_flush(vt, gp, tid, 256);
 }
 
+#if FPCDR_TWOCALL
 // ---------------------------------------------------------------------------------------------
 // Fused backward of texture('linear') -> interpolate -> rasterize (reference fit.py:158,157,151) for the render
 // path: reads dL/d colour (4C B/px) and rast (16 B/px), writes nothing dense.  A covered pixel with a non-zero
@@ -1547,6 +1524,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const float4 *__restrict__ p
         wave_group_atomic_add<3>(key2, d, g2);
     }
 }
+#endif  // FPCDR_TWOCALL
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -1629,6 +1607,9 @@ extern "C" int fpcdr_rasterize_bwd(const fpcdr_rasterize_bwd_params *p, void *st
     return FPCDR_OK;
 }
 
+// ---- the two-call form of the pixel objective and the fused render pair (include/fpcdr_twocall.h): superseded by fpcdr_objective_fwd in the
+// fit loop, kept as a parity partner and for the dense mode; compiled into libfpcdr_twocall.so only (csrc/Makefile) ----
+#if FPCDR_TWOCALL
 extern "C" int fpcdr_render_fwd(const fpcdr_render_fwd_params *p, void *stream) {
     FPCDR_REQUIRE(p != nullptr, "null params");
     FPCDR_REQUIRE(p->pos && p->tri && p->scratch && p->rast && p->uv && p->uv_tri && p->tex && p->color, "null pointer");
@@ -1786,6 +1767,8 @@ extern "C" int fpcdr_render_loss_fwd(const fpcdr_render_fwd_params *p, const fpc
     FPCDR_CHECK_LAUNCH();
     return fpcdr_launch_aa_fix(l, cmask, (const unsigned long long *)(cm + q.cm_edges), fix_list, n_fix, (int)nbins, st);
 }
+
+#endif  // FPCDR_TWOCALL
 
 // First half of fpcdr_objective_fwd (objective.hip; not part of the C ABI): set-up, the list of live bins, the rasteriser in its IDS form
 // (id planes only) and the ordered list of OCCUPIED bins + window masks for the shading kernels.  The caller has run k_sil2.

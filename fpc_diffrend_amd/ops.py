@@ -235,7 +235,7 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
 class _render_textured_func(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pos, tri, uv, uv_tri, tex, H, W, boundary):
-        lib = _lib.load()
+        lib = _lib.load_twocall()      # (include/fpcdr_twocall.h: fpcdr_render_fwd / _bwd live in the second library)
         B, V, _ = pos.shape
         T = tri.shape[0]
         Ht, Wt, C = tex.shape
@@ -380,7 +380,7 @@ class _pixel_objective_func(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, sparse, ref_bg_sumsq, use_hints,
                 queued_backward, mip_levels=None, grad_enabled=True):
-        lib = _lib.load()
+        lib = _lib.load_twocall()      # (the two-call form: include/fpcdr_twocall.h, libfpcdr_twocall.so)
         B, V, _ = pos.shape
         T = tri.shape[0]
         Ht, Wt, C = tex.shape

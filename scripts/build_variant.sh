@@ -7,7 +7,7 @@ B=_build_$NAME
 mkdir -p $B
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function -Wno-pass-failed $*"
 pids=()
-for s in abi rasterize interpolate texture antialias blend loss fused objective clip adam; do
+for s in abi rasterize interpolate texture antialias blend loss objective clip adam; do
   /opt/rocm/bin/hipcc $FLAGS -c $s.hip -o $B/$s.o &
   pids+=($!)
 done

@@ -93,12 +93,20 @@ def test_two_rank_fitter_equals_single_process(tmp_path, graph, early):
     one = torch.load(tmp_path / "w1_r0.pt")
     assert a["calls"] == steps and b["calls"] == steps      # exactly one bucket all-reduce per step
     assert a["early_fired"] == ([steps] if early else [])   # ... plus the texture's own, once per step
-    for p, q in zip(a["params"], b["params"]):
-        assert torch.equal(p, q), "replicas diverged"
+    for k, (p, q) in enumerate(zip(a["params"], b["params"])):
+        assert torch.equal(p, q), (f"replicas diverged: parameter {k} {tuple(p.shape)}: max |a - b| = {float((p - q).abs().max())}, "
+                                   f"non-finite a / b: {int((~torch.isfinite(p)).sum())} / {int((~torch.isfinite(q)).sum())}, losses {a['losses']} {b['losses']}")
     assert torch.equal(a["result"], b["result"])
     assert np.allclose(a["losses"], one["losses"], rtol=1e-5), (a["losses"], one["losses"])
-    for p, q in zip(a["params"], one["params"]):
-        assert float((p - q).abs().max()) <= 1e-5 * max(1.0, float(q.abs().max())), float((p - q).abs().max())
+    # two ranks against one process: the same gradients up to the ORDER of the float additions (atomics inside a rank, the all-reduce
+    # across ranks).  Adam turns a gradient component that cancels to ~0 into a step of about the learning rate whose sign is that
+    # order's (one texel in 260 k moved by 1.16e-3 = its learning rate in one run out of three, everything else agreed to 1e-6): all
+    # but a vanishing share of every tensor's entries must agree to 1e-5, and no entry may be further off than a few steps
+    for k, (p, q) in enumerate(zip(a["params"], one["params"])):
+        d = (p - q).abs()
+        tol = 1e-5 * max(1.0, float(q.abs().max()))
+        share = float((d > tol).float().mean())
+        assert share <= 2e-4 and float(d.max()) <= 5e-3 * steps, (k, tuple(p.shape), share, float(d.max()))
     # every frame's final mesh is present after the gather (rank 1's rows are not left at zero) and equals the single run
     assert float(a["result"].abs().sum(dim=1).min()) > 0
     assert float((a["result"] - one["result"]).abs().max()) < 1e-4

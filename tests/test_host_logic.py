@@ -120,13 +120,26 @@ def test_abi_library_exports_every_declared_symbol():
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()
     header = open(os.path.join(ROOT, "include", "fpcdr.h")).read()
-    declared = set(re.findall(r"\b(fpcdr_[a-z0-9_]+)\s*\(", header))
-    declared = {d for d in declared if not d.endswith("_params")}
+    header_tc = open(os.path.join(ROOT, "include", "fpcdr_twocall.h")).read()
+
+    def declared_in(text):
+        # (declarations: a return type at the start of a line; comments mention other entry points in call form)
+        return set(re.findall(r"^(?:int|size_t|const char \*)\s*(fpcdr_[a-z0-9_]+)\s*\(", text, flags=re.M))
+
+    declared, declared_tc = declared_in(header), declared_in(header_tc)
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert declared_tc == set(_lib.SYMBOLS_TWOCALL), declared_tc ^ set(_lib.SYMBOLS_TWOCALL)
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"{name} not exported"
+    # the superseded two-call form is NOT part of the product library: it lives in a second, complete library
+    for name in declared_tc:
+        assert not hasattr(lib, name), f"{name} (include/fpcdr_twocall.h) must not be exported by libfpcdr.so"
+    lib_tc = ctypes.CDLL(_lib.TWOCALL_LIB_PATH)
+    for name in declared | declared_tc:
+        assert hasattr(lib_tc, name), f"{name} not exported by libfpcdr_twocall.so"
     assert _lib.load().fpcdr_abi_version() == _lib.ABI_VERSION
+    header = header + header_tc
     # every parameter struct of the header has the size (and so the trailing-field layout) of its ctypes mirror: ask the C
     # compiler
     import subprocess
@@ -144,7 +157,7 @@ def test_abi_library_exports_every_declared_symbol():
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "sz.c")
         with open(src, "w") as f:
-            f.write('#include <stdio.h>\n#include <stddef.h>\n#include "fpcdr.h"\nint main(void) {\n')
+            f.write('#include <stdio.h>\n#include <stddef.h>\n#include "fpcdr.h"\n#include "fpcdr_twocall.h"\nint main(void) {\n')
             for name in sorted(pairs):
                 f.write(f'    printf("{name} %zu\\n", sizeof({name}));\n')
                 for field, _ in pairs[name]._fields_:      # every field of the binding exists in the header, at the same offset
