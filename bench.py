@@ -57,7 +57,7 @@ def algorithmic_bytes_per_px(C, with_db):
     }
 
 
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r04_counters_cfg3.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r05_counters_cfg3.json")
 
 
 def kernel_source_sha16():
@@ -78,7 +78,7 @@ ENTRY_KERNELS = {
     "fpcdr_render_loss_fwd": ["k_sil2", "k_init_queue", "k_setup", "k_list_count<", "k_list_scan", "k_list_write<",
                               "k_bins_list<false, true, true", "k_bins_queue<false, true, true", "k_aa_fix_list<", "k_aa_fix_queue<"],
     "fpcdr_render_aa_bwd": ["k_render_aa_bwd<", "k_render_aa_bwd_list<", "k_render_aa_bwd_queue<"],
-    "fpcdr_objective_fwd": ["k_init_objective", "k_setup<true, true", "k_list_count<", "k_list_write_sum<",
+    "fpcdr_objective_fwd": ["k_init_objective", "k_setup<true, true", "k_setup_clip<true", "k_list_count<", "k_list_write_sum<",
                             "k_bins_list<false, false, false", "k_bins_queue<false, false, false", "k_shade_list<", "k_shade_queue<",
                             "k_fix_list<", "k_fix_queue<", "k_objective_finish<"],
     "fpcdr_antialias_bwd": ["k_copy_f4_chunk", "k_aa_bwd_fix<"],
