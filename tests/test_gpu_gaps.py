@@ -447,7 +447,7 @@ def test_rccl_backend_reduces_the_gradient_bucket(tmp_path):
 # near-plane clipping (rule R1): triangles with vertices behind the camera
 # ---------------------------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("res,T,seed", [((96, 128), 60, 3), ((160, 200), 400, 4), ((75, 101), 900, 5)])
+@pytest.mark.parametrize("res,T,seed", [((96, 128), 60, 3), ((160, 200), 400, 4), ((75, 101), 900, 5), ((64, 96), 3000, 6)])
 def test_near_plane_clipping_matches_oracle(dr, oracle_ops, res, T, seed):
     """Triangles crossing the near plane are clipped against it and their one or two pieces drawn under the triangle's own index
     (the second piece through the overflow slots of the raster scratch): ids bit-exact, rast / rast_db floats from the ORIGINAL
@@ -483,9 +483,27 @@ def test_near_plane_clipping_matches_oracle(dr, oracle_ops, res, T, seed):
     tex = torch.rand(16, 16, 1, generator=g).cuda()
     _, rast2 = dr.render_textured(ctx, pos.cuda(), tri.cuda(), uv, tri.cuda(), tex, res)
     assert torch.equal(rast2[..., 3].int().cpu(), ids_ref)
+    # ... and so does the one-pass objective, whose set-up kernel files the clipped triangles on per-image lists for k_setup_clip<true>
+    # (first pieces appended to the per-bin triangle lists, chunk boxes widened by compare-and-swap; with thousands of triangles on a
+    # few bins the lists overflow and the bins fall back to scanning those chunk boxes): value and gradients of the operator chain
+    from fpc_diffrend_amd import fit
     ref_img = torch.randint(0, 141, (2,) + tuple(res), generator=g, dtype=torch.uint8).cuda()
-    loss = dr.pixel_objective(ctx, pos.cuda().requires_grad_(True), tri.cuda(), uv, tri.cuda(), tex.requires_grad_(True), ref_img, res)
-    assert torch.isfinite(loss)
+    out = []
+    for one_pass in (None, True, False):
+        p, t = pos.cuda().requires_grad_(True), tex.clone().requires_grad_(True)
+        if one_pass is None:
+            r3, _ = dr.rasterize(ctx, p, tri.cuda(), res)
+            tc, _ = dr.interpolate(uv[None], r3, tri.cuda())
+            c3 = dr.antialias(dr.texture(t[None], tc, filter_mode='linear'), r3, p, tri.cuda())
+            img = torch.where(r3[..., 3:] > 0, c3, torch.tensor(fit.BACKGROUND, device='cuda'))
+            loss = torch.mean((ref_img[..., None].float() - img * 255) ** 2)
+        else:
+            loss = dr.pixel_objective(ctx, p, tri.cuda(), uv, tri.cuda(), t, ref_img, res, one_pass=one_pass)
+        loss.backward()
+        out.append((float(loss), p.grad.double().cpu(), t.grad.double().cpu()))
+    for l, gp, gt in out[1:]:
+        assert abs(l - out[0][0]) <= 1e-5 * abs(out[0][0]), (l, out[0][0])
+        assert rel_l2(gp, out[0][1]) < TOL and rel_l2(gt, out[0][2]) < TOL, (rel_l2(gp, out[0][1]), rel_l2(gt, out[0][2]))
 
 
 def test_stale_mip_stack_is_refused_and_hints_refresh_without_backward(dr):
