@@ -72,7 +72,8 @@ class Objective(ctypes.Structure):
                 ("cap_occ", _i), ("cap_def", _i), ("sil_ready", _i), ("flags", _p), ("mip", _i), ("n_levels", _i),
                 ("tex_mip", _p * MAX_MIP), ("grad_tex_mip", _p * MAX_MIP), ("binlist", _p), ("sil_event", _p),
                 ("zero_outputs", _i), ("counts_seq", _i), ("counts_out", _p), ("bg_sumsq", _p), ("bg_coeff", ctypes.c_double),
-                ("n_total", ctypes.c_double), ("value_out", _p), ("zero_extra", _p), ("zero_extra_bytes", ctypes.c_int64)]
+                ("n_total", ctypes.c_double), ("value_out", _p), ("zero_extra", _p), ("zero_extra_bytes", ctypes.c_int64),
+                ("rec_slots", _i), ("count_only", _i), ("slot_map", _p)]
 
 
 class InterpolateFwd(ctypes.Structure):

@@ -53,7 +53,13 @@ struct ObjArgs {
     int B, V, T, H, W, Ht, Wt, boundary;
     float bg, color_scale, grad_scale;
     unsigned long long *flags;      // optional (tests / diagnostics): the antialias flag planes of fpcdr_antialias_fwd, zero-filled by the caller
+    // COMPACT records (fpcdr_objective_params.rec_slots > 0): rec / color / g_aa hold pool_cap slots of 1 024 pixels instead of the whole
+    // batch; a bin that shows a silhouette triangle (the only bins that can hold a deferred pixel) takes the next slot (pool_count, header
+    // [1] of occ: it keeps counting beyond the capacity, so that the caller learns the need), slot_of[bin] = its slot or -1
+    int32_t *slot_of; int32_t *pool_count; int32_t *overflow; int pool_cap;
 };
+// element index of pixel (xx, yy) of image-bin `lin` (+ the offset to a neighbouring bin) in the record arrays
+__device__ __forceinline__ size_t rec_slot_index(int slot, int xx, int yy) { return (size_t)(slot < 0 ? 0 : slot) * (OB * OB) + (yy & 31) * OB + (xx & 31); }
 
 // MIP instantiations (the reference's enable_mip branch, fit.py:153-155): level l of the chain = tex[l - 1] / grad[l - 1]; level 0 is
 // ObjArgs.tex / grad_tex
@@ -187,6 +193,24 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     // four bins in five of a face show none at all -- the interior of the mesh -- and skip the four neighbour tests of their pixels
     const bool bin_sil = __builtin_amdgcn_readfirstlane(__syncthreads_or(sil_seen != 0u ? 1 : 0)) != 0;
     OPROF_T(2);
+    // compact records: this bin's slot (one global fetch-add and a barrier in the one bin in five that shows a silhouette triangle)
+    const bool compact = a.pool_cap > 0;      // (uniform)
+    __shared__ int s_slot;
+    int slot = -1;
+    if (compact) {
+        if (bin_sil) {
+            if (tid == 0) {
+                int sl = atomicAdd(a.pool_count, 1);
+                if (sl >= a.pool_cap) { sl = -1; *a.overflow = 1; }      // (no room: the bin's pixels go un-deferred and the call says so)
+                s_slot = sl;
+                a.slot_of[bin_lin] = sl;
+            }
+            __syncthreads();
+            slot = __builtin_amdgcn_readfirstlane(s_slot);
+        } else if (tid == 0) {
+            a.slot_of[bin_lin] = -1;
+        }
+    }
 
     const size_t img = (size_t)b * H * W;
     const size_t bin_off = img + (size_t)by0 * W + bx0;
@@ -253,6 +277,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 const unsigned int nU = s_id[(zy + 2) * OS + col + 1], nD = s_id[zy * OS + col + 1];
                 deferred = (x + 1 < W && pair_maybe(me, nR)) || (y + 1 < H && pair_maybe(me, nU)) || (x > 0 && pair_maybe(me, nL)) ||
                            (y > 0 && pair_maybe(me, nD));
+                if (compact && slot < 0) deferred = false;
             }
             const int t = id - 1;
             // (measured and dropped in r4: the four pixels' vertex indices fetched up front and a pixel's vertices while the one before it is
@@ -317,9 +342,10 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 any_def = true;
                 atomicOr(&s_cmask[zy], 1u << col);
                 if (!MIP) zw = shade_zw(v0, v1, v2, K.a0, K.a1, K.p0x * K.p1y - K.p0y * K.p1x);
-                a.rec[off] = make_float4(u, v, zw, (float)id);
+                const size_t ro = compact ? rec_slot_index(slot, col, zy) : off;
+                a.rec[ro] = make_float4(u, v, zw, (float)id);
 #pragma unroll
-                for (int c = 0; c < CS; ++c) { a.color[off * CS + c] = colv[c]; a.g_aa[off * CS + c] = gq[c]; }
+                for (int c = 0; c < CS; ++c) { a.color[ro * CS + c] = colv[c]; a.g_aa[ro * CS + c] = gq[c]; }
             }
             float gtu_m = 0.f, gtv_m = 0.f;
             float4 gda = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -647,6 +673,15 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
             for (int c = 0; c < CS; ++c) atomicAdd(a.grad_tex + off + c, v[c] * wgt);
         }
     };
+    // where pixel (xx, yy) of this bin or of one of its eight neighbours keeps its record / colour / gradient
+    const bool compact = a.pool_cap > 0;      // (uniform)
+    const int my_slot = compact ? __builtin_amdgcn_readfirstlane(a.slot_of[bin_lin]) : 0;
+    auto rix = [&](int xx, int yy) -> size_t {
+        if (!compact) return img + (size_t)yy * W + xx;
+        const int dbx = (xx >> 5) - bxi, dby = (yy >> 5) - byi;
+        const int sl = (dbx | dby) ? a.slot_of[(size_t)((long long)bin_lin + dby * OX + dbx)] : my_slot;
+        return rec_slot_index(sl, xx, yy);
+    };
     auto id_at = [&](int xx, int yy) -> unsigned int {      // entry of an in-image pixel of this bin or of one of its eight neighbours
         const int dbx = (xx >> 5) - bxi, dby = (yy >> 5) - byi;
         if (!((wmask >> ((dby + 1) * 4 + dbx + 1)) & 1u)) return 0u;      // a bin that was not rasterised holds empty pixels
@@ -674,7 +709,8 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
         int tkey = -1;
         int vk[3] = {0, 0, 0};
         float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const size_t off = img + (size_t)y * W + x;
+        const size_t off = img + (size_t)y * W + x;      // (the pixel in the image: reference, flag planes)
+        const size_t ro = act ? rix(x, y) : 0;           // (... and in the record arrays)
         unsigned int me = 0u;
         float4 rme = make_float4(0.f, 0.f, 0.f, 0.f);
         float cme[CS], acc[CS], go[CS];      // acc / go: THIS lane's pair's share (summed over the quad below)
@@ -683,10 +719,10 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
         bool hit = false;
         if (act) {
             me = a.idp[bin_lin * (OB * OB) + pix];
-            rme = a.rec[off];
+            rme = a.rec[ro];
             const float zX = rme.z;
 #pragma unroll
-            for (int c = 0; c < CS; ++c) cme[c] = a.color[off * CS + c];
+            for (int c = 0; c < CS; ++c) cme[c] = a.color[ro * CS + c];
             // pair (x0, y0) - (x0 + e_d): entries / depths in pair order; (ox, oy, eo) = the partner of X; first = X is the pair's first pixel
             auto visit = [&](int x0, int y0, int d, unsigned int e0, float z0, unsigned int e1, float z1, int ox, int oy, unsigned int eo,
                              bool first) {
@@ -698,7 +734,7 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                         const float amt = far ? t - 0.5f : 0.5f - t;
                         const bool rX = rx == x && ry == y;
                         const bool o_cov = (eo & 0xffffffu) != 0u;
-                        const float *co = a.color + (img + (size_t)oy * W + ox) * CS;
+                        const float *co = o_cov ? a.color + rix(ox, oy) * CS : nullptr;      // (read only for a covered partner)
                         if (PASS == 0) {
                             if (!rX) return;
                             hit = true;
@@ -709,8 +745,9 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                         }
                         if (!rX && !o_cov) return;      // the blended pixel is an empty one: no gradient arrives
                         float gr[CS];
+                        const size_t rr = rX ? ro : rix(rx, ry);
 #pragma unroll
-                        for (int c = 0; c < CS; ++c) gr[c] = a.g_aa[(img + (size_t)ry * W + rx) * CS + c];
+                        for (int c = 0; c < CS; ++c) gr[c] = a.g_aa[rr * CS + c];
                         // (branch-free: with `if (rX) go -= .. else go += ..` the compiler addressed go / esum through a selected pointer
                         //  and kept both in scratch memory)
                         const float sa = rX ? -amt : amt, ea = (rX && !o_cov) ? amt : 0.0f;
@@ -745,7 +782,7 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                 if (nx >= 0 && nx < W && ny >= 0 && ny < H) {
                     const unsigned int e = id_at(nx, ny);
                     if (pair_maybe(me, e)) {
-                        const float ze = (e & 0xffffffu) ? a.rec[img + (size_t)ny * W + nx].z : 0.0f;
+                        const float ze = (e & 0xffffffu) ? a.rec[rix(nx, ny)].z : 0.0f;
                         const bool first = dir < 2;      // X is the first pixel of its pairs towards +x / +y
                         visit(first ? x : nx, first ? y : ny, dir & 1, first ? me : e, first ? zX : ze, first ? e : me, first ? ze : zX, nx, ny, e, first);
                     }
@@ -758,7 +795,7 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
         for (int c = 0; c < CS; ++c) { acc[c] = quad_sum(acc[c]); go[c] = quad_sum(go[c]); }
         if (lead) {
 #pragma unroll
-            for (int c = 0; c < CS; ++c) { acc[c] += cme[c]; if (PASS == 1) go[c] += a.g_aa[off * CS + c]; }
+            for (int c = 0; c < CS; ++c) { acc[c] += cme[c]; if (PASS == 1) go[c] += a.g_aa[ro * CS + c]; }
             const float rf = (float)a.ref[off];
             if (PASS == 0) {
                 if (hit_any) {      // the antialiased colour replaces the plain one in this pixel's loss term and gradient
@@ -769,7 +806,7 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                         const float dn = rf - acc[c] * cs, dd = rf - cme[c] * cs;
                         lsum += dn * dn - d0 * d0;
                         lsum -= dd * dd - d0 * d0;
-                        a.g_aa[off * CS + c] = loss_grad(dn, cs, gs);
+                        a.g_aa[ro * CS + c] = loss_grad(dn, cs, gs);
                     }
                 }
             } else {
@@ -911,6 +948,33 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
     }
 }
 
+// Counting call (fpcdr_objective_params.count_only): how many occupied bins show a silhouette triangle in their plane or its apron -- the
+// bins a real call gives a record slot to.  One workgroup per occupied bin, the load phase of k_shade and nothing else.
+__global__ void __launch_bounds__(ONT) k_count_sil(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int OX, int OY,
+                                                   fpcdr_bin_decode dc, ObjArgs a) {
+    const int n = *count;
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {      // (uniform trip count)
+        const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+        int b, byi, bxi;
+        fpcdr_decode_bin(lin, dc, b, byi, bxi);
+        const size_t bin_lin = ((size_t)b * OY + byi) * OX + bxi;
+        const unsigned int wmask = (unsigned int)__builtin_amdgcn_readfirstlane((int)a.occ[bin_lin]);
+        const int tid = threadIdx.x;
+        const uint4 v = reinterpret_cast<const uint4 *>(a.idp + bin_lin * (OB * OB))[tid];
+        unsigned int seen = (v.x | v.y | v.z | v.w) >> 24;
+        if (tid < 4 * OB) {
+            const int side = tid >> 5, i = tid & 31;      // 0 left, 1 right, 2 below, 3 above (as in shade_body)
+            const int dx = side == 0 ? -1 : (side == 1 ? 1 : 0), dy = side == 2 ? -1 : (side == 3 ? 1 : 0);
+            if ((wmask >> ((dy + 1) * 4 + dx + 1)) & 1u) {
+                const size_t nb = (size_t)((long long)bin_lin + dy * OX + dx);
+                const int sx = side == 0 ? OB - 1 : (side == 1 ? 0 : i), sy = side == 2 ? OB - 1 : (side == 3 ? 0 : i);
+                seen |= a.idp[nb * (OB * OB) + sy * OB + sx] >> 24;
+            }
+        }
+        if (__syncthreads_or(seen != 0u ? 1 : 0) && tid == 0) atomicAdd(a.pool_count, 1);
+    }
+}
+
 // The last kernel of the call, one wave:
 //  * the empty pixels' share of the texture gradient: sum of the slots, times the four bilinear weights of uv = (0,0);
 //  * the objective's value from the loss slots (the arithmetic of k_objective_value, loss.hip);
@@ -948,6 +1012,7 @@ __global__ void __launch_bounds__(64) k_objective_finish(ObjArgs a, FinishArgs f
     if (f.counts_out && threadIdx.x == 0) {
         volatile int32_t *o = f.counts_out;
         for (int i = 0; i < 4; ++i) o[i] = a.def_count[i];
+        o[5] = a.def_count[4];      // (compact records: 1 = the pool was too small -- the call's results are invalid)
         __threadfence_system();
         o[4] = f.counts_seq;
     }
@@ -1052,7 +1117,10 @@ extern "C" int fpcdr_silhouette_bits(const float *pos, const int32_t *tri, const
 extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream) {
     FPCDR_REQUIRE(p != nullptr, "null params");
     FPCDR_REQUIRE(p->pos && p->tri && p->adj && p->scratch && p->uv && p->uv_tri && p->tex && p->ref, "null pointer");
-    FPCDR_REQUIRE(p->sil && p->idp && p->occ && p->cmask && p->rec && p->color && p->grad_aa && p->empty_color && p->loss_sum, "null pointer");
+    FPCDR_REQUIRE(p->sil && p->idp && p->occ && p->cmask && p->empty_color && p->loss_sum, "null pointer");
+    FPCDR_REQUIRE(p->count_only || (p->rec && p->color && p->grad_aa), "null record buffers");
+    FPCDR_REQUIRE(p->rec_slots >= 0 && (p->rec_slots == 0 || p->slot_map), "compact records (rec_slots > 0) need slot_map");
+    FPCDR_REQUIRE((int64_t)p->rec_slots * (OB * OB) * 4 < ((int64_t)1 << 31), "rec_slots too large");
     FPCDR_REQUIRE(p->B > 0 && p->V > 0 && p->T > 0 && p->H > 0 && p->W > 0 && p->Vt > 0 && p->Ht > 0 && p->Wt > 0 && p->C > 0,
                   "sizes must be positive");
     FPCDR_REQUIRE(p->C == 1 || p->C == 3 || p->C == 4, "fused objective supports C = 1, 3, 4");
@@ -1100,7 +1168,8 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
                  p->idp, p->occ, (uint8_t *)p->occ + q.occ_binflag, p->cmask, esum_slots, (int32_t *)((char *)p->occ + q.occ_bwd_list),
                  (int32_t *)((char *)p->occ + q.occ_hdr), (uint32_t *)((char *)p->cmask + q.cm_edges), (float4 *)p->rec, p->color, p->grad_aa, p->empty_color,
                  p->loss_sum, p->grad_pos, p->grad_tex, p->B, p->V, p->T, p->H, p->W, p->Ht, p->Wt, p->boundary_mode,
-                 p->bg, p->color_scale, p->grad_scale, (unsigned long long *)p->flags};
+                 p->bg, p->color_scale, p->grad_scale, (unsigned long long *)p->flags,
+                 p->slot_map, (int32_t *)((char *)p->occ + q.occ_hdr) + 1, (int32_t *)((char *)p->occ + q.occ_hdr) + 4, p->rec_slots};
     const fpcdr_bin_decode dc = fpcdr_make_bin_decode(OX, OY);
     const int cap = (p->cap_occ > 0 && p->cap_occ < nbins) ? p->cap_occ : (int)nbins;
     const dim3 grid(fpcdr_list_grid(cap));
@@ -1119,6 +1188,16 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         hipLaunchKernelGGL((k_fix_list<CS, PASS>), grid_d, dim3(FNT), 0, st, a.def_list, a.def_count, cap_d, OX, OY, dc, a);       \
         if (sweep_d) hipLaunchKernelGGL((k_fix_queue<CS, PASS>), dim3(FPCDR_SWEEP_WGS), dim3(FNT), 0, st, a.def_list, a.def_count, cap_d, OX, OY, dc, a); \
     } while (0)
+    if (p->count_only) {
+        // the lists, the id planes and the number of bins that would take a record slot (header [1]), reported through counts_out: what a
+        // caller without launch hints needs to size the compact record arrays of the real call (once per batch shape)
+        FPCDR_REQUIRE(p->counts_out != nullptr, "count_only reports through counts_out");
+        hipLaunchKernelGGL(k_count_sil, dim3(2048), dim3(ONT), 0, st, occ_list, n_occ, OX, OY, dc, a);
+        const FinishArgs fin0 = {p->counts_out, p->counts_seq, nullptr, 0.0, 1.0, nullptr, 0};
+        hipLaunchKernelGGL(k_objective_finish<1>, dim3(1), dim3(64), 0, st, a, fin0);
+        FPCDR_CHECK_LAUNCH();
+        return FPCDR_OK;
+    }
     const bool grads = p->grad_pos || p->grad_tex;
     const FinishArgs fin = {p->counts_out, p->counts_seq, p->bg_sumsq, p->bg_coeff, p->n_total, p->value_out, p->grad_tex ? 1 : 0};
     FPCDR_REQUIRE(!p->value_out || p->n_total > 0.0, "value_out needs n_total > 0");

@@ -331,6 +331,9 @@ class _MappedHints:
         self.seen = 0
         self.caps = (0, 0, 0)       # live bins, occupied bins, bins with a deferred pixel
         self.frozen = False         # tests: keep `caps` as set
+        self.sil_bins = -1          # bins that took a record slot in the last call seen (compact records; -1: none seen yet)
+        self.slots = 0              # record slots the next call gets (tests may pin it with `frozen`)
+        self.overflowed = None      # sequence number of a call that ran out of record slots
 
     def poll(self):
         if self.frozen:
@@ -338,11 +341,15 @@ class _MappedHints:
         # the device writes [0:4], fences, then writes [4]: the sequence number is read BEFORE and AFTER the counters and they are adopted
         # only if both reads agree (and are new) -- a later call's counters landing in between cannot be mixed with this call's
         before = int(self.host[4])
-        n_def, _, n_bins, n_occ = (int(v) for v in self.host[:4].tolist())
+        n_def, n_sil, n_bins, n_occ, _, overflow = (int(v) for v in self.host[:6].tolist())
         after = int(self.host[4])
         if before == after and after != self.seen:
             self.seen = after
             self.caps = tuple(n + max(256, n // 8) if n > 0 else 0 for n in (n_bins, n_occ, n_def))
+            self.sil_bins = n_sil
+            self.slots = n_sil + max(RECORD_SLOT_MARGIN, n_sil // 2)
+            if overflow:
+                self.overflowed = after
         return self.caps
 
     def next_seq(self):
@@ -351,6 +358,11 @@ class _MappedHints:
 
 
 _list_hints = {}
+# Compact records (fpcdr_objective_params.rec_slots): a call gets 1.5 x the slots the last call on the batch shape used, at least this
+# many more.  The slot demand is the number of occupied bins that show a silhouette triangle: it moves by a few per cent from one minibatch
+# of a take to the next.  A call that runs out regardless raises at the next call on the shape (its results were invalid).
+RECORD_SLOT_MARGIN = 1024
+COMPACT_RECORDS = True
 SMALL_BATCH_BINS = 16384      # (eight full-HD images) batches up to this many 32 x 32 bins run their list kernels unhinted: see _pixel_objective_onepass
 
 
@@ -513,7 +525,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, ref_bg_sumsq, use_hints, want_grad, unit_upstream,
-                flags_out=None, mip_levels=None, zero_extra=None, overlap_sil=None, bin_lists=True, idp_out=None):
+                flags_out=None, mip_levels=None, zero_extra=None, overlap_sil=None, bin_lists=True, idp_out=None, record_slots=None):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -530,11 +542,6 @@ class _pixel_objective_onepass(torch.autograd.Function):
         idp = idp_out if idp_out is not None else u8(lib.fpcdr_idplane_bytes(B, H, W))
         binlist = u8(lib.fpcdr_binlist_bytes(B, H, W)) if bin_lists else None      # per-bin triangle lists (set-up kernel -> rasteriser)
         occ, cmask = u8(lib.fpcdr_occ_bytes(B, H, W)), u8(lib.fpcdr_cmask_bytes(B, H, W))
-        # records of the DEFERRED pixels (a pixel pair at a silhouette): dense addressing, written and read for a few per cent of the
-        # covered pixels only -- nothing else of the image ever exists in HBM
-        rec = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
-        color = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
-        g_aa = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
         ecol = torch.empty(4, dtype=torch.float32, device=dev)
         # (zero_outputs: the call's first kernel zero-fills its accumulators)
         acc = torch.empty(_lib.LOSS_SLOTS, dtype=torch.float64, device=dev)
@@ -544,7 +551,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
         p = _lib.Objective(pos=_ptr(pos), tri=_ptr(tri), adj=_ptr(adj), B=B, V=V, T=T, H=H, W=W, scratch=_ptr(scratch), uv=_ptr(uv),
                            uv_tri=_ptr(uv_tri), Vt=uv.shape[0], tri_uv=_ptr(tri_uv), tex=_ptr(tex), Ht=Ht, Wt=Wt, C=C,
                            boundary_mode=boundary, ref=_ptr(ref), bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
-                           idp=_ptr(idp), occ=_ptr(occ), cmask=_ptr(cmask), rec=_ptr(rec), color=_ptr(color), grad_aa=_ptr(g_aa),
+                           idp=_ptr(idp), occ=_ptr(occ), cmask=_ptr(cmask),
                            empty_color=_ptr(ecol), loss_sum=_ptr(acc), grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex), flags=_ptr(flags_out),
                            binlist=_ptr(binlist), zero_outputs=1)
         # mip_levels = n: the reference's enable_mip branch inside the same kernels (the chain is built here, box filter as texture())
@@ -573,16 +580,49 @@ class _pixel_objective_onepass(torch.autograd.Function):
                 t_.record_stream(side)
         capturing = torch.cuda.is_current_stream_capturing()
         hints = _hints_for(('onepass', dev.index, B, V, T, H, W), _MappedHints) if use_hints else None
+        nbins = B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN)
         if hints is not None:
             p.cap_bins, p.cap_occ, p.cap_def = hints.poll()      # (live bins, occupied bins, bins with a deferred pixel)
             # a batch of few bins -- one image of the reference's run shape has 1 900 -- is launched at its full size whatever the
             # hint says: a sized launch has a strided sweep launched behind it (four per call, 4.6 us each), and the dead workgroups
             # of a full launch cost less than that
-            nbins = B * ((H + _lib.OCC_BIN - 1) // _lib.OCC_BIN) * ((W + _lib.OCC_BIN - 1) // _lib.OCC_BIN)
             if nbins <= SMALL_BATCH_BINS and not hints.frozen:
                 p.cap_bins, p.cap_occ, p.cap_def = 0, 0, 0
             if not capturing:      # (a graph replays fixed launch sizes: nothing to report)
                 p.counts_out, p.counts_seq = hints.host.data_ptr(), hints.next_seq()
+        # records of the DEFERRED pixels (a pixel pair at a silhouette; a few per cent of the covered pixels -- nothing else of the image
+        # ever exists in HBM).  Large batches: COMPACT, a slot of 1 024 records for every bin that shows a silhouette triangle, sized from
+        # the last call on the batch shape (24 B per pixel of the batch otherwise: 14 GB at 288 full-HD images, for 0.2 % of them).  The
+        # first call on a shape asks the rasteriser for the count (one extra rasterisation and a host wait, once per shape).  Small
+        # batches, captured calls and calls without hints address the records by pixel.
+        slots = 0
+        if record_slots is not None:
+            slots = int(record_slots)
+        elif COMPACT_RECORDS and hints is not None and not capturing and nbins > SMALL_BATCH_BINS:
+            if hints.overflowed is not None:
+                seq, hints.overflowed, hints.sil_bins = hints.overflowed, None, -1
+                raise RuntimeError(f"pixel_objective: call {seq} on this batch shape ran out of record slots (the take's silhouette "
+                                   "grew by more than half within one step); its value and gradients were invalid -- repeat the step")
+            if hints.sil_bins < 0 and not hints.frozen:
+                p.count_only = 1
+                _lib.call("fpcdr_objective_fwd", ctypes.byref(p), _stream())
+                p.count_only = 0
+                torch.cuda.current_stream(dev).synchronize()
+                p.cap_bins, p.cap_occ, p.cap_def = hints.poll()
+                p.counts_seq = hints.next_seq()
+                if hints.sil_bins < 0:
+                    raise RuntimeError("pixel_objective: the counting call reported nothing")
+            slots = max(hints.slots, 1)
+        if slots > 0:
+            n_rec = slots * _lib.OCC_BIN * _lib.OCC_BIN
+            slot_map = torch.empty(nbins, dtype=torch.int32, device=dev)
+            p.rec_slots, p.slot_map = slots, _ptr(slot_map)
+        else:
+            n_rec = B * H * W
+        rec = torch.empty(n_rec, 4, dtype=torch.float32, device=dev)
+        color = torch.empty(n_rec, C, dtype=torch.float32, device=dev)
+        g_aa = torch.empty(n_rec, C, dtype=torch.float32, device=dev)
+        p.rec, p.color, p.grad_aa = _ptr(rec), _ptr(color), _ptr(g_aa)
         # the value from the call's last kernel: (loss slots + C * background share) / n_total
         bg_sum = (reference_background_sumsq(ref, bg).sum() if ref_bg_sumsq is None
                   else torch.as_tensor(ref_bg_sumsq, device=dev)).to(torch.float64).contiguous()
@@ -614,7 +654,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
             g = g.to(torch.float32)
             g_pos = g_pos * g if g_pos is not None else None
             g_tex = g_tex * g if g_tex is not None else None
-        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 20
+        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 21
 
 
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
@@ -632,7 +672,7 @@ def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
 def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_total=None, background=45.0 / 255.0,
                     boundary_mode='wrap', sparse=True, ref_bg_sumsq=None, launch_hints=True, queued_backward=False,
                     enable_mip=False, max_mip_level=None, one_pass=True, unit_upstream=False, aa_flags_out=None, zero_extra=None,
-                    id_plane_out=None):
+                    id_plane_out=None, record_slots=None):
     """The whole pixel term of the reference's loss (fit.py:151-161 + the first term of :579) for a minibatch,
     as three kernels:  mean((ref - 255 * where(rast.w > 0, antialias(texture(interpolate(rasterize(pos)))), bg))^2)
     over n_total elements (default: all of this call's).  pos [B,V,4], tex [Ht,Wt,C] (C in 1,3,4), ref_u8 [B,H,W] uint8.
@@ -653,7 +693,9 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     receives the antialias flag planes (which pixel pairs were blended).  zero_extra (one_pass): a contiguous float32 / int32 tensor of the
     caller's that the call's first kernel zero-fills along with its own buffers (a fit step's small gradient accumulators).
     id_plane_out (one_pass; tests / diagnostics): a zero-filled tensor of fpcdr_idplane_bytes(B,H,W) bytes that is used as the call's id
-    planes and so keeps them -- 1024 uint32 per 32 x 32 bin, bin-major, (triangle + 1) | silhouette bits << 24 (include/fpcdr.h)."""
+    planes and so keeps them -- 1024 uint32 per 32 x 32 bin, bin-major, (triangle + 1) | silhouette bits << 24 (include/fpcdr.h).
+    record_slots (one_pass): the records of deferred pixels in that many slots of 1 024 (fpcdr_objective_params.rec_slots) instead of the
+    default -- by pixel for batches of up to SMALL_BATCH_BINS bins, compact and sized from the last call on the shape beyond; 0 = by pixel."""
     assert isinstance(glctx, RasterizeHipContext)
     _check_tensor('pos', pos, torch.float32, 3)
     _check_tensor('tri', tri, torch.int32, 2)
@@ -686,7 +728,9 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
         return _pixel_objective_onepass.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                               ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], ref_bg_sumsq,
                                               bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out, mip_levels, zero_extra,
-                                              None, True, id_plane_out)
+                                              None, True, id_plane_out, record_slots)
+    if record_slots is not None:
+        raise ValueError("record_slots belongs to the one-pass form")
     if id_plane_out is not None:
         raise ValueError("id_plane_out is an output of the one-pass form")
     return _pixel_objective_func.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),

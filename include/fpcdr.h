@@ -151,7 +151,7 @@ typedef struct {
     uint16_t *occ;          /* scratch+out, fpcdr_occ_bytes(B,H,W): window masks; counts at FPCDR_OCC_COUNTS_OFFSET: [0] bins with a deferred
                                pixel, [2] live bins of the rasteriser, [3] occupied bins (cap_def / cap_bins / cap_occ of the next call) */
     uint32_t *cmask;        /* scratch, fpcdr_cmask_bytes(B,H,W), 8-byte aligned */
-    float *rec;             /* scratch [B,H,W,4]: (u, v, z/w, -) of DEFERRED pixels only (dense addressing, sparse writes) */
+    float *rec;             /* scratch [B,H,W,4]: (u, v, z/w, -) of DEFERRED pixels only (dense addressing, sparse writes; or rec_slots, below) */
     float *color;           /* scratch [B,H,W,C]: colour of deferred pixels only */
     float *grad_aa;         /* scratch [B,H,W,C]: d(objective)/d(antialiased colour) of deferred pixels only */
     float *empty_color;     /* out [4]: the colour of an empty pixel (the texture at uv = (0,0)) */
@@ -193,6 +193,17 @@ typedef struct {
                                step's small accumulators (the gradients of the camera matrices, poses and blend weights that its backward
                                kernels add into) instead of one fill launch each */
     int64_t zero_extra_bytes;
+    /* ABI v10: COMPACT records.  rec / color / grad_aa are addressed by pixel of the whole batch above -- 24 B per pixel allocated (14 GB
+     * at 288 x 1080p) for the 0.2 % of the pixels that are deferred.  With rec_slots > 0 they hold rec_slots SLOTS of 1 024 pixels instead
+     * ([rec_slots * 1024, 4] / [.., C] / [.., C]); every occupied bin that shows a triangle with a silhouette edge -- the only bins that can
+     * hold a deferred pixel -- takes the next slot.  The number of such bins is counted by every call (counts_out[1]; it keeps counting
+     * beyond rec_slots), so a caller sizes rec_slots from the previous call on the batch, with a margin; a call that runs out of slots
+     * sets counts_out[5] = 1: ITS RESULTS ARE THEN INVALID (the bins without a slot were shaded without their antialias pairs) and the
+     * caller must repeat it with more slots.  A caller without a previous call asks first: count_only = 1 runs the rasteriser alone and
+     * reports the exact number for this very batch through counts_out (no record buffers, no gradients needed). */
+    int32_t rec_slots;      /* 0: dense addressing */
+    int32_t count_only;
+    int32_t *slot_map;      /* scratch with rec_slots > 0: one int32 per 32 x 32 bin of the batch (B * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W)) */
 } fpcdr_objective_params;
 int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream);
 

@@ -172,3 +172,83 @@ def test_one_pass_edge_cases_clipping_empty_images_and_the_indirect_uv_path(monk
     h.caps, h.frozen = (1, 1, 1), True
     both(enable_mip=True, max_mip_level=2)
     dr.clear_hints()
+
+
+@pytest.mark.parametrize("geom,C,res", [('soup', 1, (97, 131)), ('mesh', 3, (256, 256)), ('few', 4, (64, 320))])
+def test_compact_records_equal_records_by_pixel_and_a_short_pool_says_so(geom, C, res):
+    """fpcdr_objective_params.rec_slots: the deferred pixels' records in slots of 1 024 (one per bin that shows a silhouette triangle)
+    instead of addressed by pixel -- same value, gradients and antialias flags; the call counts the slots it needs (counts_out[1]), a
+    counting call reports the same number without shading, and a pool that is too small raises the overflow flag (counts_out[5])."""
+    import ctypes
+    import fpc_diffrend_amd.ops as dr
+    from fpc_diffrend_amd import _lib
+    pos, tri, uv, uv_idx, tex, ref = _inputs(geom, C, res)
+    ctx = dr.RasterizeGLContext(device='cuda')
+    B = pos.shape[0]
+    nflag = _lib.load().fpcdr_antialias_flags_bytes(B, res[0], res[1]) // 8
+
+    def run(slots):
+        dr.clear_hints()
+        p, t = pos.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+        flags = torch.zeros(nflag, dtype=torch.int64, device='cuda')
+        loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, res, record_slots=slots, aa_flags_out=flags)
+        loss.backward()
+        torch.cuda.synchronize()
+        h = dr._list_hints[next(k for k in dr._list_hints if k[0] == 'onepass')]
+        counts = [int(v) for v in h.host[:6].tolist()]
+        return float(loss), p.grad.double().cpu(), t.grad.double().cpu(), flags.cpu(), counts
+
+    dense = run(0)
+    need = dense[4][1]
+    assert need == 0 and dense[4][5] == 0      # (records by pixel: no slot taken)
+    roomy = run(4096)
+    need = roomy[4][1]
+    assert need > 0 and roomy[4][5] == 0
+    exact = run(need)
+    assert exact[4][1] == need and exact[4][5] == 0
+    for r in (roomy, exact):
+        assert abs(r[0] - dense[0]) <= 1e-6 * abs(dense[0])
+        assert rel_l2(r[1], dense[1]) < 1e-5 and rel_l2(r[2], dense[2]) < 1e-5
+        assert torch.equal(r[3], dense[3])
+    if need > 1:
+        short = run(need - 1)
+        assert short[4][1] == need and short[4][5] == 1
+    dr.clear_hints()
+
+
+def test_large_batch_sizes_its_record_pool_from_a_counting_call_then_from_the_last_call(monkeypatch):
+    """Beyond SMALL_BATCH_BINS bins the binding runs compact by itself: the first call on a shape counts (count_only), later ones take 1.5 x
+    the last call's slots; results equal the records-by-pixel form; an overflow seen at the next call raises."""
+    import fpc_diffrend_amd.ops as dr
+    pos, tri, uv, uv_idx, tex, ref = _inputs('soup', 1, (97, 131))
+    ctx = dr.RasterizeGLContext(device='cuda')
+    res = (97, 131)
+
+    def run(**kw):
+        p, t = pos.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+        loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, res, **kw)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), p.grad.double().cpu(), t.grad.double().cpu()
+
+    dr.clear_hints()
+    dense = run(record_slots=0)
+    dr.clear_hints()
+    monkeypatch.setattr(dr, "SMALL_BATCH_BINS", 0)
+    monkeypatch.setattr(dr, "RECORD_SLOT_MARGIN", 1)
+    first = run()
+    h = dr._list_hints[next(k for k in dr._list_hints if k[0] == 'onepass')]
+    assert h.sil_bins > 0 and h.slots == h.sil_bins + max(1, h.sil_bins // 2)
+    second = run()
+    for r in (first, second):
+        assert abs(r[0] - dense[0]) <= 1e-6 * abs(dense[0])
+        assert rel_l2(r[1], dense[1]) < 1e-5 and rel_l2(r[2], dense[2]) < 1e-5
+    h.poll()
+    h.slots, h.frozen = 1, True      # (a pool that cannot hold the batch)
+    run()
+    h.frozen = False
+    with pytest.raises(RuntimeError, match="ran out of record slots"):
+        run()
+    third = run()      # (the shape counts afresh and carries on)
+    assert abs(third[0] - dense[0]) <= 1e-6 * abs(dense[0])
+    dr.clear_hints()
