@@ -143,6 +143,7 @@ SYMBOLS = {
     "fpcdr_rasterize_bwd": (_int, [ctypes.POINTER(RasterizeBwd), _p]),
     "fpcdr_occ_bytes": (_sz, [_i, _i, _i]),
     "fpcdr_cmask_bytes": (_sz, [_i, _i, _i]),
+    "fpcdr_objective_cmask_bytes": (_sz, [_i, _i, _i]),
     "fpcdr_ref_bg_sumsq": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, _p, _p]),
     "fpcdr_objective_value": (_int, [_p, _i, _p, ctypes.c_double, ctypes.c_double, _p, _p]),
     "fpcdr_idplane_bytes": (_sz, [_i, _i, _i]),

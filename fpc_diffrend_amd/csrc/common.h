@@ -61,13 +61,14 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
 // Byte offsets inside the two buffers of the sparse objective (include/fpcdr.h: fpcdr_occ_bytes / fpcdr_cmask_bytes).
 //   occ   (saved for the backward call): window masks u16[nb] | raw occupancy u8[nb] | "bin holds antialias flags" u8[nb] |
 //         header i32[16] | backward bin list i32[nb]
-//   cmask (forward scratch): candidate row masks u32[nb*32] | border lines u64[nb*128] | header i32[16] | live bin list i32[nb] |
+//   cmask (forward scratch): candidate row masks u32[nb*32] | border lines u64[nb*128] (one-pass: hit masks u32[nb*32] | f32[128]) | header i32[16] | live bin list i32[nb] |
 //         antialias-fix bin list i32[nb] | live map u8[nb] | per-block counts i32[2][ceil(nb / 256)]
 struct fpcdr_queue_layout {
     size_t occ_raw, occ_binflag, occ_hdr, occ_bwd_list, occ_bytes;
-    size_t cm_edges, cm_hdr, cm_bin_list, cm_fix_list, cm_live, cm_blk, cm_bytes;
+    size_t cm_edges, cm_esum, cm_hdr, cm_bin_list, cm_fix_list, cm_live, cm_blk, cm_bytes;
 };
-static inline fpcdr_queue_layout fpcdr_queue_layout_of(int B, int H, int W) {
+// (onepass: fpcdr_objective_fwd keeps 32 row masks per bin where the two-call form keeps 128 border lines of 8 bytes: 128 B instead of 1 KB)
+static inline fpcdr_queue_layout fpcdr_queue_layout_of(int B, int H, int W, bool onepass = false) {
     const size_t nb = (size_t)B * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W);
     const size_t nb4 = (nb + 3) / 4 * 4;
     fpcdr_queue_layout q;
@@ -77,7 +78,8 @@ static inline fpcdr_queue_layout fpcdr_queue_layout_of(int B, int H, int W) {
     q.occ_bwd_list = q.occ_hdr + 64;
     q.occ_bytes = q.occ_bwd_list + 4 * nb;
     q.cm_edges = nb * 128;
-    q.cm_hdr = q.cm_edges + nb * 1024;
+    q.cm_esum = q.cm_edges + nb * 128;      // (onepass: 512 B of gradient slots behind the hit masks)
+    q.cm_hdr = q.cm_edges + nb * (onepass ? 128 : 1024) + (onepass ? 512 : 0);
     q.cm_bin_list = q.cm_hdr + 64;
     q.cm_fix_list = q.cm_bin_list + 4 * nb;
     q.cm_live = q.cm_fix_list + 4 * nb;

@@ -1143,10 +1143,10 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
     const int32_t *occ_list = nullptr, *n_occ = nullptr;
     const int OX = FPCDR_OCC_DIM(p->W), OY = FPCDR_OCC_DIM(p->H);
     const long long nbins = (long long)p->B * OY * OX;
-    const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W);
-    // (the border-line region of cmask, 1 KB per bin, is free in this form: 128 B per bin of hit masks, then the slots)
-    float *esum_slots = (float *)((char *)p->cmask + q.cm_edges + (size_t)nbins * 128);
-    static_assert(ESLOTS * 4 * sizeof(float) <= 1024 - 128, "the slots must fit behind one bin's hit masks");
+    const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W, true);
+    // (this form's cmask: 128 B per bin of candidate masks, 128 B per bin of hit masks, then the slots)
+    float *esum_slots = (float *)((char *)p->cmask + q.cm_esum);
+    static_assert(ESLOTS * 4 * sizeof(float) <= 512, "the slots' room in fpcdr_queue_layout_of");
     // what the first kernel zero-fills beside its own maps: the slots, and with zero_outputs the caller's accumulators
     FpcdrZeroList zl = {};
     if (p->grad_tex) zl.add(esum_slots, ESLOTS * 4);

@@ -1778,7 +1778,7 @@ int fpcdr_launch_raster_ids(const fpcdr_objective_params *p, hipStream_t st, con
     const int OX = fpcdr_cdiv(p->W, BIN), OY = fpcdr_cdiv(p->H, BIN);
     const size_t nbins = (size_t)p->B * OY * OX;
     FPCDR_REQUIRE(nbins < 0x7ffffff0ULL, "too many bins for one call");
-    const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W);
+    const fpcdr_queue_layout q = fpcdr_queue_layout_of(p->B, p->H, p->W, true);
     char *cm = (char *)p->cmask, *oc = (char *)p->occ;
     int32_t *hdr = (int32_t *)(cm + q.cm_hdr), *bin_list = (int32_t *)(cm + q.cm_bin_list), *olist = (int32_t *)(cm + q.cm_fix_list);
     uint8_t *live = (uint8_t *)(cm + q.cm_live);
@@ -1886,4 +1886,9 @@ extern "C" size_t fpcdr_occ_bytes(int32_t B, int32_t H, int32_t W) {
 extern "C" size_t fpcdr_cmask_bytes(int32_t B, int32_t H, int32_t W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     return fpcdr_queue_layout_of(B, H, W).cm_bytes;
+}
+
+extern "C" size_t fpcdr_objective_cmask_bytes(int32_t B, int32_t H, int32_t W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return fpcdr_queue_layout_of(B, H, W, true).cm_bytes;
 }

@@ -541,7 +541,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
                 raise ValueError("id_plane_out must be a contiguous device tensor of fpcdr_idplane_bytes(B, H, W) bytes")
         idp = idp_out if idp_out is not None else u8(lib.fpcdr_idplane_bytes(B, H, W))
         binlist = u8(lib.fpcdr_binlist_bytes(B, H, W)) if bin_lists else None      # per-bin triangle lists (set-up kernel -> rasteriser)
-        occ, cmask = u8(lib.fpcdr_occ_bytes(B, H, W)), u8(lib.fpcdr_cmask_bytes(B, H, W))
+        occ, cmask = u8(lib.fpcdr_occ_bytes(B, H, W)), u8(lib.fpcdr_objective_cmask_bytes(B, H, W))
         ecol = torch.empty(4, dtype=torch.float32, device=dev)
         # (zero_outputs: the call's first kernel zero-fills its accumulators)
         acc = torch.empty(_lib.LOSS_SLOTS, dtype=torch.float64, device=dev)

@@ -98,6 +98,8 @@ int fpcdr_rasterize_bwd(const fpcdr_rasterize_bwd_params *p, void *stream);
 #define FPCDR_OCC_COUNTS_OFFSET(B, H, W) ((((size_t)(B) * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W) * 4) + 3) / 4 * 4)
 size_t fpcdr_occ_bytes(int32_t B, int32_t H, int32_t W);
 size_t fpcdr_cmask_bytes(int32_t B, int32_t H, int32_t W);
+/* the scratch buffer of fpcdr_objective_fwd alone (its cmask): a quarter of the above (ABI v10) */
+size_t fpcdr_objective_cmask_bytes(int32_t B, int32_t H, int32_t W);
 
 /* out[i] += sum over the px_per_image pixels of image i of (ref - bg_scaled)^2, i < n_images; ref [n_images, px_per_image]
  * uint8, out f64 (zero-filled by the caller).  The part of the pixel loss (fit.py:579) that a sparse fpcdr_aa_loss_fwd
@@ -150,7 +152,7 @@ typedef struct {
     uint32_t *idp;          /* scratch, fpcdr_idplane_bytes(B,H,W), 16-byte aligned */
     uint16_t *occ;          /* scratch+out, fpcdr_occ_bytes(B,H,W): window masks; counts at FPCDR_OCC_COUNTS_OFFSET: [0] bins with a deferred
                                pixel, [2] live bins of the rasteriser, [3] occupied bins (cap_def / cap_bins / cap_occ of the next call) */
-    uint32_t *cmask;        /* scratch, fpcdr_cmask_bytes(B,H,W), 8-byte aligned */
+    uint32_t *cmask;        /* scratch, fpcdr_objective_cmask_bytes(B,H,W), 8-byte aligned */
     float *rec;             /* scratch [B,H,W,4]: (u, v, z/w, -) of DEFERRED pixels only (dense addressing, sparse writes; or rec_slots, below) */
     float *color;           /* scratch [B,H,W,C]: colour of deferred pixels only */
     float *grad_aa;         /* scratch [B,H,W,C]: d(objective)/d(antialiased colour) of deferred pixels only */
