@@ -24,7 +24,13 @@ for case in range(n_cases):
     ref = torch.randint(0, 141, (B, H, W), generator=g, dtype=torch.uint8).to(dev)
     out = {}
     dr.clear_hints()
-    for name in ("chain", "fused", "fused again (launch hints)", "two-call form"):      # fused = the one-pass objective (value + gradient in one call)
+    # fused = the one-pass objective (value + gradient in one call); compact = with the deferred pixels' records in slots sized by a counting
+    # call, then by the previous call (what batches beyond ops.SMALL_BATCH_BINS bins do by themselves)
+    small_batch_bins = dr.SMALL_BATCH_BINS
+    for name in ("chain", "fused", "fused again (launch hints)", "compact records", "compact again", "two-call form"):
+        dr.SMALL_BATCH_BINS = 0 if name.startswith("compact") else small_batch_bins
+        if name == "compact records":
+            dr.clear_hints()
         p = pos.to(dev).clone().requires_grad_(True); t = tex0.to(dev).clone().requires_grad_(True)
         if name == "chain":
             rast, rdb = dr.rasterize(ctx, p, tri, (H, W))
