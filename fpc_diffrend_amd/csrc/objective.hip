@@ -69,7 +69,30 @@ struct MipO {
     TexLevels lv;      // tex[0] = ObjArgs.tex, grad[0] = ObjArgs.grad_tex; grad[] all null when no texture gradient is wanted
     int n_levels;
 };
-constexpr int OTW1 = 24;      // texel window of level 1 (a bin's footprint there is a quarter of its level-0 one)
+// MIP: the texel gradients of a bin go through THREE LDS windows, for the finest level any of its sampled pixels uses (lb) and the two
+// above it -- a pixel's lookup blends two adjacent levels, so a bin whose level of detail spans less than two levels stays inside.  A
+// window is a rectangle of at most MWIN_CELLS[j] / CS cells whose shape follows the bin's footprint in its level (the prepass of
+// shade_body measures it: the extent of the texture coordinates of the pass-0 pixels), because a footprint is rarely square: the rig's
+// face runs at 1.6 texels per pixel along v and 1.0 along u, 52 x 33 texels of level 0 under a 32 x 32 bin.  (r4/r5 first form: a fixed
+// 40 x 40 window of level 0 and 24 x 24 of level 1.  A third of the pixels' taps fell outside and went to memory one float atomic
+// each -- 2.3 ms of the kernel's 4.8 at cfg3, profiles/r05_mip_windows.txt.)
+#ifdef FPCDR_MIPSTAT
+__device__ unsigned long long g_mipstat[16];
+#endif
+template <int CS> struct MipWinCaps {
+#ifndef FPCDR_MIPW_N0
+#define FPCDR_MIPW_N0 2304
+#define FPCDR_MIPW_N1 704
+#define FPCDR_MIPW_N2 256
+#endif
+    static constexpr int N0 = CS == 1 ? FPCDR_MIPW_N0 : 1152, N1 = CS == 1 ? FPCDR_MIPW_N1 : 384, N2 = CS == 1 ? FPCDR_MIPW_N2 : 128;      // cells
+    static constexpr int TOTAL = N0 + N1 + N2;
+};
+// a tap's column (row) relative to a window's unwrapped origin, modulo the level's width (height): both lie within one period of zero
+__device__ __forceinline__ int wrap_cell(int d, int n) { return d < 0 ? d + n : (d >= n ? d - n : d); }
+// order-preserving float <-> int keys for the integer wave / LDS min and max
+__device__ __forceinline__ int fkey(float x) { const int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float fkey_inv(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
 
 // texture coordinates of triangle t through the index buffer (callers that did not pre-gather uv[uv_tri]); out of line, see fused.hip
 // (returns BY VALUE, in registers: reference arguments of an out-of-line function live in scratch memory, and a kernel with a private
@@ -134,12 +157,12 @@ template <int CS, int BMODE, bool MIP = false>
 __device__ __forceinline__ void shade_body(const int b, const int bxi, const int byi, const int OX, const int OY, const ObjArgs &a,
                                            const MipO *ma = nullptr) {
     const int boundary = BMODE >= 0 ? BMODE : a.boundary;
-    __shared__ double s_tex1[MIP ? OTW1 * OTW1 * CS : 1];      // MIP: window of level 1 (coarser levels go to memory)
-    __shared__ int s_org1[2];
+    __shared__ int s_mred[9];      // MIP prepass: min level, min / max keys of the prepared u and v, and of both shifted by half a period
     __shared__ unsigned int s_id[(OB + 2) * OS];
     __shared__ int s_vkey[FPCDR_VT_SLOTS];
     __shared__ double s_vacc[FPCDR_VT_SLOTS][3];
-    __shared__ double s_tex[OTW * OTW * CS];      // texel window, doubles: ds_add_f64 (common.h lds_add_f64)
+    constexpr int TEX_CELLS = MIP ? MipWinCaps<CS>::TOTAL : OTW * OTW;
+    __shared__ double s_tex[TEX_CELLS * CS];      // texel window(s), doubles: ds_add_f64 (common.h lds_add_f64)
     __shared__ int s_org[2];
     __shared__ unsigned int s_cmask[OB];
     __shared__ float s_fy[OB];
@@ -180,10 +203,12 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     }
     if (want_pos) vtable_init(vt, tid, ONT);
     if (want_tex)
-        for (int k = tid; k < OTW * OTW * CS; k += ONT) s_tex[k] = 0.0;
-    if (MIP && want_tex)
-        for (int k = tid; k < OTW1 * OTW1 * CS; k += ONT) s_tex1[k] = 0.0;
-    if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; s_org1[0] = 0x7fffffff; s_org1[1] = 0x7fffffff; }
+        for (int k = tid; k < TEX_CELLS * CS; k += ONT) s_tex[k] = 0.0;
+    if (tid == 0) {
+        s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff;
+        s_mred[0] = 0x7fffffff;
+        for (int k = 1; k < 9; k += 2) { s_mred[k] = 0x7fffffff; s_mred[k + 1] = (int)0x80000000; }
+    }
     if (tid < OB) {
         s_cmask[tid] = 0u;
         s_fy[tid] = (2.0f * (float)(by0 + tid) + 1.0f) / (float)H - 1.0f;      // NDC y of the bin's rows: one IEEE division per row
@@ -222,7 +247,13 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     float lsum = 0.0f;
     bool any_def = false;
     int ox = 0, oy = 0;      // origin of the texel window (set behind the barrier after pass 0)
-    int ox1 = 0x7fffffff, oy1 = 0x7fffffff;      // MIP: origin of the level-1 window
+    // MIP: the three windows (set behind the prepass's barrier), as scalars -- structs selected per lane ended up in scratch memory
+    int w0x = 0, w0y = 0, w0s = 1, w0r = 1, w1x = 0, w1y = 0, w1s = 1, w1r = 1, w2x = 0, w2y = 0, w2s = 1, w2r = 1;
+    constexpr int w0b = 0, w1b = MipWinCaps<CS>::N0, w2b = MipWinCaps<CS>::N0 + MipWinCaps<CS>::N1;
+#ifdef FPCDR_MIPSTAT
+    int mfit0 = 0, mfit1 = 0, mfit2 = 0;
+#endif
+    int mlb = 0;                                             // ... and the level of the first
 
     // the four texel adds of one pixel: into the window, or -- outside it -- to memory
     auto add_taps = [&](const float (&gc)[CS], float fx, float fy, int x0, int y0) {
@@ -350,19 +381,58 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             float gtu_m = 0.f, gtv_m = 0.f;
             float4 gda = make_float4(0.f, 0.f, 0.f, 0.f);
             if (MIP && want_grad && nz) {
-                // texel gradients of levels 0 and 1 through the two LDS windows (origins: the prepass below), anything else to memory;
-                // the footprint's gradient goes back through the derivative outputs of the rasteriser
-                const int lx0 = (int)floorf(prep_coord(tu, boundary) * (float)Wt - 0.5f) - ox;
-                const int ly0 = (int)floorf(prep_coord(tv, boundary) * (float)Ht - 0.5f) - oy;
-                const bool in0 = (unsigned int)lx0 < (unsigned int)(OTW - 1) && (unsigned int)ly0 < (unsigned int)(OTW - 1);
-                const int lx1 = (int)floorf(prep_coord(tu, boundary) * (float)(Wt >> 1) - 0.5f) - ox1;
-                const int ly1 = (int)floorf(prep_coord(tv, boundary) * (float)(Ht >> 1) - 0.5f) - oy1;
-                const bool in1 = (unsigned int)lx1 < (unsigned int)(OTW1 - 1) && (unsigned int)ly1 < (unsigned int)(OTW1 - 1);
+                // texel gradients of the pixel's two levels through the windows of those levels (the prepass below), anything else to
+                // memory; the footprint's gradient goes back through the derivative outputs of the rasteriser
+                const float pu = prep_coord(tu, boundary), pv = prep_coord(tv, boundary);
+                // where the pixel's taps fall in each of the three windows (uniform descriptors: no per-lane table -- a select chain on
+                // `level - mlb` was compiled into a lookup table in scratch memory), then which window each of its two levels takes
+                int cl[3], sl[3];
+                bool il[3];
+                {
+                    int lx = (int)floorf(pu * (float)(Wt >> mlb) - 0.5f) - w0x, ly = (int)floorf(pv * (float)(Ht >> mlb) - 0.5f) - w0y;
+                    if (boundary == FPCDR_BOUNDARY_WRAP) { lx = wrap_cell(lx, Wt >> mlb); ly = wrap_cell(ly, Ht >> mlb); }
+                    cl[0] = w0b + ly * w0s + lx; sl[0] = w0s;
+                    il[0] = (unsigned int)lx < (unsigned int)(w0s - 1) && (unsigned int)ly < (unsigned int)(w0r - 1);
+                }
+                {
+                    int lx = (int)floorf(pu * (float)(Wt >> (mlb + 1)) - 0.5f) - w1x, ly = (int)floorf(pv * (float)(Ht >> (mlb + 1)) - 0.5f) - w1y;
+                    if (boundary == FPCDR_BOUNDARY_WRAP) { lx = wrap_cell(lx, Wt >> (mlb + 1)); ly = wrap_cell(ly, Ht >> (mlb + 1)); }
+                    cl[1] = w1b + ly * w1s + lx; sl[1] = w1s;
+                    il[1] = (unsigned int)lx < (unsigned int)(w1s - 1) && (unsigned int)ly < (unsigned int)(w1r - 1);
+                }
+                {
+                    int lx = (int)floorf(pu * (float)(Wt >> (mlb + 2)) - 0.5f) - w2x, ly = (int)floorf(pv * (float)(Ht >> (mlb + 2)) - 0.5f) - w2y;
+                    if (boundary == FPCDR_BOUNDARY_WRAP) { lx = wrap_cell(lx, Wt >> (mlb + 2)); ly = wrap_cell(ly, Ht >> (mlb + 2)); }
+                    cl[2] = w2b + ly * w2s + lx; sl[2] = w2s;
+                    il[2] = (unsigned int)lx < (unsigned int)(w2s - 1) && (unsigned int)ly < (unsigned int)(w2r - 1);
+                }
+                const int d0 = MK.l0 - mlb, d1 = MK.l1 - mlb;
+                const bool a0 = d0 == 0 && il[0], a1 = d0 == 1 && il[1], a2 = d0 == 2 && il[2];
+                const bool b0 = d1 == 0 && il[0], b1 = d1 == 1 && il[1], b2 = d1 == 2 && il[2];
+                const bool in0 = a0 || a1 || a2, in1 = b0 || b1 || b2;
+                const int cell0 = a0 ? cl[0] : (a1 ? cl[1] : cl[2]), st0 = a0 ? sl[0] : (a1 ? sl[1] : sl[2]);
+                const int cell1 = b0 ? cl[0] : (b1 ? cl[1] : cl[2]), st1 = b0 ? sl[0] : (b1 ? sl[1] : sl[2]);
+#ifdef FPCDR_MIPSTAT
+                {   // taps by (level - mlb) and in / out of its window: [0..2] in, [3..5] out, [6] beyond the third window, [7] pixels
+                    const int dd[2] = {d0, d1};
+                    const bool ii[2] = {in0, in1};
+                    for (int q = 0; q < 2; ++q) {
+                        const int slot = (unsigned int)dd[q] < 3u ? (ii[q] ? dd[q] : 3 + dd[q]) : 6;
+                        atomicAdd(&g_mipstat[slot], 1ull);
+                        // outside a window that FITTED its footprint [8..10]; finer than lb [11]; no window at all (no sampled pixel) [12]
+                        const int fits = dd[q] == 0 ? mfit0 : (dd[q] == 1 ? mfit1 : mfit2);
+                        if ((unsigned int)dd[q] < 3u && !ii[q] && fits) atomicAdd(&g_mipstat[8 + dd[q]], 1ull);
+                        if (dd[q] < 0) atomicAdd(&g_mipstat[11], 1ull);
+                        if (mlb == 0x7fffffff) atomicAdd(&g_mipstat[12], 1ull);
+                    }
+                    atomicAdd(&g_mipstat[7], 1ull);
+                }
+#endif
                 mip_lookup_bwd<MIP ? CS : 1>(ma->lv, ma->n_levels, MK, reinterpret_cast<const float (&)[MIP ? CS : 1]>(gq), Ht, Wt, gtu_m, gtv_m, gda,
                                   [&](int level, int tap, size_t offs, int c, float vv) {
                                       const int dx = tap & 1, dy = tap >> 1;
-                                      if (level == 0 && in0) lds_add_f64(&s_tex[((ly0 + dy) * OTW + lx0 + dx) * CS + c], vv);
-                                      else if (level == 1 && in1) lds_add_f64(&s_tex1[((ly1 + dy) * OTW1 + lx1 + dx) * CS + c], vv);
+                                      const bool first = level == MK.l0;
+                                      if (first ? in0 : in1) lds_add_f64(&s_tex[((first ? cell0 : cell1) + dy * (first ? st0 : st1) + dx) * CS + c], vv);
                                       else atomicAdd(ma->lv.grad[level] + offs + c, vv);
                                   });
             }
@@ -403,29 +473,85 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     };
 
     if (MIP) {
-        // MIP: the scatter of a pixel's texel gradients is buried in the level / footprint arithmetic, so the origins of both windows
-        // come from a PREPASS that only forms the texture coordinate of the pass-0 pixels (one pixel in four shaded twice)
+        // MIP: the scatter of a pixel's texel gradients is buried in the level / footprint arithmetic, so the windows are placed by a
+        // PREPASS that forms the texture coordinate and the level of the pass-0 pixels only (one pixel in four shaded twice): the finest
+        // level in use, and the extent of the prepared coordinates -- which every level's window scales by its own size
         if (want_tex) {
             const int zy = 2 * shade_row_pair(0, wave) + (lane >> 5);
             const int id = (int)(s_id[(zy + 1) * OS + col + 1] & 0xffffffu);
-            int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = 0x7fffffff, y1 = 0x7fffffff;
+            int l0 = 0x7fffffff, ku0 = 0x7fffffff, ku1 = (int)0x80000000, kv0 = 0x7fffffff, kv1 = (int)0x80000000;
+            int su0 = 0x7fffffff, su1 = (int)0x80000000, sv0 = 0x7fffffff, sv1 = (int)0x80000000;      // (the same, half a period on)
             if (id > 0) {
                 const int t = id - 1;
                 const I3 ti = ld32(reinterpret_cast<const I3 *>(a.tri), t);
-                ShadeKeep K;
-                float u, v, zw;
-                shade_uvz<false>(ld32(pos_img, ti.a), ld32(pos_img, ti.b), ld32(pos_img, ti.c), fx_col, s_fy[zy], K, u, v, zw);
+                const Shade sd = shade_pixel(ld32(pos_img, ti.a), ld32(pos_img, ti.b), ld32(pos_img, ti.c), fx_col, s_fy[zy], 2.0f / (float)W, 2.0f / (float)H);
                 const UV3 tq = a.tri_uv ? ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t) : uv_indirect(a.uv, a.uv_tri, t);
-                const float w = 1.0f - u - v;
-                const float tu = u * tq.q0.x + v * tq.q1.x + w * tq.q2.x, tv = u * tq.q0.y + v * tq.q1.y + w * tq.q2.y;
-                x0 = (int)floorf(prep_coord(tu, boundary) * (float)Wt - 0.5f); y0 = (int)floorf(prep_coord(tv, boundary) * (float)Ht - 0.5f);
-                x1 = (int)floorf(prep_coord(tu, boundary) * (float)(Wt >> 1) - 0.5f); y1 = (int)floorf(prep_coord(tv, boundary) * (float)(Ht >> 1) - 0.5f);
+                const float w = 1.0f - sd.u - sd.v;
+                const float tu = sd.u * tq.q0.x + sd.v * tq.q1.x + w * tq.q2.x, tv = sd.u * tq.q0.y + sd.v * tq.q1.y + w * tq.q2.y;
+                const float e0x = tq.q0.x - tq.q2.x, e0y = tq.q0.y - tq.q2.y, e1x = tq.q1.x - tq.q2.x, e1y = tq.q1.y - tq.q2.y;
+                const float4 da = make_float4(sd.dudx * e0x + sd.dvdx * e1x, sd.dudy * e0x + sd.dvdy * e1x, sd.dudx * e0y + sd.dvdx * e1y,
+                                              sd.dudy * e0y + sd.dvdy * e1y);
+                const float lev = fminf(fmaxf(compute_lod(da, Ht, Wt, 0.0f).level, 0.0f), (float)ma->n_levels);
+                l0 = min((int)floorf(lev), ma->n_levels);
+                const float pu = prep_coord(tu, boundary), pv = prep_coord(tv, boundary);
+                ku0 = ku1 = fkey(pu);
+                kv0 = kv1 = fkey(pv);
+                if (boundary == FPCDR_BOUNDARY_WRAP) {      // a bin across the seam of a periodic coordinate is compact half a period on
+                    su0 = su1 = fkey(pu + 0.5f - floorf(pu + 0.5f));
+                    sv0 = sv1 = fkey(pv + 0.5f - floorf(pv + 0.5f));
+                }
             }
-            const int m0 = wave_min_dpp(x0), m1 = wave_min_dpp(y0), m2 = wave_min_dpp(x1), m3 = wave_min_dpp(y1);
-            if (lane == 0 && m0 != 0x7fffffff) { atomicMin(&s_org[0], m0); atomicMin(&s_org[1], m1); atomicMin(&s_org1[0], m2); atomicMin(&s_org1[1], m3); }
+            const int m0 = wave_min_dpp(l0), m1 = wave_min_dpp(ku0), m2 = ~wave_min_dpp(~ku1), m3 = wave_min_dpp(kv0), m4 = ~wave_min_dpp(~kv1);
+            int m5 = 0, m6 = 0, m7 = 0, m8 = 0;
+            if (boundary == FPCDR_BOUNDARY_WRAP) { m5 = wave_min_dpp(su0); m6 = ~wave_min_dpp(~su1); m7 = wave_min_dpp(sv0); m8 = ~wave_min_dpp(~sv1); }
+            if (lane == 0 && m0 != 0x7fffffff) {
+                atomicMin(&s_mred[0], m0); atomicMin(&s_mred[1], m1); atomicMax(&s_mred[2], m2); atomicMin(&s_mred[3], m3); atomicMax(&s_mred[4], m4);
+                if (boundary == FPCDR_BOUNDARY_WRAP) { atomicMin(&s_mred[5], m5); atomicMax(&s_mred[6], m6); atomicMin(&s_mred[7], m7); atomicMax(&s_mred[8], m8); }
+            }
             __syncthreads();
-            ox = s_org[0]; oy = s_org[1]; ox1 = s_org1[0]; oy1 = s_org1[1];
-            if (ox != 0x7fffffff) { ox -= OWIN_MARGIN + 1; oy -= OWIN_MARGIN + 1; ox1 -= 1; oy1 -= 1; }
+            mlb = __builtin_amdgcn_readfirstlane(s_mred[0]);
+            if (mlb != 0x7fffffff) {      // (uniform)
+                float ua = fkey_inv(__builtin_amdgcn_readfirstlane(s_mred[1])), ub = fkey_inv(__builtin_amdgcn_readfirstlane(s_mred[2]));
+                float va = fkey_inv(__builtin_amdgcn_readfirstlane(s_mred[3])), vb = fkey_inv(__builtin_amdgcn_readfirstlane(s_mred[4]));
+                if (boundary == FPCDR_BOUNDARY_WRAP) {
+                    // the narrower of the two views of each coordinate; the shifted one, shifted back, runs from below zero to above it
+                    // (window coordinates are unwrapped: the pixels find their cell modulo the level's size, the flush wraps)
+                    const float ua2 = fkey_inv(__builtin_amdgcn_readfirstlane(s_mred[5])), ub2 = fkey_inv(__builtin_amdgcn_readfirstlane(s_mred[6]));
+                    const float va2 = fkey_inv(__builtin_amdgcn_readfirstlane(s_mred[7])), vb2 = fkey_inv(__builtin_amdgcn_readfirstlane(s_mred[8]));
+                    if (ub2 - ua2 < ub - ua) { ua = ua2 - 0.5f; ub = ub2 - 0.5f; }
+                    if (vb2 - va2 < vb - va) { va = va2 - 0.5f; vb = vb2 - 0.5f; }
+                }
+                auto place = [&](int j, int cap, int &ox_, int &oy_, int &os_, int &or_) __attribute__((always_inline)) {
+                    const int l = mlb + j;
+                    if (l > ma->n_levels) return;
+                    const float wl = (float)(Wt >> l), hl = (float)(Ht >> l), big = 1073741824.0f;
+                    // the taps of the sampled pixels and one texel around them (rows in between shift by a fraction of a texel)
+                    int xa = (int)fminf(fmaxf(floorf(ua * wl - 0.5f), -big), big) - 1, ya = (int)fminf(fmaxf(floorf(va * hl - 0.5f), -big), big) - 1;
+                    const long long nw = (long long)(int)fminf(fmaxf(floorf(ub * wl - 0.5f), -big), big) + 2 - xa + 1;
+                    const long long nh = (long long)(int)fminf(fmaxf(floorf(vb * hl - 0.5f), -big), big) + 2 - ya + 1;
+                    int stride, rows;
+#ifdef FPCDR_MIPSTAT
+                    if (nw * nh <= cap) { if (j == 0) mfit0 = 1; else if (j == 1) mfit1 = 1; else mfit2 = 1; }
+#endif
+                    if (nw * nh <= cap) {      // it fits: the rows that are left over go half below, half above
+                        stride = (int)nw;
+                        rows = cap / stride;
+                        ya -= (rows - (int)nh) >> 1;
+                    } else {                   // it does not (a uv seam, a second surface): a window of the footprint's aspect around its centre
+                        const float aspect = fminf(fmaxf((float)nw / (float)nh, 1.0f / (float)cap), (float)cap);
+                        stride = min(max((int)sqrtf((float)cap * aspect), 2), cap / 2);
+                        rows = cap / stride;
+                        xa += (int)((nw - stride) >> 1);
+                        ya += (int)((nh - rows) >> 1);
+                    }
+                    // (uniform values formed on the vector unit: back into scalar registers)
+                    ox_ = __builtin_amdgcn_readfirstlane(xa); oy_ = __builtin_amdgcn_readfirstlane(ya);
+                    os_ = __builtin_amdgcn_readfirstlane(stride); or_ = __builtin_amdgcn_readfirstlane(rows);
+                };
+                place(0, MipWinCaps<CS>::N0, w0x, w0y, w0s, w0r);
+                place(1, MipWinCaps<CS>::N1, w1x, w1y, w1s, w1r);
+                place(2, MipWinCaps<CS>::N2, w2x, w2y, w2s, w2r);
+            }
         }
         pixel(0, false);
     } else {
@@ -471,7 +597,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     if (!want_grad) return;
     // ---- flush: every vertex slot and window cell once (the barrier above has made all adds visible) ----
     if (want_pos) vtable_flush(vt, gp, tid, ONT);
-    if (want_tex && ox != 0x7fffffff) {
+    if (!MIP && want_tex && ox != 0x7fffffff) {
         for (int k = tid; k < OTW * OTW * CS; k += ONT) {
             const float v = (float)s_tex[k];
             if (v != 0.0f) {
@@ -481,16 +607,26 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             }
         }
     }
-    if (MIP && want_tex && ox1 != 0x7fffffff && ma->n_levels >= 1) {
-        const int Wt1 = Wt >> 1, Ht1 = Ht >> 1;
-        for (int k = tid; k < OTW1 * OTW1 * CS; k += ONT) {
-            const float v = (float)s_tex1[k];
-            if (v != 0.0f) {
-                const int c = k % CS, cell = k / CS;
-                const int gx = wrap_near(ox1 + cell % OTW1, Wt1, boundary), gy = wrap_near(oy1 + cell / OTW1, Ht1, boundary);
-                atomicAdd(ma->lv.grad[1] + (size_t)(gy * Wt1 + gx) * CS + c, v);
+    if (MIP && want_tex) {
+        auto flush = [&](int wx, int wy, int ws, int wr, int wb, int level) __attribute__((always_inline)) {
+            if (ws <= 1) return;      // (uniform: an unused window)
+            const int wl = Wt >> level, hl = Ht >> level;
+            const float inv = 1.0f / (float)ws;
+            float *const g = ma->lv.grad[level];
+            const int n = ws * wr * CS;
+            for (int k = tid; k < n; k += ONT) {
+                const float v = (float)s_tex[wb * CS + k];
+                if (v != 0.0f) {
+                    const int c = k % CS, cell = k / CS;
+                    const int ly = (int)(((float)cell + 0.5f) * inv), lx = cell - ly * ws;      // (exact: cell < 2^12)
+                    const int gx = wrap_near(wx + lx, wl, boundary), gy = wrap_near(wy + ly, hl, boundary);
+                    atomicAdd(g + (size_t)(gy * wl + gx) * CS + c, v);
+                }
             }
-        }
+        };
+        flush(w0x, w0y, w0s, w0r, w0b, mlb);
+        flush(w1x, w1y, w1s, w1r, w1b, mlb + 1);
+        flush(w2x, w2y, w2s, w2r, w2b, mlb + 2);
     }
     OPROF_T(7);
     OPROF_ADD(6, 6, 7);
@@ -1253,3 +1389,9 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
     FPCDR_CHECK_LAUNCH();
     return FPCDR_OK;
 }
+
+#ifdef FPCDR_MIPSTAT
+extern "C" int fpcdr_debug_mipstat(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mipstat), sizeof(unsigned long long) * 16);
+}
+#endif
