@@ -34,7 +34,13 @@ namespace {
 #endif
 constexpr int OB = 32;            // pixels per bin side
 constexpr int OS = 36;            // LDS row stride of the id plane with its one-pixel apron (34 entries used)
-constexpr int OTW = FPCDR_OTEXWIN;
+// cells of the (non-mip) texel window, a rectangle shaped by the bin's footprint.  One channel: 1 728 cells of 8 bytes are what six
+// workgroups per CU leave (26.4 KB each; cfg3: 1 600 -> 1 393 us, 1 728 -> 1 366, 1 792 -> five workgroups, 1 469; 2 400 -> 1 455 with 7 %
+// of the pixels outside instead of 13); three / four channels: 1 600 cells of 24 / 32 bytes, under 64 KB with the rest
+#ifndef FPCDR_OWIN_CELLS
+#define FPCDR_OWIN_CELLS 1728
+#endif
+template <int CS> constexpr int owin_cells() { return CS == 1 ? FPCDR_OWIN_CELLS : FPCDR_OTEXWIN * FPCDR_OTEXWIN; }
 constexpr int ONT = 256;          // threads of k_shade
 #ifndef FPCDR_FNT
 #define FPCDR_FNT 64
@@ -85,7 +91,7 @@ template <int CS> struct MipWinCaps {
 #define FPCDR_MIPW_N1 704
 #define FPCDR_MIPW_N2 256
 #endif
-    static constexpr int N0 = CS == 1 ? FPCDR_MIPW_N0 : 1152, N1 = CS == 1 ? FPCDR_MIPW_N1 : 384, N2 = CS == 1 ? FPCDR_MIPW_N2 : 128;      // cells
+    static constexpr int N0 = CS == 1 ? FPCDR_MIPW_N0 : 1088, N1 = CS == 1 ? FPCDR_MIPW_N1 : 384, N2 = CS == 1 ? FPCDR_MIPW_N2 : 128;      // cells
     static constexpr int TOTAL = N0 + N1 + N2;
 };
 // a tap's column (row) relative to a window's unwrapped origin, modulo the level's width (height): both lie within one period of zero
@@ -161,9 +167,9 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     __shared__ unsigned int s_id[(OB + 2) * OS];
     __shared__ int s_vkey[FPCDR_VT_SLOTS];
     __shared__ double s_vacc[FPCDR_VT_SLOTS][3];
-    constexpr int TEX_CELLS = MIP ? MipWinCaps<CS>::TOTAL : OTW * OTW;
+    constexpr int OCELLS = owin_cells<CS>();
+    constexpr int TEX_CELLS = MIP ? MipWinCaps<CS>::TOTAL : OCELLS;
     __shared__ double s_tex[TEX_CELLS * CS];      // texel window(s), doubles: ds_add_f64 (common.h lds_add_f64)
-    __shared__ int s_org[2];
     __shared__ unsigned int s_cmask[OB];
     __shared__ float s_fy[OB];
     __shared__ float s_lpart[ONT / 64];
@@ -205,7 +211,6 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     if (want_tex)
         for (int k = tid; k < TEX_CELLS * CS; k += ONT) s_tex[k] = 0.0;
     if (tid == 0) {
-        s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff;
         s_mred[0] = 0x7fffffff;
         for (int k = 1; k < 9; k += 2) { s_mred[k] = 0x7fffffff; s_mred[k + 1] = (int)0x80000000; }
     }
@@ -246,7 +251,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     const float bgs = a.bg * cs;
     float lsum = 0.0f;
     bool any_def = false;
-    int ox = 0, oy = 0;      // origin of the texel window (set behind the barrier after pass 0)
+    int ox = 0, oy = 0, ows = 1, owr = 1;      // origin, row stride and rows of the texel window (set behind the barrier after pass 0; stride 1: none)
     // MIP: the three windows (set behind the prepass's barrier), as scalars -- structs selected per lane ended up in scratch memory
     int w0x = 0, w0y = 0, w0s = 1, w0r = 1, w1x = 0, w1y = 0, w1s = 1, w1r = 1, w2x = 0, w2y = 0, w2s = 1, w2r = 1;
     constexpr int w0b = 0, w1b = MipWinCaps<CS>::N0, w2b = MipWinCaps<CS>::N0 + MipWinCaps<CS>::N1;
@@ -264,16 +269,21 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         }
         const float w00 = (valid & 1u) ? (1.0f - fx) * (1.0f - fy) : 0.0f, w10 = (valid & 2u) ? fx * (1.0f - fy) : 0.0f;
         const float w01 = (valid & 4u) ? (1.0f - fx) * fy : 0.0f, w11 = (valid & 8u) ? fx * fy : 0.0f;
-        const int lx = x0 - ox, ly = y0 - oy;
-        // (unsigned compares: a tap below the origin wraps to a huge value; 0x7fffffff origin = no sample in pass 0: everything outside)
-        if ((unsigned int)lx < (unsigned int)(OTW - 1) && (unsigned int)ly < (unsigned int)(OTW - 1)) {
+        int lx = (int)((unsigned int)x0 - (unsigned int)ox), ly = (int)((unsigned int)y0 - (unsigned int)oy);
+        if (boundary == FPCDR_BOUNDARY_WRAP) { lx = wrap_cell(lx, Wt); ly = wrap_cell(ly, Ht); }      // (the window's origin is unwrapped)
+        // (unsigned compares: a tap below the origin wraps to a huge value; stride 1 = no sample in pass 0: everything outside)
+        const bool inside = (unsigned int)lx < (unsigned int)(ows - 1) && (unsigned int)ly < (unsigned int)(owr - 1);
+#ifdef FPCDR_MIPSTAT
+        atomicAdd(&g_mipstat[inside ? 13 : 14], 1ull);
+#endif
+        if (inside) {
 #pragma unroll
             for (int c = 0; c < CS; ++c) {
-                double *wp = s_tex + (ly * OTW + lx) * CS + c;
+                double *wp = s_tex + (ly * ows + lx) * CS + c;
                 lds_add_f64(wp, gc[c] * w00);
                 lds_add_f64(wp + CS, gc[c] * w10);
-                lds_add_f64(wp + OTW * CS, gc[c] * w01);
-                lds_add_f64(wp + OTW * CS + CS, gc[c] * w11);
+                lds_add_f64(wp + ows * CS, gc[c] * w01);
+                lds_add_f64(wp + ows * CS + CS, gc[c] * w11);
             }
         } else {
             const int ix0 = wrap_near(x0, Wt, boundary), ix1 = wrap_near(x0 == 0x7fffffff ? x0 : x0 + 1, Wt, boundary);
@@ -559,13 +569,53 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     pixel(0, true);
     }
     if (!MIP && want_tex) {
-        const int mx = wave_min_dpp(k_x0), my = wave_min_dpp(k_y0);
-        if (lane == 0 && mx != 0x7fffffff) { atomicMin(&s_org[0], mx); atomicMin(&s_org[1], my); }
+        // the window: the bounding box of the taps of pass 0, as a rectangle of at most OCELLS cells.  A footprint is rarely square (the rig's
+        // face: 1.6 texels per pixel along v, 1.0 along u -- 52 x 33 texels under a bin), and a bin across the seam of a periodic coordinate is
+        // compact only in the CENTRED view of it (x >= n / 2 counted as x - n).  (r4 form: a fixed 40 x 40 window from the smallest tap; 22 %
+        // of the pixels' adds fell outside and went to memory one by one: profiles/r05_tex_window.txt)
+        const bool on = k_on && k_x0 != 0x7fffffff && k_y0 != 0x7fffffff;
+        const int NONE_LO = 0x7fffffff, NONE_HI = (int)0x80000000;
+        int r1 = wave_min_dpp(on ? k_x0 : NONE_LO), r2 = ~wave_min_dpp(~(on ? k_x0 : NONE_HI));
+        int r3 = wave_min_dpp(on ? k_y0 : NONE_LO), r4 = ~wave_min_dpp(~(on ? k_y0 : NONE_HI));
+        int r5 = 0, r6 = 0, r7 = 0, r8 = 0;
+        if (boundary == FPCDR_BOUNDARY_WRAP) {
+            const int cx = k_x0 >= (Wt >> 1) ? k_x0 - Wt : k_x0, cy = k_y0 >= (Ht >> 1) ? k_y0 - Ht : k_y0;
+            r5 = wave_min_dpp(on ? cx : NONE_LO); r6 = ~wave_min_dpp(~(on ? cx : NONE_HI));
+            r7 = wave_min_dpp(on ? cy : NONE_LO); r8 = ~wave_min_dpp(~(on ? cy : NONE_HI));
+        }
+        if (lane == 0 && r1 != NONE_LO) {
+            atomicMin(&s_mred[1], r1); atomicMax(&s_mred[2], r2); atomicMin(&s_mred[3], r3); atomicMax(&s_mred[4], r4);
+            if (boundary == FPCDR_BOUNDARY_WRAP) { atomicMin(&s_mred[5], r5); atomicMax(&s_mred[6], r6); atomicMin(&s_mred[7], r7); atomicMax(&s_mred[8], r8); }
+        }
         OPROF_T(3);
         __syncthreads();
         OPROF_T(4);
-        ox = s_org[0]; oy = s_org[1];
-        if (ox != 0x7fffffff) { ox -= OWIN_MARGIN; oy -= OWIN_MARGIN; }
+        int xa = __builtin_amdgcn_readfirstlane(s_mred[1]);
+        if (xa != NONE_LO) {      // (uniform)
+            int xb = __builtin_amdgcn_readfirstlane(s_mred[2]), ya = __builtin_amdgcn_readfirstlane(s_mred[3]), yb = __builtin_amdgcn_readfirstlane(s_mred[4]);
+            if (boundary == FPCDR_BOUNDARY_WRAP) {
+                const int xa2 = __builtin_amdgcn_readfirstlane(s_mred[5]), xb2 = __builtin_amdgcn_readfirstlane(s_mred[6]);
+                const int ya2 = __builtin_amdgcn_readfirstlane(s_mred[7]), yb2 = __builtin_amdgcn_readfirstlane(s_mred[8]);
+                if (xb2 - xa2 < xb - xa) { xa = xa2; xb = xb2; }
+                if (yb2 - ya2 < yb - ya) { ya = ya2; yb = yb2; }
+            }
+            const long long nw = (long long)xb - xa + 2 + 2 * OWIN_MARGIN, nh = (long long)yb - ya + 2 + 2 * OWIN_MARGIN;      // (taps x0 and x0 + 1)
+            int stride, rows;
+            long long sx0 = (long long)xa - OWIN_MARGIN, sy0 = (long long)ya - OWIN_MARGIN;
+            if (nw * nh <= OCELLS) {      // it fits: the rows that are left over go half below, half above
+                stride = (int)nw;
+                rows = OCELLS / stride;
+                sy0 -= (rows - (int)nh) >> 1;
+            } else {                      // it does not: a window of the footprint's aspect around its centre
+                const float aspect = fminf(fmaxf((float)nw / (float)nh, 1.0f / (float)OCELLS), (float)OCELLS);
+                stride = min(max((int)sqrtf((float)OCELLS * aspect), 2), OCELLS / 2);
+                rows = OCELLS / stride;
+                sx0 += (nw - stride) >> 1;
+                sy0 += (nh - rows) >> 1;
+            }
+            ox = __builtin_amdgcn_readfirstlane((int)sx0); oy = __builtin_amdgcn_readfirstlane((int)sy0);
+            ows = __builtin_amdgcn_readfirstlane(stride); owr = __builtin_amdgcn_readfirstlane(rows);
+        }
         if (k_on) add_taps(k_gc, k_fx, k_fy, k_x0, k_y0);
     } else {
         OPROF_T(3);
@@ -597,12 +647,15 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     if (!want_grad) return;
     // ---- flush: every vertex slot and window cell once (the barrier above has made all adds visible) ----
     if (want_pos) vtable_flush(vt, gp, tid, ONT);
-    if (!MIP && want_tex && ox != 0x7fffffff) {
-        for (int k = tid; k < OTW * OTW * CS; k += ONT) {
+    if (!MIP && want_tex && ows > 1) {
+        const float inv = 1.0f / (float)ows;
+        const int n = ows * owr * CS;
+        for (int k = tid; k < n; k += ONT) {
             const float v = (float)s_tex[k];
             if (v != 0.0f) {
                 const int c = k % CS, cell = k / CS;
-                const int gx = wrap_near(ox + cell % OTW, Wt, boundary), gy = wrap_near(oy + cell / OTW, Ht, boundary);
+                const int ly = (int)(((float)cell + 0.5f) * inv), lx = cell - ly * ows;      // (exact: cell < 2^12)
+                const int gx = wrap_near(ox + lx, Wt, boundary), gy = wrap_near(oy + ly, Ht, boundary);
                 atomicAdd(&at32(a.grad_tex, (unsigned int)((gy * Wt + gx) * CS + c)), v);
             }
         }

@@ -15,7 +15,7 @@ ctx = dr.RasterizeGLContext(device=dev)
 for case in range(n_cases):
     B = int(rng.integers(1, 12)); H = int(rng.integers(20, 300)); W = int(rng.integers(20, 420))
     nt = int(rng.choice([3, 17, 120, 900])); C = int(rng.choice([1, 1, 3, 4]))
-    boundary = str(rng.choice(['wrap', 'clamp', 'zero'])); mip = bool(C == 1 and rng.random() < 0.4)
+    boundary = str(rng.choice(['wrap', 'clamp', 'zero'])); mip = bool(rng.random() < 0.4)
     pos, tri = random_soup(B, nt, seed=int(rng.integers(1 << 30)), spread=float(rng.uniform(0.4, 1.1)), size=float(rng.uniform(0.05, 0.9)))
     tri = tri.to(dev)
     g = torch.Generator().manual_seed(case)
