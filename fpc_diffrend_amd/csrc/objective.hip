@@ -251,6 +251,9 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     const float bgs = a.bg * cs;
     float lsum = 0.0f;
     bool any_def = false;
+#ifdef FPCDR_MIPSTAT
+    int ofit = 0;
+#endif
     int ox = 0, oy = 0, ows = 1, owr = 1;      // origin, row stride and rows of the texel window (set behind the barrier after pass 0; stride 1: none)
     // MIP: the three windows (set behind the prepass's barrier), as scalars -- structs selected per lane ended up in scratch memory
     int w0x = 0, w0y = 0, w0s = 1, w0r = 1, w1x = 0, w1y = 0, w1s = 1, w1r = 1, w2x = 0, w2y = 0, w2s = 1, w2r = 1;
@@ -275,6 +278,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         const bool inside = (unsigned int)lx < (unsigned int)(ows - 1) && (unsigned int)ly < (unsigned int)(owr - 1);
 #ifdef FPCDR_MIPSTAT
         atomicAdd(&g_mipstat[inside ? 13 : 14], 1ull);
+        if (!inside && ofit) atomicAdd(&g_mipstat[15], 1ull);      // outside a window that held the whole sampled footprint
 #endif
         if (inside) {
 #pragma unroll
@@ -603,6 +607,9 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             int stride, rows;
             long long sx0 = (long long)xa - OWIN_MARGIN, sy0 = (long long)ya - OWIN_MARGIN;
             if (nw * nh <= OCELLS) {      // it fits: the rows that are left over go half below, half above
+#ifdef FPCDR_MIPSTAT
+                ofit = 1;
+#endif
                 stride = (int)nw;
                 rows = OCELLS / stride;
                 sy0 -= (rows - (int)nh) >> 1;

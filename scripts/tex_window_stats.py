@@ -13,3 +13,4 @@ lib = ctypes.CDLL(os.environ["FPCDR_LIB_PATH"])
 assert lib.fpcdr_debug_mipstat(out) == 0
 v = list(out)
 print(f"pixels whose taps go through the window: {v[13]} ({100 * v[13] / (v[13] + v[14]):.1f} %), to memory: {v[14]} ({100 * v[14] / (v[13] + v[14]):.1f} %)")
+print(f"  of those, outside a window that held the whole footprint of pass 0: {v[15]}")
