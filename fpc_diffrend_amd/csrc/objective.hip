@@ -254,6 +254,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
 #ifdef FPCDR_MIPSTAT
     int ofit = 0;
 #endif
+    bool owrap = false;      // the window reaches across the edge of a periodic coordinate
     int ox = 0, oy = 0, ows = 1, owr = 1;      // origin, row stride and rows of the texel window (set behind the barrier after pass 0; stride 1: none)
     // MIP: the three windows (set behind the prepass's barrier), as scalars -- structs selected per lane ended up in scratch memory
     int w0x = 0, w0y = 0, w0s = 1, w0r = 1, w1x = 0, w1y = 0, w1s = 1, w1r = 1, w2x = 0, w2y = 0, w2s = 1, w2r = 1;
@@ -273,7 +274,8 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         const float w00 = (valid & 1u) ? (1.0f - fx) * (1.0f - fy) : 0.0f, w10 = (valid & 2u) ? fx * (1.0f - fy) : 0.0f;
         const float w01 = (valid & 4u) ? (1.0f - fx) * fy : 0.0f, w11 = (valid & 8u) ? fx * fy : 0.0f;
         int lx = (int)((unsigned int)x0 - (unsigned int)ox), ly = (int)((unsigned int)y0 - (unsigned int)oy);
-        if (boundary == FPCDR_BOUNDARY_WRAP) { lx = wrap_cell(lx, Wt); ly = wrap_cell(ly, Ht); }      // (the window's origin is unwrapped)
+        // (the window's origin is unwrapped; a window that lies inside the texture -- nearly all do -- needs no wrapping: uniform branch)
+        if (boundary == FPCDR_BOUNDARY_WRAP && owrap) { lx = wrap_cell(lx, Wt); ly = wrap_cell(ly, Ht); }
         // (unsigned compares: a tap below the origin wraps to a huge value; stride 1 = no sample in pass 0: everything outside)
         const bool inside = (unsigned int)lx < (unsigned int)(ows - 1) && (unsigned int)ly < (unsigned int)(owr - 1);
 #ifdef FPCDR_MIPSTAT
@@ -579,17 +581,10 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         // of the pixels' adds fell outside and went to memory one by one: profiles/r05_tex_window.txt)
         const bool on = k_on && k_x0 != 0x7fffffff && k_y0 != 0x7fffffff;
         const int NONE_LO = 0x7fffffff, NONE_HI = (int)0x80000000;
-        int r1 = wave_min_dpp(on ? k_x0 : NONE_LO), r2 = ~wave_min_dpp(~(on ? k_x0 : NONE_HI));
-        int r3 = wave_min_dpp(on ? k_y0 : NONE_LO), r4 = ~wave_min_dpp(~(on ? k_y0 : NONE_HI));
-        int r5 = 0, r6 = 0, r7 = 0, r8 = 0;
-        if (boundary == FPCDR_BOUNDARY_WRAP) {
-            const int cx = k_x0 >= (Wt >> 1) ? k_x0 - Wt : k_x0, cy = k_y0 >= (Ht >> 1) ? k_y0 - Ht : k_y0;
-            r5 = wave_min_dpp(on ? cx : NONE_LO); r6 = ~wave_min_dpp(~(on ? cx : NONE_HI));
-            r7 = wave_min_dpp(on ? cy : NONE_LO); r8 = ~wave_min_dpp(~(on ? cy : NONE_HI));
-        }
-        if (lane == 0 && r1 != NONE_LO) {
-            atomicMin(&s_mred[1], r1); atomicMax(&s_mred[2], r2); atomicMin(&s_mred[3], r3); atomicMax(&s_mred[4], r4);
-            if (boundary == FPCDR_BOUNDARY_WRAP) { atomicMin(&s_mred[5], r5); atomicMax(&s_mred[6], r6); atomicMin(&s_mred[7], r7); atomicMax(&s_mred[8], r8); }
+        {
+            const int r1 = wave_min_dpp(on ? k_x0 : NONE_LO), r2 = ~wave_min_dpp(~(on ? k_x0 : NONE_HI));
+            const int r3 = wave_min_dpp(on ? k_y0 : NONE_LO), r4 = ~wave_min_dpp(~(on ? k_y0 : NONE_HI));
+            if (lane == 0 && r1 != NONE_LO) { atomicMin(&s_mred[1], r1); atomicMax(&s_mred[2], r2); atomicMin(&s_mred[3], r3); atomicMax(&s_mred[4], r4); }
         }
         OPROF_T(3);
         __syncthreads();
@@ -597,7 +592,13 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         int xa = __builtin_amdgcn_readfirstlane(s_mred[1]);
         if (xa != NONE_LO) {      // (uniform)
             int xb = __builtin_amdgcn_readfirstlane(s_mred[2]), ya = __builtin_amdgcn_readfirstlane(s_mred[3]), yb = __builtin_amdgcn_readfirstlane(s_mred[4]);
-            if (boundary == FPCDR_BOUNDARY_WRAP) {
+            if (boundary == FPCDR_BOUNDARY_WRAP && (xb - xa >= (Wt >> 1) || yb - ya >= (Ht >> 1))) {
+                // (uniform, rare) a box across half the texture: a bin on the seam.  The centred view of the taps, reduced the same way
+                const int cx = k_x0 >= (Wt >> 1) ? k_x0 - Wt : k_x0, cy = k_y0 >= (Ht >> 1) ? k_y0 - Ht : k_y0;
+                const int r5 = wave_min_dpp(on ? cx : NONE_LO), r6 = ~wave_min_dpp(~(on ? cx : NONE_HI));
+                const int r7 = wave_min_dpp(on ? cy : NONE_LO), r8 = ~wave_min_dpp(~(on ? cy : NONE_HI));
+                if (lane == 0 && r5 != NONE_LO) { atomicMin(&s_mred[5], r5); atomicMax(&s_mred[6], r6); atomicMin(&s_mred[7], r7); atomicMax(&s_mred[8], r8); }
+                __syncthreads();
                 const int xa2 = __builtin_amdgcn_readfirstlane(s_mred[5]), xb2 = __builtin_amdgcn_readfirstlane(s_mred[6]);
                 const int ya2 = __builtin_amdgcn_readfirstlane(s_mred[7]), yb2 = __builtin_amdgcn_readfirstlane(s_mred[8]);
                 if (xb2 - xa2 < xb - xa) { xa = xa2; xb = xb2; }
@@ -622,6 +623,8 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             }
             ox = __builtin_amdgcn_readfirstlane((int)sx0); oy = __builtin_amdgcn_readfirstlane((int)sy0);
             ows = __builtin_amdgcn_readfirstlane(stride); owr = __builtin_amdgcn_readfirstlane(rows);
+            // (taps run from -1 to n - 1: a window from 0 on misses only the column / row of taps at -1, which then go to memory)
+            owrap = ox < 0 || oy < 0 || ox + ows > Wt || oy + owr > Ht;
         }
         if (k_on) add_taps(k_gc, k_fx, k_fy, k_x0, k_y0);
     } else {
