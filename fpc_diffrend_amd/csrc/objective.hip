@@ -38,7 +38,10 @@ constexpr int OS = 36;            // LDS row stride of the id plane with its one
 // workgroups per CU leave (26.4 KB each; cfg3: 1 600 -> 1 393 us, 1 728 -> 1 366, 1 792 -> five workgroups, 1 469; 2 400 -> 1 455 with 7 %
 // of the pixels outside instead of 13); three / four channels: 1 600 cells of 24 / 32 bytes, under 64 KB with the rest
 #ifndef FPCDR_OWIN_CELLS
-#define FPCDR_OWIN_CELLS 1728
+#define FPCDR_OWIN_CELLS 1216
+#endif
+#ifndef FPCDR_SHADE_HALVES
+#define FPCDR_SHADE_HALVES 1
 #endif
 template <int CS> constexpr int owin_cells() { return CS == 1 ? FPCDR_OWIN_CELLS : FPCDR_OTEXWIN * FPCDR_OTEXWIN; }
 constexpr int ONT = 256;          // threads of k_shade
@@ -146,7 +149,7 @@ __device__ unsigned long long g_oprof[16];
 #define FPCDR_SHADE_MIP_WPE
 #endif
 #ifndef FPCDR_SHADE_WPE
-#define FPCDR_SHADE_WPE
+#define FPCDR_SHADE_WPE __attribute__((amdgpu_waves_per_eu(CS == 1 ? 7 : 1, 8)))      // one channel: seven workgroups per CU (72 registers, 22.4 KB of LDS)
 #endif
 #ifndef FPCDR_OWIN_MARGIN
 #define FPCDR_OWIN_MARGIN 0          // cfg3, 40-texel window: margin 0 / 1 / 2 / 3 -> 2.89 / 2.90 / 2.93 / 2.97 ms per call
@@ -163,7 +166,7 @@ template <int CS, int BMODE, bool MIP = false>
 __device__ __forceinline__ void shade_body(const int b, const int bxi, const int byi, const int OX, const int OY, const ObjArgs &a,
                                            const MipO *ma = nullptr) {
     const int boundary = BMODE >= 0 ? BMODE : a.boundary;
-    __shared__ int s_mred[9];      // MIP prepass: min level, min / max keys of the prepared u and v, and of both shifted by half a period
+    __shared__ int s_mred[18];      // MIP prepass: min level, min / max keys of the prepared u and v, and of both shifted by half a period
     __shared__ unsigned int s_id[(OB + 2) * OS];
     __shared__ int s_vkey[FPCDR_VT_SLOTS];
     __shared__ double s_vacc[FPCDR_VT_SLOTS][3];
@@ -212,7 +215,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         for (int k = tid; k < TEX_CELLS * CS; k += ONT) s_tex[k] = 0.0;
     if (tid == 0) {
         s_mred[0] = 0x7fffffff;
-        for (int k = 1; k < 9; k += 2) { s_mred[k] = 0x7fffffff; s_mred[k + 1] = (int)0x80000000; }
+        for (int k = 1; k < 9; k += 2) { s_mred[k] = 0x7fffffff; s_mred[k + 1] = (int)0x80000000; s_mred[9 + k] = 0x7fffffff; s_mred[10 + k] = (int)0x80000000; }
     }
     if (tid < OB) {
         s_cmask[tid] = 0u;
@@ -310,8 +313,12 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     bool k_on = false;
 
     // ---- one pixel: shade, loss, chain back.  FIRST: pass 0 (texel adds deferred to behind the origin's barrier) ----
-    auto pixel = [&](const int k, const bool FIRST) {
-        const int zy = 2 * shade_row_pair(k, wave) + (lane >> 5), y = by0 + zy;
+    auto pixel = [&](const int row_pair, const bool FIRST) {
+        // (seven workgroups per CU leave 72 registers: two values the compiler would otherwise hold -- and, at 72, spill -- across the whole
+        //  kernel are formed where they are used: lane >> 5 here, three instructions per pixel, and the column's bit in the deferred branch)
+        int upper;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshrrev_b32 %0, 5, %0" : "=v"(upper));
+        const int zy = 2 * row_pair + upper, y = by0 + zy;
         const unsigned int me = s_id[(zy + 1) * OS + col + 1];
         const int id = (int)(me & 0xffffffu);      // (pixels beyond the image hold 0)
         int tkey = -1;
@@ -387,10 +394,12 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             }
             if (deferred) {      // k_fix reads these back: a few per cent of the covered pixels
                 any_def = true;
-                atomicOr(&s_cmask[zy], 1u << col);
+                unsigned int colbit;      // (1 << col, not hoisted: see above)
+                asm volatile("v_lshlrev_b32 %0, %1, 1" : "=v"(colbit) : "v"(col));
+                atomicOr(&s_cmask[zy], colbit);
                 if (!MIP) zw = shade_zw(v0, v1, v2, K.a0, K.a1, K.p0x * K.p1y - K.p0y * K.p1x);
                 const size_t ro = compact ? rec_slot_index(slot, col, zy) : off;
-                a.rec[ro] = make_float4(u, v, zw, (float)id);
+                a.rec[ro] = make_float4(u, v, zw, (float)(t + 1));      // (= id; t stays live for the vertex table's key, id need not)
 #pragma unroll
                 for (int c = 0; c < CS; ++c) { a.color[ro * CS + c] = colv[c]; a.g_aa[ro * CS + c] = gq[c]; }
             }
@@ -569,12 +578,10 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 place(2, MipWinCaps<CS>::N2, w2x, w2y, w2s, w2r);
             }
         }
-        pixel(0, false);
-    } else {
-    // ---- pass 0: row pairs 0, 5, 10, 15; the window's origin ----
-    pixel(0, true);
+        pixel(shade_row_pair(0, wave), false);
     }
-    if (!MIP && want_tex) {
+    // (non-mip) the texel window of the pixels whose taps the FIRST pass kept: reductions in s_mred[red .. red + 8]
+    auto setup_window = [&](const int red) __attribute__((always_inline)) {
         // the window: the bounding box of the taps of pass 0, as a rectangle of at most OCELLS cells.  A footprint is rarely square (the rig's
         // face: 1.6 texels per pixel along v, 1.0 along u -- 52 x 33 texels under a bin), and a bin across the seam of a periodic coordinate is
         // compact only in the CENTRED view of it (x >= n / 2 counted as x - n).  (r4 form: a fixed 40 x 40 window from the smallest tap; 22 %
@@ -584,23 +591,24 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         {
             const int r1 = wave_min_dpp(on ? k_x0 : NONE_LO), r2 = ~wave_min_dpp(~(on ? k_x0 : NONE_HI));
             const int r3 = wave_min_dpp(on ? k_y0 : NONE_LO), r4 = ~wave_min_dpp(~(on ? k_y0 : NONE_HI));
-            if (lane == 0 && r1 != NONE_LO) { atomicMin(&s_mred[1], r1); atomicMax(&s_mred[2], r2); atomicMin(&s_mred[3], r3); atomicMax(&s_mred[4], r4); }
+            if (lane == 0 && r1 != NONE_LO) { atomicMin(&s_mred[red + 1], r1); atomicMax(&s_mred[red + 2], r2); atomicMin(&s_mred[red + 3], r3); atomicMax(&s_mred[red + 4], r4); }
         }
         OPROF_T(3);
         __syncthreads();
         OPROF_T(4);
-        int xa = __builtin_amdgcn_readfirstlane(s_mred[1]);
+        int xa = __builtin_amdgcn_readfirstlane(s_mred[red + 1]);
+        ox = 0; oy = 0; ows = 1; owr = 1; owrap = false;
         if (xa != NONE_LO) {      // (uniform)
-            int xb = __builtin_amdgcn_readfirstlane(s_mred[2]), ya = __builtin_amdgcn_readfirstlane(s_mred[3]), yb = __builtin_amdgcn_readfirstlane(s_mred[4]);
+            int xb = __builtin_amdgcn_readfirstlane(s_mred[red + 2]), ya = __builtin_amdgcn_readfirstlane(s_mred[red + 3]), yb = __builtin_amdgcn_readfirstlane(s_mred[red + 4]);
             if (boundary == FPCDR_BOUNDARY_WRAP && (xb - xa >= (Wt >> 1) || yb - ya >= (Ht >> 1))) {
                 // (uniform, rare) a box across half the texture: a bin on the seam.  The centred view of the taps, reduced the same way
                 const int cx = k_x0 >= (Wt >> 1) ? k_x0 - Wt : k_x0, cy = k_y0 >= (Ht >> 1) ? k_y0 - Ht : k_y0;
                 const int r5 = wave_min_dpp(on ? cx : NONE_LO), r6 = ~wave_min_dpp(~(on ? cx : NONE_HI));
                 const int r7 = wave_min_dpp(on ? cy : NONE_LO), r8 = ~wave_min_dpp(~(on ? cy : NONE_HI));
-                if (lane == 0 && r5 != NONE_LO) { atomicMin(&s_mred[5], r5); atomicMax(&s_mred[6], r6); atomicMin(&s_mred[7], r7); atomicMax(&s_mred[8], r8); }
+                if (lane == 0 && r5 != NONE_LO) { atomicMin(&s_mred[red + 5], r5); atomicMax(&s_mred[red + 6], r6); atomicMin(&s_mred[red + 7], r7); atomicMax(&s_mred[red + 8], r8); }
                 __syncthreads();
-                const int xa2 = __builtin_amdgcn_readfirstlane(s_mred[5]), xb2 = __builtin_amdgcn_readfirstlane(s_mred[6]);
-                const int ya2 = __builtin_amdgcn_readfirstlane(s_mred[7]), yb2 = __builtin_amdgcn_readfirstlane(s_mred[8]);
+                const int xa2 = __builtin_amdgcn_readfirstlane(s_mred[red + 5]), xb2 = __builtin_amdgcn_readfirstlane(s_mred[red + 6]);
+                const int ya2 = __builtin_amdgcn_readfirstlane(s_mred[red + 7]), yb2 = __builtin_amdgcn_readfirstlane(s_mred[red + 8]);
                 if (xb2 - xa2 < xb - xa) { xa = xa2; xb = xb2; }
                 if (yb2 - ya2 < yb - ya) { ya = ya2; yb = yb2; }
             }
@@ -627,13 +635,49 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             owrap = ox < 0 || oy < 0 || ox + ows > Wt || oy + owr > Ht;
         }
         if (k_on) add_taps(k_gc, k_fx, k_fy, k_x0, k_y0);
-    } else {
-        OPROF_T(3);
-        OPROF_T(4);
-    }
-    // ---- passes 1 .. 3 ----
+    };
+    // ... and its flush: every cell once (a barrier has made all adds visible); rezero: the window is used again
+    auto flush_window = [&](const bool rezero) __attribute__((always_inline)) {
+        if (ows <= 1) return;      // (uniform)
+        const float inv = 1.0f / (float)ows;
+        const int n = ows * owr * CS;
+        for (int k = tid; k < n; k += ONT) {
+            const float v = (float)s_tex[k];
+            if (v != 0.0f) {
+                const int c = k % CS, cell = k / CS;
+                const int ly = (int)(((float)cell + 0.5f) * inv), lx = cell - ly * ows;      // (exact: cell < 2^12)
+                const int gx = wrap_near(ox + lx, Wt, boundary), gy = wrap_near(oy + ly, Ht, boundary);
+                atomicAdd(&at32(a.grad_tex, (unsigned int)((gy * Wt + gx) * CS + c)), v);
+                if (rezero) s_tex[k] = 0.0;
+            }
+        }
+    };
+    if (MIP) {
 #pragma unroll
-    for (int k = 1; k < 4; ++k) pixel(k, false);
+        for (int k = 1; k < 4; ++k) pixel(shade_row_pair(k, wave), false);
+    } else if (FPCDR_SHADE_HALVES) {
+        // THE BIN IN TWO HALVES (rows 0-15, then 16-31), each with a window of its own in the same LDS: half the rows have half the
+        // footprint along one axis, and 52 x 33 texels under a whole bin do not fit 1 728 cells where 27 x 33 do.  A half is two passes:
+        // the first (row pairs 0, 2, 5, 7 of the half: its first and last rows are among them) keeps its taps until the window is placed;
+        // the flush of the first half's window -- its atomics drain under the second half's arithmetic -- costs one more barrier.
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            k_on = false; k_x0 = 0x7fffffff; k_y0 = 0x7fffffff;
+            pixel(8 * half + (int)((0x7520u >> (4 * wave)) & 15u), true);
+            if (want_tex) setup_window(9 * half);
+            pixel(8 * half + (int)((0x6431u >> (4 * wave)) & 15u), false);
+            if (half == 0 && want_tex) {
+                __syncthreads();
+                flush_window(true);
+            }
+        }
+    } else {
+        // ---- pass 0: row pairs 0, 5, 10, 15; the window's origin ----
+        pixel(shade_row_pair(0, wave), true);
+        if (want_tex) setup_window(0);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) pixel(shade_row_pair(k, wave), false);
+    }
 
     lsum = wave_sum_dpp(lsum);
     if (lane == 0) s_lpart[wave] = lsum;
@@ -657,19 +701,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     if (!want_grad) return;
     // ---- flush: every vertex slot and window cell once (the barrier above has made all adds visible) ----
     if (want_pos) vtable_flush(vt, gp, tid, ONT);
-    if (!MIP && want_tex && ows > 1) {
-        const float inv = 1.0f / (float)ows;
-        const int n = ows * owr * CS;
-        for (int k = tid; k < n; k += ONT) {
-            const float v = (float)s_tex[k];
-            if (v != 0.0f) {
-                const int c = k % CS, cell = k / CS;
-                const int ly = (int)(((float)cell + 0.5f) * inv), lx = cell - ly * ows;      // (exact: cell < 2^12)
-                const int gx = wrap_near(ox + lx, Wt, boundary), gy = wrap_near(oy + ly, Ht, boundary);
-                atomicAdd(&at32(a.grad_tex, (unsigned int)((gy * Wt + gx) * CS + c)), v);
-            }
-        }
-    }
+    if (!MIP && want_tex) flush_window(false);
     if (MIP && want_tex) {
         auto flush = [&](int wx, int wy, int ws, int wr, int wb, int level) __attribute__((always_inline)) {
             if (ws <= 1) return;      // (uniform: an unused window)
@@ -1430,8 +1462,11 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
 #undef FIX_MIP
     } else
     if (p->C == 1) {
+#ifndef FPCDR_SHADE_GENERIC
         if (p->boundary_mode == FPCDR_BOUNDARY_WRAP) SHADE(1, FPCDR_BOUNDARY_WRAP);      // the reference's case, as compile-time constants
-        else SHADE(1, -1);
+        else
+#endif
+        SHADE(1, -1);
         FIX(1, 0);
         if (grads) FIX(1, 1);
         FINISH(1);
