@@ -965,13 +965,15 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                         const float amt = far ? t - 0.5f : 0.5f - t;
                         const bool rX = rx == x && ry == y;
                         const bool o_cov = (eo & 0xffffffu) != 0u;
-                        const float *co = o_cov ? a.color + rix(ox, oy) * CS : nullptr;      // (read only for a covered partner)
+                        // (the partner's colour through an INDEX that is valid either way -- element 0 for an empty partner, whose bin may have no
+                        //  slot --: a pointer selected between the array and `ecol` put `ecol` into scratch memory)
+                        const size_t ci = o_cov ? rix(ox, oy) * CS : 0;
                         if (PASS == 0) {
                             if (!rX) return;
                             hit = true;
                             hit_o |= o_cov;
 #pragma unroll
-                            for (int c = 0; c < CS; ++c) acc[c] += amt * ((o_cov ? co[c] : ecol[c]) - cme[c]);
+                            for (int c = 0; c < CS; ++c) { const float cv = a.color[ci + c]; acc[c] += amt * ((o_cov ? cv : ecol[c]) - cme[c]); }
                             return;
                         }
                         if (!rX && !o_cov) return;      // the blended pixel is an empty one: no gradient arrives
@@ -990,7 +992,8 @@ __device__ __forceinline__ void fix_body(const int b, const int bxi, const int b
                         float G = 0.f;
 #pragma unroll
                         for (int c = 0; c < CS; ++c) {
-                            const float cO = o_cov ? co[c] : ecol[c];
+                            const float cv = a.color[ci + c];
+                            const float cO = o_cov ? cv : ecol[c];
                             G += gr[c] * (PisX ? cme[c] - cO : cO - cme[c]);
                         }
                         if (G == 0.0f) return;

@@ -293,3 +293,37 @@ def test_mapped_hints_and_zero_pool_bookkeeping():
     a += 1.0
     assert float(buf[:15].sum()) == 15.0 and float(buf[15:].sum()) == 0.0
     assert other.off == 0 and other.zeros((4,), dev).data_ptr() == other.buf.data_ptr()     # (no shared state between pools)
+
+
+def test_fit_loop_kernels_have_no_private_segment():
+    """a kernel with a private segment (scratch) is dispatched several times slower, taken or not -- k_fix<1> spent 220 us
+    launching one-wave workgroups with 16 bytes of it, 47 without.  The kernels the fit loop launches (one-pass objective, its rasteriser,
+    the step's small kernels) must report private_segment_fixed_size 0 in the code object built from the sources here."""
+    import os, re, shutil, subprocess, tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    build = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fpc_diffrend_amd", "csrc", "_build")
+    if not (os.path.isdir(build) and os.path.exists(os.path.join(llvm, "llvm-readelf"))):
+        pytest.skip("no built objects / llvm tools")
+    hot = {"objective.o": r"k_shade_list|k_fix_list|k_shade_mip_list|k_fix_mip_list|k_objective_finish|k_count_sil",
+           "rasterize.o": r"k_setupILb1ELb1|k_bins_listILb0ELb0ELb0ELi0ELin1ELb0ELb1|k_list_|k_init_objective",      # (k_setup_clip keeps the clipper's)
+           "clip.o": r"k_clip_|k_mvp_|k_lap_", "blend.o": r"k_blend_fwd_lds|k_blend_bwd_w|k_rig_", "adam.o": r"k_adam"}
+    seen = 0
+    for obj, pattern in hot.items():
+        path = os.path.join(build, obj)
+        if not os.path.exists(path):
+            pytest.skip("objects not built")
+        tmp = tempfile.mkdtemp()
+        try:
+            subprocess.check_call([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={tmp}/fb.bin", path], stderr=subprocess.DEVNULL)
+            subprocess.check_call([f"{llvm}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                   f"--input={tmp}/fb.bin", f"--output={tmp}/dev.co", "--unbundle"], stderr=subprocess.DEVNULL)
+            notes = subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", f"{tmp}/dev.co"], text=True)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        for blk in re.split(r"\n\s*- \.agpr_count", notes)[1:]:
+            name = re.search(r"\.name:\s*(\S+)", blk).group(1)
+            if re.search(pattern, name):
+                seen += 1
+                scratch = int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", blk).group(1))
+                assert scratch == 0, (obj, name, scratch)
+    assert seen >= 20
