@@ -641,12 +641,15 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         if (ows <= 1) return;      // (uniform)
         const float inv = 1.0f / (float)ows;
         const int n = ows * owr * CS;
+        // (a window inside the texture -- nearly all -- holds texel (ox + lx, oy + ly) as it is: no wrapping, no clamping; uniform branch)
+        const bool plain = !owrap && ox >= 0 && oy >= 0 && ox + ows <= Wt && oy + owr <= Ht;
         for (int k = tid; k < n; k += ONT) {
             const float v = (float)s_tex[k];
             if (v != 0.0f) {
                 const int c = k % CS, cell = k / CS;
                 const int ly = (int)(((float)cell + 0.5f) * inv), lx = cell - ly * ows;      // (exact: cell < 2^12)
-                const int gx = wrap_near(ox + lx, Wt, boundary), gy = wrap_near(oy + ly, Ht, boundary);
+                int gx = ox + lx, gy = oy + ly;
+                if (!plain) { gx = wrap_near(gx, Wt, boundary); gy = wrap_near(gy, Ht, boundary); }
                 atomicAdd(&at32(a.grad_tex, (unsigned int)((gy * Wt + gx) * CS + c)), v);
                 if (rezero) s_tex[k] = 0.0;
             }
