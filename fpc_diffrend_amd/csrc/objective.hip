@@ -261,6 +261,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     int ox = 0, oy = 0, ows = 1, owr = 1;      // origin, row stride and rows of the texel window (set behind the barrier after pass 0; stride 1: none)
     // MIP: the three windows (set behind the prepass's barrier), as scalars -- structs selected per lane ended up in scratch memory
     int w0x = 0, w0y = 0, w0s = 1, w0r = 1, w1x = 0, w1y = 0, w1s = 1, w1r = 1, w2x = 0, w2y = 0, w2s = 1, w2r = 1;
+    bool w0wrap = false, w1wrap = false, w2wrap = false;      // the window reaches across the edge of its level (then cells are found modulo its size)
     constexpr int w0b = 0, w1b = MipWinCaps<CS>::N0, w2b = MipWinCaps<CS>::N0 + MipWinCaps<CS>::N1;
 #ifdef FPCDR_MIPSTAT
     int mfit0 = 0, mfit1 = 0, mfit2 = 0;
@@ -415,19 +416,19 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 bool il[3];
                 {
                     int lx = (int)floorf(pu * (float)(Wt >> mlb) - 0.5f) - w0x, ly = (int)floorf(pv * (float)(Ht >> mlb) - 0.5f) - w0y;
-                    if (boundary == FPCDR_BOUNDARY_WRAP) { lx = wrap_cell(lx, Wt >> mlb); ly = wrap_cell(ly, Ht >> mlb); }
+                    if (boundary == FPCDR_BOUNDARY_WRAP && w0wrap) { lx = wrap_cell(lx, Wt >> mlb); ly = wrap_cell(ly, Ht >> mlb); }      // (uniform)
                     cl[0] = w0b + ly * w0s + lx; sl[0] = w0s;
                     il[0] = (unsigned int)lx < (unsigned int)(w0s - 1) && (unsigned int)ly < (unsigned int)(w0r - 1);
                 }
                 {
                     int lx = (int)floorf(pu * (float)(Wt >> (mlb + 1)) - 0.5f) - w1x, ly = (int)floorf(pv * (float)(Ht >> (mlb + 1)) - 0.5f) - w1y;
-                    if (boundary == FPCDR_BOUNDARY_WRAP) { lx = wrap_cell(lx, Wt >> (mlb + 1)); ly = wrap_cell(ly, Ht >> (mlb + 1)); }
+                    if (boundary == FPCDR_BOUNDARY_WRAP && w1wrap) { lx = wrap_cell(lx, Wt >> (mlb + 1)); ly = wrap_cell(ly, Ht >> (mlb + 1)); }      // (uniform)
                     cl[1] = w1b + ly * w1s + lx; sl[1] = w1s;
                     il[1] = (unsigned int)lx < (unsigned int)(w1s - 1) && (unsigned int)ly < (unsigned int)(w1r - 1);
                 }
                 {
                     int lx = (int)floorf(pu * (float)(Wt >> (mlb + 2)) - 0.5f) - w2x, ly = (int)floorf(pv * (float)(Ht >> (mlb + 2)) - 0.5f) - w2y;
-                    if (boundary == FPCDR_BOUNDARY_WRAP) { lx = wrap_cell(lx, Wt >> (mlb + 2)); ly = wrap_cell(ly, Ht >> (mlb + 2)); }
+                    if (boundary == FPCDR_BOUNDARY_WRAP && w2wrap) { lx = wrap_cell(lx, Wt >> (mlb + 2)); ly = wrap_cell(ly, Ht >> (mlb + 2)); }      // (uniform)
                     cl[2] = w2b + ly * w2s + lx; sl[2] = w2s;
                     il[2] = (unsigned int)lx < (unsigned int)(w2s - 1) && (unsigned int)ly < (unsigned int)(w2r - 1);
                 }
@@ -576,6 +577,9 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 place(0, MipWinCaps<CS>::N0, w0x, w0y, w0s, w0r);
                 place(1, MipWinCaps<CS>::N1, w1x, w1y, w1s, w1r);
                 place(2, MipWinCaps<CS>::N2, w2x, w2y, w2s, w2r);
+                w0wrap = w0x < 0 || w0y < 0 || w0x + w0s > (Wt >> mlb) || w0y + w0r > (Ht >> mlb);
+                w1wrap = w1x < 0 || w1y < 0 || w1x + w1s > (Wt >> (mlb + 1)) || w1y + w1r > (Ht >> (mlb + 1));
+                w2wrap = w2x < 0 || w2y < 0 || w2x + w2s > (Wt >> (mlb + 2)) || w2y + w2r > (Ht >> (mlb + 2));
             }
         }
         pixel(shade_row_pair(0, wave), false);
@@ -712,12 +716,14 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             const float inv = 1.0f / (float)ws;
             float *const g = ma->lv.grad[level];
             const int n = ws * wr * CS;
+            const bool plain = wx >= 0 && wy >= 0 && wx + ws <= wl && wy + wr <= hl;      // (uniform) the window lies inside its level
             for (int k = tid; k < n; k += ONT) {
                 const float v = (float)s_tex[wb * CS + k];
                 if (v != 0.0f) {
                     const int c = k % CS, cell = k / CS;
                     const int ly = (int)(((float)cell + 0.5f) * inv), lx = cell - ly * ws;      // (exact: cell < 2^12)
-                    const int gx = wrap_near(wx + lx, wl, boundary), gy = wrap_near(wy + ly, hl, boundary);
+                    int gx = wx + lx, gy = wy + ly;
+                    if (!plain) { gx = wrap_near(gx, wl, boundary); gy = wrap_near(gy, hl, boundary); }
                     atomicAdd(g + (size_t)(gy * wl + gx) * CS + c, v);
                 }
             }
