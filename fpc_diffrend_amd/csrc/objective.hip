@@ -30,13 +30,14 @@ namespace {
 #include "sil_bits.h"
 
 #ifndef FPCDR_OTEXWIN
-#define FPCDR_OTEXWIN 40          // texel window of a bin (see fused.hip: capacity swept 8 .. 64 at ~1 texel per pixel)
+#define FPCDR_OTEXWIN 40          // three / four channels: the window holds FPCDR_OTEXWIN^2 cells (one channel: FPCDR_OWIN_CELLS, below)
 #endif
 constexpr int OB = 32;            // pixels per bin side
 constexpr int OS = 36;            // LDS row stride of the id plane with its one-pixel apron (34 entries used)
-// cells of the (non-mip) texel window, a rectangle shaped by the bin's footprint.  One channel: 1 728 cells of 8 bytes are what six
-// workgroups per CU leave (26.4 KB each; cfg3: 1 600 -> 1 393 us, 1 728 -> 1 366, 1 792 -> five workgroups, 1 469; 2 400 -> 1 455 with 7 %
-// of the pixels outside instead of 13); three / four channels: 1 600 cells of 24 / 32 bytes, under 64 KB with the rest
+// cells of the (non-mip) texel window, a rectangle shaped by the footprint of half a bin.  One channel: 1 216 cells of 8 bytes hold a
+// half's footprint on the face rig (27 x 33 texels) and leave LDS for SEVEN workgroups per CU (22.4 KB each); for the whole bin 1 728
+// cells were what six workgroups left (profiles/r05_flush_experiments.txt 10, 13).  Three / four channels: 1 600 cells of 24 / 32
+// bytes, under 64 KB with the rest
 #ifndef FPCDR_OWIN_CELLS
 #define FPCDR_OWIN_CELLS 1216
 #endif
@@ -139,12 +140,15 @@ __device__ unsigned long long g_oprof[16];
 // to left, so that the pixels of a triangle are neighbours in lane order and ONE segmented scan per pass sums the nine vertex gradient
 // components of every run (common.h wave_segment_reduce9).
 //
-// The texel window needs its origin -- the bin's smallest tap -- before the first add.  Pass 0 of the four waves covers the row pairs
-// 0/1, 10/11, 20/21, 30/31: for a locally affine uv map the smallest tap lies in the bin's first or last row, which pass 0 holds, and
-// no row is more than four from a sampled one; the window starts OWIN_MARGIN texels below the minimum of pass 0 and whatever still
-// falls outside (uv seams, a second surface in the bin) goes to memory with atomics.  So a pixel's four texel adds happen right where
-// its weights are formed: nothing is kept across a barrier (the two-phase form held 20 registers per thread for it: 88 VGPRs and
-// 5 waves per SIMD, where this form runs 7 -- worth 0.2 ms at cfg3 on the same instructions).
+// The texel gradients of the bin are summed in an LDS window and flushed once per cell ("The texel window" / "Two halves,
+// seven workgroups").  The bin is shaded as two HALVES (rows 0-15, 16-31) of two wave passes each.  A half's first pass covers its row
+// pairs 0, 2, 5, 7 -- its first and last rows among them: for a locally affine uv map the extreme taps lie there -- and keeps each
+// pixel's taps in registers; their bounding box, reduced over the workgroup, places the half's window (a rectangle of at most 1 216
+// cells shaped by the box, seam-aware); the kept taps and the second pass add into it; whatever still falls outside (3.8 % of the
+// pixels at cfg3: a second surface, a pole of the uv map) goes to memory with float atomics.  The first half's window is flushed and
+// zeroed before the second half's is placed.  So a pixel's four texel adds happen right where its weights are formed: apart from the
+// first pass's taps nothing is kept across a barrier (the two-phase form of r3 held 20 registers per thread for it: 88 VGPRs and 5
+// waves per SIMD, where this form runs 7).
 #ifndef FPCDR_SHADE_MIP_WPE
 #define FPCDR_SHADE_MIP_WPE
 #endif
@@ -152,10 +156,10 @@ __device__ unsigned long long g_oprof[16];
 #define FPCDR_SHADE_WPE __attribute__((amdgpu_waves_per_eu(CS == 1 ? 7 : 1, 8)))      // one channel: seven workgroups per CU (72 registers, 22.4 KB of LDS)
 #endif
 #ifndef FPCDR_OWIN_MARGIN
-#define FPCDR_OWIN_MARGIN 0          // cfg3, 40-texel window: margin 0 / 1 / 2 / 3 -> 2.89 / 2.90 / 2.93 / 2.97 ms per call
+#define FPCDR_OWIN_MARGIN 0          // texels around the box of the first pass's taps (1: no gain, profiles/r05_flush_experiments.txt 10)
 #endif
 constexpr int OWIN_MARGIN = FPCDR_OWIN_MARGIN;
-// row pair (rows 2 p, 2 p + 1) of wave w in pass k
+// row pair (rows 2 p, 2 p + 1) of wave w in pass k of the whole-bin order (the mip instantiation; -DFPCDR_SHADE_HALVES=0)
 __device__ __forceinline__ int shade_row_pair(int k, int w) {
     // k = 0: 0, 5, 10, 15;  k = 1: 1, 6, 11, 14;  k = 2: 2, 7, 12, 13;  k = 3: 3, 4, 8, 9
     const unsigned int packed = k == 0 ? 0xFA50u : (k == 1 ? 0xEB61u : (k == 2 ? 0xDC72u : 0x9843u));
@@ -586,10 +590,10 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     }
     // (non-mip) the texel window of the pixels whose taps the FIRST pass kept: reductions in s_mred[red .. red + 8]
     auto setup_window = [&](const int red) __attribute__((always_inline)) {
-        // the window: the bounding box of the taps of pass 0, as a rectangle of at most OCELLS cells.  A footprint is rarely square (the rig's
-        // face: 1.6 texels per pixel along v, 1.0 along u -- 52 x 33 texels under a bin), and a bin across the seam of a periodic coordinate is
-        // compact only in the CENTRED view of it (x >= n / 2 counted as x - n).  (r4 form: a fixed 40 x 40 window from the smallest tap; 22 %
-        // of the pixels' adds fell outside and went to memory one by one: profiles/r05_tex_window.txt)
+        // the window: the bounding box of the taps the FIRST pass kept, as a rectangle of at most OCELLS cells.  A footprint is rarely square
+        // (the rig's face: 1.6 texels per pixel along v, 1.0 along u -- 52 x 33 texels under a bin), and a bin across the seam of a periodic
+        // coordinate is compact only in the CENTRED view of it (x >= n / 2 counted as x - n).  (r4 form: a fixed 40 x 40 window from the
+        // smallest tap; 22 % of the pixels' adds fell outside and went to memory one by one: profiles/r05_flush_experiments.txt 10)
         const bool on = k_on && k_x0 != 0x7fffffff && k_y0 != 0x7fffffff;
         const int NONE_LO = 0x7fffffff, NONE_HI = (int)0x80000000;
         {
