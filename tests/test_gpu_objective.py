@@ -252,3 +252,44 @@ def test_large_batch_sizes_its_record_pool_from_a_counting_call_then_from_the_la
     third = run()      # (the shape counts afresh and carries on)
     assert abs(third[0] - dense[0]) <= 1e-6 * abs(dense[0])
     dr.clear_hints()
+
+
+@pytest.mark.parametrize("tex_hw", [(4, 4), (2, 8), (16, 4), (64, 64)])
+@pytest.mark.parametrize("boundary", ['wrap', 'clamp', 'zero'])
+def test_texel_windows_with_tiny_textures_and_coordinates_far_outside_the_unit_square(tex_hw, boundary):
+    """The shading kernels sum texel gradients in LDS windows shaped by a bin's footprint: rectangles in unwrapped texel
+    coordinates, cells found modulo the texture's size.  Textures smaller than a window, footprints across many periods and all three
+    boundary modes, with and without mip levels, against the operator chain."""
+    import fpc_diffrend_amd.ops as dr
+    from fpc_diffrend_amd import fit
+    dev = 'cuda'
+    ctx = dr.RasterizeGLContext(device=dev)
+    res, B, nt = (96, 128), 2, 40
+    Ht, Wt = tex_hw
+    pos, tri = random_soup(B, nt, seed=Ht * 31 + Wt, spread=0.8, size=0.7)
+    tri = tri.to(dev)
+    g = torch.Generator().manual_seed(3)
+    tex0 = torch.rand(Ht, Wt, 1, generator=g) * 0.6
+    ref = torch.randint(0, 141, (B,) + res, generator=g, dtype=torch.uint8).to(dev)
+    for scale in (0.3, 6.0):
+        uv = ((torch.rand(3 * nt, 2, generator=g) - 0.3) * scale).to(dev)
+        for mip in (False, True):
+            out = {}
+            for name in ('chain', 'one'):
+                p, t = pos.to(dev).clone().requires_grad_(True), tex0.to(dev).clone().requires_grad_(True)
+                if name == 'chain':
+                    rast, rdb = dr.rasterize(ctx, p, tri, res)
+                    if mip:
+                        texc, texd = dr.interpolate(uv[None], rast, tri, rast_db=rdb, diff_attrs='all')
+                        col = dr.texture(t[None], texc, texd, filter_mode='linear-mipmap-linear', boundary_mode=boundary, max_mip_level=1)
+                    else:
+                        texc, _ = dr.interpolate(uv[None], rast, tri)
+                        col = dr.texture(t[None], texc, filter_mode='linear', boundary_mode=boundary)
+                    img = torch.where(rast[..., 3:] > 0, dr.antialias(col, rast, p, tri), torch.tensor(fit.BACKGROUND, device=dev))
+                    loss = torch.mean((ref[..., None].float() - img * 255) ** 2)
+                else:
+                    loss = dr.pixel_objective(ctx, p, tri, uv, tri, t, ref, res, boundary_mode=boundary, enable_mip=mip, max_mip_level=1)
+                loss.backward()
+                out[name] = (float(loss.detach()), p.grad.double().cpu(), t.grad.double().cpu())
+            assert abs(out['one'][0] - out['chain'][0]) <= 3e-6 * abs(out['chain'][0]), (scale, mip)
+            assert rel_l2(out['one'][1], out['chain'][1]) < 1e-4 and rel_l2(out['one'][2], out['chain'][2]) < 1e-4, (scale, mip)
