@@ -300,8 +300,16 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 lds_add_f64(wp + ows * CS + CS, gc[c] * w11);
             }
         } else {
-            const int ix0 = wrap_near(x0, Wt, boundary), ix1 = wrap_near(x0 == 0x7fffffff ? x0 : x0 + 1, Wt, boundary);
-            const int iy0 = wrap_near(y0, Ht, boundary), iy1 = wrap_near(y0 == 0x7fffffff ? y0 : y0 + 1, Ht, boundary);
+            // (a wave with ONE pixel outside its window issues all of this: with the coordinate wrapped into [0, 1) the taps lie in
+            //  [-1, n - 1], so one conditional add and the clamp that make_taps_fast uses do what wrap_near's general form does)
+            int ix0, ix1, iy0, iy1;
+            if (boundary == FPCDR_BOUNDARY_WRAP) {
+                ix0 = clamp_idx(x0 + (x0 < 0 ? Wt : 0), Wt); iy0 = clamp_idx(y0 + (y0 < 0 ? Ht : 0), Ht);
+                ix1 = clamp_idx(x0 >= Wt - 1 ? x0 + 1 - Wt : x0 + 1, Wt); iy1 = clamp_idx(y0 >= Ht - 1 ? y0 + 1 - Ht : y0 + 1, Ht);
+            } else {
+                ix0 = wrap_near(x0, Wt, boundary); ix1 = wrap_near(x0 == 0x7fffffff ? x0 : x0 + 1, Wt, boundary);
+                iy0 = wrap_near(y0, Ht, boundary); iy1 = wrap_near(y0 == 0x7fffffff ? y0 : y0 + 1, Ht, boundary);
+            }
 #pragma unroll
             for (int c = 0; c < CS; ++c) {
                 atomicAdd(&at32(a.grad_tex, (unsigned int)((iy0 * Wt + ix0) * CS + c)), gc[c] * w00);
