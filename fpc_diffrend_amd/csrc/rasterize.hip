@@ -817,8 +817,14 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
             if (tid < n * split) {
                 const int part = (tid >= n) + (tid >= 2 * n) + (tid >= 3 * n);
                 const int t = gl ? ld32(gl, (unsigned int)(gl_base + tid - part * n)) : s_list[pending - n + (tid - part * n)];
+                // IDS: the triangle's silhouette bits ride BELOW its index in the depth key -- (index << 3) | bits keeps the order of the
+                // indices (rule R6) -- so that the read-out has them with the winner: one byte gather per (bin, triangle), in flight beside
+                // the record's, instead of a dependent one per pixel at the workgroup's end
+                unsigned int silb = IDS ? (unsigned int)ld32(sh.sil + (size_t)b * T, (unsigned int)(t < T ? t : 0)) : 0u;
                 const TriRec r = ld32(rc, t);
                 const TriBox q = ld32(bx, t);
+                if (IDS && t >= T) silb = (unsigned int)ld32(sh.sil + (size_t)b * T, (unsigned int)r.tid);      // (second piece of a clipped triangle)
+                const int zkey = IDS ? (int)(((unsigned int)r.tid << 3) | silb) : r.tid;
                 const int ext_x = max(r.X0, max(r.X1, r.X2)) - min(r.X0, min(r.X1, r.X2));
                 const int ext_y = max(r.Y0, max(r.Y1, r.Y2)) - min(r.Y0, min(r.Y1, r.Y2));
                 const int x0 = max((int)q.x0, bin_x0), x1 = min((int)q.x1, bin_x1);
@@ -854,7 +860,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                         for (int c = 0; c < bw; ++c) {
                             if ((E0 | E1 | E2) >= 0) {
                                 const float d = __fmaf_rn(r.zA, (float)rx, dzr);
-                                if (d >= -1.0f && d <= 1.0f) atomicMin(&zrow[c], zpack(d, r.tid));
+                                if (d >= -1.0f && d <= 1.0f) atomicMin(&zrow[c], zpack(d, zkey));
                             }
                             E0 += A0s; E1 += A1s; E2 += A2s; rx += SUBPIX;
                         }
@@ -878,7 +884,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                     const TriRec r = ld32(rc, t);
                     const TriBox q = ld32(bx, t);
                     EdgeRec e;
-                    e.id = r.tid;
+                    e.id = IDS ? (int)(((unsigned int)r.tid << 3) | (unsigned int)ld32(sh.sil + (size_t)b * T, (unsigned int)r.tid)) : r.tid;      // (the depth key's low word)
                     e.zA = r.zA; e.zB = r.zB; e.z0 = r.z0;
                     e.X0 = r.X0; e.Y0 = r.Y0;
                     const int ext_x = max(r.X0, max(r.X1, r.X2)) - min(r.X0, min(r.X1, r.X2));
@@ -1063,15 +1069,15 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
     if (IDS) {
         // one-pass objective: the plane of this bin's winners, 16 bytes per thread (four adjacent pixels of row tid >> 3); the
         // silhouette bits of a pixel's triangle ride above its id, so that the shading kernel classifies pixel pairs from ids alone
-        const uint8_t *const sil_img = sh.sil + (size_t)b * T;
         const int r = tid >> 3, c4 = (tid & 7) * 4;
         unsigned int e[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned long long z = s_z[r * BIN + c4 + j];
             // (the tile path resolves whole 16 x 16 tiles: a winner beyond the image's right / top border is not a pixel)
-            const int t = (z == Z_EMPTY || bin_x0 + c4 + j >= W || bin_y0 + r >= H) ? -1 : (int)(unsigned int)z;
-            e[j] = t >= 0 ? (((unsigned int)ld32(sil_img, t) << 24) | (unsigned int)(t + 1)) : 0u;
+            const unsigned int key = (unsigned int)z;      // (triangle << 3) | silhouette bits
+            const bool none = z == Z_EMPTY || bin_x0 + c4 + j >= W || bin_y0 + r >= H;
+            e[j] = none ? 0u : (((key & 7u) << 24) | ((key >> 3) + 1u));
         }
         reinterpret_cast<uint4 *>(sh.idp + bin_lin * (BIN * BIN))[tid] = make_uint4(e[0], e[1], e[2], e[3]);
         return;
