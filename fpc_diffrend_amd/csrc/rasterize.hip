@@ -777,6 +777,10 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         for (int q = 0; q < 4; ++q) { best_d[k][q] = 2.0f; best_id[k][q] = -1; }
 
     int total_hits = 0;   // block-uniform: triangles whose bounding box touches this bin
+    // IDS: the bin's list count is requested HERE, beside the image box, not behind the depth buffer's initialisation and its barrier: one
+    // hop less in the chain count -> entry -> record that every workgroup waits through.  (This thread's list entry requested here as well
+    // cost the one-pass instantiation a spilled register -- 72 are what seven workgroups per CU leave -- and so a private segment.)
+    const int cnt_early = (IDS && sh.bin_cnt) ? sh.bin_cnt[bin_lin] : -1;
     const ImgBox ib = ibox[b];
     const bool bin_live = !(ib.x1 < bin_x0 || ib.x0 > bin_x1 || ib.y1 < bin_y0 || ib.y0 > bin_y1);
     const bool sparse = (SHADE || IDS) && sh.occ != nullptr;
@@ -945,7 +949,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
             __syncthreads();
         };
         // ---- the bin's own triangle list (one count, one gather), unless it overflowed ----
-        const int n_listed = (IDS && sh.bin_cnt) ? __builtin_amdgcn_readfirstlane(sh.bin_cnt[bin_lin]) : -1;
+        const int n_listed = (IDS && sh.bin_cnt) ? __builtin_amdgcn_readfirstlane(cnt_early) : -1;
         if (n_listed >= 0 && n_listed <= BL_CAP) {
             gl = sh.bin_list + bin_lin * BL_CAP;
             total_hits = n_listed;
