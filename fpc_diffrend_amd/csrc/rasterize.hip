@@ -777,10 +777,13 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         for (int q = 0; q < 4; ++q) { best_d[k][q] = 2.0f; best_id[k][q] = -1; }
 
     int total_hits = 0;   // block-uniform: triangles whose bounding box touches this bin
-    // IDS: the bin's list count is requested HERE, beside the image box, not behind the depth buffer's initialisation and its barrier: one
-    // hop less in the chain count -> entry -> record that every workgroup waits through.  (This thread's list entry requested here as well
-    // cost the one-pass instantiation a spilled register -- 72 are what seven workgroups per CU leave -- and so a private segment.)
+    // IDS: the bin's list count and this thread's entry of the list are requested HERE, beside the image box, not behind the depth
+    // buffer's initialisation and its barrier: two hops less in the chain count -> entry -> record that every workgroup waits through.
+    // The entry goes to s_list with the initialisation (it must not live in a register across the walk: 72 are what seven workgroups per
+    // CU leave); entries at or beyond the count are never read, and the list holds BL_CAP = 256 slots per bin: the address is valid.
+    static_assert(BL_CAP == BATCH, "one list entry per thread");
     const int cnt_early = (IDS && sh.bin_cnt) ? sh.bin_cnt[bin_lin] : -1;
+    const int entry_early = (IDS && sh.bin_cnt) ? sh.bin_list[bin_lin * BL_CAP + tid] : 0;
     const ImgBox ib = ibox[b];
     const bool bin_live = !(ib.x1 < bin_x0 || ib.x0 > bin_x1 || ib.y1 < bin_y0 || ib.y0 > bin_y1);
     const bool sparse = (SHADE || IDS) && sh.occ != nullptr;
@@ -797,6 +800,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         for (int k = tid; k < BIN * BIN; k += 256) s_z[k] = Z_EMPTY;
         for (int k = tid; k < 4 * NTILES * (BIGB / 64); k += 256) (&s_mask[0][0][0][0])[k] = 0ull;
         if (tid == 0) { s_nbig = 0; s_pending = 0; s_nlive = 0; }
+        if (IDS && sh.bin_cnt) s_list[tid] = entry_early;
         __syncthreads();
         // record slots of the image: [0, T) one per triangle, [Tp, Tp + n_over) the second pieces of clipped triangles (k_setup); slot =
         // chunk * 256 + lane in both regions (Tp is chunk-aligned), and the overflow chunks, which carry no chunk box, are all scanned
@@ -810,8 +814,6 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
         int round_no = 0; // block-uniform: tile-path rounds done (parity selects the mask buffer)
         // The winner of a pixel is the minimum of (depth, triangle index), which does not depend on the order in which
         // triangles arrive: lists are filled with one LDS atomic per wave and consumed from the top, no ordered compaction.
-        const int32_t *gl = nullptr;      // the bin's own list (k_setup<true>): entries [gl_base, gl_base + n) instead of s_list
-        int gl_base = 0;
         auto process_batch = [&](const int n) {
             // consumes entries [pending - n, pending) of s_list; a barrier has been passed since they were appended
             // ---- lane path: a thread rasterises one triangle of the batch over its bounding box; a batch of at most 128 (64)
@@ -820,7 +822,7 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
             const int split = n <= 64 ? 4 : (n <= 128 ? 2 : 1);
             if (tid < n * split) {
                 const int part = (tid >= n) + (tid >= 2 * n) + (tid >= 3 * n);
-                const int t = gl ? ld32(gl, (unsigned int)(gl_base + tid - part * n)) : s_list[pending - n + (tid - part * n)];
+                const int t = s_list[pending - n + (tid - part * n)];
                 // IDS: the triangle's silhouette bits ride BELOW its index in the depth key -- (index << 3) | bits keeps the order of the
                 // indices (rule R6) -- so that the read-out has them with the winner: one byte gather per (bin, triangle), in flight beside
                 // the record's, instead of a dependent one per pixel at the workgroup's end
@@ -944,16 +946,18 @@ __device__ __forceinline__ void bins_body(const int b, const int bxi, const int 
                 // this parity's masks are next written two rounds from now, with a barrier in between
                 for (int k = tid; k < 2 * NTILES * (BIGB / 64); k += 256) (&mask[0][0][0])[k] = 0ull;
             }
-            if (tid == 0) { if (!gl) s_pending = pending - n; s_nbig = 0; }
-            if (!gl) pending -= n;
+            if (tid == 0) { s_pending = pending - n; s_nbig = 0; }
+            pending -= n;
             __syncthreads();
         };
         // ---- the bin's own triangle list (one count, one gather), unless it overflowed ----
         const int n_listed = (IDS && sh.bin_cnt) ? __builtin_amdgcn_readfirstlane(cnt_early) : -1;
         if (n_listed >= 0 && n_listed <= BL_CAP) {
-            gl = sh.bin_list + bin_lin * BL_CAP;
             total_hits = n_listed;
-            for (gl_base = 0; gl_base < n_listed; gl_base += BATCH) process_batch(min(BATCH, n_listed - gl_base));
+            if (n_listed > 0) {      // (the list is in s_list[0 .. n_listed): one batch)
+                pending = n_listed;
+                process_batch(n_listed);
+            }
         } else
         for (int seg = 0; seg < n_chunks; seg += 256) {
             // ---- which of the next 256 chunks touch this bin?  (one box test per chunk) ----
