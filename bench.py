@@ -28,6 +28,101 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def requested_gpus(argv):
+    """The N of `--gpus N` / `--gpus=N` on a command line (1 when absent)."""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    return n
+
+
+def wants_self_launch(argv, env=None):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a torchrun environment: the process is then a launcher, not a rank."""
+    env = os.environ if env is None else env
+    return requested_gpus(argv) > 1 and int(env.get("WORLD_SIZE", "1")) <= 1 and "RANK" not in env
+
+
+def self_launch(argv, timeout_s=None):
+    """One process per GPU, started from here: this parent touches no GPU (it does not even import torch), picks a free rendezvous port on
+    127.0.0.1 and starts N FRESH children `python bench.py <argv>` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- no exec of a
+    process that initialised a device.  Rank 0's stdout is relayed as this process's stdout (its JSON line is the last line); the other
+    ranks' stdout and every stderr go to stderr.  A child that fails, or the timeout (FPCDR_BENCH_LAUNCH_TIMEOUT seconds, default 1500),
+    ends the others by their own PIDs and makes the launcher exit non-zero."""
+    import socket
+    import subprocess
+    import threading
+    n = requested_gpus(argv)
+    timeout_s = float(os.environ.get("FPCDR_BENCH_LAUNCH_TIMEOUT", "1500")) if timeout_s is None else timeout_s
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs, relays, last_line = [], [], [None]
+
+    def relay(stream, to_stdout):
+        for raw in iter(stream.readline, b""):
+            line = raw.decode(errors="replace")
+            if to_stdout:
+                if line.strip():
+                    last_line[0] = line.strip()
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(line)
+                sys.stderr.flush()
+        stream.close()
+
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdin=subprocess.DEVNULL,
+                             stdout=subprocess.PIPE, stderr=None)
+        procs.append(p)
+        t = threading.Thread(target=relay, args=(p.stdout, r == 0), daemon=True)
+        t.start()
+        relays.append(t)
+    deadline = time.monotonic() + timeout_s
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            failed = f"timeout after {timeout_s:.0f} s"
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:              # exactly the PIDs started above
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    for t in relays:
+        t.join(timeout=5.0)
+    if failed:
+        sys.stderr.write(f"bench.py launcher (--gpus {n}): {failed}; the other ranks were stopped\n")
+        return 1
+    if last_line[0] is None or not last_line[0].startswith("{"):
+        sys.stderr.write(f"bench.py launcher (--gpus {n}): rank 0 printed no JSON line\n")
+        return 1
+    return 0
+
+
+if __name__ == "__main__" and wants_self_launch(sys.argv[1:]):
+    sys.exit(self_launch(sys.argv[1:]))
+
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
@@ -305,7 +400,8 @@ def main():
     from fpc_diffrend_amd import _lib, dist as fdist, fit, scene
 
     rank, world, local_rank = fdist.init()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, (f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` (it launches "
+                                "its own ranks) or through torch.distributed.run with --nproc-per-node equal to --gpus")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)

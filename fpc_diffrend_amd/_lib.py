@@ -15,7 +15,7 @@ MAX_ATTR = 32
 MAX_MIP = 16
 LOSS_SLOTS = 256
 OCC_BIN = 32         # FPCDR_OCC_BIN
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 FILTER = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
 BOUNDARY = {'wrap': 0, 'clamp': 1, 'zero': 2}
@@ -73,7 +73,7 @@ class Objective(ctypes.Structure):
                 ("tex_mip", _p * MAX_MIP), ("grad_tex_mip", _p * MAX_MIP), ("binlist", _p), ("sil_event", _p),
                 ("zero_outputs", _i), ("counts_seq", _i), ("counts_out", _p), ("bg_sumsq", _p), ("bg_coeff", ctypes.c_double),
                 ("n_total", ctypes.c_double), ("value_out", _p), ("zero_extra", _p), ("zero_extra_bytes", ctypes.c_int64),
-                ("rec_slots", _i), ("count_only", _i), ("slot_map", _p)]
+                ("rec_slots", _i), ("count_only", _i), ("slot_map", _p), ("skip_out", _p)]
 
 
 class InterpolateFwd(ctypes.Structure):
@@ -123,13 +123,14 @@ ADAM_MAX_TENSORS = 16     # FPCDR_ADAM_MAX_TENSORS
 
 class AdamTensor(ctypes.Structure):
     _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("n", ctypes.c_int64),
-                ("step_size", ctypes.c_float), ("bc2_sqrt", ctypes.c_float), ("renorm", _i), ("table_row", _i)]
+                ("step_size", ctypes.c_float), ("bc2_sqrt", ctypes.c_float), ("renorm", _i), ("table_row", _i),
+                ("step", _i), ("lr", ctypes.c_float)]
 
 
 class AdamParams(ctypes.Structure):
     _fields_ = [("n_tensors", _i), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
                 ("one_minus_beta1", ctypes.c_float), ("one_minus_beta2", ctypes.c_float), ("t", AdamTensor * ADAM_MAX_TENSORS),
-                ("step_table", _p)]
+                ("step_table", _p), ("skip_flag", _p), ("skipped", _p), ("lr_skip_gain", ctypes.c_double)]
 
 
 # every symbol include/fpcdr.h declares: name -> (restype, argtypes)

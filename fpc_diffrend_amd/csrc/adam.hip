@@ -17,9 +17,24 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 }
 
 __global__ void __launch_bounds__(256) k_adam_step(fpcdr_adam_params P) {
+    // a step whose gradients are invalid (fpcdr_objective_params.skip_out, summed over the ranks): nothing is touched -- neither parameters
+    // nor moments nor the quaternion division -- and the launch counts it.  (Every workgroup reads the counter only on the other branch.)
+    if (P.skip_flag && P.skip_flag[0] != 0.0f) {
+        if (P.skipped && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.skipped[0] = P.skipped[0] + 1;
+        return;
+    }
     fpcdr_adam_tensor t = P.t[blockIdx.y];
     const long long n = t.n;
     if (P.step_table) { t.step_size = P.step_table[2 * t.table_row]; t.bc2_sqrt = P.step_table[2 * t.table_row + 1]; }
+    else if (P.skipped && t.grad) {
+        // the host's step counters and schedule ran on through the skipped steps: the update of the run that never drew them
+        const int s = P.skipped[0];      // (uniform)
+        if (s > 0) {
+            const double ns = (double)(t.step - s);
+            t.step_size = (float)((double)t.lr * pow(P.lr_skip_gain, (double)s) / (1.0 - pow((double)P.beta1, ns)));
+            t.bc2_sqrt = (float)sqrt(1.0 - pow((double)P.beta2, ns));
+        }
+    }
     const float step_size = t.step_size;
     if (!t.renorm) {
         if (!t.grad) return;
@@ -71,6 +86,7 @@ extern "C" int fpcdr_adam_step(const fpcdr_adam_params *p, void *stream) {
     FPCDR_REQUIRE(p != nullptr, "null params");
     FPCDR_REQUIRE(p->n_tensors >= 0 && p->n_tensors <= FPCDR_ADAM_MAX_TENSORS, "too many tensors for one call");
     if (p->n_tensors == 0) return FPCDR_OK;
+    FPCDR_REQUIRE(!p->skipped || p->lr_skip_gain > 0.0, "skipped: lr_skip_gain must be positive (1 for a constant learning rate)");
     long long nmax = 0;
     for (int i = 0; i < p->n_tensors; ++i) {
         const fpcdr_adam_tensor &t = p->t[i];
@@ -79,6 +95,7 @@ extern "C" int fpcdr_adam_step(const fpcdr_adam_params *p, void *stream) {
         FPCDR_REQUIRE(t.grad != nullptr || t.renorm, "a tensor without a gradient has nothing to do");
         FPCDR_REQUIRE(t.grad == nullptr || p->step_table || t.bc2_sqrt > 0.0f, "the bias correction must be positive");
         FPCDR_REQUIRE(!p->step_table || (t.table_row >= 0 && t.table_row < FPCDR_ADAM_MAX_TENSORS), "table_row outside the table");
+        FPCDR_REQUIRE(!p->skipped || p->step_table || t.grad == nullptr || (t.step >= 1 && t.lr >= 0.0f), "skipped: every tensor needs its step count and learning rate");
         if (!t.renorm && t.n > nmax) nmax = t.n;
     }
     const int bx = (int)fpcdr_cdiv(fpcdr_cdiv(nmax > 0 ? nmax : 1, 4), 256);

@@ -1239,10 +1239,14 @@ struct FinishArgs {
     int32_t *counts_out; int32_t counts_seq;
     const double *bg_sumsq; double bg_coeff, n_total; float *value_out;
     int esum;
+    float *skip_out;      // [1] device: 1 when the call ran out of record slots (fpcdr_adam_params.skip_flag), else 0
+    int slots_valid;      // counts_out[7]: header [1] counts record slots (compact records or a counting call)
 };
 template <int CS>
 __global__ void __launch_bounds__(64) k_objective_finish(ObjArgs a, FinishArgs f) {
     const int c = threadIdx.x;
+    // compact records: 1 = the pool was too small -- some bins were shaded without their antialias pairs, the call's results are invalid
+    const bool overflow = a.def_count[4] != 0;
     if (f.esum && c < CS) {
         float e = 0.0f;
         for (int sl = 0; sl < ESLOTS; ++sl) e += a.esum[4 * sl + c];
@@ -1261,13 +1265,21 @@ __global__ void __launch_bounds__(64) k_objective_finish(ObjArgs a, FinishArgs f
         for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
         if (threadIdx.x == 0) {
             if (f.bg_sumsq) acc = acc + f.bg_coeff * f.bg_sumsq[0];
-            f.value_out[0] = (float)(acc / f.n_total);
+            // (an invalid call says so in its value: nobody mistakes it for a loss)
+            f.value_out[0] = overflow ? __int_as_float(0x7fc00000) : (float)(acc / f.n_total);
         }
     }
+    if (f.skip_out && threadIdx.x == 0) f.skip_out[0] = overflow ? 1.0f : 0.0f;
     if (f.counts_out && threadIdx.x == 0) {
+        // a sequence lock (include/fpcdr.h): [6] = seq, counters, [4] = seq -- a reader that finds [4] == [6] around its reads of the
+        // counters has the counters of one call.  [5] is CUMULATIVE (a later call on the shape must not wipe an overflow the host has
+        // not polled yet): host-mapped memory this kernel reads back, one load over the bus in a call of milliseconds
         volatile int32_t *o = f.counts_out;
+        o[6] = f.counts_seq;
+        __threadfence_system();
         for (int i = 0; i < 4; ++i) o[i] = a.def_count[i];
-        o[5] = a.def_count[4];      // (compact records: 1 = the pool was too small -- the call's results are invalid)
+        if (overflow) o[5] = o[5] + 1;
+        o[7] = f.slots_valid;
         __threadfence_system();
         o[4] = f.counts_seq;
     }
@@ -1448,17 +1460,18 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
         // caller without launch hints needs to size the compact record arrays of the real call (once per batch shape)
         FPCDR_REQUIRE(p->counts_out != nullptr, "count_only reports through counts_out");
         hipLaunchKernelGGL(k_count_sil, dim3(2048), dim3(ONT), 0, st, occ_list, n_occ, OX, OY, dc, a);
-        const FinishArgs fin0 = {p->counts_out, p->counts_seq, nullptr, 0.0, 1.0, nullptr, 0};
+        const FinishArgs fin0 = {p->counts_out, p->counts_seq, nullptr, 0.0, 1.0, nullptr, 0, nullptr, 1};
         hipLaunchKernelGGL(k_objective_finish<1>, dim3(1), dim3(64), 0, st, a, fin0);
         FPCDR_CHECK_LAUNCH();
         return FPCDR_OK;
     }
     const bool grads = p->grad_pos || p->grad_tex;
-    const FinishArgs fin = {p->counts_out, p->counts_seq, p->bg_sumsq, p->bg_coeff, p->n_total, p->value_out, p->grad_tex ? 1 : 0};
+    const FinishArgs fin = {p->counts_out, p->counts_seq, p->bg_sumsq, p->bg_coeff, p->n_total, p->value_out, p->grad_tex ? 1 : 0,
+                            p->skip_out, p->rec_slots > 0 ? 1 : 0};
     FPCDR_REQUIRE(!p->value_out || p->n_total > 0.0, "value_out needs n_total > 0");
 #define FINISH(CS)                                                                                                                \
     do {                                                                                                                          \
-        if (fin.esum || fin.value_out || fin.counts_out) hipLaunchKernelGGL(k_objective_finish<CS>, dim3(1), dim3(64), 0, st, a, fin); \
+        if (fin.esum || fin.value_out || fin.counts_out || fin.skip_out) hipLaunchKernelGGL(k_objective_finish<CS>, dim3(1), dim3(64), 0, st, a, fin); \
     } while (0)
     if (p->mip) {      // the reference's enable_mip branch (fit.py:153-155)
         MipO ma;

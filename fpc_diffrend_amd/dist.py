@@ -117,7 +117,11 @@ class EarlyReduce:
 
 class GradBucket:
     """Flat gradient bucket.  `bucket(params)` packs every existing .grad into one contiguous f32 buffer,
-    all-reduces it (sum) and unpacks -- exactly one collective per optimisation step."""
+    all-reduces it (sum) and unpacks -- exactly one collective per optimisation step.
+    `bucket.flag`: ONE more float behind the gradients, a view into the same buffer, that rides in the same collective.  The fit loop lets
+    the pixel objective's last kernel write it (1 = this rank's gradients of this step are invalid: fpcdr_objective_params.skip_out) and
+    hands it, summed over the ranks, to the Adam launch (fpcdr_adam_params.skip_flag): every rank skips the same step, no rank raises
+    between two collectives.  Nobody else writes it; it starts at 0."""
 
     def __init__(self, params, device, always_reduce=False, timed=False, early=(), early_before=None):
         # early: parameters whose gradient is reduced on its own as soon as it exists (EarlyReduce); the bucket skips them
@@ -137,12 +141,16 @@ class GradBucket:
         self.sig = tuple(p.requires_grad for p in self.all_params) if sig is None else sig
         self.params = [p for p in self.all_params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
-        self.flat = torch.zeros(max(sum(self.sizes), 1), dtype=torch.float32, device=self.device)
+        self.n_grad = max(sum(self.sizes), 1)
+        self.flat = torch.zeros(self.n_grad + 1, dtype=torch.float32, device=self.device)
+        self.flag = self.flat[self.n_grad:]
 
     def __call__(self, params=None):
         sig = tuple(p.requires_grad for p in self.all_params)
         if sig != self.sig:
+            old_flag = self.flag
             self._layout(sig)
+            self.flag.copy_(old_flag)      # (what this step's objective wrote moves into the new buffer)
         # pack / unpack with ONE multi-tensor copy each (a copy per tensor is ~5 us of launch in the serial tail of the step)
         views, off = [], 0
         for p, n in zip(self.params, self.sizes):
@@ -175,7 +183,8 @@ class GradBucket:
 
     @property
     def nbytes(self):
-        return self.flat.numel() * 4
+        """Bytes of gradient in the bucket (the collective carries four more: `flag`)."""
+        return self.n_grad * 4
 
     def reduce_ms(self, reset=True):
         """Mean HIP-event time of the timed collectives since the last call (None if none were timed).  Synchronises."""

@@ -544,6 +544,20 @@ class GroupedAdam(torch.optim.Optimizer):
         self.capturable = bool(capturable)
         self._table_host = self._table_dev = None
         self._ring, self._ring_i = [], 0
+        # steps skipped on the device (fpcdr_adam_params.skip_flag / skipped, include/fpcdr.h ABI v11): `skip_flag` is a one-element float32
+        # device tensor the launch reads -- non-zero: this step's gradients are invalid, touch nothing --, set by the caller before every
+        # step() (None: never skip); `skipped` the device counter the kernel keeps; `lr_skip_gain` = lr(i - 1) / lr(i) of the schedule
+        self.skip_flag = None
+        self.skipped = None
+        self.lr_skip_gain = 1.0
+
+    def enable_skips(self, lr_skip_gain=1.0):
+        """Allocate the device counter of skipped steps (see __init__); returns it."""
+        if self.skipped is None:
+            dev = self.param_groups[0]['params'][0].device
+            self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_skip_gain = float(lr_skip_gain)
+        return self.skipped
 
     def _rows(self):
         """(group, parameter, row of the device table) of EVERY parameter: a parameter's row is its position in the optimiser, whatever
@@ -621,6 +635,12 @@ class GroupedAdam(torch.optim.Optimizer):
         row = -1
         if self.capturable:
             P.step_table = self.table_dev().data_ptr()
+        if self.skip_flag is not None:
+            assert self.skip_flag.dtype == torch.float32 and self.skip_flag.is_cuda and self.skip_flag.numel() >= 1
+            P.skip_flag = self.skip_flag.data_ptr()
+            keep.append(self.skip_flag)
+            if self.skipped is not None:
+                P.skipped, P.lr_skip_gain = self.skipped.data_ptr(), self.lr_skip_gain
         for g in self.param_groups:
             b1, b2 = g['betas']
             assert (b1, b2, g['eps']) == (self.param_groups[0]['betas'] + (self.param_groups[0]['eps'],)), \
@@ -629,6 +649,11 @@ class GroupedAdam(torch.optim.Optimizer):
             for p in g['params']:
                 row += 1
                 ren = id(p) in self._renorm
+                if p.grad is None and self.capturable and p.requires_grad:
+                    # prepare() counted a step for this tensor in front of the backward pass (it cannot know which gradients will exist):
+                    # a trainable tensor without one would leave its bias corrections ahead of torch.optim.Adam's
+                    raise RuntimeError("GroupedAdam(capturable=True): a trainable parameter received no gradient this step "
+                                       f"(tensor {row} of the optimiser, shape {tuple(p.shape)})")
                 if p.grad is None and not ren:
                     continue
                 assert p.is_contiguous() and p.dtype == torch.float32
@@ -644,6 +669,7 @@ class GroupedAdam(torch.optim.Optimizer):
                         st['step'] += 1
                         n_step = float(st['step'])
                         t.step_size, t.bc2_sqrt = float(g['lr']) / (1.0 - b1 ** n_step), math.sqrt(1.0 - b2 ** n_step)
+                    t.step, t.lr = int(st['step']), float(g['lr'])
                 k += 1
         P.n_tensors = k
         _lib.call("fpcdr_adam_step", ctypes.byref(P), _stream())
@@ -804,6 +830,14 @@ class Fitter:
         else:
             self.optimizer = GroupedAdam(groups, lr=cfg.lr_base, renorm=(self.q_opt, self.per_frame_q)) if cfg.grouped_adam \
                 else torch.optim.Adam(groups, lr=cfg.lr_base, fused=True)
+        # a step whose pixel objective ran out of record slots (ops.pixel_objective, skip_out) is skipped ON THE DEVICE: the call's last
+        # kernel writes the flag, the gradient bucket carries it over the ranks, the Adam launch reads it -- no host read-back, no
+        # exception on one rank between two collectives.  The kernel also re-forms bias corrections and learning rates for the steps
+        # that did happen (lr_skip_gain = lr(i - 1) / lr(i) of LambdaLR's lr_ramp^(i / max_iter), fit.py:506-507)
+        self._skip_flag = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._skip_cur = None
+        if isinstance(self.optimizer, GroupedAdam) and not self.optimizer.capturable:
+            self.optimizer.enable_skips(lr_skip_gain=float(cfg.lr_ramp) ** (-1.0 / float(cfg.max_iter)))
         self._graphs, self._graph_key, self._frame_idx, self._view_idx = None, None, None, None
         self._side_stream = torch.cuda.Stream(device=dev)
         self._one = torch.ones((), dtype=torch.float32, device=dev)
@@ -1000,6 +1034,7 @@ class Fitter:
         cfg = self.cfg
         i = self.iteration
         self._mode_switch()
+        self._skip_cur = None
         Fb, Nc = self._n(frame_ids), (len(self.cam_idxs) if view_ids is None else int(view_ids.shape[0]))
         C = self.tex_opt.shape[2]
         # (the mip branch of the reference's render(), fit.py:153-155, runs inside the same kernels)
@@ -1092,11 +1127,13 @@ class Fitter:
                     bg_sum = bg.reshape(()) if bg.numel() == 1 else bg.sum()
                 else:
                     bg_sum = self.target_bg_sumsq[local].sum()
+            self._skip_cur = self._skip_target() if (cfg.one_pass and cfg.sparse_objective) else None
             pix = dr.pixel_objective(self.glctx, pos_clip, self.pos_idx, self.uv, self.uv_idx, self.tex_opt, ref, self.resolution,
                                      n_total, BACKGROUND, sparse=cfg.sparse_objective, ref_bg_sumsq=bg_sum,
                                      enable_mip=cfg.enable_mip, max_mip_level=cfg.max_mip_level,
                                      queued_backward=cfg.queued_backward and not self.use_graph,
-                                     one_pass=cfg.one_pass, unit_upstream=True, zero_extra=zero_buf)      # (the seeds below are 1)
+                                     one_pass=cfg.one_pass, unit_upstream=True, zero_extra=zero_buf,      # (the seeds below are 1)
+                                     skip_out=self._skip_cur)
             # d loss / d pix = d loss / d reg = 1, handed over as a cached device scalar: `(pix + reg).backward()` would put an add and
             # a fill between the forward and the backward kernel; the sum is formed after the backward pass has been enqueued
             roots, seeds = [pix], [self._one]
@@ -1159,9 +1196,26 @@ class Fitter:
             self._flush_result()
             self._result_full[frame_ids] = v
 
+    def _skip_target(self):
+        """Where this step's pixel objective writes its "my results are invalid" flag (None: the optimiser cannot skip): the gradient
+        bucket's extra element when the reducer has one (dist.GradBucket.flag -- summed over the ranks with the gradients), else the
+        Fitter's own float (all-reduced on its own in step() when there are other ranks)."""
+        if not isinstance(self.optimizer, GroupedAdam) or self.optimizer.skipped is None:
+            return None
+        flag = getattr(self.reduce_fn, "flag", None) if self.reduce_fn is not None else None
+        return flag if flag is not None else self._skip_flag
+
+    @property
+    def skipped_steps(self):
+        """Steps skipped on the device so far (a host read-back: call it where a synchronisation is acceptable)."""
+        sk = getattr(self.optimizer, "skipped", None)
+        return int(sk.item()) if sk is not None else 0
+
     def _update(self, prepared=False):
         if isinstance(self.optimizer, GroupedAdam) and self.optimizer.capturable and not prepared:
             self.optimizer.prepare()      # (an eager step of a graph-mode Fitter: warm-up, or a new set of trainable tensors)
+        if isinstance(self.optimizer, GroupedAdam):
+            self.optimizer.skip_flag = self._skip_cur
         self.optimizer.step()
         if isinstance(self.optimizer, GroupedAdam):     # (the division of fit.py:616-618 happened inside the launch)
             return
@@ -1184,6 +1238,12 @@ class Fitter:
             loss = self.loss_and_backward(frame_ids, view_ids)
             if self.reduce_fn is not None:
                 self.reduce_fn(self.params)
+                if self._skip_cur is not None and getattr(self.reduce_fn, "flag", None) is not None:
+                    self._skip_cur = self.reduce_fn.flag      # (the bucket lays itself out anew when the set of trainable tensors changes)
+            if self.world > 1 and self._skip_cur is self._skip_flag:      # (a reducer without a flag element: the flag travels alone)
+                import torch.distributed as tdist
+                if tdist.is_initialized():
+                    tdist.all_reduce(self._skip_flag, op=tdist.ReduceOp.SUM)
             self._update(prepared)
         self.scheduler.step()
         if self.cfg.log_interval:
@@ -1302,6 +1362,7 @@ class Fitter:
                 "requires_grad": [bool(p.requires_grad) for p in self.params],
                 "optimizer": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict(),
                 "iteration": self.iteration, "rng": self.rng.bit_generator.state,
+                "skipped_steps": self.skipped_steps,      # (device-side skips: the update kernel subtracts them from the step counters)
                 "result": self.result.clone(),      # this rank's rows (others zero): checkpoints are per rank
                 "frame_range": (self.frame_lo, self.frame_hi),
                 "config": dict(self.cfg.__dict__)}
@@ -1315,6 +1376,8 @@ class Fitter:
         self.optimizer.load_state_dict(state["optimizer"])
         self.scheduler.load_state_dict(state["scheduler"])
         self.iteration = int(state["iteration"])
+        if getattr(self.optimizer, "skipped", None) is not None:
+            self.optimizer.skipped.fill_(int(state.get("skipped_steps", 0)))
         self.rng.bit_generator.state = state["rng"]
         self.result.copy_(state["result"].to(self.result.device))
         self._graphs, self._graph_key = None, None

@@ -320,8 +320,8 @@ class _ListHints:
 
 class _MappedHints:
     """The same for the one-pass objective, without a copy in the stream: the call's last kernel writes the counters straight into
-    pinned host memory (fpcdr_objective_params.counts_out) with the call's sequence number behind them; poll() uses whatever has
-    landed (a device-to-host copy per step was a blit kernel between two barriers: ~20 us of the step's serial tail)."""
+    pinned host memory (fpcdr_objective_params.counts_out) as a sequence lock -- the call's sequence number in front of AND behind them;
+    poll() uses whatever has landed (a device-to-host copy per step was a blit kernel between two barriers: ~20 us of the step's serial tail)."""
 
     def __init__(self):
         self.host = torch.zeros(8, dtype=torch.int32)
@@ -333,24 +333,36 @@ class _MappedHints:
         self.frozen = False         # tests: keep `caps` as set
         self.sil_bins = -1          # bins that took a record slot in the last call seen (compact records; -1: none seen yet)
         self.slots = 0              # record slots the next call gets (tests may pin it with `frozen`)
-        self.overflowed = None      # sequence number of a call that ran out of record slots
+        self.overflowed = None      # sequence number of the newest call seen at or before which a call ran out of record slots
+        self.overflow_count = 0     # the device's cumulative count of such calls, as last read (host[5]: only clear_hints resets it)
+        self.skipped_calls = 0      # ... of them, calls whose caller took the device-side flag (skip_out): handled, not raised
 
     def poll(self):
         if self.frozen:
+            self._poll_overflow(int(self.host[4]))
             return self.caps
-        # the device writes [0:4], fences, then writes [4]: the sequence number is read BEFORE and AFTER the counters and they are adopted
-        # only if both reads agree (and are new) -- a later call's counters landing in between cannot be mixed with this call's
-        before = int(self.host[4])
-        n_def, n_sil, n_bins, n_occ, _, overflow = (int(v) for v in self.host[:6].tolist())
-        after = int(self.host[4])
-        if before == after and after != self.seen:
-            self.seen = after
+        # include/fpcdr.h, counts_out: the device writes [6] = seq, fences, the counters, fences, [4] = seq.  Read the other way round --
+        # [4], the counters, [6] -- the counters are ONE call's iff both numbers agree: a later call that has started to write has
+        # already changed [6], one that has not finished has not yet changed [4]
+        end = int(self.host[4])
+        n_def, n_sil, n_bins, n_occ = (int(v) for v in self.host[:4].tolist())
+        slots_valid = int(self.host[7])
+        begin = int(self.host[6])
+        if begin == end and end != self.seen:
+            self.seen = end
             self.caps = tuple(n + max(256, n // 8) if n > 0 else 0 for n in (n_bins, n_occ, n_def))
-            self.sil_bins = n_sil
-            self.slots = n_sil + max(RECORD_SLOT_MARGIN, n_sil // 2)
-            if overflow:
-                self.overflowed = after
+            if slots_valid:      # (a dense call takes no record slots: its zero says nothing about the demand)
+                self.sil_bins = n_sil
+                self.slots = n_sil + max(RECORD_SLOT_MARGIN, n_sil // 2)
+        self._poll_overflow(end)
         return self.caps
+
+    def _poll_overflow(self, seq):
+        # cumulative on the device: an overflow in call N is still there when call N + 1 has finished before this poll
+        n_over = int(self.host[5])
+        if n_over != self.overflow_count:
+            self.overflow_count = n_over
+            self.overflowed = seq
 
     def next_seq(self):
         self.seq = self.seq % 0x7ffffff0 + 1
@@ -360,7 +372,8 @@ class _MappedHints:
 _list_hints = {}
 # Compact records (fpcdr_objective_params.rec_slots): a call gets 1.5 x the slots the last call on the batch shape used, at least this
 # many more.  The slot demand is the number of occupied bins that show a silhouette triangle: it moves by a few per cent from one minibatch
-# of a take to the next.  A call that runs out regardless raises at the next call on the shape (its results were invalid).
+# of a take to the next.  A call that runs out regardless says so itself -- NaN value, skip_out = 1 (include/fpcdr.h ABI v11): Fitter skips
+# that update on the device --; a caller that did not hand over skip_out gets a RuntimeError at its next call on the shape.
 RECORD_SLOT_MARGIN = 1024
 COMPACT_RECORDS = True
 SMALL_BATCH_BINS = 16384      # (eight full-HD images) batches up to this many 32 x 32 bins run their list kernels unhinted: see _pixel_objective_onepass
@@ -525,7 +538,8 @@ class _pixel_objective_onepass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, tex, tri, adj, uv, uv_tri, ref, H, W, n_total, bg, boundary, ref_bg_sumsq, use_hints, want_grad, unit_upstream,
-                flags_out=None, mip_levels=None, zero_extra=None, overlap_sil=None, bin_lists=True, idp_out=None, record_slots=None):
+                flags_out=None, mip_levels=None, zero_extra=None, overlap_sil=None, bin_lists=True, idp_out=None, record_slots=None,
+                skip_out=None):
         lib = _lib.load()
         B, V, _ = pos.shape
         T = tri.shape[0]
@@ -553,7 +567,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
                            boundary_mode=boundary, ref=_ptr(ref), bg=bg, color_scale=255.0, grad_scale=1.0 / n_total, sil=_ptr(sil),
                            idp=_ptr(idp), occ=_ptr(occ), cmask=_ptr(cmask),
                            empty_color=_ptr(ecol), loss_sum=_ptr(acc), grad_pos=_ptr(g_pos), grad_tex=_ptr(g_tex), flags=_ptr(flags_out),
-                           binlist=_ptr(binlist), zero_outputs=1)
+                           binlist=_ptr(binlist), zero_outputs=1, skip_out=_ptr(skip_out))
         # mip_levels = n: the reference's enable_mip branch inside the same kernels (the chain is built here, box filter as texture())
         chain = _build_mips(tex[None], mip_levels)[1:] if mip_levels is not None else []
         g_chain = [torch.empty_like(t) for t in chain] if want_tex else []
@@ -596,13 +610,21 @@ class _pixel_objective_onepass(torch.autograd.Function):
         # first call on a shape asks the rasteriser for the count (one extra rasterisation and a host wait, once per shape).  Small
         # batches, captured calls and calls without hints address the records by pixel.
         slots = 0
+        if hints is not None and hints.overflowed is not None and not capturing:
+            # an earlier call on this shape ran out of record slots: its value was NaN and its gradients incomplete.  A caller that hands
+            # over skip_out had the device flag of that very call (Fitter: the update was skipped on the device) -- nothing to raise; the
+            # demand the call counted (it keeps counting beyond the pool) has sized this call.  Anybody else learns it here.
+            seq, hints.overflowed = hints.overflowed, None
+            if skip_out is not None:
+                hints.skipped_calls += 1
+            else:
+                hints.sil_bins = -1      # (re-count in front of the next call)
+                raise RuntimeError(f"pixel_objective: a call on this batch shape (sequence number <= {seq}) ran out of record slots (the "
+                                   "take's silhouette grew by more than half within one step); its value was NaN and its gradients "
+                                   "incomplete -- repeat the step, or pass skip_out= and skip the update as Fitter does")
         if record_slots is not None:
             slots = int(record_slots)
         elif COMPACT_RECORDS and hints is not None and not capturing and nbins > SMALL_BATCH_BINS:
-            if hints.overflowed is not None:
-                seq, hints.overflowed, hints.sil_bins = hints.overflowed, None, -1
-                raise RuntimeError(f"pixel_objective: call {seq} on this batch shape ran out of record slots (the take's silhouette "
-                                   "grew by more than half within one step); its value and gradients were invalid -- repeat the step")
             if hints.sil_bins < 0 and not hints.frozen:
                 p.count_only = 1
                 _lib.call("fpcdr_objective_fwd", ctypes.byref(p), _stream())
@@ -654,7 +676,7 @@ class _pixel_objective_onepass(torch.autograd.Function):
             g = g.to(torch.float32)
             g_pos = g_pos * g if g_pos is not None else None
             g_tex = g_tex * g if g_tex is not None else None
-        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 21
+        return (g_pos if ctx.needs_input_grad[0] else None, g_tex if ctx.needs_input_grad[1] else None) + (None,) * 22
 
 
 def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
@@ -672,7 +694,7 @@ def reference_background_sumsq(ref_u8, background=45.0 / 255.0):
 def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_total=None, background=45.0 / 255.0,
                     boundary_mode='wrap', sparse=True, ref_bg_sumsq=None, launch_hints=True, queued_backward=False,
                     enable_mip=False, max_mip_level=None, one_pass=True, unit_upstream=False, aa_flags_out=None, zero_extra=None,
-                    id_plane_out=None, record_slots=None):
+                    id_plane_out=None, record_slots=None, skip_out=None):
     """The whole pixel term of the reference's loss (fit.py:151-161 + the first term of :579) for a minibatch,
     as three kernels:  mean((ref - 255 * where(rast.w > 0, antialias(texture(interpolate(rasterize(pos)))), bg))^2)
     over n_total elements (default: all of this call's).  pos [B,V,4], tex [Ht,Wt,C] (C in 1,3,4), ref_u8 [B,H,W] uint8.
@@ -695,7 +717,11 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
     id_plane_out (one_pass; tests / diagnostics): a zero-filled tensor of fpcdr_idplane_bytes(B,H,W) bytes that is used as the call's id
     planes and so keeps them -- 1024 uint32 per 32 x 32 bin, bin-major, (triangle + 1) | silhouette bits << 24 (include/fpcdr.h).
     record_slots (one_pass): the records of deferred pixels in that many slots of 1 024 (fpcdr_objective_params.rec_slots) instead of the
-    default -- by pixel for batches of up to SMALL_BATCH_BINS bins, compact and sized from the last call on the shape beyond; 0 = by pixel."""
+    default -- by pixel for batches of up to SMALL_BATCH_BINS bins, compact and sized from the last call on the shape beyond; 0 = by pixel.
+    skip_out (one_pass): a one-element float32 device tensor that receives 1.0 when the call ran out of record slots -- its value is then
+    NaN and its gradients are incomplete -- and 0.0 otherwise, written by the call's last kernel: hand it to GroupedAdam.skip_flag (summed
+    over the ranks under data parallelism) and the update of such a step does not happen, without a host read-back.  Without it the
+    NEXT call on the batch shape raises."""
     assert isinstance(glctx, RasterizeHipContext)
     _check_tensor('pos', pos, torch.float32, 3)
     _check_tensor('tri', tri, torch.int32, 2)
@@ -718,6 +744,9 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
         if not sparse:
             raise NotImplementedError("pixel_objective(enable_mip=True) runs in sparse mode (use the separate operators otherwise)")
         mip_levels = _num_mip_levels(tex.shape[0], tex.shape[1], max_mip_level)
+    if skip_out is not None and not (torch.is_tensor(skip_out) and skip_out.dtype == torch.float32 and skip_out.device == pos.device
+                                     and skip_out.numel() >= 1 and skip_out.is_contiguous()):
+        raise ValueError("skip_out must be a contiguous float32 tensor of at least one element on the device of pos")
     if zero_extra is not None:
         # (the kernel zero-fills numel * itemsize bytes from data_ptr(): a view with gaps would have other storage overwritten)
         if not (zero_extra.is_contiguous() and zero_extra.dtype in (torch.float32, torch.int32) and zero_extra.device == pos.device):
@@ -728,7 +757,9 @@ def pixel_objective(glctx, pos, tri, uv, uv_tri, tex, ref_u8, resolution, n_tota
         return _pixel_objective_onepass.apply(pos.contiguous(), tex.contiguous(), tri, adj, uv.contiguous(), uv_tri.contiguous(),
                                               ref_u8.contiguous(), H, W, n_total, background, _lib.BOUNDARY[boundary_mode], ref_bg_sumsq,
                                               bool(launch_hints), torch.is_grad_enabled(), bool(unit_upstream), aa_flags_out, mip_levels, zero_extra,
-                                              None, True, id_plane_out, record_slots)
+                                              None, True, id_plane_out, record_slots, skip_out)
+    if skip_out is not None:
+        raise ValueError("skip_out belongs to the one-pass form")
     if record_slots is not None:
         raise ValueError("record_slots belongs to the one-pass form")
     if id_plane_out is not None:

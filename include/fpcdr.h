@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FPCDR_ABI_VERSION 10
+#define FPCDR_ABI_VERSION 11
 
 enum {
     FPCDR_OK = 0,
@@ -182,10 +182,12 @@ typedef struct {
     int32_t zero_outputs;   /* 1: the call's first kernel zero-fills loss_sum, grad_pos, grad_tex and grad_tex_mip (they need no initialisation);
                                0: they are accumulated into, as above */
     int32_t counts_seq;     /* any number that differs from call to call (see counts_out) */
-    int32_t *counts_out;    /* optional [8]: the last kernel copies the four counters at FPCDR_OCC_COUNTS_OFFSET of occ to [0..3] and then writes
-                               counts_seq to [4].  May be HOST memory the device can write (hipHostMalloc / pinned): the launch hints of the
-                               next call then need no device-to-host copy in the stream; a reader that sees its counts_seq at [4] reads
-                               counters at least as new as that call's */
+    int32_t *counts_out;    /* optional [8]: a sequence lock.  The last kernel writes counts_seq to [6], then the four counters at
+                               FPCDR_OCC_COUNTS_OFFSET of occ to [0..3], [5] += 1 if this call ran out of record slots (CUMULATIVE: only the
+                               reader ever resets it), [7] = 1 if [1] is meaningful (compact records or count_only; a dense call counts no
+                               slots), then counts_seq to [4], with system-scope fences in between.  May be HOST memory the device can write
+                               (hipHostMalloc / pinned): the launch hints of the next call then need no device-to-host copy in the stream.
+                               A reader takes [4], the counters, then [6]: the counters belong to ONE call iff [4] == [6] */
     const double *bg_sumsq; /* optional [1] (with value_out): the sum over the call's images of fpcdr_ref_bg_sumsq */
     double bg_coeff;        /* its coefficient (the number of colour channels) */
     double n_total;         /* the mean's denominator */
@@ -200,12 +202,19 @@ typedef struct {
      * ([rec_slots * 1024, 4] / [.., C] / [.., C]); every occupied bin that shows a triangle with a silhouette edge -- the only bins that can
      * hold a deferred pixel -- takes the next slot.  The number of such bins is counted by every call (counts_out[1]; it keeps counting
      * beyond rec_slots), so a caller sizes rec_slots from the previous call on the batch, with a margin; a call that runs out of slots
-     * sets counts_out[5] = 1: ITS RESULTS ARE THEN INVALID (the bins without a slot were shaded without their antialias pairs) and the
-     * caller must repeat it with more slots.  A caller without a previous call asks first: count_only = 1 runs the rasteriser alone and
-     * reports the exact number for this very batch through counts_out (no record buffers, no gradients needed). */
+     * bumps counts_out[5]: ITS RESULTS ARE THEN INVALID (the bins without a slot were shaded without their antialias pairs) and it SAYS SO
+     * IN THE SAME CALL -- value_out receives NaN and skip_out 1 -- so that no optimiser step consumes them (fpcdr_adam_params.skip_flag).
+     * The next call on the batch is sized from the demand this one counted.  A caller without a previous call asks first: count_only = 1
+     * runs the rasteriser alone and reports the exact number for this very batch through counts_out (no record buffers, no gradients
+     * needed). */
     int32_t rec_slots;      /* 0: dense addressing */
     int32_t count_only;
     int32_t *slot_map;      /* scratch with rec_slots > 0: one int32 per 32 x 32 bin of the batch (B * FPCDR_OCC_DIM(H) * FPCDR_OCC_DIM(W)) */
+    /* ABI v11 */
+    float *skip_out;        /* optional DEVICE [1]: the last kernel WRITES 1.0f when the call ran out of record slots (its value and gradients
+                               are invalid), 0.0f otherwise.  Handed to fpcdr_adam_step as skip_flag the update of that step does not
+                               happen; under data parallelism the caller sums it over the ranks first (it may be an element of the gradient
+                               bucket), so that every rank skips the same step */
 } fpcdr_objective_params;
 int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream);
 
@@ -456,6 +465,10 @@ typedef struct {
     float bc2_sqrt;        /* sqrt(1 - beta2^step) */
     int32_t renorm;
     int32_t table_row;     /* ABI v10, with fpcdr_adam_params.step_table: this tensor's row of the table (step_size / bc2_sqrt above unused) */
+    /* ABI v11, with fpcdr_adam_params.skipped: what step_size / bc2_sqrt were formed from -- the tensor's step count (this step included)
+     * and its learning rate --, so that the kernel can re-form them for step - *skipped once a step has been skipped */
+    int32_t step;
+    float lr;
 } fpcdr_adam_tensor;
 typedef struct {
     int32_t n_tensors;
@@ -466,6 +479,18 @@ typedef struct {
      * of t[] -- a step captured in a HIP graph replays fixed kernel arguments, and its learning-rate schedule and bias corrections arrive
      * through this table (one small host-to-device copy per step in front of the replay) */
     const float *step_table;
+    /* ABI v11: a step whose gradients are invalid is SKIPPED ON THE DEVICE (no host read-back, no exception between two collectives):
+     * skip_flag  optional DEVICE [1]; when it holds a non-zero value the launch touches neither parameters nor moments (nor the
+     *            quaternion division) -- fpcdr_objective_params.skip_out, summed over the ranks
+     * skipped    optional DEVICE [1] counter of the steps skipped so far, kept by this kernel (+1 per skipped launch).  The host's step
+     *            counters and learning-rate schedule have moved on regardless: with *skipped = s > 0 (and no step_table) the kernel forms
+     *            step_size = lr * lr_skip_gain^s / (1 - beta1^(step - s)) and bc2_sqrt = sqrt(1 - beta2^(step - s)) itself, in double,
+     *            i.e. the update of the run that never drew the skipped steps
+     * lr_skip_gain  lr(i - 1) / lr(i) of the caller's schedule (1 for a constant rate; the reference's lr_ramp^(i / max_iter) decays by
+     *            a constant factor per step, fit.py:506-507) */
+    const float *skip_flag;
+    int32_t *skipped;
+    double lr_skip_gain;
 } fpcdr_adam_params;
 int fpcdr_adam_step(const fpcdr_adam_params *p, void *stream);
 

@@ -36,15 +36,22 @@ def _worker(rank, world, port, ret):
     opt = torch.optim.Adam([M1, M2, tex], lr=1e-2)
     target = torch.linspace(0, 1, F * K).reshape(F, K)
     lo, hi = rank * F // world, (rank + 1) * F // world        # contiguous frame shard
-    for _ in range(3):
+    flags = []
+    for it in range(4):
         opt.zero_grad()
         frames = torch.arange(lo, hi)
         w_f = (M2 @ (M1[:, frames] + torch.eye(F)[:, frames])).t()          # [Fb,K]
         loss = ((w_f - target[frames]) ** 2).sum() / F + (tex ** 2).mean() / world
         loss.backward()
+        # the skip flag rides behind the gradients (GradBucket.flag): every step each rank WRITES it, as the pixel objective's last kernel
+        # does -- here the last rank alone calls step 1 invalid -- and after the one collective every rank holds the same sum
+        bucket.flag.fill_(1.0 if (it == 1 and rank == world - 1) else 0.0)
         bucket(params)
-        opt.step()
-    assert bucket.calls == 3 and (not early or bucket.early[0].fired == 3)
+        flags.append(float(bucket.flag))
+        if flags[-1] == 0.0:      # (fpcdr_adam_step does this on the device)
+            opt.step()
+    assert flags == [0.0, 1.0, 0.0, 0.0], flags
+    assert bucket.calls == 4 and (not early or bucket.early[0].fired == 4)
     ret[rank] = torch.cat([p.detach().reshape(-1) for p in (M1, M2, tex)])
     fdist.barrier()
     assert fdist.max_over_ranks(float(rank), "cpu") == world - 1
@@ -59,7 +66,7 @@ def _single(F=8, K=5):
     tex = torch.rand(4, 4).requires_grad_(True)
     opt = torch.optim.Adam([M1, M2, tex], lr=1e-2)
     target = torch.linspace(0, 1, F * K).reshape(F, K)
-    for _ in range(3):
+    for _ in range(3):      # (the replicas' four iterations minus the one they all skip)
         opt.zero_grad()
         w_f = (M2 @ (M1 + torch.eye(F))).t()
         loss = ((w_f - target) ** 2).sum() / F + (tex ** 2).mean()
@@ -71,7 +78,8 @@ def _single(F=8, K=5):
 @pytest.mark.parametrize("world,early", [(2, False), (2, True), (4, False), (4, True)])
 def test_data_parallel_replicas_equal_single_process(world, early, monkeypatch):
     """World size 2 and 4 over gloo.  early: the texture's gradient travels in its own all-reduce, launched from an autograd hook as
-    soon as it exists (dist.EarlyReduce), the rest in the bucket -- same replicas, same result."""
+    soon as it exists (dist.EarlyReduce), the rest in the bucket -- same replicas, same result.  One rank declares one step invalid
+    through the bucket's flag element: every rank skips that update, nobody hangs, the result is the run without that iteration."""
     monkeypatch.setenv("FPCDR_TEST_EARLY", "1" if early else "0")
     port = _free_port()
     mgr = mp.Manager()

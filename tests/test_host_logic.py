@@ -257,26 +257,50 @@ def test_fitter_host_rules_graph_choice_and_frame_selection():
 
 
 def test_mapped_hints_and_zero_pool_bookkeeping():
-    """Host side of two round-4 mechanisms, without a GPU.  ops._MappedHints: the objective's last kernel writes four counters and then
-    the call's sequence number into host memory; poll() adopts counters only when a NEW sequence number stands behind them, adds the
-    launch margin, and keeps the old caps otherwise.  fit.ZeroPool: views of one flat buffer, 16-byte aligned, plain zeros when the
+    """Host side of two round-4 mechanisms, without a GPU.  ops._MappedHints: the objective's last kernel writes its counters into host
+    memory as a sequence lock (the call's number in front of and behind them); poll() adopts counters only when both numbers agree and
+    are NEW, adds the launch margin, and keeps the old caps otherwise; the overflow count is cumulative, so none is lost between polls.  fit.ZeroPool: views of one flat buffer, 16-byte aligned, plain zeros when the
     pool has no buffer or is exhausted; two pools are independent objects."""
     import fpc_diffrend_amd.ops as dr
     from fpc_diffrend_amd import fit
     h = dr._MappedHints()
     assert h.poll() == (0, 0, 0)
+
+    def device_writes(seq, counters, overflow=False, slots_valid=1, finish=True):
+        # the order of k_objective_finish (include/fpcdr.h counts_out): [6] = seq, the counters, [5] += overflow, [7], then [4] = seq
+        h.host[6] = seq
+        h.host[:4] = torch.tensor(counters, dtype=torch.int32)
+        if overflow:
+            h.host[5] += 1
+        h.host[7] = slots_valid
+        if finish:
+            h.host[4] = seq
+
     s1 = h.next_seq()
-    h.host[:4] = torch.tensor([40, 0, 8000, 7000], dtype=torch.int32)      # [deferred bins, -, live bins, occupied bins]
-    assert h.poll() == (0, 0, 0)                                            # (the sequence number has not landed yet)
+    device_writes(s1, [40, 500, 8000, 7000], finish=False)                 # [deferred bins, slot demand, live bins, occupied bins]
+    assert h.poll() == (0, 0, 0)                                            # (a writer in progress: [4] != [6])
     h.host[4] = s1
     assert h.poll() == (8000 + 1000, 7000 + 875, 40 + 256)                  # max(256, n / 8) of margin
-    h.host[:4] = torch.tensor([1, 0, 2, 3], dtype=torch.int32)              # counters of a later call, its number still missing
+    assert h.sil_bins == 500 and h.slots == 500 + max(dr.RECORD_SLOT_MARGIN, 250)
+    s2 = h.next_seq()
+    device_writes(s2, [1, 0, 2, 3], slots_valid=0, finish=False)            # a later call has begun to write: nothing is adopted, nothing torn
     assert h.poll() == (9000, 7875, 296)
-    h.host[4] = h.next_seq()
+    h.host[4] = s2
     assert h.poll() == (2 + 256, 3 + 256, 1 + 256)
+    assert h.sil_bins == 500                                                # (a dense call -- [7] = 0 -- says nothing about the slot demand)
+    # an overflow is cumulative on the device: call s3 overflows, call s4 lands before the host polls -- still seen
+    assert h.overflowed is None
+    s3, s4 = h.next_seq(), h.next_seq()
+    device_writes(s3, [5, 900, 10, 9], overflow=True)
+    device_writes(s4, [5, 600, 10, 9])
+    h.poll()
+    assert h.overflowed == s4 and h.overflow_count == 1 and h.sil_bins == 600
+    h.overflowed = None
+    h.poll()
+    assert h.overflowed is None                                             # (reported once)
     h.frozen, h.caps = True, (3, 2, 1)
-    h.host[4] = h.next_seq()
-    assert h.poll() == (3, 2, 1)
+    device_writes(h.next_seq(), [7, 7, 7, 7], overflow=True)
+    assert h.poll() == (3, 2, 1) and h.overflowed is not None               # frozen caps, but an overflow is never missed
     assert 0 < h.next_seq() < 0x7ffffff1
 
     dev = torch.device("cpu")
@@ -327,3 +351,32 @@ def test_fit_loop_kernels_have_no_private_segment():
                 scratch = int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", blk).group(1))
                 assert scratch == 0, (obj, name, scratch)
     assert seen >= 20
+
+
+def test_bench_launcher_decides_from_the_command_line_and_fails_with_its_ranks():
+    """bench.py: `--gpus N` (N > 1) without a torchrun environment makes the process a LAUNCHER of N fresh ranks (it never imports torch,
+    let alone touches a GPU); with WORLD_SIZE / RANK set it is a rank.  A rank that fails takes the launcher down: here -- no GPU -- both
+    children stop at "bench.py needs a GPU", the launcher ends the survivors by PID and exits non-zero without a result line."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import importlib.util
+    src = open(os.path.join(root, "bench.py")).read()
+    head = src[:src.index("import torch  # noqa: E402")]
+    assert "import torch" not in head.replace("does not even import torch", "")      # the launcher part stands in front of the torch import
+    ns = {"__name__": "bench_head", "__file__": os.path.join(root, "bench.py")}
+    exec(compile(head, "bench.py", "exec"), ns)
+    assert ns["requested_gpus"](["--steps", "3"]) == 1 and ns["requested_gpus"](["--gpus", "8"]) == 8 and ns["requested_gpus"](["--gpus=4"]) == 4
+    assert ns["wants_self_launch"](["--gpus", "2"], env={}) and not ns["wants_self_launch"](["--gpus", "1"], env={})
+    assert not ns["wants_self_launch"](["--gpus", "2"], env={"WORLD_SIZE": "2", "RANK": "0"})      # started by torch.distributed.run
+    assert not ns["wants_self_launch"](["--gpus", "2"], env={"RANK": "1"})
+    import torch
+    if torch.cuda.is_available():
+        return      # (the GPU box runs the real thing: tests/test_gpu_dist.py::test_bench_launches_its_own_ranks)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FPCDR_BENCH_LAUNCH_TIMEOUT"] = "240"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "cfg1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode != 0 and "bench.py launcher (--gpus 2)" in err and "needs a GPU" in err, err[-2000:]
+    assert not r.stdout.decode().strip().startswith("{")
