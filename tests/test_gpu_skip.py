@@ -36,24 +36,33 @@ def _snapshot(ft):
     return state
 
 
-def test_short_record_pool_skips_the_update_on_the_device_and_the_run_continues(monkeypatch):
+def _close(ft_a, ft_b, steps_apart=1):
+    """Two Fitters that took the same step from the same state: equal up to the order of the float atomics inside a step -- every entry
+    of every tensor to 1e-5, except that Adam turns a texel gradient that cancels to ~0 with no history into a step of the learning
+    rate whose sign is that order's: the texture and its moments may hold a vanishing share of such entries."""
+    sa, sb = _snapshot(ft_a), _snapshot(ft_b)
+    assert len(sa) == len(sb)
+    n_par = len(ft_a.params)
+    tex_like = {i for i, t in enumerate(sa) if t.shape == ft_a.tex_opt.shape}
+    for i, (a, b) in enumerate(zip(sa, sb)):
+        d = (a - b).abs()
+        tol = 1e-5 * max(1.0, float(b.abs().max())) if i < n_par else 1e-4 * max(float(b.abs().max()), 1e-30)
+        if i in tex_like:
+            assert float((d > tol).float().mean()) <= 2e-4 and float(d.max()) <= 2.0 * 2.5e-3 * steps_apart, (i, float(d.max()))
+        else:
+            assert float(d.max()) <= tol, (i, tuple(a.shape), float(d.max()), tol)
+
+
+def test_short_record_pool_skips_the_update_on_the_device_and_the_run_continues(tmp_path, monkeypatch):
     import fpc_diffrend_amd.ops as dr
     dr.clear_hints()
     monkeypatch.setattr(dr, "SMALL_BATCH_BINS", 0)       # compact records for this small batch too
     monkeypatch.setattr(dr, "RECORD_SLOT_MARGIN", 1)
     k = 3
-    plain = _make()
-    want = []
-    for _ in range(k + 2):
-        plain.step()
-        want.append(_snapshot(plain))
-    assert plain.skipped_steps == 0
-    dr.clear_hints()
-
-    ft = _make(targets=plain.targets)
-    losses = [float(ft.step()) for _ in range(k)]
-    for a, b in zip(_snapshot(ft), want[k - 1]):
-        assert torch.equal(a, b)                         # (same inputs, same kernels: the two runs agree bit for bit up to here)
+    ft = _make()
+    for _ in range(k):
+        assert math.isfinite(float(ft.step()))
+    ft.save_checkpoint(str(tmp_path / "before.pt"))      # the state in front of iteration k
     before = _snapshot(ft)
     h = _onepass_hints(dr)
     h.poll()
@@ -67,20 +76,25 @@ def test_short_record_pool_skips_the_update_on_the_device_and_the_run_continues(
     for a, b in zip(_snapshot(ft), before):
         assert torch.equal(a, b)                         # ... and touched neither parameters nor moments (nor the quaternion division)
     # the run continues without an exception; the next call is sized from the demand the short call counted
-    nxt = float(ft.step())
-    assert math.isfinite(nxt)
+    assert math.isfinite(float(ft.step()))
     h.poll()
     assert h.skipped_calls == 1 and h.overflowed is None and h.slots >= need
-    # ... and it is the run that never drew the skipped iteration: launch k + 1 of this run = step k of the plain one (the kernel re-forms
-    # the bias corrections for step - skipped and the learning rate of one schedule step earlier, in double)
-    for a, b in zip(_snapshot(ft), want[k]):
-        tol = 2e-6 * max(1.0, float(b.abs().max()))
-        assert float((a - b).abs().max()) <= tol, (tuple(a.shape), float((a - b).abs().max()), tol)
+    # ... as the run that never drew the skipped iteration: a second Fitter resumes from the state in front of iteration k and takes
+    # its step k with host counters and a schedule that never saw the skipped one -- the same update (the kernel re-forms the bias
+    # corrections for step - skipped and the learning rate of one schedule step earlier, in double).  max_iter = 40 puts 12 % between two
+    # consecutive learning rates and Adam's first bias corrections differ by 20 % from step to step: an update formed for the wrong
+    # step would be off by 1e-3, not 1e-5
+    plain = _make(targets=ft.targets)
+    plain.load_checkpoint(str(tmp_path / "before.pt"))
+    for a, b in zip(_snapshot(plain), before):
+        assert torch.equal(a, b)
+    plain.step()
+    assert plain.skipped_steps == 0
+    _close(ft, plain)
     ft.step()
-    for a, b in zip(_snapshot(ft), want[k + 1]):
-        tol = 4e-6 * max(1.0, float(b.abs().max()))
-        assert float((a - b).abs().max()) <= tol, (tuple(a.shape), float((a - b).abs().max()), tol)
-    assert ft.skipped_steps == 1
+    plain.step()
+    _close(ft, plain, steps_apart=2)
+    assert ft.skipped_steps == 1 and ft.iteration == plain.iteration + 1
     dr.clear_hints()
 
 
@@ -124,7 +138,7 @@ def test_a_caller_without_skip_out_still_learns_of_the_overflow(monkeypatch):
         loss = dr.pixel_objective(ctx, p, tri, uv, uv_idx, t, ref, res, **kw)
         loss.backward()
         torch.cuda.synchronize()
-        return float(loss)
+        return float(loss.detach())
 
     def enqueue(**kw):      # (no synchronisation: the host runs ahead of the device, as a fit loop does)
         p, t = pos.clone().requires_grad_(True), tex.clone().requires_grad_(True)
