@@ -21,6 +21,11 @@ Outputs (data only -- inputs and expected outputs, no reference source text):
                          any missing library is involved and no source text is stored.
     numframes_golden.json  assertNumFrames (fit.py:29-43, os only; taken out the same way) on two throw-away
                          directory trees: the (count, zero-pad digits) pairs and the assertion on unequal counts
+    rerender_golden.json make_img (src/torch/utils.py:179-190, numpy only; `import src.torch.utils` fails on the absent cv2) on
+                         seeded image stacks, and compareSequenceNumerical (src/torch/comparisons.py:54-81, numpy + PIL; the module
+                         runs a comparison on the author's W: drive at import) on 120 synthetic 1600 x 1200 image pairs
+                         (tests/helpers.py::comparison_pair) written to a temporary directory under the file names the function
+                         reads: the 120 image means, the final mean, the first row means of three lines and a hash of the whole CSV
 
     python tests/golden/make_golden.py
 """
@@ -95,13 +100,14 @@ def main():
                    "fuv": md.fuv.tolist(), "fuv_dtype": str(md.fuv.dtype)}, f, indent=1)
     blend_golden()
     numframes_golden()
-    print("wrote camera_golden.json, meshdata_golden.json, blend_golden.json, numframes_golden.json")
+    rerender_golden()
+    print("wrote camera_golden.json, meshdata_golden.json, blend_golden.json, numframes_golden.json, rerender_golden.json")
 
 
-def reference_functions(names, extra_globals):
-    """The named top-level functions of the reference's src/torch/fit.py, compiled from the file's own syntax tree (the module
-    itself cannot be imported: roma, nvdiffrast, pytorch3d, torchvision and imageio are absent)."""
-    path = os.path.join(REF, "src", "torch", "fit.py")
+def reference_functions(names, extra_globals, module="fit.py"):
+    """The named top-level functions of the reference's src/torch/<module>, compiled from the file's own syntax tree (the modules
+    themselves cannot be imported: roma, nvdiffrast, pytorch3d, torchvision, imageio and cv2 are absent)."""
+    path = os.path.join(REF, "src", "torch", module)
     with open(path) as f:
         tree = ast.parse(f.read(), filename=path)
     nodes = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
@@ -174,5 +180,59 @@ def numframes_golden():
         json.dump({"reference_lines": lines, "cases": cases}, f, indent=1)
 
 
+def rerender_golden():
+    """f-4: the reference's grid tiler and its numerical sequence comparison, run as they are."""
+    import contextlib
+    import hashlib
+    import io
+    from pathlib import Path
+    from PIL import Image
+    sys.path[:0] = [os.path.dirname(HERE), os.path.dirname(os.path.dirname(HERE))]
+    from helpers import comparison_pair
+    out = {}
+    fns, lines = reference_functions(("make_img",), {"np": np}, module="utils.py")
+    out["make_img_lines"] = lines
+    rng = np.random.default_rng(11)
+    cases = []
+    for n, h, w, c, ncols in ((6, 2, 3, 1, 3), (9, 4, 5, 1, 3), (4, 3, 2, 3, 2), (8, 2, 2, 1, 4)):
+        arr = rng.integers(0, 256, size=(n, h, w, c)).astype(np.float32)
+        kw = {} if ncols == 2 else {"ncols": ncols}        # (the reference's default is two columns)
+        cases.append({"shape": [n, h, w, c], "ncols": ncols, "input": arr.astype(np.float64).tolist(),
+                      "grid": fns["make_img"](arr, **kw).astype(np.float64).tolist()})
+    try:
+        fns["make_img"](np.zeros((5, 2, 2, 1)), 3)
+        cases.append({"uneven": "no error"})
+    except AssertionError:
+        cases.append({"uneven": "AssertionError"})
+    out["make_img"] = cases
+
+    fns, lines = reference_functions(("compareSequenceNumerical",), {"np": np, "os": os, "Path": Path, "Image": Image}, module="comparisons.py")
+    out["compare_lines"] = lines
+    with tempfile.TemporaryDirectory() as d:
+        inf, ref, save = (os.path.join(d, k) for k in ("inferred", "reference", "save"))
+        os.makedirs(inf)
+        os.makedirs(ref)
+        for i in range(120):
+            a, b = comparison_pair(i)
+            Image.fromarray(a).save(os.path.join(inf, f"frame{i}_pose.png"))
+            Image.fromarray(b).save(os.path.join(ref, f"pod2colour_pod2primary_{i:03d}.tif"))
+        with contextlib.redirect_stdout(io.StringIO()):
+            fns["compareSequenceNumerical"](inf, ref, save, colour=False)
+        text = open(os.path.join(save, "numerical_clip.csv")).read()
+    rows = text.split("\n")
+    assert len(rows) == 121
+    out["compare"] = {"images": 120, "shape": [1600, 1200], "file": "numerical_clip.csv",
+                      "csv_sha256": hashlib.sha256(text.encode()).hexdigest(), "csv_bytes": len(text),
+                      "image_means": [r.split(", ")[0] for r in rows[:120]],            # as the text the reference wrote
+                      "values_per_line": len(rows[0].split(", ")),
+                      "first_values": {str(k): rows[k].split(", ")[:12] for k in (0, 57, 119)},
+                      "last_line": rows[120]}
+    with open(os.path.join(HERE, "rerender_golden.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rerender":
+        rerender_golden()
+    else:
+        main()

@@ -94,3 +94,15 @@ def decode_id_planes(idp, B, H, W):
     OY, OX = (H + 31) // 32, (W + 31) // 32
     v = idp.detach().cpu().contiguous().view(torch.int32).reshape(B, OY, OX, 32, 32) & 0xffffff
     return v.permute(0, 1, 3, 2, 4).reshape(B, OY * 32, OX * 32)[:, :H, :W].contiguous()
+
+
+def comparison_pair(i, height=1600, width=1200):
+    """Image pair i of the re-render comparison fixture (tests/golden/make_golden.py::rerender_golden and
+    tests/test_next_rows.py regenerate the same 120 pairs from this formula): two smooth 8-bit images of the reference's
+    1600 x 1200 shape (comparisons.py:10) that differ by a slow pattern depending on i -- low entropy, so the PNG / TIFF
+    files the generator writes are small."""
+    y = np.arange(height, dtype=np.int64)[:, None]
+    x = np.arange(width, dtype=np.int64)[None, :]
+    ref = ((y // 8) * 3 + (x // 16) * 5 + 7 * i) % 200
+    img = (ref + ((y // 64 + x // 32 + i) % 9) * ((y // 32 + i) % 3) - ((x // 128 + 2 * i) % 5)).clip(0, 255)
+    return img.astype(np.uint8), ref.astype(np.uint8)
