@@ -152,7 +152,30 @@ def algorithmic_bytes_per_px(C, with_db):
     }
 
 
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r05_counters_cfg3.json")
+COUNTERS_TAG = "r06"
+
+
+def counters_file(workload, mip=False, channels=1):
+    """The committed PMC passes of a workload (scripts/measure_round.sh): profiles/r06_counters_<workload>[_mip][_c3].json"""
+    return os.path.join(ROOT, "profiles", f"{COUNTERS_TAG}_counters_{workload}{'_mip' if mip else ''}{f'_c{channels}' if channels != 1 else ''}.json")
+
+
+def workload_config(workload, mip=False):
+    """(FitConfig, frames per GPU, use a HIP graph) of a bench workload -- ONE definition for bench.py and for scripts/prof_objective.py,
+    whose rocprofv3 passes the bench pairs with its own timings."""
+    from fpc_diffrend_amd import fit
+    cfg = fit.FitConfig(max_iter=80000, enable_mip=mip, frames_per_step=0, init_texture="random")
+    if workload == "cfg2":       # BASELINE configs[1]: single frame, rasterize + interpolate only, no texture
+        cfg.optimize_texture = False
+        cfg.shading = "vertex"
+    if workload == "ref":        # the reference's loop: one random (camera, frame) image per iteration
+        cfg.frames_per_step = 1
+        cfg.views_per_step = 1
+    if workload == "cfg5":       # BASELINE configs[4]: 4K, per-vertex free-form offsets on top of the blendshapes
+        cfg.mode = "combined"
+        cfg.max_iter = 2              # the reference enables the free-form basis after max_iter / 2 (fit.py:603-608)
+    fpg = {"cfg1": 4, "cfg2": 1, "cfg3": 32, "cfg5": 4, "ref": 8}[workload]
+    return cfg, fpg, workload in ("cfg2", "ref")
 
 
 def kernel_source_sha16():
@@ -170,21 +193,35 @@ def kernel_source_sha16():
 # kernels behind each C-ABI entry point (the PMC passes are per kernel)
 # kernels of each entry point, by name prefix (template arguments vary with the instantiation the launch picked)
 ENTRY_KERNELS = {
+    # the nvdiffrast-style operators (cfg2's timed step; the stand-alone sweep of cfg3)
+    "fpcdr_rasterize_fwd": ["k_init_ibox", "k_setup<false, false", "k_setup_clip<false", "k_bins<", "k_hint_dilate"],
+    "fpcdr_rasterize_bwd": ["k_grad<"],
+    "fpcdr_interpolate_fwd": ["k_interp_fwd"],
+    "fpcdr_interpolate_bwd": ["k_interp_bwd"],
+    "fpcdr_texture_fwd": ["k_tex_fwd", "k_tex_empty"],
+    "fpcdr_texture_bwd": ["k_tex_bwd"],
+    "fpcdr_antialias_fwd": ["k_sil", "k_aa_fill", "k_aa_fwd<"],
+    "fpcdr_pixel_loss": ["k_pixel_loss"],
     "fpcdr_render_loss_fwd": ["k_sil2", "k_init_queue", "k_setup", "k_list_count<", "k_list_scan", "k_list_write<",
                               "k_bins_list<false, true, true", "k_bins_queue<false, true, true", "k_aa_fix_list<", "k_aa_fix_queue<"],
     "fpcdr_render_aa_bwd": ["k_render_aa_bwd<", "k_render_aa_bwd_list<", "k_render_aa_bwd_queue<"],
     "fpcdr_objective_fwd": ["k_init_objective", "k_setup<true, true", "k_setup_clip<true", "k_list_count<", "k_list_write_sum<",
                             "k_bins_list<false, false, false", "k_bins_queue<false, false, false", "k_shade_list<", "k_shade_queue<",
-                            "k_fix_list<", "k_fix_queue<", "k_objective_finish<"],
+                            "k_shade_mip_list<", "k_shade_mip_queue<", "k_fix_list<", "k_fix_queue<", "k_fix_mip_list<", "k_fix_mip_queue<",
+                            "k_objective_finish<"],
     "fpcdr_antialias_bwd": ["k_copy_f4_chunk", "k_aa_bwd_fix<"],
     "fpcdr_blend_fwd": ["k_blend_fwd_lds"],
 }
+# entry points that move their algorithmic bytes for EVERY pixel of the batch whatever the region hints say: rasterize forward writes
+# every pixel, antialias backward is a full copy, the pixel loss reads every pixel.  The other operators skip the reads of empty bins:
+# bytes/px x all pixels / time is then a dense-EQUIVALENT rate (it can exceed the HBM peak), not a roofline figure
+MOVES_ALL = ("fpcdr_rasterize_fwd", "fpcdr_antialias_bwd", "fpcdr_pixel_loss")
 OBJECTIVE_CALLS = ("fpcdr_objective_fwd", "fpcdr_render_loss_fwd", "fpcdr_render_aa_bwd")   # one-pass form / two-call form
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
 F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X dense f32 matrix peak (MI355X_MICROARCH.md)
 
 
-def measured_counters(name, workload, n_images, C, t_ms=None):
+def measured_counters(name, workload, n_images, C, t_ms=None, mip=False):
     """Per-launch PMC figures of one entry point from the committed rocprofv3 passes (COUNTERS_FILE: separate --pmc passes of
     scripts/prof_objective.py, scripts/measure_round.sh).  Returns (figures, None) or (None, reason): the figures are used only
     if the file describes this workload, was measured on THESE kernel sources (kernel_source_sha16) and -- t_ms given -- the
@@ -192,14 +229,18 @@ def measured_counters(name, workload, n_images, C, t_ms=None):
     HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE: on gfx950 FETCH_SIZE reports exactly half the bytes of a coalesced stream of ANY
     width per lane (1, 2, 4, 8, 16 B: profiles/r02_fetch_calibration.txt); the kernels' gathers (vertices, texels) hit L2 and do
     not reach the counter."""
+    path = counters_file(workload, mip, C)
+    src = os.path.relpath(path, ROOT)
     try:
-        with open(COUNTERS_FILE) as f:
+        with open(path) as f:
             t = json.load(f)
     except Exception as e:
-        return None, f"no counters file ({e!r})"
-    src = os.path.relpath(COUNTERS_FILE, ROOT)
-    if t.get("workload") != workload or t.get("images") != n_images or t.get("channels") != C:
-        return None, f"{src} describes {t.get('workload')} / {t.get('images')} images / C = {t.get('channels')}, not this run"
+        return None, f"no counters file for this workload ({src}: {e!r})"
+    if name not in ENTRY_KERNELS:
+        return None, f"no kernel list for {name}"
+    if t.get("workload") != workload or t.get("images") != n_images or t.get("channels") != C or bool(t.get("mip", 0)) != bool(mip):
+        return None, (f"{src} describes {t.get('workload')} / {t.get('images')} images / C = {t.get('channels')} / mip = {t.get('mip', 0)}, "
+                      "not this run")
     if t.get("kernel_source_sha16") != kernel_source_sha16():
         return None, (f"{src} was measured on kernel sources {t.get('kernel_source_sha16')} (commit {t.get('git_head')}), this run's are "
                       f"{kernel_source_sha16()}: counters of other kernels are not paired with these times")
@@ -208,7 +249,7 @@ def measured_counters(name, workload, n_images, C, t_ms=None):
     for kname, entry in t["kernels"].items():
         short = kname[5:] if kname.startswith("void ") else kname
         c = entry.get("counters")
-        if not c or not any(short == pre or (pre.endswith(("<", "true", "false")) and short.startswith(pre)) for pre in ENTRY_KERNELS[name]):
+        if not c or not any(short.startswith(pre) for pre in ENTRY_KERNELS[name]):
             continue
         tot["fetch_kb"] += c.get("FETCH_SIZE", 0.0)
         tot["write_kb"] += c.get("WRITE_SIZE", 0.0)
@@ -411,7 +452,8 @@ def main():
     if os.environ.get("FPCDR_BENCH_ALLOW_ANY_BACKEND", "0") != "1":
         fdist.check_world(args.gpus, device, require_backend="nccl" if world > 1 else None)
 
-    fpg = args.frames_per_gpu or {"cfg1": 4, "cfg2": 1, "cfg3": 32, "cfg5": 4, "ref": 8}[args.workload]
+    cfg, fpg_default, graph_default = workload_config(args.workload, args.mip)
+    fpg = args.frames_per_gpu or fpg_default
     n_frames = fpg * world
     sc = scene.cfg(args.workload, n_frames=n_frames)
     if args.fill:
@@ -419,17 +461,7 @@ def main():
     if args.channels != 1:
         import numpy as np
         sc.texture = np.repeat(sc.texture, args.channels, axis=2)[:, :, :args.channels].copy()
-    cfg = fit.FitConfig(max_iter=80000, enable_mip=args.mip, frames_per_step=0, init_texture="random")
-    if args.workload == "cfg2":       # BASELINE configs[1]: single frame, rasterize + interpolate only, no texture
-        cfg.optimize_texture = False
-        cfg.shading = "vertex"
-    if args.workload == "ref":        # the reference's loop: one random (camera, frame) image per iteration
-        cfg.frames_per_step = 1
-        cfg.views_per_step = 1
-    if args.workload == "cfg5":       # BASELINE configs[4]: 4K, per-vertex free-form offsets on top of the blendshapes
-        cfg.mode = "combined"
-        cfg.max_iter = 2              # the reference enables the free-form basis after max_iter / 2 (fit.py:603-608)
-    use_graph = bool(args.graph) if args.graph >= 0 else args.workload in ("cfg2", "ref")
+    use_graph = bool(args.graph) if args.graph >= 0 else graph_default
     cfg.hip_graph = use_graph
     bucket = None
     fitter = fit.Fitter(sc, cfg, device=device, rank=rank, world=world)
@@ -540,13 +572,19 @@ def main():
         npix = frames_step * n_views_step * H * W
 
         def table_of(summ):
+            """Per entry point: calls, mean HIP-event ms and its per-pixel rate.  Only the calls that move their bytes for every pixel
+            of the batch (MOVES_ALL) carry it as algorithmic_GBps; the operators that skip the reads of empty bins through the region
+            hints, and the objective calls that run over bin lists, carry a dense_equivalent_GBps (it may exceed the HBM peak)."""
             table = {}
             for name, (calls, ms) in summ.items():
                 per = ms / max(calls, 1)
                 row = {"calls": calls, "avg_ms": per}
                 if name in bpp:
-                    row["algorithmic_GBps"] = bpp[name] * npix / (per * 1e-3) / 1e9
+                    key = "algorithmic_GBps" if name in MOVES_ALL else "dense_equivalent_GBps"
+                    row[key] = bpp[name] * npix / (per * 1e-3) / 1e9
                     row["bytes_per_px"] = bpp[name]
+                    if name not in MOVES_ALL and name not in OBJECTIVE_CALLS:
+                        row["note"] = "region hints skip the reads of empty bins: not a roofline figure"
                 table[name] = row
             return table
 
@@ -556,7 +594,7 @@ def main():
         out["hip_graph"] = use_graph
         if use_graph:
             out["kernels_note"] = "per-kernel HIP-event durations from an eager pass before the timed region; the timed steps replay two HIP graphs"
-        px_ops = {k: v for k, v in table.items() if "algorithmic_GBps" in v}
+        px_ops = {k: v for k, v in table.items() if "bytes_per_px" in v}
         # pixels the SPARSE objective has to touch: 1024 per bin on its lists (counts of the last step, ops._ListHints)
         import fpc_diffrend_amd.ops as dr_ops
         sparse_px = {}
@@ -574,26 +612,30 @@ def main():
         if px_ops:
             def hbm_roofline(name_):
                 """HBM roofline of one per-pixel entry point: algorithmic bytes / HIP-event time against the 8 TB/s peak, the PMC
-                traffic of its kernels beside it, and what the counters say bounds it."""
+                traffic of its kernels beside it, and what the counters say bounds it.  `achieved` / `frac` exist only where the
+                algorithmic bytes are known: the calls of MOVES_ALL (every pixel of the batch) and the sparse objective (1 024 pixels x
+                the bins on its list, counted live).  A hinted operator skips the reads of an unknown share of the batch: null, with
+                the dense-equivalent rate and the measured traffic beside it."""
                 t_s_ = px_ops[name_]["avg_ms"] * 1e-3
-                pmc_, why_ = measured_counters(name_, args.workload, fpg * n_cam, C, t_ms=px_ops[name_]["avg_ms"])
-                alg_ = bpp[name_] * sparse_px.get(name_, npix)
-                a_ = alg_ / t_s_ / 1e9
+                pmc_, why_ = measured_counters(name_, args.workload, fpg * n_cam, C, t_ms=px_ops[name_]["avg_ms"], mip=args.mip)
+                known = name_ in MOVES_ALL or name_ in sparse_px
+                alg_ = bpp[name_] * sparse_px.get(name_, npix) if known else None
+                a_ = alg_ / t_s_ / 1e9 if known else None
                 valu_bound = bool(pmc_ and pmc_.get("valu_issue_frac") and pmc_["valu_issue_frac"] > (pmc_["hbm_bytes"] / t_s_ / 1e9 / HBM_PEAK_GBS))
                 return {"kernel": name_,
                         # what the counters say limits the call; achieved / peak / frac are the HBM figures the metric asks for
                         # (algorithmic bytes against the 8 TB/s peak), whatever the bound
                         # (no counters for this workload / these sources: no evidence either way -> null, not "hbm")
                         "bound": None if not pmc_ else ("valu-issue" if valu_bound else "hbm"),
-                        "achieved": a_, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_ / HBM_PEAK_GBS, "ms": px_ops[name_]["avg_ms"],
-                        "algorithmic_bytes": alg_,
+                        "achieved": a_, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (a_ / HBM_PEAK_GBS) if known else None,
+                        "ms": px_ops[name_]["avg_ms"], "algorithmic_bytes": alg_,
                         "traffic": pmc_["hbm_bytes"] if pmc_ else None,
                         "traffic_GBps": (pmc_["hbm_bytes"] / t_s_ / 1e9) if pmc_ else None,
                         "traffic_frac": (pmc_["hbm_bytes"] / t_s_ / 1e9 / HBM_PEAK_GBS) if pmc_ else None,
                         "valu_issue_frac": pmc_.get("valu_issue_frac") if pmc_ else None,
                         "traffic_source": pmc_["source"] if pmc_ else None,
                         "traffic_unavailable": why_,
-                        "dense_equivalent_GBps": px_ops[name_]["algorithmic_GBps"]}, pmc_
+                        "dense_equivalent_GBps": bpp[name_] * npix / t_s_ / 1e9}, pmc_
 
             dom = max(px_ops, key=lambda k: px_ops[k]["avg_ms"] * px_ops[k]["calls"])
             t_s = px_ops[dom]["avg_ms"] * 1e-3
@@ -607,14 +649,24 @@ def main():
                                                           "GBps": eq_bytes / t_s / 1e9, "frac": eq_bytes / t_s / 1e9 / HBM_PEAK_GBS,
                                                           "note": "the work of fpcdr_render_loss_fwd + fpcdr_render_aa_bwd (round 3: 45 B/px "
                                                                   "on the listed bins, frac 0.14-0.15 per call) done in this call's time"}
-            out["roofline"]["note"] = ("fpcdr_objective_fwd computes value AND gradient in one call and moves 9 B/px (id plane out and in, "
-                                       "8-bit reference): it is bound by vector issue, not by HBM -- see roofline_valu.  "
-                                       "achieved = algorithmic bytes of the SPARSE call (B/px x 1024 px x the bins on its list, counted "
-                                       "live) / HIP-event time inside the timed region; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the "
-                                       "call's kernels from the committed PMC passes named in traffic_source (null, with the reason in "
-                                       "traffic_unavailable, when they were measured on other kernel sources or their durations differ "
-                                       "from this run's by more than 10 %); dense_equivalent counts every pixel of the batch although "
-                                       "80 % are never touched")
+            if dom == "fpcdr_objective_fwd":
+                out["roofline"]["note"] = ("fpcdr_objective_fwd computes value AND gradient in one call and moves 9 B/px (id plane out and in, "
+                                           "8-bit reference): it is bound by vector issue, not by HBM -- see roofline_valu.  "
+                                           "achieved = algorithmic bytes of the SPARSE call (B/px x 1024 px x the bins on its list, counted "
+                                           "live) / HIP-event time inside the timed region; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the "
+                                           "call's kernels from the committed PMC passes named in traffic_source (null, with the reason in "
+                                           "traffic_unavailable, when they were measured on other kernel sources or their durations differ "
+                                           "from this run's by more than 10 %); dense_equivalent counts every pixel of the batch although "
+                                           "80 % are never touched")
+            elif dom in MOVES_ALL:
+                out["roofline"]["note"] = (f"{dom}: achieved = bytes/px x every pixel of the batch / HIP-event time (the call moves them "
+                                           "whatever the region hints say); traffic = 2 x FETCH_SIZE + WRITE_SIZE of its kernels from the "
+                                           "committed PMC passes named in traffic_source")
+            else:
+                out["roofline"]["note"] = (f"{dom} skips the reads of the bins the region hint calls empty: its algorithmic bytes are not "
+                                           "bytes/px x the batch, so achieved / frac are null; dense_equivalent_GBps prices every pixel "
+                                           "(not a roofline figure, it may exceed the peak); traffic / traffic_frac are the measured HBM "
+                                           "bytes of its kernels (committed PMC passes) against the 8 TB/s peak")
             # the two calls of the objective take nearly the same time and swap places from run to run: both are reported
             out["roofline_objective_calls"] = {n_: hbm_roofline(n_)[0] for n_ in OBJECTIVE_CALLS if n_ in px_ops}
             if pmc and pmc.get("valu_issue_frac") is not None:
@@ -632,13 +684,13 @@ def main():
             vpp = {}
             for name_ in OBJECTIVE_CALLS:
                 if name_ in table and sparse_px.get(name_):
-                    pm, _ = measured_counters(name_, args.workload, fpg * n_cam, C, t_ms=table[name_]["avg_ms"])
+                    pm, _ = measured_counters(name_, args.workload, fpg * n_cam, C, t_ms=table[name_]["avg_ms"], mip=args.mip)
                     if pm and pm["valu_insts"]:
                         vpp[name_] = pm["valu_insts"] / (sparse_px[name_] / 64.0)
             if vpp:
                 out["valu_insts_per_px"] = dict(vpp, note="SQ_INSTS_VALU of the call's kernels / (pixels on its bin list / 64): vector "
                                                           "wave-instructions issued per 64 pixels")
-        bl, _ = measured_counters("fpcdr_blend_fwd", args.workload, fpg * n_cam, C)
+        bl, _ = measured_counters("fpcdr_blend_fwd", args.workload, fpg * n_cam, C, mip=args.mip)
         if bl and bl.get("mfma_busy_frac") is not None:
             Mrows, Kb = 3 * (sc.v_base.shape[0] // 3), sc.blendshapes.shape[1]
             out["roofline_blend_mfma"] = {"kernel": "k_blend_fwd_lds (V = v_base + W B^T, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
@@ -652,15 +704,6 @@ def main():
         if not args.mip and args.workload in ("cfg1", "cfg3") and world == 1:   # (scaling runs: all ranks leave together)
             try:
                 st = table_of(standalone_op_sweep(fitter))
-                # with region hints (include/fpcdr.h) the operators skip the READS of empty bins: bytes/px x every pixel of the batch
-                # is then a dense-EQUIVALENT rate, not traffic, and may exceed the HBM peak.  Only the calls that really move those
-                # bytes keep the name algorithmic_GBps: rasterize forward (writes every pixel), antialias backward (a full copy), the
-                # pixel loss.
-                moves_all = ("fpcdr_rasterize_fwd", "fpcdr_antialias_bwd", "fpcdr_pixel_loss")
-                for name_, row in st.items():
-                    if "algorithmic_GBps" in row and name_ not in moves_all:
-                        row["dense_equivalent_GBps"] = row.pop("algorithmic_GBps")
-                        row["note"] = "region hints skip the reads of empty bins: not a roofline figure"
                 out["kernels_standalone_ops"] = st
                 if "fpcdr_antialias_bwd" in st:
                     a = st["fpcdr_antialias_bwd"]["algorithmic_GBps"]
@@ -705,12 +748,6 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {e!r}"}
     if rank == 0:
-        # the two objective calls run over bin lists (sparse mode): 25 / 20 B per pixel of the WHOLE batch divided by their time is a
-        # dense-equivalent rate (it exceeds the HBM peak), not a roofline figure -- roofline_objective_calls has that
-        for name_ in OBJECTIVE_CALLS:
-            row = out.get("kernels", {}).get(name_) if isinstance(out.get("kernels"), dict) else None
-            if row and "algorithmic_GBps" in row:
-                row["dense_equivalent_GBps"] = row.pop("algorithmic_GBps")
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as tdist

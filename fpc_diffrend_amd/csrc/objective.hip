@@ -68,6 +68,16 @@ struct ObjArgs {
     // [1] of occ: it keeps counting beyond the capacity, so that the caller learns the need), slot_of[bin] = its slot or -1
     int32_t *slot_of; int32_t *pool_count; int32_t *overflow; int pool_cap;
 };
+// COLD kernel arguments.  The compiler loads every kernel argument a kernel uses at its entry and keeps it to where it is used -- in a
+// scalar register or, once those run out, in a lane of a vector register (v_writelane / v_readlane: vector-issue slots, the resource
+// k_shade is bound by; r5: 47 spilled scalar registers, 173 v_readlane).  What shade_body needs once or rarely -- the record arrays of
+// the deferred branch, the index-buffer form of the texture coordinates, everything the bin's epilogue writes -- is read from the
+// kernel-argument segment WHERE IT IS USED: cold(ka)->field is a scalar load behind an opaque barrier it cannot be hoisted across.
+typedef const __attribute__((address_space(4))) ObjArgs *KArgs;
+__device__ __forceinline__ KArgs cold(KArgs p) { asm volatile("" : "+s"(p)); return p; }
+template <typename K> __device__ __forceinline__ KArgs kernarg_objargs() {      // K: the kernel's ONE parameter, a struct with a member `a`
+    return (KArgs)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(K, a));
+}
 // element index of pixel (xx, yy) of image-bin `lin` (+ the offset to a neighbouring bin) in the record arrays
 __device__ __forceinline__ size_t rec_slot_index(int slot, int xx, int yy) { return (size_t)(slot < 0 ? 0 : slot) * (OB * OB) + (yy & 31) * OB + (xx & 31); }
 
@@ -168,7 +178,7 @@ __device__ __forceinline__ int shade_row_pair(int k, int w) {
 
 template <int CS, int BMODE, bool MIP = false>
 __device__ __forceinline__ void shade_body(const int b, const int bxi, const int byi, const int OX, const int OY, const ObjArgs &a,
-                                           const MipO *ma = nullptr) {
+                                           const KArgs ka, const MipO *ma = nullptr) {
     const int boundary = BMODE >= 0 ? BMODE : a.boundary;
     __shared__ int s_mred[18];      // MIP prepass: min level, min / max keys of the prepared u and v, and of both shifted by half a period
     __shared__ unsigned int s_id[(OB + 2) * OS];
@@ -248,6 +258,9 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             a.slot_of[bin_lin] = -1;
         }
     }
+
+    // (a bin the pool had no slot for defers nothing -- the call reports the overflow --: one uniform flag for both facts)
+    const bool bin_sil_rec = bin_sil && !(compact && slot < 0);
 
     const size_t img = (size_t)b * H * W;
     const size_t bin_off = img + (size_t)by0 * W + bx0;
@@ -339,12 +352,11 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         float gv9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (id > 0) {
             bool deferred = false;
-            if (bin_sil) {      // (uniform)
+            if (bin_sil_rec) {      // (uniform)
                 const unsigned int nR = s_id[(zy + 1) * OS + col + 2], nL = s_id[(zy + 1) * OS + col];
                 const unsigned int nU = s_id[(zy + 2) * OS + col + 1], nD = s_id[zy * OS + col + 1];
                 deferred = (x + 1 < W && pair_maybe(me, nR)) || (y + 1 < H && pair_maybe(me, nU)) || (x > 0 && pair_maybe(me, nL)) ||
                            (y > 0 && pair_maybe(me, nD));
-                if (compact && slot < 0) deferred = false;
             }
             const int t = id - 1;
             // (measured and dropped in r4: the four pixels' vertex indices fetched up front and a pixel's vertices while the one before it is
@@ -364,7 +376,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 shade_uvz<false>(v0, v1, v2, fx_col, fy, K, u, v, zw);      // (z/w: deferred pixels only, below)
             }
             // interpolate (fit.py:157) + texture 'linear' (fit.py:158): the arithmetic of the stand-alone kernels
-            const UV3 tq = a.tri_uv ? ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t) : uv_indirect(a.uv, a.uv_tri, t);
+            const UV3 tq = a.tri_uv ? ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t) : uv_indirect(cold(ka)->uv, cold(ka)->uv_tri, t);
             const float2 q0 = tq.q0, q1 = tq.q1, q2 = tq.q2;
             const float w = 1.0f - u - v;
             const float tu = u * q0.x + v * q1.x + w * q2.x;
@@ -412,9 +424,11 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 atomicOr(&s_cmask[zy], colbit);
                 if (!MIP) zw = shade_zw(v0, v1, v2, K.a0, K.a1, K.p0x * K.p1y - K.p0y * K.p1x);
                 const size_t ro = compact ? rec_slot_index(slot, col, zy) : off;
-                a.rec[ro] = make_float4(u, v, zw, (float)(t + 1));      // (= id; t stays live for the vertex table's key, id need not)
+                const KArgs kc = cold(ka);
+                kc->rec[ro] = make_float4(u, v, zw, (float)(t + 1));      // (= id; t stays live for the vertex table's key, id need not)
+                float *const colp = kc->color, *const gaap = kc->g_aa;
 #pragma unroll
-                for (int c = 0; c < CS; ++c) { a.color[ro * CS + c] = colv[c]; a.g_aa[ro * CS + c] = gq[c]; }
+                for (int c = 0; c < CS; ++c) { colp[ro * CS + c] = colv[c]; gaap[ro * CS + c] = gq[c]; }
             }
             float gtu_m = 0.f, gtv_m = 0.f;
             float4 gda = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -523,7 +537,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 const int t = id - 1;
                 const I3 ti = ld32(reinterpret_cast<const I3 *>(a.tri), t);
                 const Shade sd = shade_pixel(ld32(pos_img, ti.a), ld32(pos_img, ti.b), ld32(pos_img, ti.c), fx_col, s_fy[zy], 2.0f / (float)W, 2.0f / (float)H);
-                const UV3 tq = a.tri_uv ? ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t) : uv_indirect(a.uv, a.uv_tri, t);
+                const UV3 tq = a.tri_uv ? ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t) : uv_indirect(cold(ka)->uv, cold(ka)->uv_tri, t);
                 const float w = 1.0f - sd.u - sd.v;
                 const float tu = sd.u * tq.q0.x + sd.v * tq.q1.x + w * tq.q2.x, tv = sd.u * tq.q0.y + sd.v * tq.q1.y + w * tq.q2.y;
                 const float e0x = tq.q0.x - tq.q2.x, e0y = tq.q0.y - tq.q2.y, e1x = tq.q1.x - tq.q2.x, e1y = tq.q1.y - tq.q2.y;
@@ -704,17 +718,18 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     const bool bin_def = __builtin_amdgcn_readfirstlane(__syncthreads_or(any_def ? 1 : 0)) != 0;
     OPROF_T(6);
     // ---- the bin's deferred pixels for k_fix; loss ----
-    if (tid < OB) { a.cmask[bin_lin * OB + tid] = s_cmask[tid]; a.hitmask[bin_lin * OB + tid] = 0u; }
+    const KArgs ke = cold(ka);      // (the epilogue's pointers: scalar loads here, not registers held across the shading code)
+    if (tid < OB) { ke->cmask[bin_lin * OB + tid] = s_cmask[tid]; ke->hitmask[bin_lin * OB + tid] = 0u; }
     if (tid == 0) {
         if (bin_def) {
-            a.binflag[bin_lin] = 1;      // (zero-filled by the call's first kernel)
+            ke->binflag[bin_lin] = 1;      // (zero-filled by the call's first kernel)
             // k_fix runs over the bins with a deferred pixel only -- one in six of the occupied ones on a face rig.  (One-wave workgroups
             // that leave at once are not free: k_fix<1> over ALL occupied bins was bound by workgroup dispatch, 220 us for 90 k of them.)
-            a.def_list[atomicAdd(a.def_count, 1)] = (int32_t)bin_lin;
+            ke->def_list[atomicAdd(ke->def_count, 1)] = (int32_t)bin_lin;
         }
         const double tot = (double)s_lpart[0] + (double)s_lpart[1] + (double)s_lpart[2] + (double)s_lpart[3];
         const unsigned int slot = ((unsigned int)bxi + 31u * (unsigned int)byi + 977u * (unsigned int)b) % FPCDR_LOSS_SLOTS;
-        if (tot != 0.0) atomicAdd(a.loss_sum + slot, tot);
+        if (tot != 0.0) atomicAdd(ke->loss_sum + slot, tot);
     }
     OPROF_ADD(0, 0, 1); OPROF_ADD(1, 1, 2); OPROF_ADD(2, 2, 3); OPROF_ADD(3, 3, 4); OPROF_ADD(4, 4, 5); OPROF_ADD(5, 5, 6);
     if (!want_grad) return;
@@ -755,51 +770,53 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
 //  waits -- drain while the next bin is shaded: 1 597 us with one bin per workgroup, 1 630 with two in a loop (96 VGPRs: the loop's hoisted
 //  scalar loads; arguments re-read from the kernel-argument segment per trip), 1 615 with two unrolled (84 VGPRs, and 80 with five spills),
 //  1 639 with four.  What the flush costs is not the idle slot: profiles/r05_flush_experiments.txt.)
+// ONE kernel parameter, a struct: the position of ObjArgs in the kernel-argument segment is then offsetof(K, a) (kernarg_objargs)
+struct ShadeK { const int32_t *list; const int32_t *count; int cap, OX, OY; fpcdr_bin_decode dc; ObjArgs a; };      // cap: of a sweep, its first entry
+struct ShadeMipK { const int32_t *list; const int32_t *count; int cap, OX, OY; fpcdr_bin_decode dc; ObjArgs a; MipO ma; };
 template <int CS, int BMODE>
-__global__ void __launch_bounds__(ONT) FPCDR_SHADE_WPE k_shade_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int cap,
-                                                                    int OX, int OY, fpcdr_bin_decode dc, ObjArgs a) {
-    const int item = fpcdr_list_item(*count, cap);      // (XCD x takes the x-th eighth of the entries: common.h)
+__global__ void __launch_bounds__(ONT) FPCDR_SHADE_WPE k_shade_list(const ShadeK k) {
+    const int item = fpcdr_list_item(*k.count, k.cap);      // (XCD x takes the x-th eighth of the entries: common.h)
     if (item < 0) return;
-    const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+    const int lin = __builtin_amdgcn_readfirstlane(k.list[item]);
     int b, byi, bxi;
-    fpcdr_decode_bin(lin, dc, b, byi, bxi);
-    shade_body<CS, BMODE>(b, bxi, byi, OX, OY, a);
+    fpcdr_decode_bin(lin, k.dc, b, byi, bxi);
+    shade_body<CS, BMODE>(b, bxi, byi, k.OX, k.OY, k.a, kernarg_objargs<ShadeK>());
 }
 
 // the MIP instantiation (boundary mode at run time): list form and strided sweep
 template <int CS>
-__global__ void __launch_bounds__(ONT) FPCDR_SHADE_MIP_WPE k_shade_mip_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int cap, int OX, int OY,
-                                                        fpcdr_bin_decode dc, ObjArgs a, MipO ma) {
-    const int item = fpcdr_list_item(*count, cap);
+__global__ void __launch_bounds__(ONT) FPCDR_SHADE_MIP_WPE k_shade_mip_list(const ShadeMipK k) {
+    const int item = fpcdr_list_item(*k.count, k.cap);
     if (item < 0) return;
-    const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+    const int lin = __builtin_amdgcn_readfirstlane(k.list[item]);
     int b, byi, bxi;
-    fpcdr_decode_bin(lin, dc, b, byi, bxi);
-    shade_body<CS, -1, true>(b, bxi, byi, OX, OY, a, &ma);
+    fpcdr_decode_bin(lin, k.dc, b, byi, bxi);
+    shade_body<CS, -1, true>(b, bxi, byi, k.OX, k.OY, k.a, kernarg_objargs<ShadeMipK>(), &k.ma);
 }
+// (the level chain as a kernel parameter of its own: as a member of the one struct, indexed at run time inside the loop, it was copied
+//  to a 48-byte private segment -- and a kernel with a private segment is dispatched several times slower, taken or not)
 template <int CS>
-__global__ void __launch_bounds__(ONT) k_shade_mip_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int first, int OX,
-                                                         int OY, fpcdr_bin_decode dc, ObjArgs a, MipO ma) {
-    const int n = *count;
-    for (int item = first + blockIdx.x; item < n; item += gridDim.x) {
-        const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+__global__ void __launch_bounds__(ONT) k_shade_mip_queue(const ShadeK k, const MipO ma) {
+    const int n = *k.count;
+    const KArgs ka = kernarg_objargs<ShadeK>();
+    for (int item = k.cap + blockIdx.x; item < n; item += gridDim.x) {
+        const int lin = __builtin_amdgcn_readfirstlane(k.list[item]);
         int b, byi, bxi;
-        fpcdr_decode_bin(lin, dc, b, byi, bxi);
-        shade_body<CS, -1, true>(b, bxi, byi, OX, OY, a, &ma);
+        fpcdr_decode_bin(lin, k.dc, b, byi, bxi);
+        shade_body<CS, -1, true>(b, bxi, byi, k.OX, k.OY, k.a, ka, &ma);
         __syncthreads();
     }
 }
 
 // strided sweep of the entries beyond the hinted launch (normally none; scalar loop variable: see k_bins_queue in rasterize.hip)
 template <int CS>
-__global__ void __launch_bounds__(ONT) k_shade_queue(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int first, int OX, int OY,
-                                                     fpcdr_bin_decode dc, ObjArgs a) {
-    const int n = *count;
-    for (int item = first + blockIdx.x; item < n; item += gridDim.x) {
-        const int lin = __builtin_amdgcn_readfirstlane(list[item]);
+__global__ void __launch_bounds__(ONT) k_shade_queue(const ShadeK k) {
+    const int n = *k.count;
+    for (int item = k.cap + blockIdx.x; item < n; item += gridDim.x) {
+        const int lin = __builtin_amdgcn_readfirstlane(k.list[item]);
         int b, byi, bxi;
-        fpcdr_decode_bin(lin, dc, b, byi, bxi);
-        shade_body<CS, -1>(b, bxi, byi, OX, OY, a);
+        fpcdr_decode_bin(lin, k.dc, b, byi, bxi);
+        shade_body<CS, -1>(b, bxi, byi, k.OX, k.OY, k.a, kernarg_objargs<ShadeK>());
         __syncthreads();     // the next bin's first LDS writes must not overtake this bin's last LDS reads
     }
 }
@@ -1441,10 +1458,11 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
     const int cap = (p->cap_occ > 0 && p->cap_occ < nbins) ? p->cap_occ : (int)nbins;
     const dim3 grid(fpcdr_list_grid(cap));
     const bool sweep = cap < nbins;
+    const ShadeK shade_k = {occ_list, n_occ, cap, OX, OY, dc, a};
 #define SHADE(CS, BM)                                                                                                             \
     do {                                                                                                                          \
-        hipLaunchKernelGGL((k_shade_list<CS, BM>), grid, dim3(ONT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a);                   \
-        if (sweep) hipLaunchKernelGGL(k_shade_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(ONT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a); \
+        hipLaunchKernelGGL((k_shade_list<CS, BM>), grid, dim3(ONT), 0, st, shade_k);                                               \
+        if (sweep) hipLaunchKernelGGL(k_shade_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(ONT), 0, st, shade_k);                        \
     } while (0)
     // k_fix: over the bins k_shade found a deferred pixel in (count at occ header [0]; p->cap_def: launch hint)
     const int cap_d = (p->cap_def > 0 && p->cap_def < nbins) ? p->cap_def : (int)nbins;
@@ -1482,10 +1500,11 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
             ma.lv.grad[lvl] = (lvl <= p->n_levels && p->grad_tex) ? p->grad_tex_mip[lvl - 1] : nullptr;
         }
         ma.n_levels = p->n_levels;
+        const ShadeMipK shade_mip_k = {occ_list, n_occ, cap, OX, OY, dc, a, ma};
 #define SHADE_MIP(CS)                                                                                                             \
     do {                                                                                                                          \
-        hipLaunchKernelGGL(k_shade_mip_list<CS>, grid, dim3(ONT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a, ma);                 \
-        if (sweep) hipLaunchKernelGGL(k_shade_mip_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(ONT), 0, st, occ_list, n_occ, cap, OX, OY, dc, a, ma); \
+        hipLaunchKernelGGL(k_shade_mip_list<CS>, grid, dim3(ONT), 0, st, shade_mip_k);                                             \
+        if (sweep) hipLaunchKernelGGL(k_shade_mip_queue<CS>, dim3(FPCDR_SWEEP_WGS), dim3(ONT), 0, st, shade_k, ma);               \
     } while (0)
 #define FIX_MIP(CS)                                                                                                               \
     do {                                                                                                                          \

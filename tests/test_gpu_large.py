@@ -212,11 +212,11 @@ def _scene_at_fill(sc, fill):
     return sc2
 
 
-@pytest.mark.parametrize("fill,cam,frame,seed,lo,hi", [(1.4, 4, 1, 11, 0.30, 0.60), (2.4, 2, 0, 12, 0.85, 1.0)])
+@pytest.mark.parametrize("fill,cam,frame,seed,lo,hi", [(1.4, 4, 1, 11, 0.30, 0.60), (2.4, 2, 0, 12, 0.55, 1.0)])
 def test_1080p_one_image_at_other_coverages_matches_oracle(big, oracle_ops, fill, cam, frame, seed, lo, hi):
     """Off the one operating point: the footprint-shaped texel windows, the two halves of a bin, the deferred-pixel records and the bin
     lists all depend on how many texels and triangles lie under a bin.  At fill 1.4 a bin sees ~2.3 x 1.5 texels per pixel and
-    fewer, larger triangles; at 2.4 the head overflows the frame (every bin occupied, guard-band clipping at the image border)."""
+    fewer, larger triangles; at 2.4 the head overflows the frame top and bottom (68 % covered, geometry cut by the image border)."""
     dr, sc, _, tri = big
     sc2 = _scene_at_fill(sc, fill)
     pos1, _ = clip_positions(sc2, [cam], frames=[frame])

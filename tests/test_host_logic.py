@@ -328,7 +328,7 @@ def test_fit_loop_kernels_have_no_private_segment():
     build = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fpc_diffrend_amd", "csrc", "_build")
     if not (os.path.isdir(build) and os.path.exists(os.path.join(llvm, "llvm-readelf"))):
         pytest.skip("no built objects / llvm tools")
-    hot = {"objective.o": r"k_shade_list|k_fix_list|k_shade_mip_list|k_fix_mip_list|k_objective_finish|k_count_sil",
+    hot = {"objective.o": r"k_shade_list|k_fix_list|k_shade_mip_list|k_fix_mip_list|k_objective_finish|k_count_sil|k_shade_queue|k_shade_mip_queue|k_fix_queue|k_fix_mip_queue",
            "rasterize.o": r"k_setupILb1ELb1|k_bins_listILb0ELb0ELb0ELi0ELin1ELb0ELb1|k_list_|k_init_objective",      # (k_setup_clip keeps the clipper's)
            "clip.o": r"k_clip_|k_mvp_|k_lap_", "blend.o": r"k_blend_fwd_lds|k_blend_bwd_w|k_rig_", "adam.o": r"k_adam"}
     seen = 0
