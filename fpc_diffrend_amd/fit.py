@@ -882,9 +882,36 @@ class Fitter:
     def _n(frame_ids):
         return frame_ids.stop - frame_ids.start if isinstance(frame_ids, slice) else len(frame_ids)
 
-    def mvp(self, frame_ids, view_ids=None, pool=None):
+    def check_indices(self, frame_ids, view_ids=None):
+        """Raise IndexError for frame numbers outside the take or outside this rank's shard, and for view positions outside cam_idxs.
+        The indexed kernels behind mvp() / vertices() / loss_and_backward() gather from -- and scatter-add into -- the full parameter
+        tables WITHOUT bounds checks (the index_select calls they replaced raised): a caller's own index tensors are checked here,
+        once, on the host (one read-back per tensor); the loop's own draws (pick_frames / pick_views) are in range by construction."""
+        if isinstance(frame_ids, slice):
+            lo, hi = frame_ids.start or 0, frame_ids.stop
+            if frame_ids.step not in (None, 1) or hi is None or not (self.frame_lo <= lo <= hi <= self.frame_hi):
+                raise IndexError(f"frames {frame_ids} outside this rank's frames [{self.frame_lo}, {self.frame_hi})")
+        else:
+            f = torch.as_tensor(frame_ids)
+            if f.dtype not in (torch.int64, torch.int32) or f.dim() != 1 or f.numel() == 0:
+                raise IndexError("frame_ids must be a non-empty 1-D integer tensor or a slice")
+            lo, hi = int(f.min()), int(f.max())
+            if lo < self.frame_lo or hi >= self.frame_hi:
+                raise IndexError(f"frame numbers {lo}..{hi} outside this rank's frames [{self.frame_lo}, {self.frame_hi})")
+        if view_ids is not None:
+            v = torch.as_tensor(view_ids)
+            if v.dtype not in (torch.int64, torch.int32) or v.dim() != 1 or v.numel() == 0:
+                raise IndexError("view_ids must be a non-empty 1-D integer tensor")
+            lo, hi = int(v.min()), int(v.max())
+            if lo < 0 or hi >= len(self.cam_idxs):
+                raise IndexError(f"view positions {lo}..{hi} outside cam_idxs (0..{len(self.cam_idxs) - 1})")
+
+    def mvp(self, frame_ids, view_ids=None, pool=None, validate=True):
         """mvp[f,c] = P_c . Rt(q_f,t_f) . Rt(q_c,t_c) . MV_c . T(0,170,0)   (fit.py:541-553), [Fb*Nc,4,4].
-        view_ids: positions in cam_idxs of the cameras of this step (a device index tensor; None = all of them).  pool: the step's ZeroPool."""
+        view_ids: positions in cam_idxs of the cameras of this step (a device index tensor; None = all of them).  pool: the step's ZeroPool.
+        validate: check_indices (index tensors only; the loop's own calls pass False)."""
+        if validate and (torch.is_tensor(frame_ids) or view_ids is not None):
+            self.check_indices(frame_ids, view_ids)
         all_cams = self.cam_idxs == list(range(self.q_opt.shape[0]))    # no gather (and no sort in its backward) then
         if view_ids is not None or torch.is_tensor(frame_ids):
             # rows named by index: one launch each way on the full parameter tables (the gathers happen inside the kernels)
@@ -908,10 +935,13 @@ class Fitter:
             return t[ids] if dim == 0 else t[:, ids]
         return t.index_select(dim, ids)
 
-    def vertices(self, frame_ids, iteration=None, pool=None):
+    def vertices(self, frame_ids, iteration=None, pool=None, validate=True):
         """Blended vertex buffers [Fb,3V] for a batch of frames (fit.py:555-562).  The reference multiplies by a
         one-hot frame vector (fit.py:536, 115-116); M e_f is column f of M, so the batch selects columns
-        (a slice -- no copy -- when the frames are a contiguous range)."""
+        (a slice -- no copy -- when the frames are a contiguous range).  validate: check_indices for an index tensor."""
+        if validate and torch.is_tensor(frame_ids):
+            if int(frame_ids.min()) < 0 or int(frame_ids.max()) >= self.n_frames:
+                raise IndexError(f"frame numbers outside the take (0..{self.n_frames - 1})")
         if self.cfg.mode in ('prior', 'combined'):
             # (validate=False: the frame indices are pick_frames' own, drawn from this rank's range)
             out = blend_batched(self.v_base, self.datasets['local'],
@@ -1029,8 +1059,11 @@ class Fitter:
             for m in (self.m1, self.m2, self.m3):
                 m.requires_grad = True
 
-    def loss_and_backward(self, frame_ids, view_ids=None):
-        """Forward + backward of fit.py:556-611 for a batch of frames x cameras (view_ids: see mvp).  Returns the loss (tensor)."""
+    def loss_and_backward(self, frame_ids, view_ids=None, validate=True):
+        """Forward + backward of fit.py:556-611 for a batch of frames x cameras (view_ids: see mvp).  Returns the loss (tensor).
+        validate: check a caller's index tensors on the host first (check_indices); step() passes False for its own draws."""
+        if validate and not torch.cuda.is_current_stream_capturing():
+            self.check_indices(frame_ids, view_ids)
         cfg = self.cfg
         i = self.iteration
         self._mode_switch()
@@ -1048,9 +1081,9 @@ class Fitter:
             zero_buf = torch.empty(Fb * Nc * 16 + 7 * n_pose + 64 + Fb * (self.datasets['local'].shape[1] + self.m3.shape[1]),
                                    dtype=torch.float32, device=self.device)
             pool = ZeroPool(zero_buf)
-        vtx_pos = self.vertices(frame_ids, pool=pool)                 # [Fb,3V]
+        vtx_pos = self.vertices(frame_ids, pool=pool, validate=False)                 # [Fb,3V]
         vtx_pos_split = vtx_pos.reshape(Fb, -1, 3)
-        mvp = self.mvp(frame_ids, view_ids, pool)
+        mvp = self.mvp(frame_ids, view_ids, pool, validate=False)
         ref = None
         n_img_global = Fb * Nc * self.world
         local = slice(frame_ids.start - self.frame_lo, frame_ids.stop - self.frame_lo) if isinstance(frame_ids, slice) \
@@ -1235,7 +1268,7 @@ class Fitter:
         if self.use_graph and self.iteration >= self.GRAPH_WARMUP:
             loss = self._step_graphed(frame_ids, view_ids, prepared)
         else:
-            loss = self.loss_and_backward(frame_ids, view_ids)
+            loss = self.loss_and_backward(frame_ids, view_ids, validate=False)
             if self.reduce_fn is not None:
                 self.reduce_fn(self.params)
                 if self._skip_cur is not None and getattr(self.reduce_fn, "flag", None) is not None:
@@ -1268,7 +1301,7 @@ class Fitter:
             self._log_t, self._log_it = time.perf_counter(), i
         if cfg.reg_log_interval and i % cfg.reg_log_interval == 0:
             with torch.no_grad():
-                v = self.vertices(frame_ids).reshape(self._n(frame_ids), -1, 3)
+                v = self.vertices(frame_ids, validate=False).reshape(self._n(frame_ids), -1, 3)
                 rec = rec or {"it": i}
                 rec["MEL"] = float(cfg.weight_meshedge * mesh_edge_loss(v, self.topo, 0.1))
                 rec["LAP"] = float(cfg.weight_laplacian * (mesh_laplacian_smoothing(v, self.topo, per_mesh=True) ** 2).mean())
@@ -1303,7 +1336,7 @@ class Fitter:
         if self._graph_key != key:
             # new set of trainable tensors: one eager step first, so that Adam creates their state outside a capture
             self._graph_key, self._graphs = key, None
-            loss = self.loss_and_backward(frame_ids, view_ids)
+            loss = self.loss_and_backward(frame_ids, view_ids, validate=False)
             if self.reduce_fn is not None:
                 self.reduce_fn(self.params)
             self._update(prepared)
@@ -1319,7 +1352,7 @@ class Fitter:
             ga, gb = torch.cuda.CUDAGraph(), (None if one_graph else torch.cuda.CUDAGraph())
             self.optimizer.zero_grad(set_to_none=True)
             with torch.cuda.graph(ga):
-                loss = self.loss_and_backward(frame_ids, view_ids)
+                loss = self.loss_and_backward(frame_ids, view_ids, validate=False)
                 if one_graph:
                     self._update(prepared=True)
             if not one_graph:
@@ -1411,31 +1444,42 @@ class Fitter:
     def save(self, directory):
         """Result files in the reference's layout (fit.py:235-286): result/{i}.obj, texture.png, pose.json.
         With several ranks the shards are gathered first (collective) and rank 0 writes."""
-        from PIL import Image
         result = self.gather_result()
         if self.rank != 0:
             return
-        directory = os.path.join(directory, "result")
-        os.makedirs(directory, exist_ok=True)
-        uv = self.uv.cpu().numpy()
-        faces = ["f " + " ".join(f"{int(v) + 1}/{int(t) + 1}" for v, t in zip(fv, ft)) + "\n"
-                 for fv, ft in zip(self.sc.pos_idx, self.sc.uv_idx)]
-        for i, mesh in enumerate(result.cpu().numpy()):
-            with open(os.path.join(directory, f"{i}.obj"), "w") as f:
-                for v in mesh.reshape(-1, 3):
-                    f.write(f"v {v[0]} {v[1]} {v[2]}\n")
-                for u in uv:
-                    f.write(f"vt {u[0]} {u[1]}\n")
-                f.writelines(faces)
-        tex = self.tex_opt.detach().cpu().numpy()
-        # the reference casts (flip(tex) * 255) straight to uint8 (fit.py:268), which WRAPS values outside [0,255]
-        # (an unconstrained Adam texture can leave the range): reproduced via int64 so the wrap is defined behaviour
-        img = (np.flip(tex, 0) * 255).astype(np.int64).astype(np.uint8)
-        Image.fromarray(img[..., 0] if img.shape[2] == 1 else img).save(os.path.join(directory, "texture.png"))
-        with open(os.path.join(directory, "pose.json"), "w", encoding="utf-8") as f:
-            json.dump({'translation': self.per_frame_t.detach().cpu().tolist(),
-                       'rotation': self.per_frame_q.detach().cpu().tolist()}, f, separators=(',', ':'), sort_keys=True,
-                      indent=4)
+        write_result(directory, result.cpu().numpy(), self.uv.cpu().numpy(), face_lines(self.sc.pos_idx, self.sc.uv_idx),
+                     self.tex_opt.detach().cpu().numpy(), self.per_frame_t.detach().cpu().tolist(), self.per_frame_q.detach().cpu().tolist())
+
+
+def face_lines(pos_idx, uv_idx):
+    """The 'f v/vt v/vt v/vt' lines of an OBJ (1-based).  The reference copies them from a faces.txt it expects in the result directory
+    (fit.py:252-257); the build writes them from the index buffers."""
+    return ["f " + " ".join(f"{int(v) + 1}/{int(t) + 1}" for v, t in zip(fv, ft)) + "\n" for fv, ft in zip(pos_idx, uv_idx)]
+
+
+def write_result(directory, meshes, uv, faces, texture, translation, rotation):
+    """The files of the reference's save() (fit.py:235-286), byte for byte (tests/golden/save_golden.json holds what the reference's own
+    function wrote): <directory>/result/{i}.obj -- 'v x y z' per vertex, 'vt u v' per uv vertex, then the face lines --, pose.json and
+    texture.png.  meshes [F,3V] and uv [Vt,2] float32 arrays, translation / rotation nested lists.
+    Numbers: the reference formats 0-dim torch tensors, i.e. Python floats -- the float32 value widened to double and printed with
+    repr() ('0.10000000149011612', not numpy's shortest float32 form '0.1')."""
+    from PIL import Image
+    directory = os.path.join(directory, "result")
+    os.makedirs(directory, exist_ok=True)
+    uv_txt = "".join(f"vt {float(u[0])} {float(u[1])}\n" for u in np.asarray(uv, dtype=np.float32))
+    for i, mesh in enumerate(np.asarray(meshes, dtype=np.float32)):
+        with open(os.path.join(directory, f"{i}.obj"), "w") as f:
+            for v in mesh.reshape(-1, 3):
+                f.write(f"v {float(v[0])} {float(v[1])} {float(v[2])}\n")
+            f.write(uv_txt)
+            f.writelines(faces)
+    tex = np.asarray(texture)
+    # the reference casts (flip(tex) * 255) straight to uint8 (fit.py:268), which WRAPS values outside [0,255]
+    # (an unconstrained Adam texture can leave the range): reproduced via int64 so the wrap is defined behaviour
+    img = (np.flip(tex, 0) * 255).astype(np.int64).astype(np.uint8)
+    Image.fromarray(img[..., 0] if img.shape[2] == 1 else img).save(os.path.join(directory, "texture.png"))
+    with open(os.path.join(directory, "pose.json"), "w", encoding="utf-8") as f:
+        json.dump({'translation': translation, 'rotation': rotation}, f, separators=(',', ':'), sort_keys=True, indent=4)
 
 
 # ----------------------------------------------------------------------------------------------

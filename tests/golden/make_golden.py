@@ -21,6 +21,10 @@ Outputs (data only -- inputs and expected outputs, no reference source text):
                          any missing library is involved and no source text is stored.
     numframes_golden.json  assertNumFrames (fit.py:29-43, os only; taken out the same way) on two throw-away
                          directory trees: the (count, zero-pad digits) pairs and the assertion on unequal counts
+    save_golden.json     save (fit.py:235-286: os / json / codecs / numpy; taken out of the file's syntax tree like the blend functions) on two
+                         small meshes: the text of the OBJ files and of pose.json as the reference's own function wrote them.  Its
+                         texture.png goes through imageio, which is absent: the function's own try / except reports that and carries
+                         on, so the texture file is NOT pinned (recorded as such)
     rerender_golden.json make_img (src/torch/utils.py:179-190, numpy only; `import src.torch.utils` fails on the absent cv2) on
                          seeded image stacks, and compareSequenceNumerical (src/torch/comparisons.py:54-81, numpy + PIL; the module
                          runs a comparison on the author's W: drive at import) on 120 synthetic 1600 x 1200 image pairs
@@ -101,7 +105,8 @@ def main():
     blend_golden()
     numframes_golden()
     rerender_golden()
-    print("wrote camera_golden.json, meshdata_golden.json, blend_golden.json, numframes_golden.json, rerender_golden.json")
+    save_golden()
+    print("wrote camera_golden.json, meshdata_golden.json, blend_golden.json, numframes_golden.json, rerender_golden.json, save_golden.json")
 
 
 def reference_functions(names, extra_globals, module="fit.py"):
@@ -231,8 +236,44 @@ def rerender_golden():
         json.dump(out, f)
 
 
+def save_golden():
+    """f-3: the reference's result writer, run as it is on CPU tensors."""
+    import codecs
+    import contextlib
+    import io
+    import torch
+    fns, lines = reference_functions(("save",), {"os": os, "json": json, "codecs": codecs, "np": np})
+    rng = np.random.default_rng(5)
+    meshes = (rng.normal(size=(2, 12)) * 7.3).astype(np.float32)
+    meshes[0, :4] = [0.1, -2.5, 1e-7, 123456.789]               # values whose float32 / double text forms differ
+    uv = rng.uniform(size=(5, 2)).astype(np.float32)
+    uv[0] = [0.0, 1.0]
+    tex = rng.uniform(size=(4, 4, 1)).astype(np.float32)
+    t = (rng.normal(size=(2, 3)) * 0.3).astype(np.float32)
+    q = np.array([[0, 0, 0, 1], [0.01, -0.02, 0.03, 0.999]], dtype=np.float32)
+    faces = ["f 1/1 2/2 3/3\n", "f 1/5 3/3 4/4\n"]
+    with tempfile.TemporaryDirectory() as d:
+        os.mkdir(os.path.join(d, "result"))
+        with open(os.path.join(d, "result", "faces.txt"), "w") as f:          # (the reference copies the face lines from this file)
+            f.writelines(faces)
+        log = io.StringIO()
+        with contextlib.redirect_stdout(log):
+            fns["save"](torch.tensor(meshes), torch.tensor(uv), None, tex, torch.tensor(t), torch.tensor(q), d)
+        files = sorted(os.listdir(os.path.join(d, "result")))
+        text = {n: open(os.path.join(d, "result", n)).read() for n in files if n.endswith((".obj", ".json"))}
+    assert "imageio failed" in log.getvalue() and "texture.png" not in files      # imageio is absent here: the texture is not pinned
+    with open(os.path.join(HERE, "save_golden.json"), "w") as f:
+        json.dump({"reference_lines": lines, "inputs": {"meshes": meshes.astype(np.float64).tolist(), "uv": uv.astype(np.float64).tolist(),
+                                                        "texture": tex.astype(np.float64).tolist(), "translation": t.astype(np.float64).tolist(),
+                                                        "rotation": q.astype(np.float64).tolist(), "faces": faces},
+                   "files": files, "text": text,
+                   "texture_png": "not written: imageio is absent in the build container, the function's own except branch reported it"}, f, indent=1)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rerender":
         rerender_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "save":
+        save_golden()
     else:
         main()

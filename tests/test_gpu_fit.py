@@ -879,3 +879,28 @@ def test_rig_weights_kernel_matches_the_torch_products():
         assert rel_l2(w3[okrow], (mi3.detach() @ maps3.detach()[:, int(bad[okrow])])) < 1e-6
         w3[okrow].sum().backward()
         assert torch.isfinite(mi3.grad).all() and torch.isfinite(maps3.grad).all()
+
+
+def test_caller_supplied_indices_are_checked_on_the_host():
+    """the indexed MVP / rig-weight kernels gather from and scatter-add into the full parameter tables without bounds
+    checks (the index_select calls they replaced raised).  A caller's own index tensors are checked at the public entry points."""
+    from fpc_diffrend_amd import fit, scene
+    sc = scene.cfg('cfg1', n_frames=4)
+    ft = fit.Fitter(sc, fit.FitConfig(max_iter=10, cam_idxs=(0, 3, 6)), device='cuda')
+    dev = 'cuda'
+    ok = ft.loss_and_backward(torch.tensor([1, 3], device=dev), torch.tensor([0, 2], device=dev))
+    assert bool(torch.isfinite(ok))
+    for frames, views in ((torch.tensor([1, 4], device=dev), None), (torch.tensor([-1, 2], device=dev), None),
+                          (torch.tensor([0, 1], device=dev), torch.tensor([0, 3], device=dev)), (slice(2, 5), None),
+                          (torch.tensor([0.0, 1.0], device=dev), None)):
+        with pytest.raises(IndexError):
+            ft.loss_and_backward(frames, views)
+        if torch.is_tensor(frames) and frames.dtype == torch.int64:
+            with pytest.raises(IndexError):
+                ft.mvp(frames, views)
+    with pytest.raises(IndexError):
+        ft.vertices(torch.tensor([0, 9], device=dev))
+    shard = fit.Fitter(sc, fit.FitConfig(max_iter=10, cam_idxs=(0, 3)), device='cuda', rank=1, world=2, targets=ft.targets[2:, :2].contiguous())
+    with pytest.raises(IndexError):
+        shard.loss_and_backward(torch.tensor([1], device=dev))      # a frame of the take, but of the other rank's shard
+    assert bool(torch.isfinite(shard.loss_and_backward(torch.tensor([3], device=dev))))
