@@ -431,5 +431,48 @@ __device__ __forceinline__ int wave_min_dpp(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// __syncthreads_or for four-wave workgroups without its DPP reduction (the library's is ~27 vector instructions): every wave votes
+// (one v_cmp into a scalar pair), its first lane stores the verdict in the wave's OWN slot -- nothing to initialise --, and behind the
+// barrier everybody reads the four slots.  `slots`: four ints of LDS that nobody else touches between this call and the next barrier.
+__device__ __forceinline__ bool block4_any(int *slots, bool pred) {
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(pred);
+    if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = bal != 0ull ? 1 : 0;
+    __syncthreads();
+    const int4 v = *reinterpret_cast<const int4 *>(slots);
+    return __builtin_amdgcn_readfirstlane(v.x | v.y | v.z | v.w) != 0;
+}
+
+// ds_min_i32 / ds_max_i32 on an LDS word from whichever lanes are active, as ONE instruction each.  (atomicMin / atomicMax on LDS go
+// through the compiler's atomic optimiser, which first reduces over the wave -- ten vector instructions per call -- although the
+// callers here have already reduced and a single lane publishes.)  The trailing wait makes the update visible to a following barrier.
+__device__ __forceinline__ void lds_minmax4(int *p_min0, int v_min0, int *p_max0, int v_max0, int *p_min1, int v_min1, int *p_max1, int v_max1) {
+    typedef __attribute__((address_space(3))) int lds_int;
+    asm volatile("ds_min_i32 %0, %1\n\tds_max_i32 %2, %3\n\tds_min_i32 %4, %5\n\tds_max_i32 %6, %7\n\ts_waitcnt lgkmcnt(0)"
+                 :: "v"((lds_int *)p_min0), "v"(v_min0), "v"((lds_int *)p_max0), "v"(v_max0), "v"((lds_int *)p_min1), "v"(v_min1),
+                    "v"((lds_int *)p_max1), "v"(v_max1) : "memory");
+}
+
+// Four full-wave integer minima at once, written out as v_min_i32_dpp (one instruction per value and step: the permuted neighbour is
+// an operand of the minimum itself, where update_dpp + min is a v_mov_b32_dpp and a v_min_i32).  The four chains are interleaved, so
+// the two wait states a DPP read needs after the VALU write of its source are filled with the other three values' instructions: 24
+// vector instructions for four reductions instead of ~53.  The results are valid in LANE 63 ONLY (the last row of the last broadcast
+// step): callers let that lane publish them.  Maxima: pass ~x and invert the result.
+__device__ __forceinline__ void wave_min4_dpp_lane63(int &a, int &b, int &c, int &d) {
+#define FPCDR_MIN4_STEP(CTRL)                          \
+    "v_min_i32_dpp %0, %0, %0 " CTRL "\n\t"            \
+    "v_min_i32_dpp %1, %1, %1 " CTRL "\n\t"            \
+    "v_min_i32_dpp %2, %2, %2 " CTRL "\n\t"            \
+    "v_min_i32_dpp %3, %3, %3 " CTRL "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 FPCDR_MIN4_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 FPCDR_MIN4_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 FPCDR_MIN4_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 FPCDR_MIN4_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+                 FPCDR_MIN4_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 FPCDR_MIN4_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef FPCDR_MIN4_STEP
+}
+
 // (An LDS-atomic variant of the per-group sums -- leaders store, members ds_add_f32 into a wave-private scratch --
 // was measured 75 % SLOWER than the DPP reductions above: same-address LDS float atomics serialise badly.)

@@ -188,6 +188,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     constexpr int TEX_CELLS = MIP ? MipWinCaps<CS>::TOTAL : OCELLS;
     __shared__ double s_tex[TEX_CELLS * CS];      // texel window(s), doubles: ds_add_f64 (common.h lds_add_f64)
     __shared__ unsigned int s_cmask[OB];
+    __shared__ __attribute__((aligned(16))) int s_vote[8];      // block4_any: one slot per wave and vote
     __shared__ float s_fy[OB];
     __shared__ float s_lpart[ONT / 64];
     const VTable vt = {s_vkey, s_vacc};
@@ -238,7 +239,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     OPROF_T(1);
     // (barrier: plane, apron and tables are in place.)  A pixel pair can be deferred only if one of its triangles owns a silhouette edge:
     // four bins in five of a face show none at all -- the interior of the mesh -- and skip the four neighbour tests of their pixels
-    const bool bin_sil = __builtin_amdgcn_readfirstlane(__syncthreads_or(sil_seen != 0u ? 1 : 0)) != 0;
+    const bool bin_sil = block4_any(s_vote, sil_seen != 0u);
     OPROF_T(2);
     // compact records: this bin's slot (one global fetch-add and a barrier in the one bin in five that shows a silhouette triangle)
     const bool compact = a.pool_cap > 0;      // (uniform)
@@ -376,7 +377,9 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 shade_uvz<false>(v0, v1, v2, fx_col, fy, K, u, v, zw);      // (z/w: deferred pixels only, below)
             }
             // interpolate (fit.py:157) + texture 'linear' (fit.py:158): the arithmetic of the stand-alone kernels
-            const UV3 tq = a.tri_uv ? ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t) : uv_indirect(cold(ka)->uv, cold(ka)->uv_tri, t);
+            // (BMODE >= 0 -- the reference's case as compile-time constants -- is launched only with the gathered table: no call, and
+            //  with it no calling convention, in that kernel)
+            const UV3 tq = (BMODE >= 0 || a.tri_uv) ? ld32(reinterpret_cast<const UV3 *>(a.tri_uv), t) : uv_indirect(cold(ka)->uv, cold(ka)->uv_tri, t);
             const float2 q0 = tq.q0, q1 = tq.q1, q2 = tq.q2;
             const float w = 1.0f - u - v;
             const float tu = u * q0.x + v * q1.x + w * q2.x;
@@ -508,12 +511,24 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 const float gvv = gtu * (q1.x - q2.x) + gtv * (q1.y - q2.y);
                 // MIP: interpolate backward of the derivative outputs, d (uv_da) / d (rast_db)
                 const float4 gdb = make_float4(gda.x * e0x + gda.z * e0y, gda.y * e0x + gda.w * e0y, gda.x * e1x + gda.z * e1y, gda.y * e1x + gda.w * e1y);
-                if (gu != 0.0f || gvv != 0.0f || (MIP && (gdb.x != 0.0f || gdb.y != 0.0f || gdb.z != 0.0f || gdb.w != 0.0f))) {
-                    tkey = t;
+                if (MIP) {
+                    if (gu != 0.0f || gvv != 0.0f || gdb.x != 0.0f || gdb.y != 0.0f || gdb.z != 0.0f || gdb.w != 0.0f) {
+                        tkey = t;
+                        vk[0] = ti.a; vk[1] = ti.b; vk[2] = ti.c;
+                        float g0[3], g1[3], g2[3];
+                        shade_pixel_bwd<true>(v0, v1, v2, fx_col, fy, sx, sy, make_float4(gu, gvv, 0.f, 0.f), gdb, g0, g1, g2);
+                        gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
+                        gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
+                        gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
+                    }
+                } else {
+                    // the chain is LINEAR in (gu, gvv): a pixel without gradient gets exact zeros from it, so every covered pixel runs it
+                    // and only the table key says whether its run has anything to add (a branch around the chain made the nine values
+                    // a merge of two definitions: nine copies per pixel for a case -- no gradient at a covered pixel -- that is rare)
+                    tkey = (gu != 0.0f || gvv != 0.0f) ? t : -1;
                     vk[0] = ti.a; vk[1] = ti.b; vk[2] = ti.c;
                     float g0[3], g1[3], g2[3];
-                    if (MIP) shade_pixel_bwd<true>(v0, v1, v2, fx_col, fy, sx, sy, make_float4(gu, gvv, 0.f, 0.f), gdb, g0, g1, g2);
-                    else shade_uv_bwd(K, fx_col, fy, gu, gvv, g0, g1, g2);
+                    shade_uv_bwd(K, fx_col, fy, gu, gvv, g0, g1, g2);
                     gv9[0] = g0[0]; gv9[1] = g0[1]; gv9[2] = g0[2];
                     gv9[3] = g1[0]; gv9[4] = g1[1]; gv9[5] = g1[2];
                     gv9[6] = g2[0]; gv9[7] = g2[1]; gv9[8] = g2[2];
@@ -619,9 +634,10 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         const bool on = k_on && k_x0 != 0x7fffffff && k_y0 != 0x7fffffff;
         const int NONE_LO = 0x7fffffff, NONE_HI = (int)0x80000000;
         {
-            const int r1 = wave_min_dpp(on ? k_x0 : NONE_LO), r2 = ~wave_min_dpp(~(on ? k_x0 : NONE_HI));
-            const int r3 = wave_min_dpp(on ? k_y0 : NONE_LO), r4 = ~wave_min_dpp(~(on ? k_y0 : NONE_HI));
-            if (lane == 0 && r1 != NONE_LO) { atomicMin(&s_mred[red + 1], r1); atomicMax(&s_mred[red + 2], r2); atomicMin(&s_mred[red + 3], r3); atomicMax(&s_mred[red + 4], r4); }
+            // (four reductions in 24 vector instructions, results in lane 63: common.h)
+            int r1 = on ? k_x0 : NONE_LO, r2 = ~(on ? k_x0 : NONE_HI), r3 = on ? k_y0 : NONE_LO, r4 = ~(on ? k_y0 : NONE_HI);
+            wave_min4_dpp_lane63(r1, r2, r3, r4);
+            if (lane == 63 && r1 != NONE_LO) lds_minmax4(&s_mred[red + 1], r1, &s_mred[red + 2], ~r2, &s_mred[red + 3], r3, &s_mred[red + 4], ~r4);
         }
         OPROF_T(3);
         __syncthreads();
@@ -633,9 +649,9 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
             if (boundary == FPCDR_BOUNDARY_WRAP && (xb - xa >= (Wt >> 1) || yb - ya >= (Ht >> 1))) {
                 // (uniform, rare) a box across half the texture: a bin on the seam.  The centred view of the taps, reduced the same way
                 const int cx = k_x0 >= (Wt >> 1) ? k_x0 - Wt : k_x0, cy = k_y0 >= (Ht >> 1) ? k_y0 - Ht : k_y0;
-                const int r5 = wave_min_dpp(on ? cx : NONE_LO), r6 = ~wave_min_dpp(~(on ? cx : NONE_HI));
-                const int r7 = wave_min_dpp(on ? cy : NONE_LO), r8 = ~wave_min_dpp(~(on ? cy : NONE_HI));
-                if (lane == 0 && r5 != NONE_LO) { atomicMin(&s_mred[red + 5], r5); atomicMax(&s_mred[red + 6], r6); atomicMin(&s_mred[red + 7], r7); atomicMax(&s_mred[red + 8], r8); }
+                int r5 = on ? cx : NONE_LO, r6 = ~(on ? cx : NONE_HI), r7 = on ? cy : NONE_LO, r8 = ~(on ? cy : NONE_HI);
+                wave_min4_dpp_lane63(r5, r6, r7, r8);
+                if (lane == 63 && r5 != NONE_LO) lds_minmax4(&s_mred[red + 5], r5, &s_mred[red + 6], ~r6, &s_mred[red + 7], r7, &s_mred[red + 8], ~r8);
                 __syncthreads();
                 const int xa2 = __builtin_amdgcn_readfirstlane(s_mred[red + 5]), xb2 = __builtin_amdgcn_readfirstlane(s_mred[red + 6]);
                 const int ya2 = __builtin_amdgcn_readfirstlane(s_mred[red + 7]), yb2 = __builtin_amdgcn_readfirstlane(s_mred[red + 8]);
@@ -669,7 +685,9 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     // ... and its flush: every cell once (a barrier has made all adds visible); rezero: the window is used again
     auto flush_window = [&](const bool rezero) __attribute__((always_inline)) {
         if (ows <= 1) return;      // (uniform)
-        const float inv = 1.0f / (float)ows;
+        // (v_rcp_f32, 1 ulp: the quotient below is at least 0.5 / ows away from an integer, the error at most rows * 1.2e-7 -- an IEEE
+        //  division is fourteen vector instructions, twice per workgroup)
+        const float inv = __builtin_amdgcn_rcpf((float)ows);
         const int n = ows * owr * CS;
         // (a window inside the texture -- nearly all -- holds texel (ox + lx, oy + ly) as it is: no wrapping, no clamping; uniform branch)
         const bool plain = !owrap && ox >= 0 && oy >= 0 && ox + ows <= Wt && oy + owr <= Ht;
@@ -715,7 +733,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     lsum = wave_sum_dpp(lsum);
     if (lane == 0) s_lpart[wave] = lsum;
     OPROF_T(5);
-    const bool bin_def = __builtin_amdgcn_readfirstlane(__syncthreads_or(any_def ? 1 : 0)) != 0;
+    const bool bin_def = block4_any(s_vote + 4, any_def);
     OPROF_T(6);
     // ---- the bin's deferred pixels for k_fix; loss ----
     const KArgs ke = cold(ka);      // (the epilogue's pointers: scalar loads here, not registers held across the shading code)
@@ -1519,7 +1537,7 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
     } else
     if (p->C == 1) {
 #ifndef FPCDR_SHADE_GENERIC
-        if (p->boundary_mode == FPCDR_BOUNDARY_WRAP) SHADE(1, FPCDR_BOUNDARY_WRAP);      // the reference's case, as compile-time constants
+        if (p->boundary_mode == FPCDR_BOUNDARY_WRAP && p->tri_uv) SHADE(1, FPCDR_BOUNDARY_WRAP);      // the reference's case, as compile-time constants
         else
 #endif
         SHADE(1, -1);

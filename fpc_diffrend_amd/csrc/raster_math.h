@@ -125,7 +125,7 @@ __device__ __forceinline__ void shade_pixel_bwd(float4 v0, float4 v1, float4 v2,
 // One-pass objective (objective.hip): the pixel that is shaded also chains its gradient back, so the forward's intermediates are
 // KEPT instead of recomputed.  shade_uvz is shade_pixel without the derivative outputs, shade_uv_bwd is shade_pixel_bwd<false> on the
 // kept values: same operations in the same order, bit-identical results.
-struct ShadeKeep { float p0x, p0y, p1x, p1y, p2x, p2y, a0, a1, iw, b0, b1, uc, vc; };
+struct ShadeKeep { float p0x, p0y, p1x, p1y, p2x, p2y, a0, a1, iw, b0, b1, uc, vc, sc; };      // sc: 1 / (uc + vc) where that sum exceeds 1, else 1
 
 // z/w of shade_pixel from the three unnormalised barycentric weights
 __device__ __forceinline__ float shade_zw(float4 v0, float4 v1, float4 v2, float a0, float a1, float a2) {
@@ -153,6 +153,7 @@ __device__ __forceinline__ void shade_uvz(float4 v0, float4 v1, float4 v2, float
         asm volatile("; renormalise" : "+v"(sum));
         if (sum > 1.0f) sc = 1.0f / sum;
     }
+    k.sc = sc;
     u = k.uc * sc;
     v = k.vc * sc;
 }
@@ -162,9 +163,7 @@ __device__ __forceinline__ void shade_uv_bwd(const ShadeKeep &k, float fx, float
     float guc = gu, gvc = gv;
     const float sum = k.uc + k.vc;
     if (__builtin_amdgcn_ballot_w64(sum > 1.0f) != 0 && sum > 1.0f) {
-        float sum_ = sum;
-        asm volatile("; renormalise" : "+v"(sum_));
-        const float s = 1.0f / sum_;
+        const float s = k.sc;      // (= 1.0f / sum, the forward's IEEE division of the same sum: kept, not repeated -- 11 instructions a pixel)
         const float dot = (k.uc * gu + k.vc * gv) * s * s;
         guc = gu * s - dot;
         gvc = gv * s - dot;

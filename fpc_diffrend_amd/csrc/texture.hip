@@ -160,17 +160,21 @@ __global__ void __launch_bounds__(256) k_tex_bwd(TexLevels lv, int n_levels, con
 
 // Bin-shaped backward for the reference's texture call (one 1-channel texture, 'linear', W % 4 == 0): one workgroup per
 // 32 x 32-pixel bin, four horizontally adjacent pixels per thread (16-byte loads of dy / uv, 16-byte stores of grad_uv).  The
-// texel gradient goes through a TW x TW LDS window of DOUBLES anchored at the bin's smallest tap (ds_add_f64; ds_add_f32 costs
+// texel gradient goes through an LDS window of DOUBLES shaped by the bin's footprint (below; ds_add_f64: ds_add_f32 costs
 // 3 cycles per lane on gfx950) and is flushed once, row-contiguously; taps outside the window (uv seams) and the empty
 // pixels' share (uv = (0,0): summed per workgroup) go to memory directly.  4 global atomics per covered pixel -- the
 // generic kernel -- bound the operator at 4.3 ms for cfg3.
-constexpr int TW = 40;
+// r6: the window is a RECTANGLE of at most TWC cells shaped by the bounding box of the bin's taps (as k_shade's, objective.hip): a
+// footprint is rarely square -- the rig's face is sampled at 1.6 texels per pixel along v and 1.0 along u, 53 x 34 texels under a bin --
+// and the fixed 40 x 40 window anchored at the smallest tap left 22 % of the pixels' adds outside, four float atomics each to memory.
+// A box that does not fit (a bin across the seam of a periodic coordinate) gets a window of its aspect around its centre.
+constexpr int TWC = 2048;
 __global__ void __launch_bounds__(256) k_tex_bwd_bin1(const float *__restrict__ tex, float *__restrict__ grad_tex,
                                                       const float4 *__restrict__ uv4, const float4 *__restrict__ dy4, int H, int W, int B,
                                                       int Ht, int Wt, int boundary, float4 *__restrict__ grad_uv4,
                                                       const uint8_t *__restrict__ hint) {
-    __shared__ double s_tex[TW * TW];      // in double: ds_add_f64 (common.h lds_add_f64)
-    __shared__ int s_org[2];
+    __shared__ double s_tex[TWC];      // in double: ds_add_f64 (common.h lds_add_f64)
+    __shared__ int s_org[4];           // min x0, min y0, max x0, max y0 of the bin's taps
     __shared__ float s_esum;
     const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.z;
     const int px = blockIdx.x * 32 + (tid & 7) * 4, py = blockIdx.y * 32 + (tid >> 3);
@@ -188,23 +192,43 @@ __global__ void __launch_bounds__(256) k_tex_bwd_bin1(const float *__restrict__ 
     float4 ua = z4, ub = z4;
     if (inside && any && !known_zero) { ua = uv4[i / 2]; ub = uv4[i / 2 + 1]; }
     const float qu[4] = {ua.x, ua.z, ub.x, ub.z}, qv[4] = {ua.y, ua.w, ub.y, ub.w}, gq[4] = {g.x, g.y, g.z, g.w};
-    if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; s_esum = 0.0f; }
-    for (int k = tid; k < TW * TW; k += 256) s_tex[k] = 0.0;
-    // window origin: the smallest tap of the pixels with a gradient and a texture coordinate other than (0,0)
-    int ux0 = 0x7fffffff, uy0 = 0x7fffffff;
+    if (tid == 0) { s_org[0] = 0x7fffffff; s_org[1] = 0x7fffffff; s_org[2] = (int)0x80000000; s_org[3] = (int)0x80000000; s_esum = 0.0f; }
+    for (int k = tid; k < TWC; k += 256) s_tex[k] = 0.0;
+    // the bounding box of the taps of the pixels with a gradient and a texture coordinate other than (0,0)
+    int ux0 = 0x7fffffff, uy0 = 0x7fffffff, ux1 = (int)0x80000000, uy1 = (int)0x80000000;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (inside && gq[k] != 0.0f && (qu[k] != 0.0f || qv[k] != 0.0f)) {
-            ux0 = min(ux0, (int)floorf(prep_coord(qu[k], boundary) * (float)Wt - 0.5f));
-            uy0 = min(uy0, (int)floorf(prep_coord(qv[k], boundary) * (float)Ht - 0.5f));
+            const int tx = (int)floorf(prep_coord(qu[k], boundary) * (float)Wt - 0.5f), ty = (int)floorf(prep_coord(qv[k], boundary) * (float)Ht - 0.5f);
+            ux0 = min(ux0, tx); ux1 = max(ux1, tx);
+            uy0 = min(uy0, ty); uy1 = max(uy1, ty);
         }
     __syncthreads();
     {
-        const int mx = wave_min_dpp(ux0), my = wave_min_dpp(uy0);
-        if (lane == 0 && mx != 0x7fffffff) { atomicMin(&s_org[0], mx); atomicMin(&s_org[1], my); }
+        int mx = ux0, my = uy0, nx = ~ux1, ny = ~uy1;
+        wave_min4_dpp_lane63(mx, my, nx, ny);      // (results in lane 63)
+        if (lane == 63 && mx != 0x7fffffff) { atomicMin(&s_org[0], mx); atomicMin(&s_org[1], my); atomicMax(&s_org[2], ~nx); atomicMax(&s_org[3], ~ny); }
     }
     __syncthreads();
-    const int ox = s_org[0], oy = s_org[1];
+    int ox = __builtin_amdgcn_readfirstlane(s_org[0]), oy = __builtin_amdgcn_readfirstlane(s_org[1]);
+    int stride = 1, rows = 1;      // (stride 1: no window -- every add outside)
+    if (ox != 0x7fffffff) {      // (uniform)
+        const long long nw = (long long)__builtin_amdgcn_readfirstlane(s_org[2]) - ox + 2, nh = (long long)__builtin_amdgcn_readfirstlane(s_org[3]) - oy + 2;      // (taps x0 and x0 + 1)
+        long long sx0 = ox, sy0 = oy;
+        if (nw * nh <= TWC) {      // it fits: the rows that are left over go half below, half above
+            stride = (int)nw;
+            rows = TWC / stride;
+            sy0 -= (rows - (int)nh) >> 1;
+        } else {                   // it does not: a window of the footprint's aspect around its centre
+            const float aspect = fminf(fmaxf((float)nw / (float)nh, 1.0f / (float)TWC), (float)TWC);
+            stride = min(max((int)sqrtf((float)TWC * aspect), 2), TWC / 2);
+            rows = TWC / stride;
+            sx0 += (nw - stride) >> 1;
+            sy0 += (nh - rows) >> 1;
+        }
+        ox = __builtin_amdgcn_readfirstlane((int)sx0); oy = __builtin_amdgcn_readfirstlane((int)sy0);
+        stride = __builtin_amdgcn_readfirstlane(stride); rows = __builtin_amdgcn_readfirstlane(rows);
+    }
     float gu[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f}, esum = 0.0f;
     // The eight lanes of a row own pixels 4 j .. 4 j + 3.  Visiting them in the same order would put the lanes of one LDS
     // instruction 4 texels = 8 words apart: with the eight rows of the wave 64 lanes on 4 double-wide banks.  Each lane
@@ -235,12 +259,12 @@ __global__ void __launch_bounds__(256) k_tex_bwd_bin1(const float *__restrict__ 
         const float w00 = (1.0f - t.fx) * (1.0f - t.fy), w10 = t.fx * (1.0f - t.fy), w01 = (1.0f - t.fx) * t.fy, w11 = t.fx * t.fy;
         const int lx = (int)floorf(prep_coord(qu_k, boundary) * (float)Wt - 0.5f) - ox;
         const int ly = (int)floorf(prep_coord(qv_k, boundary) * (float)Ht - 0.5f) - oy;
-        if (lx >= 0 && ly >= 0 && lx + 1 < TW && ly + 1 < TW) {
-            double *w = s_tex + ly * TW + lx;
+        if ((unsigned int)lx < (unsigned int)(stride - 1) && (unsigned int)ly < (unsigned int)(rows - 1)) {
+            double *w = s_tex + ly * stride + lx;
             lds_add_f64(w, gc * w00);
             lds_add_f64(w + 1, gc * w10);
-            lds_add_f64(w + TW, gc * w01);
-            lds_add_f64(w + TW + 1, gc * w11);
+            lds_add_f64(w + stride, gc * w01);
+            lds_add_f64(w + stride + 1, gc * w11);
         } else {
             atomicAdd(grad_tex + t.i00, gc * w00);
             atomicAdd(grad_tex + t.i10, gc * w10);
@@ -264,11 +288,14 @@ __global__ void __launch_bounds__(256) k_tex_bwd_bin1(const float *__restrict__ 
         atomicAdd(grad_tex + t0.i01, e * ((1.0f - t0.fx) * t0.fy));
         atomicAdd(grad_tex + t0.i11, e * (t0.fx * t0.fy));
     }
-    if (ox != 0x7fffffff) {
-        for (int k = tid; k < TW * TW; k += 256) {
+    if (stride > 1) {
+        const float inv = 1.0f / (float)stride;
+        const int n = stride * rows;
+        for (int k = tid; k < n; k += 256) {
             const float v = (float)s_tex[k];
             if (v != 0.0f) {
-                const int gx = wrap_near(ox + k % TW, Wt, boundary), gy = wrap_near(oy + k / TW, Ht, boundary);
+                const int ly = (int)(((float)k + 0.5f) * inv), lx = k - ly * stride;      // (exact: k < 2^12)
+                const int gx = wrap_near(ox + lx, Wt, boundary), gy = wrap_near(oy + ly, Ht, boundary);
                 atomicAdd(grad_tex + (size_t)gy * Wt + gx, v);
             }
         }
