@@ -621,12 +621,18 @@ def main():
                 known = name_ in MOVES_ALL or name_ in sparse_px
                 alg_ = bpp[name_] * sparse_px.get(name_, npix) if known else None
                 a_ = alg_ / t_s_ / 1e9 if known else None
-                valu_bound = bool(pmc_ and pmc_.get("valu_issue_frac") and pmc_["valu_issue_frac"] > (pmc_["hbm_bytes"] / t_s_ / 1e9 / HBM_PEAK_GBS))
+                # what the counters say limits the call: the larger of the two shares -- vector issue slots, HBM bytes against the peak --
+                # if it is at least half; a call that fills neither (a one-frame batch, a chain of dependent gathers) is bound by
+                # latency / occupancy and says so
+                hbm_share_ = (pmc_["hbm_bytes"] / t_s_ / 1e9 / HBM_PEAK_GBS) if pmc_ else 0.0
+                valu_share_ = (pmc_.get("valu_issue_frac") or 0.0) if pmc_ else 0.0
+                bound_ = None if not pmc_ else ("valu-issue" if valu_share_ >= 0.5 and valu_share_ > hbm_share_ else
+                                                ("hbm" if hbm_share_ >= 0.5 else "latency (neither vector issue nor HBM is half used)"))
                 return {"kernel": name_,
                         # what the counters say limits the call; achieved / peak / frac are the HBM figures the metric asks for
                         # (algorithmic bytes against the 8 TB/s peak), whatever the bound
                         # (no counters for this workload / these sources: no evidence either way -> null, not "hbm")
-                        "bound": None if not pmc_ else ("valu-issue" if valu_bound else "hbm"),
+                        "bound": bound_,
                         "achieved": a_, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (a_ / HBM_PEAK_GBS) if known else None,
                         "ms": px_ops[name_]["avg_ms"], "algorithmic_bytes": alg_,
                         "traffic": pmc_["hbm_bytes"] if pmc_ else None,

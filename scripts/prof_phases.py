@@ -18,7 +18,10 @@ for _ in range(n):
 torch.cuda.synchronize()
 lib.fpcdr_debug_oprof(buf, 0)
 v = list(buf)
-names = ["phase0 loads+init", "barrier0", "phase1 shade+chain", "barrier1", "phase2 texel adds", "barrier2", "flush"]
+# (the bin is shaded as two halves, each: first pass -> window set-up with one barrier -> kept taps + second pass; the timers of the
+#  set-up are taken in the SECOND half, so the first half lies wholly inside the third interval)
+names = ["prologue: id plane, apron, tables", "barrier (plane in place)", "first half (2 passes, window, flush) + second half's first pass",
+         "barrier (second half's window)", "second half: kept taps + second pass", "barrier (end of shading)", "epilogue: vertex table + window flush"]
 tot = sum(v[:7])
 print(json.dumps({"k_fix pass0: pixels, bins with deferred pixels (per launch)": [v[8] / n, v[9] / n],
                   "k_fix pass1: pixels, bins": [v[10] / n, v[11] / n]}))
