@@ -202,9 +202,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd_lds(const float *__restrict__
 
 // grad_w[f][k] += sum_i gout[f][i] Bmat[i][k];  D[i = frame][j = k]; the long i reduction is split over
 // blockIdx.y slabs of SLAB rows and finished with f32 atomics (few adders per address).
-#ifndef FPCDR_BLEND_SLAB
 #define FPCDR_BLEND_SLAB 512
-#endif
 constexpr int SLAB = FPCDR_BLEND_SLAB;
 __global__ void __launch_bounds__(256) k_blend_bwd_w(const float *__restrict__ Bmat, const float *__restrict__ gout,
                                                      float *__restrict__ grad_w, int M, int K, int F) {

@@ -144,9 +144,7 @@ template <typename T> __device__ __forceinline__ T &at32(T *base, unsigned int i
 // would deal NEIGHBOURING bins -- which share vertices, triangle records and texels -- to eight different L2s; instead XCD x takes
 // the x-th eighth of the entries [0, m), m = min(entries, launch size), in order.  The launch is rounded up to a multiple of 8
 // workgroups (fpcdr_list_grid) so that every entry below m has a workgroup.  Returns -1 for a workgroup without an entry.
-#ifndef FPCDR_XCD_LISTS
 #define FPCDR_XCD_LISTS 1
-#endif
 __host__ __device__ inline int fpcdr_list_grid(int cap) { return FPCDR_XCD_LISTS ? (cap + 7) / 8 * 8 : cap; }
 __device__ __forceinline__ int fpcdr_list_item(int n_entries, int cap) {
     const int m = min(n_entries, cap);
@@ -364,9 +362,7 @@ __device__ __forceinline__ void wave_segment_reduce9(int key, const float (&val)
 // ---- per-workgroup vertex-gradient table in LDS (shared by the backward kernels) ------------------------------------
 // Scattered global f32 atomics retire slowly (one per run tail tripled the time of rasterize backward), so a workgroup sums
 // the (x, y, w) gradients of its vertices in a small open-addressed LDS table first and flushes every slot once.
-#ifndef FPCDR_VT_SLOTS_N
 #define FPCDR_VT_SLOTS_N 256
-#endif
 constexpr int FPCDR_VT_SLOTS = FPCDR_VT_SLOTS_N;      // (a power of two)
 struct VTable {
     int *key;             // [FPCDR_VT_SLOTS], -1 = free

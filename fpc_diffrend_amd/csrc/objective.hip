@@ -29,27 +29,15 @@ namespace {
 #include "aa_pairs.h"
 #include "sil_bits.h"
 
-#ifndef FPCDR_OTEXWIN
-#define FPCDR_OTEXWIN 40          // three / four channels: the window holds FPCDR_OTEXWIN^2 cells (one channel: FPCDR_OWIN_CELLS, below)
-#endif
 constexpr int OB = 32;            // pixels per bin side
 constexpr int OS = 36;            // LDS row stride of the id plane with its one-pixel apron (34 entries used)
 // cells of the (non-mip) texel window, a rectangle shaped by the footprint of half a bin.  One channel: 1 216 cells of 8 bytes hold a
 // half's footprint on the face rig (27 x 33 texels) and leave LDS for SEVEN workgroups per CU (22.4 KB each); for the whole bin 1 728
 // cells were what six workgroups left (profiles/r05_flush_experiments.txt 10, 13).  Three / four channels: 1 600 cells of 24 / 32
 // bytes, under 64 KB with the rest
-#ifndef FPCDR_OWIN_CELLS
-#define FPCDR_OWIN_CELLS 1216
-#endif
-#ifndef FPCDR_SHADE_HALVES
-#define FPCDR_SHADE_HALVES 1
-#endif
-template <int CS> constexpr int owin_cells() { return CS == 1 ? FPCDR_OWIN_CELLS : FPCDR_OTEXWIN * FPCDR_OTEXWIN; }
+template <int CS> constexpr int owin_cells() { return CS == 1 ? 1216 : 1600; }
 constexpr int ONT = 256;          // threads of k_shade
-#ifndef FPCDR_FNT
-#define FPCDR_FNT 64
-#endif
-constexpr int FNT = FPCDR_FNT;    // threads of k_fix per bin (a chain of dependent loads for a few dozen pixels)
+constexpr int FNT = 64;           // threads of k_fix per bin (a chain of dependent loads for a few dozen pixels)
 
 struct ObjArgs {
     const float4 *pos; const int32_t *tri; const float2 *uv; const int32_t *uv_tri; const float2 *tri_uv;
@@ -96,16 +84,8 @@ struct MipO {
 // face runs at 1.6 texels per pixel along v and 1.0 along u, 52 x 33 texels of level 0 under a 32 x 32 bin.  (r4/r5 first form: a fixed
 // 40 x 40 window of level 0 and 24 x 24 of level 1.  A third of the pixels' taps fell outside and went to memory one float atomic
 // each -- 2.3 ms of the kernel's 4.8 at cfg3, profiles/r05_mip_windows.txt.)
-#ifdef FPCDR_MIPSTAT
-__device__ unsigned long long g_mipstat[16];
-#endif
 template <int CS> struct MipWinCaps {
-#ifndef FPCDR_MIPW_N0
-#define FPCDR_MIPW_N0 2304
-#define FPCDR_MIPW_N1 704
-#define FPCDR_MIPW_N2 256
-#endif
-    static constexpr int N0 = CS == 1 ? FPCDR_MIPW_N0 : 1088, N1 = CS == 1 ? FPCDR_MIPW_N1 : 384, N2 = CS == 1 ? FPCDR_MIPW_N2 : 128;      // cells
+    static constexpr int N0 = CS == 1 ? 2304 : 1088, N1 = CS == 1 ? 704 : 384, N2 = CS == 1 ? 256 : 128;      // cells
     static constexpr int TOTAL = N0 + N1 + N2;
 };
 // a tap's column (row) relative to a window's unwrapped origin, modulo the level's width (height): both lie within one period of zero
@@ -159,17 +139,8 @@ __device__ unsigned long long g_oprof[16];
 // zeroed before the second half's is placed.  So a pixel's four texel adds happen right where its weights are formed: apart from the
 // first pass's taps nothing is kept across a barrier (the two-phase form of r3 held 20 registers per thread for it: 88 VGPRs and 5
 // waves per SIMD, where this form runs 7).
-#ifndef FPCDR_SHADE_MIP_WPE
-#define FPCDR_SHADE_MIP_WPE
-#endif
-#ifndef FPCDR_SHADE_WPE
 #define FPCDR_SHADE_WPE __attribute__((amdgpu_waves_per_eu(CS == 1 ? 7 : 1, 8)))      // one channel: seven workgroups per CU (72 registers, 22.4 KB of LDS)
-#endif
-#ifndef FPCDR_OWIN_MARGIN
-#define FPCDR_OWIN_MARGIN 0          // texels around the box of the first pass's taps (1: no gain, profiles/r05_flush_experiments.txt 10)
-#endif
-constexpr int OWIN_MARGIN = FPCDR_OWIN_MARGIN;
-// row pair (rows 2 p, 2 p + 1) of wave w in pass k of the whole-bin order (the mip instantiation; -DFPCDR_SHADE_HALVES=0)
+// row pair (rows 2 p, 2 p + 1) of wave w in pass k of the whole-bin order (the mip instantiation)
 __device__ __forceinline__ int shade_row_pair(int k, int w) {
     // k = 0: 0, 5, 10, 15;  k = 1: 1, 6, 11, 14;  k = 2: 2, 7, 12, 13;  k = 3: 3, 4, 8, 9
     const unsigned int packed = k == 0 ? 0xFA50u : (k == 1 ? 0xEB61u : (k == 2 ? 0xDC72u : 0x9843u));
@@ -272,18 +243,12 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     const float bgs = a.bg * cs;
     float lsum = 0.0f;
     bool any_def = false;
-#ifdef FPCDR_MIPSTAT
-    int ofit = 0;
-#endif
     bool owrap = false;      // the window reaches across the edge of a periodic coordinate
     int ox = 0, oy = 0, ows = 1, owr = 1;      // origin, row stride and rows of the texel window (set behind the barrier after pass 0; stride 1: none)
     // MIP: the three windows (set behind the prepass's barrier), as scalars -- structs selected per lane ended up in scratch memory
     int w0x = 0, w0y = 0, w0s = 1, w0r = 1, w1x = 0, w1y = 0, w1s = 1, w1r = 1, w2x = 0, w2y = 0, w2s = 1, w2r = 1;
     bool w0wrap = false, w1wrap = false, w2wrap = false;      // the window reaches across the edge of its level (then cells are found modulo its size)
     constexpr int w0b = 0, w1b = MipWinCaps<CS>::N0, w2b = MipWinCaps<CS>::N0 + MipWinCaps<CS>::N1;
-#ifdef FPCDR_MIPSTAT
-    int mfit0 = 0, mfit1 = 0, mfit2 = 0;
-#endif
     int mlb = 0;                                             // ... and the level of the first
 
     // the four texel adds of one pixel: into the window, or -- outside it -- to memory
@@ -300,10 +265,6 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
         if (boundary == FPCDR_BOUNDARY_WRAP && owrap) { lx = wrap_cell(lx, Wt); ly = wrap_cell(ly, Ht); }
         // (unsigned compares: a tap below the origin wraps to a huge value; stride 1 = no sample in pass 0: everything outside)
         const bool inside = (unsigned int)lx < (unsigned int)(ows - 1) && (unsigned int)ly < (unsigned int)(owr - 1);
-#ifdef FPCDR_MIPSTAT
-        atomicAdd(&g_mipstat[inside ? 13 : 14], 1ull);
-        if (!inside && ofit) atomicAdd(&g_mipstat[15], 1ull);      // outside a window that held the whole sampled footprint
-#endif
         if (inside) {
 #pragma unroll
             for (int c = 0; c < CS; ++c) {
@@ -467,22 +428,6 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 const bool in0 = a0 || a1 || a2, in1 = b0 || b1 || b2;
                 const int cell0 = a0 ? cl[0] : (a1 ? cl[1] : cl[2]), st0 = a0 ? sl[0] : (a1 ? sl[1] : sl[2]);
                 const int cell1 = b0 ? cl[0] : (b1 ? cl[1] : cl[2]), st1 = b0 ? sl[0] : (b1 ? sl[1] : sl[2]);
-#ifdef FPCDR_MIPSTAT
-                {   // taps by (level - mlb) and in / out of its window: [0..2] in, [3..5] out, [6] beyond the third window, [7] pixels
-                    const int dd[2] = {d0, d1};
-                    const bool ii[2] = {in0, in1};
-                    for (int q = 0; q < 2; ++q) {
-                        const int slot = (unsigned int)dd[q] < 3u ? (ii[q] ? dd[q] : 3 + dd[q]) : 6;
-                        atomicAdd(&g_mipstat[slot], 1ull);
-                        // outside a window that FITTED its footprint [8..10]; finer than lb [11]; no window at all (no sampled pixel) [12]
-                        const int fits = dd[q] == 0 ? mfit0 : (dd[q] == 1 ? mfit1 : mfit2);
-                        if ((unsigned int)dd[q] < 3u && !ii[q] && fits) atomicAdd(&g_mipstat[8 + dd[q]], 1ull);
-                        if (dd[q] < 0) atomicAdd(&g_mipstat[11], 1ull);
-                        if (mlb == 0x7fffffff) atomicAdd(&g_mipstat[12], 1ull);
-                    }
-                    atomicAdd(&g_mipstat[7], 1ull);
-                }
-#endif
                 mip_lookup_bwd<MIP ? CS : 1>(ma->lv, ma->n_levels, MK, reinterpret_cast<const float (&)[MIP ? CS : 1]>(gq), Ht, Wt, gtu_m, gtv_m, gda,
                                   [&](int level, int tap, size_t offs, int c, float vv) {
                                       const int dx = tap & 1, dy = tap >> 1;
@@ -597,9 +542,6 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                     const long long nw = (long long)(int)fminf(fmaxf(floorf(ub * wl - 0.5f), -big), big) + 2 - xa + 1;
                     const long long nh = (long long)(int)fminf(fmaxf(floorf(vb * hl - 0.5f), -big), big) + 2 - ya + 1;
                     int stride, rows;
-#ifdef FPCDR_MIPSTAT
-                    if (nw * nh <= cap) { if (j == 0) mfit0 = 1; else if (j == 1) mfit1 = 1; else mfit2 = 1; }
-#endif
                     if (nw * nh <= cap) {      // it fits: the rows that are left over go half below, half above
                         stride = (int)nw;
                         rows = cap / stride;
@@ -658,13 +600,11 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 if (xb2 - xa2 < xb - xa) { xa = xa2; xb = xb2; }
                 if (yb2 - ya2 < yb - ya) { ya = ya2; yb = yb2; }
             }
-            const long long nw = (long long)xb - xa + 2 + 2 * OWIN_MARGIN, nh = (long long)yb - ya + 2 + 2 * OWIN_MARGIN;      // (taps x0 and x0 + 1)
+            // (taps x0 and x0 + 1; a margin of a texel around the box gained nothing: profiles/r05_flush_experiments.txt 10)
+            const long long nw = (long long)xb - xa + 2, nh = (long long)yb - ya + 2;
             int stride, rows;
-            long long sx0 = (long long)xa - OWIN_MARGIN, sy0 = (long long)ya - OWIN_MARGIN;
+            long long sx0 = (long long)xa, sy0 = (long long)ya;
             if (nw * nh <= OCELLS) {      // it fits: the rows that are left over go half below, half above
-#ifdef FPCDR_MIPSTAT
-                ofit = 1;
-#endif
                 stride = (int)nw;
                 rows = OCELLS / stride;
                 sy0 -= (rows - (int)nh) >> 1;
@@ -706,7 +646,7 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
     if (MIP) {
 #pragma unroll
         for (int k = 1; k < 4; ++k) pixel(shade_row_pair(k, wave), false);
-    } else if (FPCDR_SHADE_HALVES) {
+    } else {
         // THE BIN IN TWO HALVES (rows 0-15, then 16-31), each with a window of its own in the same LDS: half the rows have half the
         // footprint along one axis, and 52 x 33 texels under a whole bin do not fit 1 728 cells where 27 x 33 do.  A half is two passes:
         // the first (row pairs 0, 2, 5, 7 of the half: its first and last rows are among them) keeps its taps until the window is placed;
@@ -722,12 +662,6 @@ __device__ __forceinline__ void shade_body(const int b, const int bxi, const int
                 flush_window(true);
             }
         }
-    } else {
-        // ---- pass 0: row pairs 0, 5, 10, 15; the window's origin ----
-        pixel(shade_row_pair(0, wave), true);
-        if (want_tex) setup_window(0);
-#pragma unroll
-        for (int k = 1; k < 4; ++k) pixel(shade_row_pair(k, wave), false);
     }
 
     lsum = wave_sum_dpp(lsum);
@@ -803,7 +737,7 @@ __global__ void __launch_bounds__(ONT) FPCDR_SHADE_WPE k_shade_list(const ShadeK
 
 // the MIP instantiation (boundary mode at run time): list form and strided sweep
 template <int CS>
-__global__ void __launch_bounds__(ONT) FPCDR_SHADE_MIP_WPE k_shade_mip_list(const ShadeMipK k) {
+__global__ void __launch_bounds__(ONT) k_shade_mip_list(const ShadeMipK k) {
     const int item = fpcdr_list_item(*k.count, k.cap);
     if (item < 0) return;
     const int lin = __builtin_amdgcn_readfirstlane(k.list[item]);
@@ -873,11 +807,8 @@ __device__ __forceinline__ void hacc_vadd(float *gp, int *vkeys, double *vacc, i
 // d (blend weight) / d pos of one active edge, G = d loss / d (blend weight) (see k_aa_bwd_fix in antialias.hip).  OUT OF LINE: the
 // pair analysis is inlined at twelve sites (four pairs x three edges) and this tail with its table adds made k_fix<1> 220 us of
 // instruction fetch and registers (99 VGPRs) for a few dozen pixels per bin.
-#ifndef FPCDR_EDGE_INLINE
-#define FPCDR_EDGE_INLINE __noinline__
-#endif
 struct EdgeVals { float Lx, Ly, qax, qay, wa, qbx, qby, wb; };      // (by value: see uv_indirect)
-__device__ FPCDR_EDGE_INLINE void aa_edge_pos_grad(float *gp, int *vkeys, double *vacc, EdgeVals ev, float t, float s, int d, float G,
+__device__ __noinline__ void aa_edge_pos_grad(float *gp, int *vkeys, double *vacc, EdgeVals ev, float t, float s, int d, float G,
                                               int Px, int Py, int va, int vb, float hw, float hh) {
     const float Ld = d == 0 ? ev.Lx : ev.Ly;
     const float gLz = -G / (s * Ld);
@@ -1536,11 +1467,8 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
 #undef FIX_MIP
     } else
     if (p->C == 1) {
-#ifndef FPCDR_SHADE_GENERIC
         if (p->boundary_mode == FPCDR_BOUNDARY_WRAP && p->tri_uv) SHADE(1, FPCDR_BOUNDARY_WRAP);      // the reference's case, as compile-time constants
-        else
-#endif
-        SHADE(1, -1);
+        else SHADE(1, -1);
         FIX(1, 0);
         if (grads) FIX(1, 1);
         FINISH(1);
@@ -1562,8 +1490,3 @@ extern "C" int fpcdr_objective_fwd(const fpcdr_objective_params *p, void *stream
     return FPCDR_OK;
 }
 
-#ifdef FPCDR_MIPSTAT
-extern "C" int fpcdr_debug_mipstat(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mipstat), sizeof(unsigned long long) * 16);
-}
-#endif

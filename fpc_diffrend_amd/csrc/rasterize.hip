@@ -42,9 +42,7 @@ constexpr int SUBPIX = 256;
 constexpr int HALFPIX = 128;
 constexpr double GUARD = 16777216.0;  // 2^24
 
-#ifndef FPCDR_BIN
 #define FPCDR_BIN 32   // measured at cfg3: 64 -> 5.2 ms, 32 -> 3.6 ms (fused forward): smaller bins balance the rim better
-#endif
 constexpr int BIN = FPCDR_BIN;   // pixels per bin side
 constexpr int TILE = 16;         // pixels per tile side; a wave covers a tile with 4 pixels per lane (2x2 quads of 8x8)
 constexpr int QUAD = 8;
@@ -92,9 +90,7 @@ constexpr int SMALL_EXTENT = 16384;
 // each (a loop over the box, winners folded into the bin's LDS depth buffer with 64-bit atomic min); the others go
 // through the tile path in rounds of BIGB.  On the 30k-triangle rig a triangle's box holds ~50 pixels, a 16x16 tile
 // 256: one lane per triangle issues ~4x fewer instructions than one wave per (triangle, tile).
-#ifndef FPCDR_LANE_MAX
 #define FPCDR_LANE_MAX 256
-#endif
 constexpr int LANE_MAX = FPCDR_LANE_MAX;
 constexpr int BIGB = 64;         // triangles per round of the tile path
 // (r5, measured and dropped: EARLY Z -- the lane path in two halves by the sign of the triangle's area, i.e. the layer of a closed mesh that
@@ -103,12 +99,8 @@ constexpr int BIGB = 64;         // triangles per round of the tile path
 //  681 us with the facing layer first, 881 with the other first -- the lanes of a wave walk in lockstep, so two half-empty passes cost two
 //  walks unless a whole wave's triangles are culled; compacting the survivors first would need two more barriers and a prefix per batch.)
 // latency-bound: 7 waves per SIMD (r2 sweep of the LOSS list kernel: 5 -> 2.23 ms, 6 -> 2.23, 7 -> 2.11, 8 -> 2.20; its 22 KB of LDS allow 7 workgroups per CU)
-#ifndef FPCDR_BINS_WPE
 #define FPCDR_BINS_WPE __attribute__((amdgpu_waves_per_eu(7, 8)))
-#endif
-#ifndef FPCDR_SCAN_K
 #define FPCDR_SCAN_K 4
-#endif
 constexpr int SCAN_K = FPCDR_SCAN_K;        // live chunks whose bounding boxes are tested per scan iteration
 
 // (depth, triangle) as one ordered 64-bit key: smaller depth first, ties to the smaller triangle index (R6).
@@ -1316,9 +1308,7 @@ __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins(const float4 *__res
 // ~20 % of a face-rig frame).  Dispatching one workgroup per bin of the whole batch costs 0.21 ms for 588 k workgroups
 // that mostly leave at once; the caller sizes this launch from the count of an EARLIER call (`cap`), and whatever lies
 // beyond it is swept up by the strided form below, so the result never depends on the hint.
-#ifndef FPCDR_BINSQ_WPE
 #define FPCDR_BINSQ_WPE
-#endif
 template <bool WRITE_DB, bool SHADE, bool LOSS, int CS = 0, int BMODE = -1, bool MIP = false, bool IDS = false>
 __global__ void __launch_bounds__(256) FPCDR_BINS_WPE k_bins_list(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
                                               int cap, int OX, int OY, fpcdr_bin_decode dc,

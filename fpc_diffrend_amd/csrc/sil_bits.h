@@ -7,9 +7,7 @@
 #pragma once
 #include "common.h"
 
-#ifndef FPCDR_SIL_NI
 #define FPCDR_SIL_NI 2
-#endif
 constexpr int SIL_NI = FPCDR_SIL_NI;
 
 // the three bits of ONE triangle in ONE image: own vertices c0..c2, the vertices across its three edges o0..o2 (adjacency ad[e]: -1 = no
