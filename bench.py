@@ -41,9 +41,14 @@ def requested_gpus(argv):
 
 
 def wants_self_launch(argv, env=None):
-    """`python bench.py --gpus N` (N > 1) started WITHOUT a torchrun environment: the process is then a launcher, not a rank."""
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a torchrun environment -- no WORLD_SIZE, or a wrapper's WORLD_SIZE=1 -- : the
+    process is then a launcher, not a rank.  (Its children carry WORLD_SIZE = N: they are ranks.)"""
     env = os.environ if env is None else env
-    return requested_gpus(argv) > 1 and int(env.get("WORLD_SIZE", "1")) <= 1 and "RANK" not in env
+    try:
+        world = int(env.get("WORLD_SIZE", "1") or "1")
+    except ValueError:
+        world = 1
+    return requested_gpus(argv) > 1 and world <= 1
 
 
 def self_launch(argv, timeout_s=None):

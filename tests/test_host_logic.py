@@ -369,7 +369,8 @@ def test_bench_launcher_decides_from_the_command_line_and_fails_with_its_ranks()
     assert ns["requested_gpus"](["--steps", "3"]) == 1 and ns["requested_gpus"](["--gpus", "8"]) == 8 and ns["requested_gpus"](["--gpus=4"]) == 4
     assert ns["wants_self_launch"](["--gpus", "2"], env={}) and not ns["wants_self_launch"](["--gpus", "1"], env={})
     assert not ns["wants_self_launch"](["--gpus", "2"], env={"WORLD_SIZE": "2", "RANK": "0"})      # started by torch.distributed.run
-    assert not ns["wants_self_launch"](["--gpus", "2"], env={"RANK": "1"})
+    assert ns["wants_self_launch"](["--gpus", "2"], env={"RANK": "0", "WORLD_SIZE": "1"})      # a wrapper's one-process environment: still a launcher
+    assert not ns["wants_self_launch"](["--gpus", "2"], env={"RANK": "1", "WORLD_SIZE": "2"})
     import torch
     if torch.cuda.is_available():
         return      # (the GPU box runs the real thing: tests/test_gpu_dist.py::test_bench_launches_its_own_ranks)
