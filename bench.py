@@ -6,6 +6,9 @@ bench.py -- fit-loop throughput of the MI355X-native differentiable-raster path.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
+`--gpus N` with N > 1 and no torchrun environment: the process is a LAUNCHER (below, in front of the torch import) -- it starts N fresh
+ranks of itself with a rendezvous on 127.0.0.1, relays rank 0's JSON line and exits non-zero if any rank fails.
+
 A "step" = one optimisation step of the fit loop over this rank's batch: blend (MFMA) -> MVP chain ->
 transform_clip -> rasterize -> interpolate -> texture -> antialias -> background + pixel loss, the whole
 backward, the gradient all-reduce and Adam (reference src/torch/fit.py:524-618, batched).  The default
