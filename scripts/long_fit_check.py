@@ -16,4 +16,4 @@ for i in range(600):
         print(i, float(l), flush=True)
 torch.cuda.synchronize()
 print("600 steps in %.2f s" % (time.perf_counter() - t0), "weight err", w0, "->", np.abs(ft.weights().cpu().numpy() - sc.weights_gt)[act].mean(),
-      "finite params:", all(torch.isfinite(p).all().item() for p in ft.params))
+      "finite params:", all(torch.isfinite(p).all().item() for p in ft.params), "steps skipped on the device:", ft.skipped_steps)
